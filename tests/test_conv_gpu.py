@@ -1,0 +1,47 @@
+"""HIP implicit-GEMM conv vs torch CPU fp32 ``F.conv2d`` (the op's fp32 reference)."""
+import pytest
+import torch
+from torch.nn import functional as F
+
+pytestmark = pytest.mark.gpu
+
+# (N, H, W, Cin, Cout, k, stride, relu_in, relu_out, residual)
+CASES = [
+    (1, 12, 20, 64, 64, 1, 1, False, True, False),
+    (2, 12, 20, 64, 256, 1, 1, False, False, True),
+    (1, 13, 19, 128, 128, 3, 2, False, True, False),
+    (2, 9, 14, 256, 256, 3, 1, True, False, True),
+    (1, 16, 24, 256, 512, 1, 2, False, False, False),
+    (2, 7, 11, 1024, 640, 3, 1, False, False, False),
+    (2, 30, 40, 32, 32, 3, 1, True, False, True),
+    (2, 10, 12, 256, 2, 3, 1, True, False, False),
+    (1, 33, 47, 64, 96, 3, 1, False, True, True),
+]
+
+
+@pytest.mark.parametrize('case', CASES)
+def test_conv_matches_torch_cpu(gpu, case):
+    from vfloodnet_amd import ops, weights
+    N, H, W, Cin, Cout, k, s, relu_in, relu_out, use_res = case
+    g = torch.Generator().manual_seed(hash(case) & 0xFFFF)
+    x = torch.randn(N, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, k, k, generator=g) / (Cin * k * k) ** 0.5
+    scale = 1 + 0.1 * torch.randn(Cout, generator=g)
+    shift = 0.1 * torch.randn(Cout, generator=g)
+    xin = F.relu(x) if relu_in else x
+    ref = F.conv2d(xin, w, stride=s, padding=k // 2) * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1)
+    res = torch.randn(ref.shape, generator=g) if use_res else None
+    if use_res:
+        ref = ref + res
+    if relu_out:
+        ref = F.relu(ref)
+    xd = x.permute(0, 2, 3, 1).contiguous().to(gpu)
+    wp = ops.pad_rows(weights.pack_conv_weight(w)).to(gpu)
+    resd = res.permute(0, 2, 3, 1).contiguous().to(gpu) if use_res else None
+    for cfg in range(len(ops.conv_cfg_tiles())):
+        y = ops.conv2d_nhwc(xd, wp, Cout, k, k, s, k // 2, scale.to(gpu), shift.to(gpu), resd,
+                            relu_in, relu_out, cfg=cfg)
+        torch.cuda.synchronize()
+        got = y.permute(0, 3, 1, 2).cpu()
+        err = (got - ref).abs().max().item()
+        assert err < 2e-4 * max(1.0, ref.abs().max().item()), f'cfg {cfg}: max err {err}'

@@ -1,0 +1,242 @@
+// Implicit-GEMM convolution on the gfx950 f32 matrix cores (v_mfma_f32_32x32x2_f32).
+//
+// Replaces every nn.Conv2d on the reference hot path except the 7x7 stems
+// (AFB_URR.py:20-30,96-111,114-127,191-202 and the torchvision bottlenecks behind
+// AFB_URR.py:39-47,69-77; SURVEY.md A.5 lists all 110 launches per frame).
+//
+//   GEMM view   M = N*Ho*Wo output pixels, N = Cout, K = KH*KW*Cin, K ordered (kh,kw,cin)
+//   layout      activations NHWC fp32, weights [CoutPad][K] fp32 (packed at load time)
+//   tile        BM x BN per workgroup, K walked 32 channels of one filter tap at a time
+//   MFMA        A operand = pixels (rows), B operand = filters (cols): lane l of the
+//               32x32 result holds filter column l&31 for 16 pixel rows, so one store
+//               instruction writes 2 x 128 contiguous bytes of NHWC output.
+//   LDS image   [rows][32 floats] per operand, 16-byte chunks XOR-swizzled with
+//               (row>>1)&7 so the ds_read_b128 fragment reads are conflict-free.
+//               One b128 read feeds four MFMAs: MFMA t of a k-group takes element t
+//               of the float4, i.e. k = 8*kk + 4*h + t for lane half h -- A and B use
+//               the same permutation of k, so the products pair correctly.
+//   pipeline    register-staged global->LDS double buffer, one barrier per K tile.
+//   epilogue    y = acc*scale[c] + shift[c] (+ residual) (ReLU): eval-mode BatchNorm or
+//               bias; optional ReLU on the *input* as it is staged (ResBlock applies
+//               ReLU before each conv, AFB_URR.py:24-25).
+//
+// Exact f32: the MFMA is a k-ordered fmaf chain, no reduced precision anywhere.
+#include "common.h"
+#include "../../include/vfn_hip.h"
+
+namespace {
+
+constexpr int BK = 32;
+
+template <int BM, int BN, int WM, int WN>
+__global__ __launch_bounds__(WM * WN * 64)
+void conv_igemm_kernel(const vfn_conv_desc p) {
+    constexpr int NT = WM * WN * 64;
+    constexpr int TM = BM / WM / 32;
+    constexpr int TN = BN / WN / 32;
+    constexpr int AC = BM * 8 / NT;   // 16-byte chunks of the A tile per thread
+    constexpr int BC = BN * 8 / NT;
+    static_assert(AC >= 1 && BC >= 1, "tile too small for the thread count");
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* sA = reinterpret_cast<float*>(smem);          // [2][BM][32]
+    float* sB = sA + 2 * BM * BK;                        // [2][BN][32]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int li = lane & 31, lh = lane >> 5;
+
+    // tile id -> (m tile, n tile); n fastest so blocks sharing input rows are neighbours
+    const int n_tiles = (p.Cout + BN - 1) / BN;
+    const int tile = blockIdx.x;
+    const int mt = tile / n_tiles, nt = tile % n_tiles;
+    const int m0 = mt * BM, n0 = nt * BN;
+
+    const int HoWo = p.Ho * p.Wo;
+    const int cblks = p.Cin / BK;
+    const int Ktot = p.KH * p.KW * p.Cin;
+    const int nk = p.KH * p.KW * cblks;
+
+    // per-thread staging coordinates
+    const int c16 = tid & 7;               // chunk column (4 floats)
+    const int r0 = tid >> 3;               // first row this thread stages
+    constexpr int RSTEP = NT / 8;
+
+    int a_base[AC], a_hi0[AC], a_wi0[AC];
+#pragma unroll
+    for (int j = 0; j < AC; ++j) {
+        const int m = m0 + r0 + j * RSTEP;
+        if (m < p.M) {
+            const int n = m / HoWo;
+            const int rem = m - n * HoWo;
+            const int ho = rem / p.Wo;
+            const int wo = rem - ho * p.Wo;
+            a_base[j] = n * p.H * p.W;
+            a_hi0[j] = ho * p.stride - p.pad;
+            a_wi0[j] = wo * p.stride - p.pad;
+        } else {
+            a_base[j] = 0;
+            a_hi0[j] = -100000;            // never in range -> zeros
+            a_wi0[j] = 0;
+        }
+    }
+    const float* wrow[BC];
+#pragma unroll
+    for (int j = 0; j < BC; ++j)
+        wrow[j] = p.w + (size_t)(n0 + r0 + j * RSTEP) * Ktot + c16 * 4;
+
+    f32x4 ra[AC], rb[BC];
+    int kh = 0, kw = 0, cb = 0;            // tap / channel block of the tile being *loaded*
+
+    auto load_tile = [&](int kt) {
+#pragma unroll
+        for (int j = 0; j < AC; ++j) {
+            const int hi = a_hi0[j] + kh, wi = a_wi0[j] + kw;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if ((unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W) {
+                const float* src = p.in + (size_t)(a_base[j] + hi * p.W + wi) * p.in_ld + cb * BK + c16 * 4;
+                v = *reinterpret_cast<const f32x4*>(src);
+                if (p.relu_in) {
+                    v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f);
+                    v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+                }
+            }
+            ra[j] = v;
+        }
+#pragma unroll
+        for (int j = 0; j < BC; ++j)
+            rb[j] = *reinterpret_cast<const f32x4*>(wrow[j] + (size_t)kt * BK);
+        if (++cb == cblks) { cb = 0; if (++kw == p.KW) { kw = 0; ++kh; } }
+    };
+    auto store_tile = [&](int buf) {
+        float* dA = sA + buf * BM * BK;
+        float* dB = sB + buf * BN * BK;
+#pragma unroll
+        for (int j = 0; j < AC; ++j) {
+            const int r = r0 + j * RSTEP;
+            *reinterpret_cast<f32x4*>(dA + r * BK + ((c16 ^ ((r >> 1) & 7)) << 2)) = ra[j];
+        }
+#pragma unroll
+        for (int j = 0; j < BC; ++j) {
+            const int r = r0 + j * RSTEP;
+            *reinterpret_cast<f32x4*>(dB + r * BK + ((c16 ^ ((r >> 1) & 7)) << 2)) = rb[j];
+        }
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    load_tile(0);
+    store_tile(0);
+    __syncthreads();
+
+    for (int kt = 0; kt < nk; ++kt) {
+        const int buf = kt & 1;
+        if (kt + 1 < nk) load_tile(kt + 1);
+
+        const float* cA = sA + buf * BM * BK + (wm * TM * 32) * BK;
+        const float* cB = sB + buf * BN * BK + (wn * TN * 32) * BK;
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            const int lc = 2 * kk + lh;
+            f32x4 a[TM], b[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const int r = i * 32 + li;      // (wm*TM*32) is a multiple of 32: swizzle bits unchanged
+                a[i] = *reinterpret_cast<const f32x4*>(cA + r * BK + ((lc ^ ((r >> 1) & 7)) << 2));
+            }
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int r = j * 32 + li;
+                b[j] = *reinterpret_cast<const f32x4*>(cB + r * BK + ((lc ^ ((r >> 1) & 7)) << 2));
+            }
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][t], b[j][t], acc[i][j], 0, 0, 0);
+        }
+
+        if (kt + 1 < nk) store_tile(buf ^ 1);
+        __syncthreads();
+    }
+
+    // epilogue: lane holds filter column (lane&31) for rows (reg&3)+8*(reg>>2)+4*(lane>>5)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int col = n0 + (wn * TN + j) * 32 + li;
+        if (col >= p.Cout) continue;
+        const float sc = p.scale ? p.scale[col] : 1.f;
+        const float sh = p.shift ? p.shift[col] : 0.f;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const int rbase = m0 + (wm * TM + i) * 32 + 4 * lh;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = rbase + (r & 3) + 8 * (r >> 2);
+                if (row < p.M) {
+                    float v = acc[i][j][r] * sc + sh;
+                    if (p.res) v += p.res[(size_t)row * p.res_ld + col];
+                    if (p.relu_out) v = fmaxf(v, 0.f);
+                    p.out[(size_t)row * p.out_ld + col] = v;
+                }
+            }
+        }
+    }
+}
+
+template <int BM, int BN, int WM, int WN>
+int launch_cfg(const vfn_conv_desc& p, hipStream_t s) {
+    constexpr int NT = WM * WN * 64;
+    const size_t lds = 2 * (size_t)(BM + BN) * BK * sizeof(float);
+    static bool attr_set = false;
+    if (!attr_set && lds > 64 * 1024) {
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel<BM, BN, WM, WN>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_set = true;
+    }
+    const int m_tiles = cdiv(p.M, BM);
+    const int n_tiles = cdiv(p.Cout, BN);
+    hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN>), dim3(m_tiles * n_tiles), dim3(NT), lds, s, p);
+    return vfn_check_launch();
+}
+
+}  // namespace
+
+extern "C" int vfn_conv_cfg_count(void) { return 8; }
+
+extern "C" int vfn_conv_cfg_tile(int cfg, int* bm, int* bn) {
+    static const int t[8][2] = {{128, 128}, {128, 64}, {64, 128}, {64, 64}, {32, 64}, {64, 32}, {128, 32}, {256, 128}};
+    if (cfg < 0 || cfg >= 8) return VFN_ERR_ARG;
+    *bm = t[cfg][0]; *bn = t[cfg][1];
+    return VFN_OK;
+}
+
+extern "C" int vfn_conv2d_nhwc_f32(const vfn_conv_desc* d, int cfg, void* stream) {
+    if (!d || !d->in || !d->w || !d->out) return VFN_ERR_ARG;
+    if (d->Cin % BK != 0 || d->in_ld % 4 != 0 || d->M <= 0) return VFN_ERR_ARG;
+    int bm, bn;
+    if (vfn_conv_cfg_tile(cfg, &bm, &bn) != VFN_OK) return VFN_ERR_ARG;
+    if (d->cout_pad < cdiv(d->Cout, bn) * bn) return VFN_ERR_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    switch (cfg) {
+        case 0: return launch_cfg<128, 128, 2, 2>(*d, s);
+        case 1: return launch_cfg<128, 64, 2, 2>(*d, s);
+        case 2: return launch_cfg<64, 128, 2, 2>(*d, s);
+        case 3: return launch_cfg<64, 64, 2, 2>(*d, s);
+        case 4: return launch_cfg<32, 64, 1, 2>(*d, s);
+        case 5: return launch_cfg<64, 32, 2, 1>(*d, s);
+        case 6: return launch_cfg<128, 32, 4, 1>(*d, s);
+        case 7: return launch_cfg<256, 128, 4, 2>(*d, s);
+    }
+    return VFN_ERR_ARG;
+}

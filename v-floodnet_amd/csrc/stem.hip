@@ -1,0 +1,173 @@
+// Encoder stems: fused zero-pad + ImageNet normalisation + 7x7/s2 conv (+ the two
+// 1->64 mask convs of EncoderM) + eval BatchNorm + ReLU, and the 3x3/s2 max-pool.
+//
+//   AFB_URR.py:53-58  EncoderM: f=(in_f-mean)/std; conv1(f)+conv1_m(m)+conv1_o(o); bn1; relu; maxpool
+//   AFB_URR.py:83-88  EncoderQ: same without the mask convs
+//   AFB_URR.py:259-264 / :279  the frame/mask are zero-padded to a multiple of 16 *before*
+//                     normalisation (myutils/data.py:132-149), and mask_inv=(1-mask).clamp(0,1)
+//                     is formed after padding -> padded pixels carry (-mean/std, 0, 1).
+//
+// The three stem convs are one GEMM over 3 (or 5) input planes.  K is ordered
+// (plane, kh, kw) with each 7-tap filter row padded to 8 taps (zero weight) so that
+// the two k values of one v_mfma_f32_32x32x2_f32 step are neighbouring pixels and
+// every LDS address is base + immediate.  A operand = pixels, B = filters, as in
+// conv_igemm.hip.
+#include "common.h"
+#include "../../include/vfn_hip.h"
+
+namespace {
+
+constexpr int TH = 8, TW = 16;            // output tile (pixels) per workgroup
+constexpr int PH = TH * 2 + 5;            // 21 input rows
+constexpr int PW = 38;                    // 37 input cols + 1 zero column for the padded 8th tap
+
+template <int CIN>
+__global__ __launch_bounds__(256)
+void stem_kernel(const vfn_stem_desc p) {
+    constexpr int KP = CIN * 7 * 8;       // padded K
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* sW = reinterpret_cast<float*>(smem);        // [KP][64]
+    float* sP = sW + KP * 64;                          // [CIN][PH][PW]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 31, lh = lane >> 5;
+
+    const int tiles_x = (p.Wo + TW - 1) / TW;
+    const int tiles_y = (p.Ho + TH - 1) / TH;
+    int b = blockIdx.x;
+    const int n = b / (tiles_x * tiles_y);
+    b -= n * tiles_x * tiles_y;
+    const int ty = b / tiles_x, tx = b - ty * tiles_x;
+    const int oy0 = ty * TH, ox0 = tx * TW;
+
+    // filters -> LDS (already packed [KP][64] with zero 8th taps)
+    for (int i = tid * 4; i < KP * 64; i += 256 * 4)
+        *reinterpret_cast<f32x4*>(sW + i) = *reinterpret_cast<const f32x4*>(p.w + i);
+
+    // input patch -> LDS, with pad + normalisation semantics
+    const int gy0 = oy0 * 2 - 3, gx0 = ox0 * 2 - 3;     // padded-frame coordinates
+    for (int i = tid; i < CIN * PH * PW; i += 256) {
+        const int c = i / (PH * PW);
+        const int r = i - c * PH * PW;
+        const int y = r / PW, x = r - y * PW;
+        const int gy = gy0 + y, gx = gx0 + x;
+        float v = 0.f;
+        if (x < PW - 1 && (unsigned)gy < (unsigned)p.Hp && (unsigned)gx < (unsigned)p.Wp) {
+            const int ry = gy - p.pad_top, rx = gx - p.pad_left;
+            const bool inside = (unsigned)ry < (unsigned)p.H0 && (unsigned)rx < (unsigned)p.W0;
+            if (c < 3) {
+                const float raw = inside ? p.frame[((size_t)c * p.H0 + ry) * p.W0 + rx] : 0.f;
+                v = (raw - p.mean[c]) / p.std[c];
+            } else {
+                const float m = inside ? p.mask[((size_t)n * p.H0 + ry) * p.W0 + rx] : 0.f;
+                v = (c == 3) ? m : fminf(fmaxf(1.f - m, 0.f), 1.f);
+            }
+        }
+        sP[i] = v;
+    }
+    __syncthreads();
+
+    // this wave: 32 pixels = tile rows 2*wave, 2*wave+1; lane's pixel for the A operand
+    const int py = 2 * wave + (li >> 4), px = li & 15;
+    const float* pa = sP + (2 * py) * PW + 2 * px + lh;      // + (c*PH+kh)*PW + 2*q
+    const float* pb = sW + lh * 64 + li;                     // + (2*s)*64 + 32*tn
+
+    f32x16 acc0, acc1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
+
+#pragma unroll
+    for (int c = 0; c < CIN; ++c) {
+#pragma unroll
+        for (int kh = 0; kh < 7; ++kh) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int s = (c * 7 + kh) * 4 + q;          // k-step: k = 2s + lh
+                const float a = pa[(c * PH + kh) * PW + 2 * q];
+                const float b0 = pb[(2 * s) * 64];
+                const float b1 = pb[(2 * s) * 64 + 32];
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b0, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b1, acc1, 0, 0, 0);
+            }
+        }
+    }
+
+    // epilogue: BN + ReLU, NHWC store
+#pragma unroll
+    for (int tn = 0; tn < 2; ++tn) {
+        const int col = tn * 32 + li;
+        const float sc = p.scale[col], sh = p.shift[col];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int pix = (r & 3) + 8 * (r >> 2) + 4 * lh;       // 0..31 within the wave tile
+            const int oy = oy0 + 2 * wave + (pix >> 4), ox = ox0 + (pix & 15);
+            if (oy < p.Ho && ox < p.Wo) {
+                const float a = tn == 0 ? acc0[r] : acc1[r];
+                const float v = fmaxf(a * sc + sh, 0.f);
+                p.out[(((size_t)n * p.Ho + oy) * p.Wo + ox) * 64 + col] = v;
+            }
+        }
+    }
+}
+
+__global__ void maxpool3x3s2_kernel(const float* __restrict__ in, float* __restrict__ out,
+                                    int N, int H, int W, int C, int Ho, int Wo) {
+    const int c4n = C / 4;
+    const size_t total = (size_t)N * Ho * Wo * c4n;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int c4 = i % c4n;
+        size_t t = i / c4n;
+        const int ox = t % Wo; t /= Wo;
+        const int oy = t % Ho;
+        const int n = t / Ho;
+        f32x4 m = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy) {
+            const int y = oy * 2 - 1 + dy;
+            if ((unsigned)y >= (unsigned)H) continue;
+#pragma unroll
+            for (int dx = 0; dx < 3; ++dx) {
+                const int x = ox * 2 - 1 + dx;
+                if ((unsigned)x >= (unsigned)W) continue;
+                const f32x4 v = *reinterpret_cast<const f32x4*>(in + (((size_t)n * H + y) * W + x) * C + c4 * 4);
+                m.x = fmaxf(m.x, v.x); m.y = fmaxf(m.y, v.y); m.z = fmaxf(m.z, v.z); m.w = fmaxf(m.w, v.w);
+            }
+        }
+        *reinterpret_cast<f32x4*>(out + i * 4) = m;
+    }
+}
+
+template <int CIN>
+int launch_stem(const vfn_stem_desc& d, hipStream_t s) {
+    constexpr int KP = CIN * 7 * 8;
+    const size_t lds = (size_t)(KP * 64 + CIN * PH * PW) * sizeof(float);
+    static bool attr_set = false;
+    if (!attr_set && lds > 64 * 1024) {
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&stem_kernel<CIN>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_set = true;
+    }
+    const int tiles = cdiv(d.Wo, TW) * cdiv(d.Ho, TH) * d.N;
+    hipLaunchKernelGGL((stem_kernel<CIN>), dim3(tiles), dim3(256), lds, s, d);
+    return vfn_check_launch();
+}
+
+}  // namespace
+
+extern "C" int vfn_stem_conv7x7_f32(const vfn_stem_desc* d, void* stream) {
+    if (!d || !d->frame || !d->w || !d->out || !d->scale || !d->shift) return VFN_ERR_ARG;
+    if (d->Hp % 2 || d->Wp % 2 || d->Ho != d->Hp / 2 || d->Wo != d->Wp / 2) return VFN_ERR_ARG;
+    if (d->cin == 3) return launch_stem<3>(*d, (hipStream_t)stream);
+    if (d->cin == 5) { if (!d->mask) return VFN_ERR_ARG; return launch_stem<5>(*d, (hipStream_t)stream); }
+    return VFN_ERR_ARG;
+}
+
+extern "C" int vfn_maxpool3x3s2_nhwc_f32(const float* in, float* out, int N, int H, int W, int C, void* stream) {
+    if (!in || !out || C % 4) return VFN_ERR_ARG;
+    const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
+    const size_t total = (size_t)N * Ho * Wo * (C / 4);
+    const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+    hipLaunchKernelGGL(maxpool3x3s2_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, in, out, N, H, W, C, Ho, Wo);
+    return vfn_check_launch();
+}

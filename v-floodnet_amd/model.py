@@ -1,0 +1,80 @@
+"""``AFB_URR`` facade: the reference's model API on top of the HIP engine.
+
+Drop-in for ``video_module.model.AFB_URR`` (``AFB_URR.py:242-321``) as used by
+``test_video_seg.py:42-44,100,108,111``:
+
+    model = AFB_URR(device, update_bank=True, load_imagenet_params=False)
+    model = model.to(device); model.eval()
+    model.load_state_dict(checkpoint['model'], strict=False)       # 562 reference keys
+    k4_list, v4_list = model.memorize(frame, mask)                  # lists of [128,HW] / [512,HW]
+    score, _ = model.segment(frame, fb)                             # logits [1,obj_n,h,w]; bumps fb.info
+
+The module owns parameters only (``weights.py``); ``memorize`` / ``segment`` run
+entirely in hand-written HIP kernels through ``engine.Engine``.  There is no
+eager / CPU fallback: on a non-GPU device, or without the compiled library,
+both calls raise ``RuntimeError`` (the exception type the reference's matcher
+already handles, ``AFB_URR.py:147``).
+"""
+import torch
+from torch import nn
+
+from . import weights as W
+
+
+class AFB_URR(nn.Module):
+    def __init__(self, device, update_bank, load_imagenet_params=False, _allow_cpu_container=False):
+        super().__init__()
+        if load_imagenet_params:
+            # AFB_URR.py:39,69 would download torchvision ImageNet weights; inference always
+            # overwrites them from a checkpoint (test_video_seg.py:51) and there is no network.
+            raise RuntimeError('load_imagenet_params=True is a training-time option and is not supported')
+        self.device = torch.device(device)
+        self.update_bank = bool(update_bank)
+        self.encoder_m = W.make_encoder_m()
+        self.encoder_q = W.make_encoder_q()
+        self.keyval_r4 = W.make_keyval(1024, 128, 512)
+        self.decoder = W.make_decoder()
+        self._engine = None
+        self._allow_cpu_container = _allow_cpu_container
+
+    # -- weight lifecycle ---------------------------------------------------
+    def _invalidate(self):
+        self._engine = None
+
+    def load_state_dict(self, state_dict, strict=True, **kw):
+        out = super().load_state_dict(state_dict, strict=strict, **kw)
+        self._invalidate()
+        return out
+
+    def _apply(self, fn, *a, **k):
+        out = super()._apply(fn, *a, **k)
+        self._invalidate()
+        try:
+            self.device = next(self.parameters()).device
+        except StopIteration:  # pragma: no cover
+            pass
+        return out
+
+    def engine(self):
+        if self._engine is None:
+            from .engine import Engine
+            self._engine = Engine(self)
+        return self._engine
+
+    # -- reference API ------------------------------------------------------
+    @torch.no_grad()
+    def memorize(self, frame, mask):
+        """AFB_URR.py:255-272.  frame f32[1,3,h,w] in [0,1]; mask [1,K,h,w] (u8 or float)."""
+        if self.training:
+            raise RuntimeError('the HIP path implements eval-mode inference only (call model.eval())')
+        return self.engine().memorize(frame, mask)
+
+    @torch.no_grad()
+    def segment(self, frame, fb_global):
+        """AFB_URR.py:274-318 (eval branch).  Returns (logits f32[1,obj_n,h,w], None)."""
+        if self.training:
+            raise RuntimeError('the HIP path implements eval-mode inference only (call model.eval())')
+        return self.engine().segment(frame, fb_global, self.update_bank), None
+
+    def forward(self, x):  # AFB_URR.py:320-321
+        pass
