@@ -1,0 +1,227 @@
+"""Benchmark of the V-FloodNet video-segmentation hot loop on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+
+One *step* = one frame of ``test_video_seg.py:105-115``: bicubic resize (identity at 480p) ->
+``segment`` -> object softmax -> ``memorize`` -> ``FeatureBank.update`` -> resize+argmax -> label
+D2H, on a synthetic 480x854 clip (BASELINE.json config C2, fp32) that is resident in HBM when
+the timed region starts.  For N > 1 every rank runs its own clip (seed = rank + 1, weak
+scaling, no collective on the data path) and the per-clip label masks are exchanged with one
+RCCL all-gather inside the timed bracket (BASELINE.json config C4).
+
+Prints ONE JSON line (rank 0) with the driver's contract fields plus
+  roofline      the dominant kernel (f32-MFMA implicit-GEMM conv): algorithmic FLOP / HIP-event time
+                measured on sampled frames of the timed region, against the 157.3 TFLOP/s f32 matrix peak
+  cpu_baseline  the CPU oracle (oracle/afb_urr_ref.py, torch CPU, all host cores) on the first
+                frames of the same clip -- a reported baseline, not the target
+  parity        mIoU / max |dprob| of the HIP labels against that oracle run on the same frames.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+PEAK_F32_MATRIX_TFLOPS = 157.3        # MI355X_MICROARCH.md, v_mfma_f32_32x32x2_f32
+H0, W0 = 480, 854
+
+
+def miou(a, b):
+    v = []
+    for c in (0, 1):
+        inter = ((a == c) & (b == c)).sum().item()
+        union = ((a == c) | (b == c)).sum().item()
+        v.append(1.0 if union == 0 else inter / union)
+    return sum(v) / 2
+
+
+class ConvTimer:
+    """HIP events around every implicit-GEMM launch of sampled frames (events live on torch's current
+    stream, which is the stream every kernel of this package is launched on)."""
+
+    def __init__(self):
+        from vfloodnet_amd import ops
+        self.ops = ops
+        self.orig = ops.conv2d_launch
+        self.records = []        # (cfg, flops, ev0, ev1)
+        self.active = False
+
+    def install(self):
+        ops = self.ops
+
+        def timed(desc, cfg):
+            if not self.active:
+                return self.orig(desc, cfg)
+            e0 = torch.cuda.Event(enable_timing=True)
+            e1 = torch.cuda.Event(enable_timing=True)
+            e0.record()
+            self.orig(desc, cfg)
+            e1.record()
+            self.records.append((cfg, 2.0 * desc.M * desc.Cout * desc.KH * desc.KW * desc.Cin, e0, e1))
+        ops.conv2d_launch = timed
+        # launches were bound at plan-build time: rebind
+        return timed
+
+    def summary(self):
+        per = {}
+        for cfg, fl, e0, e1 in self.records:
+            ms = e0.elapsed_time(e1)
+            d = per.setdefault(cfg, [0.0, 0.0, 0])
+            d[0] += fl
+            d[1] += ms
+            d[2] += 1
+        return per
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=99)
+    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--budget', type=int, default=250000)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--cpu-frames', type=int, default=4)
+    ap.add_argument('--no-autotune', action='store_true')
+    ap.add_argument('--sample-every', type=int, default=8, help='time the conv launches on every n-th frame')
+    args = ap.parse_args()
+
+    import vfloodnet_amd
+    from vfloodnet_amd import AFB_URR, synth, ops, dist as vdist
+    from vfloodnet_amd.video_seg import ClipRunner
+    import torch.distributed as dist
+
+    rank, local_rank, world = vdist.init()
+    if not torch.cuda.is_available():
+        raise RuntimeError('bench.py needs a GPU: the hot path is HIP-only')
+    dev = torch.device('cuda', local_rank)
+    torch.cuda.set_device(dev)
+
+    K, Wm = args.steps, args.warmup
+    sd = synth.make_state_dict(20200212)
+    model = AFB_URR(dev, update_bank=True).to(dev).eval()
+    model.load_state_dict(sd, strict=True)
+
+    # ---- inputs resident in HBM
+    seed = rank + 1
+    n_frames = min(K + 1, 400)
+    frames, m0 = synth.clip(seed, n_frames, H0, W0)
+    frames = frames.to(dev)
+    onehot = synth.onehot(m0).unsqueeze(0).to(dev)
+
+    timer = ConvTimer()
+    timed_launch = timer.install()
+    eng = model.engine()
+    if not args.no_autotune:
+        eng.autotune(H0, W0, 2)
+    plan = eng.plan(H0, W0, 2)
+    for lst in (plan.seg_pre, plan.seg_post, plan.mem):
+        for l in lst:
+            if l.fn is timer.orig:
+                l.fn = timed_launch
+
+    # ---- warm-up on a throw-away bank
+    warm = ClipRunner(model, 2, args.budget)
+    warm.start(frames[0:1], onehot)
+    for t in range(1, Wm + 1):
+        warm.step(frames[(t % (n_frames - 1)) + 1:(t % (n_frames - 1)) + 2])
+    del warm
+
+    # ---- timed region: exactly K steps
+    runner = ClipRunner(model, 2, args.budget)
+    runner.start(frames[0:1], onehot)
+    labels = torch.empty(K + 1, H0, W0, dtype=torch.uint8, device=dev)
+    labels[0] = m0.to(dev)
+    bank_sum = 0
+    bank_sizes = []
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for t in range(1, K + 1):
+        idx = ((t - 1) % (n_frames - 1)) + 1
+        timer.active = (t % args.sample_every == 0)
+        runner.step(frames[idx:idx + 1], want_label=False)
+        timer.active = False
+        labels[t].copy_(runner._label_dev, non_blocking=True)
+        bank_sum += sum(runner.bank_sizes())
+        bank_sizes.append(runner.bank_sizes())
+    if world > 1:
+        all_labels = vdist.gather_masks(labels.unsqueeze(0), world, rank, world)   # one RCCL all-gather
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    t1 = time.perf_counter()
+    elapsed = torch.tensor([t1 - t0], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(elapsed, op=dist.ReduceOp.MAX)
+    elapsed = float(elapsed.item())
+
+    if rank != 0:
+        if world > 1:
+            dist.destroy_process_group()
+        return
+
+    # ---- roofline of the dominant kernel
+    per = timer.summary()
+    roof = None
+    if per:
+        tiles = ops.conv_cfg_tiles()
+        dom = max(per, key=lambda c: per[c][1])
+        tot_fl = sum(v[0] for v in per.values())
+        tot_ms = sum(v[1] for v in per.values())
+        fl, ms, n = per[dom]
+        ach = fl / (ms * 1e-3) / 1e12
+        roof = {'bound': 'mfma', 'kernel': f'conv_igemm_kernel<{tiles[dom][0]},{tiles[dom][1]}>',
+                'achieved': round(ach, 2), 'peak': PEAK_F32_MATRIX_TFLOPS, 'unit': 'TFLOP/s',
+                'frac': round(ach / PEAK_F32_MATRIX_TFLOPS, 4), 'traffic': None,
+                'launches_timed': n, 'avg_launch_us': round(ms * 1e3 / n, 2),
+                'all_conv_achieved': round(tot_fl / (tot_ms * 1e-3) / 1e12, 2),
+                'all_conv_frac': round(tot_fl / (tot_ms * 1e-3) / 1e12 / PEAK_F32_MATRIX_TFLOPS, 4)}
+
+    # ---- whole-frame roofline: F_min(B) = 538.48 GFLOP + 3072*B*HW
+    b_mean = bank_sum / (2.0 * K)
+    fps = world * K / elapsed
+    f_min = 538.48e9 + 3072.0 * b_mean * 1620
+    frame_frac = (fps / world) * f_min / (PEAK_F32_MATRIX_TFLOPS * 1e12)
+
+    # ---- CPU baseline + parity on the first frames of the same clip
+    cpu = None
+    parity = None
+    if not args.no_cpu_baseline and world == 1:
+        from oracle import afb_urr_ref as O
+        nthr = os.cpu_count() or 1
+        torch.set_num_threads(nthr)
+        n_cpu = min(args.cpu_frames, K)
+        fr_cpu = frames[:n_cpu + 1].cpu()
+        O.run_clip(sd, fr_cpu[:2], m0, budget=args.budget)                 # warm the CPU kernels
+        c0 = time.perf_counter()
+        ref = O.run_clip(sd, fr_cpu, m0, budget=args.budget, return_scores=True)
+        c1 = time.perf_counter()
+        cpu = {'value': round(n_cpu / (c1 - c0), 4), 'unit': 'frames/s', 'cores': nthr, 'kind': 'port',
+               'sample': f'first {n_cpu} frames of the same 480x854 clip (incl. first-frame memorize), torch CPU oracle'}
+        lab = labels[:n_cpu + 1].cpu()
+        parity = {'frames': n_cpu,
+                  'miou_vs_oracle': round(min(miou(lab[t], ref['labels'][t]) for t in range(1, n_cpu + 1)), 5),
+                  'bank_sizes_equal': bank_sizes[:n_cpu] == ref['bank_sizes']}
+
+    out = {'metric': 'segmented frames/sec at 480p', 'value': round(fps, 3), 'unit': 'frames/s', 'n_gpus': world,
+           'steps': K, 'warmup': Wm, 'ms_per_step': round(1e3 * elapsed / K, 3), 'higher_is_better': True,
+           'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+           'config': {'workload': f'C2: {K + 1}-frame 480x854 synthetic clip per GPU through the test_video_seg.py loop '
+                                  f'(segment+softmax+memorize+bank update+argmax), fp32, budget {args.budget}',
+                      'mean_bank_entries_per_object': round(b_mean, 1),
+                      'frame_mfma_frac_Fmin': round(frame_frac, 4)},
+           'roofline': roof, 'cpu_baseline': cpu, 'parity': parity}
+    print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -54,6 +54,163 @@ int vfn_conv_cfg_count(void);
 int vfn_conv_cfg_tile(int cfg, int* bm, int* bn);
 int vfn_conv2d_nhwc_f32(const vfn_conv_desc* d, int cfg, void* stream);
 
+/* ------------------------------------------------------------------ encoder stems
+ * vfn_stem_conv7x7_f32: pad_divide_by (myutils/data.py:132-149) + (x-mean)/std + conv1
+ * (+ conv1_m(mask) + conv1_o((1-mask).clamp(0,1))) + bn1 + relu, AFB_URR.py:53-57 / :83-87
+ * (called from AFB_URR.memorize :259-266 and .segment :279-281).
+ * vfn_maxpool3x3s2_nhwc_f32: nn.MaxPool2d(3,2,1), AFB_URR.py:58,88.
+ */
+typedef struct vfn_stem_desc {
+    const float* frame;   /* [3][H0][W0] planar, raw values in [0,1], un-padded */
+    const float* mask;    /* [N][H0][W0] (soft or 0/1) or NULL when cin == 3 */
+    const float* w;       /* [cin*7*8][64]: k = (plane*7+kh)*8+kw, 8th tap of every row = 0 */
+    const float* scale;   /* [64] BN fold */
+    const float* shift;   /* [64] */
+    float* out;           /* NHWC [N][Ho][Wo][64] */
+    float mean[3];
+    float std[3];
+    int N, cin;           /* cin = 3 (query encoder) or 5 (memory encoder: +mask, +inverse mask) */
+    int H0, W0;           /* raw frame size */
+    int pad_top, pad_left;/* zero padding applied before normalisation */
+    int Hp, Wp;           /* padded size (multiple of 16) */
+    int Ho, Wo;           /* Hp/2, Wp/2 */
+} vfn_stem_desc;
+
+int vfn_stem_conv7x7_f32(const vfn_stem_desc* d, void* stream);
+int vfn_maxpool3x3s2_nhwc_f32(const float* in, float* out, int N, int H, int W, int C, void* stream);
+
+/* ------------------------------------------------------------------ decoder pointwise / window ops
+ * vfn_upsample2x_add_nhwc_f32   out = s + bilinear_x2(pm)              AFB_URR.py:124 (Refine)
+ *     s: [N or 1][h][w][C] (s_bcast=1: one copy shared by all N), pm: [N][h/2][w/2][C]
+ * vfn_rough_uncertainty_f32     AFB_URR.py:214-223 + myutils/data.py:40-46
+ *     p: [obj][h][w][2] -> p_up [obj][2h][2w][2], rough [obj][2h][2w], unc [2h][2w]
+ * vfn_local_hpass_f32 / vfn_local_vpass_f32   AFB_URR.py:226-231 (r1*rough, AvgPool2d(7,1,3) x2,
+ *     divide, MaxPool2d(7,1,3), cat([r1, r1_local])) as a separable window
+ *     r1: [h][w][C] (shared by the objects), rough: [obj][h][w]
+ *     scratch hs [obj][h][w][C], hr/hm [obj][h][w]; lm: [obj][h][w][2C], conf: [obj][h][w]
+ * vfn_final_logits_f32          AFB_URR.py:233-237,300,309-316
+ *     score[obj][H0][W0] = logit(clamp(softmax(bilinear_x2(p_up + unc*(conf*q)))[1], 1e-7, 1-1e-7)), un-padded
+ */
+int vfn_upsample2x_add_nhwc_f32(const float* s, const float* pm, float* out, int N, int h, int w, int C,
+                                int s_bcast, void* stream);
+int vfn_rough_uncertainty_f32(const float* p, float* p_up, float* rough, float* unc, int obj_n, int h, int w,
+                              void* stream);
+int vfn_local_hpass_f32(const float* r1, const float* rough, float* hs, float* hr, float* hm, int obj_n,
+                        int h, int w, int C, void* stream);
+int vfn_local_vpass_f32(const float* r1, const float* hs, const float* hr, const float* hm, float* lm,
+                        float* conf, int obj_n, int h, int w, int C, void* stream);
+int vfn_final_logits_f32(const float* p_up, const float* unc, const float* conf, const float* q, float* score,
+                         int obj_n, int h, int w, int pad_top, int pad_left, int H0, int W0, void* stream);
+
+/* ------------------------------------------------------------------ feature-bank contractions (f32 MFMA)
+ * Bank layout: entry-major, keys [obj][cap][128], values [obj][cap][512], info [obj][cap][2]
+ * (birth frame, log-hit accumulator), live length bank_len[obj] in DEVICE memory (kernels never
+ * need the host to know it; the host passes only an upper bound through the grid/nsplit choice).
+ *
+ * vfn_bank_scan (mode 0) + vfn_bank_scan_finish: per query column q, m = max_b s, l = sum_b exp(s-m),
+ *     s = scale * <keys[b], q>           -- softmax statistics of Matcher.forward, AFB_URR.py:144-145
+ * vfn_bank_scan (mode 1) + vfn_bank_scan_finish: idx = argmax_b <keys[b], q> * rowscale[b],
+ *     corr = max * colscale[q]           -- FeatureBank.update cosine match, FeatureBank.py:63-68
+ *     (rowscale/colscale = 1/max(||.||, 1e-12) from vfn_row_norms)
+ * vfn_memread_apply: p = exp(s-m)/l recomputed per tile, hit counts cnt[b] += sum_q [p > thres],
+ *     partial O^T = P^T V per bank split      -- AFB_URR.py:145-146,163-165
+ * vfn_memread_finish: out[obj][q][0:512] = sum_split O^T, out[obj][q][512:1024] = query value
+ *     (torch.cat([mem, q_out]), AFB_URR.py:159); info[:,1] += log(cnt+1), AFB_URR.py:174
+ */
+typedef struct vfn_bankscan_desc {
+    const float* q;        /* [HW][ldq] (mode 0: one query set; mode 1 with q_per_obj: [obj][HW][ldq]) */
+    const float* bank_k;   /* [obj][cap][128] */
+    const int* bank_len;   /* [obj], device */
+    const float* rowscale; /* mode 1: [obj][stride_rs] */
+    float* part;           /* [obj][nsplit][HW][2] scratch */
+    long long stride_q, stride_k, stride_rs;   /* elements between objects */
+    float scale;           /* mode 0: 1/sqrt(128) */
+    int ldq, q_per_obj, HW, obj_n, nsplit, mode;
+} vfn_bankscan_desc;
+
+typedef struct vfn_memread_desc {
+    const float* q;        /* [HW][ldq] query keys */
+    const float* qv;       /* [HW][ldqv] query values (copied into out[..][512:1024]) */
+    const float* bank_k;   /* [obj][cap][128] */
+    const float* bank_v;   /* [obj][cap][512] */
+    const int* bank_len;   /* [obj], device */
+    const float* ml;       /* [obj][HW][2] from the mode-0 scan */
+    float* o_part;         /* [obj][nsplit][HW][512] scratch */
+    int* cnt;              /* [obj][stride_cnt] zero-initialised hit counters, or NULL (update_bank=False) */
+    float* info;           /* [obj][cap][2] */
+    float* out;            /* [obj][HW][ld_out] decoder input, ld_out >= 1024 */
+    long long stride_k, stride_v, stride_cnt, stride_info;
+    float scale, thres;
+    int ldq, ldqv, ld_out, HW, obj_n, nsplit;
+} vfn_memread_desc;
+
+int vfn_bank_scan(const vfn_bankscan_desc* d, void* stream);
+int vfn_bank_scan_finish(const float* part, int nsplit, int HW, int obj_n, int mode, float* ml, int* idx,
+                         float* corr, const float* colscale, void* stream);
+int vfn_memread_apply(const vfn_memread_desc* d, void* stream);
+int vfn_memread_finish(const vfn_memread_desc* d, void* stream);
+
+/* ------------------------------------------------------------------ feature-bank maintenance
+ * vfn_row_norms     ||x_r||_2 per row (bank entries or new features)        FeatureBank.py:63-65,87-89
+ * vfn_bank_merge    scatter_mean of normalised new features into their matched entries
+ *                   (corr > thres_close) + magnitude-preserving blend         FeatureBank.py:71-97
+ * vfn_bank_append   append set (corr <= thres_close) in ascending source order; LFU eviction
+ *                   (remove(), FeatureBank.py:117-143) when class_budget < B + n_append;
+ *                   order-preserving compaction; new info rows (frame_idx, new_hit_init);
+ *                   clamp(info[:,1],0,1e5); new length -> bank_len; stats[obj] =
+ *                   {len, peak_n, replace_n, n_append}                        FeatureBank.py:100-115
+ * vfn_scatter_mean_f32  torch_scatter.scatter_mean(src[D,S], index, dim=1, out=out[D,B]):
+ *                   out[:,t] = (out[:,t] + sum_{index[s]==t} src[:,s]) / max(count_t,1) for every
+ *                   t that occurs in index (other columns: out/1 = unchanged)   FeatureBank.py:78,92
+ */
+typedef struct vfn_bank_desc {
+    float* bank_k;             /* [obj][cap][128] */
+    float* bank_v;             /* [obj][cap][512] */
+    float* info;               /* [obj][cap][2]   */
+    float* scratch_k;          /* same shapes: staging for order-preserving compaction */
+    float* scratch_v;
+    float* scratch_info;
+    const int* bank_len;       /* [obj] device */
+    int* bank_len_rw;          /* same buffer, written last */
+    const float* bank_knorm;   /* [obj][stride_n] ||key_b||   */
+    const float* bank_vnorm;   /* [obj][stride_n] ||value_b|| */
+    const int* match_idx;      /* [obj][HW] arg-max bank entry per new feature */
+    const float* match_corr;   /* [obj][HW] its cosine */
+    const float* new_k;        /* [obj][HW][ld_new]: key at +0 (128), value at +voff (512) */
+    const float* new_knorm;    /* [obj][HW] */
+    const float* new_vnorm;    /* [obj][HW] */
+    int* app_pos;              /* [obj][HW] scratch */
+    int* keep_dst;             /* [obj][stride_n] scratch */
+    int* plan;                 /* [obj][4] scratch */
+    int* stats;                /* [obj][4] persistent: len, peak_n, replace_n, last n_append */
+    long long stride_k, stride_v, stride_info, stride_n, stride_new;
+    double class_budget;       /* FeatureBank.py:20-22: float 0.8*(budget//obj_n) when obj_n == 2 */
+    float thres_close, update_rate, new_hit_init;
+    int frame_idx, ld_new, voff, HW, obj_n, cap;
+} vfn_bank_desc;
+
+int vfn_row_norms(const float* x, long long stride_obj, int ld, int dim, const int* len_dev, int rows,
+                  int obj_n, float* nrm, float* inv /* 1/max(nrm,1e-12) or NULL */, long long stride_n, void* stream);
+int vfn_bank_merge(const vfn_bank_desc* d, void* stream);
+int vfn_bank_append(const vfn_bank_desc* d, void* stream);
+int vfn_scatter_mean_f32(const float* src, long long src_s0, long long src_s1, const long long* index,
+                         int S, float* out, long long out_s0, long long out_s1, int D, void* stream);
+
+/* ------------------------------------------------------------------ per-frame loop operators (planar NCHW)
+ * vfn_resize_bicubic_f32    TF.resize(frame, 480, BICUBIC)                       test_video_seg.py:88,107
+ * vfn_resize_nearest_f32    TF.resize(first_mask, 480, NEAREST)                  test_video_seg.py:89
+ * vfn_softmax_objects_f32   F.softmax(score, dim=1)                              test_video_seg.py:109
+ * vfn_resize_argmax_u8      TF.resize(pred_mask, ori_size, BICUBIC); argmax(dim=0) -> uint8   test_video_seg.py:114-115
+ * vfn_postprocess_pred_u8   myutils.postprocessing_pred (HOST buffers; the reference runs cv2 CCL on the
+ *                           CPU as well)                                          myutils/data.py:17-37
+ */
+int vfn_resize_bicubic_f32(const float* in, float* out, int C, int Hi, int Wi, int Ho, int Wo, void* stream);
+int vfn_resize_nearest_f32(const float* in, float* out, int C, int Hi, int Wi, int Ho, int Wo, void* stream);
+int vfn_softmax_objects_f32(const float* score, float* prob, int obj_n, int n, void* stream);
+int vfn_resize_argmax_u8(const float* prob, unsigned char* label, int obj_n, int Hi, int Wi, int Ho, int Wo,
+                         void* stream);
+int vfn_postprocess_pred_u8(const unsigned char* pred_host, int H, int W, unsigned char* out_host);
+
 #ifdef __cplusplus
 }
 #endif

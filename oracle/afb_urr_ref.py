@@ -170,7 +170,7 @@ def memorize(sd, frame, mask):
     _, K, H, W = mask.shape
     (frame, mask), pad = pad_divide_by([frame, mask], 16, (frame.shape[2], frame.shape[3]))
     frame = frame.expand(K, -1, -1, -1)
-    mask = mask[0].unsqueeze(1).float()
+    mask = mask[0].unsqueeze(1).to(torch.float64 if frame.dtype == torch.float64 else torch.float32)  # .float()
     mask_inv = (torch.ones_like(mask) - mask).clamp(0, 1)
     r4, _ = encoder_m(sd, frame, mask, mask_inv)
     k4, v4 = keyval(sd, r4)
@@ -267,14 +267,14 @@ class FeatureBankRef:
             cls_idx = rel_idx[0, sel[:, 0]]
             uniq, _ = cls_idx.unique(dim=0, return_counts=True)
 
-            kupd = torch.zeros((d_key, bank_n))
+            kupd = torch.zeros((d_key, bank_n), dtype=self.keys[c].dtype)   # dtype=torch.float in the reference
             scatter_mean(npk[:, sel[:, 0]], cls_idx.unsqueeze(0).expand(d_key, -1), 1, kupd)
             self.keys[c][:, uniq] = mag_k[uniq] * ((1 - update_rate) * nk[:, uniq] + update_rate * kupd[:, uniq])
 
             nv = F.normalize(self.values[c], dim=0)
             npv = F.normalize(prev_value[c], dim=0)
             mag_v = self.values[c].norm(p=2, dim=0)
-            vupd = torch.zeros((d_val, bank_n))
+            vupd = torch.zeros((d_val, bank_n), dtype=self.values[c].dtype)
             scatter_mean(npv[:, sel[:, 0]], cls_idx.unsqueeze(0).expand(d_val, -1), 1, vupd)
             self.values[c][:, uniq] = mag_v[uniq] * ((1 - update_rate) * nv[:, uniq] + update_rate * vupd[:, uniq])
 

@@ -1,0 +1,214 @@
+"""Generate the golden vectors under tests/golden/ from THE REFERENCE ITSELF.
+
+Build-container only: imports /root/reference under ``oracle/refstubs.py`` (the reference never
+travels; only these small input/output fixtures do).  Re-run after any change to
+``v-floodnet_amd/synth.py`` (the synthetic checkpoint recipe):
+
+    python oracle/gen_golden.py
+
+Every fixture stores its inputs (or the seeds that regenerate them plus a checksum) and the outputs
+of the reference's own code: ``AFB_URR.memorize/segment`` (AFB_URR.py:255-318), ``FeatureBank.update``
+(FeatureBank.py:53-143), ``myutils.pad_divide_by / postprocessing_pred`` (data.py:17-37,132-149) and the
+whole ``test_video_seg.main`` loop (test_video_seg.py:41-123) through its PNG outputs.
+"""
+import json
+import os
+import shutil
+import sys
+import tempfile
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+OUT = os.path.join(ROOT, 'tests', 'golden')
+SEED = 20200212
+
+
+def checksum(t):
+    t = t.double()
+    return [float(t.sum()), float(t.abs().sum()), float((t * t).sum())]
+
+
+def sample_idx(n, k, seed):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randint(0, n, (k,), generator=g)
+
+
+def main():
+    import vfloodnet_amd  # noqa: F401
+    from vfloodnet_amd import synth
+    from oracle import refstubs
+    ref = refstubs.import_reference()
+    os.makedirs(OUT, exist_ok=True)
+    torch.set_num_threads(8)
+    torch.manual_seed(0)
+    cpu = torch.device('cpu')
+
+    sd = synth.make_state_dict(SEED)
+    model = ref.AFB_URR(cpu, update_bank=True, load_imagenet_params=False).eval()
+    model.load_state_dict(sd, strict=True)
+    with open(os.path.join(OUT, 'state_dict_names.txt'), 'w') as f:
+        for k, v in model.state_dict().items():
+            f.write(f'{k} {tuple(v.shape)}\n')
+    meta = {'seed': SEED, 'torch': torch.__version__, 'knobs': synth.DEFAULT_KNOBS,
+            'weights_checksum': {k: checksum(sd[k]) for k in ['encoder_q.conv1.weight', 'encoder_m.res4.5.bn3.running_var',
+                                                              'decoder.pred2.weight', 'decoder.pred2.bias',
+                                                              'decoder.local_pred2.bias', 'keyval_r4.Key.weight']}}
+
+    # ---- (a) blocks at 96x160 and a padded 90x150 --------------------------------------------------
+    with torch.no_grad():
+        for tag, (H, W) in {'96x160': (96, 160), '90x150': (90, 150)}.items():
+            frames, m0 = synth.clip(1, 2, H, W)
+            oh = synth.onehot(m0).unsqueeze(0)
+            k, v = model.memorize(frames[0:1], oh)
+            fb = ref.FeatureBank(2, 250000, cpu)
+            fb.init_bank(k, v)
+            # encoder internals (AFB_URR.py:82-93) on the padded query frame
+            [fp], pad = ref.myutils.pad_divide_by([frames[1:2]], 16, (H, W))
+            r4, r3, r2, r1 = model.encoder_q(fp)
+            score, _ = model.segment(frames[1:2], fb)
+            pm = torch.softmax(score, dim=1)
+            k2, v2 = model.memorize(frames[1:2], pm)
+            ii = {n: sample_idx(t.numel(), 2048, 7) for n, t in dict(r1=r1, r2=r2, r3=r3, r4=r4).items()}
+            np.savez_compressed(
+                os.path.join(OUT, f'blocks_{tag}.npz'),
+                frames=frames.numpy(), mask=m0.numpy(), pad=np.array(pad),
+                key0=torch.stack(k).numpy(), val0=torch.stack(v).numpy(),
+                **{f'{n}_idx': ii[n].numpy() for n in ii},
+                **{f'{n}_val': t.flatten()[ii[n]].numpy() for n, t in dict(r1=r1, r2=r2, r3=r3, r4=r4).items()},
+                **{f'{n}_sum': np.array(checksum(t)) for n, t in dict(r1=r1, r2=r2, r3=r3, r4=r4).items()},
+                score=score.numpy(), info0=fb.info[0].numpy(), info1=fb.info[1].numpy(),
+                key1=torch.stack(k2).numpy(), val1=torch.stack(v2).numpy())
+
+        # ---- (b) full-size segment / memorize: checksums + sparse samples --------------------------
+        H, W = 480, 854
+        frames, m0 = synth.clip(1, 2, H, W)
+        oh = synth.onehot(m0).unsqueeze(0)
+        k, v = model.memorize(frames[0:1], oh)
+        fb = ref.FeatureBank(2, 250000, cpu)
+        fb.init_bank(k, v)
+        score, _ = model.segment(frames[1:2], fb)
+        si = sample_idx(score.numel(), 4096, 11)
+        ki = sample_idx(k[0].numel(), 2048, 12)
+        vi = sample_idx(v[0].numel(), 2048, 13)
+        np.savez_compressed(
+            os.path.join(OUT, 'full_480x854.npz'),
+            frames_sum=np.array(checksum(frames)), mask_sum=np.array(checksum(m0.float())),
+            score_idx=si.numpy(), score_val=score.flatten()[si].numpy(), score_sum=np.array(checksum(score.clamp(-8, 8))),
+            label_water_frac=np.array(float((score[0, 1] > score[0, 0]).float().mean())),
+            key_idx=ki.numpy(), key_val=torch.stack([x.flatten()[ki] for x in k]).numpy(),
+            val_idx=vi.numpy(), val_val=torch.stack([x.flatten()[vi] for x in v]).numpy(),
+            info_sum=np.array([checksum(fb.info[i]) for i in range(2)]))
+
+        # ---- (c) FeatureBank.update regimes ---------------------------------------------------------
+        for regime, rs in {'append': 1, 'merge': 2, 'mixed': 3, 'evict': 4}.items():
+            g = torch.Generator().manual_seed(rs)
+            hw = 60
+            budget = 250000 if regime != 'evict' else 400          # class_budget 0.8*200 = 160
+            k0 = [torch.randn(128, hw, generator=g) for _ in range(2)]
+            v0 = [torch.randn(512, hw, generator=g) for _ in range(2)]
+            fb = ref.FeatureBank(2, budget, cpu, update_rate=0.1, thres_close=0.95)
+            fb.init_bank([x.clone() for x in k0], [x.clone() for x in v0])
+            steps = {}
+            for t in range(1, 5):
+                if regime == 'append':
+                    k1 = [torch.randn(128, hw, generator=g) for _ in range(2)]
+                    v1 = [torch.randn(512, hw, generator=g) for _ in range(2)]
+                elif regime == 'merge':
+                    k1 = [1.3 * x + 0.02 * torch.randn(x.shape, generator=g) for x in k0]
+                    v1 = [0.7 * x + 0.02 * torch.randn(x.shape, generator=g) for x in v0]
+                else:
+                    k1 = [torch.randn(128, hw, generator=g) for _ in range(2)]
+                    v1 = [torch.randn(512, hw, generator=g) for _ in range(2)]
+                    for i in range(2):
+                        src = torch.randint(0, hw // 3, (hw // 2,), generator=g)
+                        k1[i][:, :hw // 2] = 0.9 * k0[i][:, src] + 0.03 * torch.randn(128, hw // 2, generator=g)
+                bump = [torch.rand(fb.info[i].shape[0], generator=g) * 3 for i in range(2)]
+                for i in range(2):
+                    fb.info[i][:, 1] += bump[i]
+                steps[f'k1_{t}'] = torch.stack(k1).numpy()
+                steps[f'v1_{t}'] = torch.stack(v1).numpy()
+                for i in range(2):
+                    steps[f'bump_{t}_{i}'] = bump[i].numpy()
+                fb.update([x.clone() for x in k1], [x.clone() for x in v1], t)
+                for i in range(2):
+                    steps[f'keys_{t}_{i}'] = fb.keys[i].numpy().copy()
+                    steps[f'values_{t}_{i}'] = fb.values[i].numpy().copy()
+                    steps[f'info_{t}_{i}'] = fb.info[i].numpy().copy()
+            np.savez_compressed(os.path.join(OUT, f'bank_{regime}.npz'), k0=torch.stack(k0).numpy(),
+                                v0=torch.stack(v0).numpy(), budget=np.array(budget), peak_n=fb.peak_n,
+                                replace_n=fb.replace_n, **steps)
+
+    # ---- (d) postprocessing_pred / pad_divide_by ------------------------------------------------------
+    rng = np.random.RandomState(0)
+    cases = {'zeros': np.zeros((20, 30), np.uint8), 'ones': np.ones((20, 30), np.uint8)}
+    a = np.zeros((24, 40), np.uint8); a[2:6, 3:9] = 1; a[10:20, 12:30] = 1; a[7, 9] = 1
+    cases['two_blobs'] = a
+    b = np.zeros((9, 9), np.uint8); b[1:4, 1:4] = 1
+    cases['one_blob'] = b
+    for thr in (45, 55, 70):
+        cases[f'rand{thr}'] = (rng.rand(64, 80) > thr / 100).astype(np.uint8)
+    pp = {}
+    for n, c in cases.items():
+        pp['in_' + n] = c
+        pp['out_' + n] = ref.myutils.postprocessing_pred(c.copy())
+    np.savez_compressed(os.path.join(OUT, 'postprocess.npz'), **pp)
+    pads = {}
+    for h, w in [(480, 854), (480, 853), (1080, 1920), (96, 160), (90, 150), (481, 17)]:
+        outs, pad = ref.myutils.pad_divide_by([torch.zeros(1, 1, h, w)], 16, (h, w))
+        pads[f'{h}x{w}'] = {'pad': [int(x) for x in pad], 'shape': list(outs[0].shape[-2:])}
+    meta['pad_divide_by'] = pads
+
+    # ---- (e) the whole test_video_seg.main loop through its PNG outputs ---------------------------------
+    from PIL import Image
+    T, H, W = 6, 120, 200                       # main() resizes to short edge 480 -> 480x800 inside
+    frames, m0 = synth.clip(2, T, H, W)
+    tmp = tempfile.mkdtemp()
+    cwd = os.getcwd()
+    try:
+        os.chdir(tmp)
+        fdir = os.path.join(tmp, 'frames')
+        os.makedirs(fdir)
+        u8 = (frames * 255).round().clamp(0, 255).to(torch.uint8)
+        for t in range(T):
+            Image.fromarray(u8[t].permute(1, 2, 0).numpy()).save(os.path.join(fdir, f'{t:05d}.png'))
+        ckpt = os.path.join(tmp, 'ckpt.pth')
+        torch.save({'epoch': 0, 'model': sd, 'loss': 0.0, 'seed': SEED}, ckpt)
+        os.makedirs(os.path.join(tmp, 'output', 'segs', 'clip', 'mask'))
+        ref.myutils.save_seg_mask(m0.numpy(), os.path.join(tmp, 'output', 'segs', 'clip', 'mask', '00000.png'),
+                                  ref.myutils.color_palette)
+        import argparse
+        args = argparse.Namespace(gpu=-1, budget=250000, viz=True, model_path=ckpt, update_rate=0.1, merge_thres=0.95,
+                                  test_path=fdir, test_name='clip')
+        # DataLoader worker processes cannot see the stub modules: run the loader in-process
+        tvs = ref.test_video_seg
+        orig_loader = tvs.utils.data.DataLoader
+        tvs.utils.data.DataLoader = lambda ds, **kw: orig_loader(ds, batch_size=1, shuffle=False, num_workers=0)
+        try:
+            tvs.main(args, cpu)
+        finally:
+            tvs.utils.data.DataLoader = orig_loader
+        labels, overlays = [], []
+        for t in range(T):
+            im = Image.open(os.path.join(tmp, 'output', 'segs', 'clip', 'mask', f'{t:05d}.png'))
+            assert im.mode == 'P'
+            labels.append(np.array(im))
+            overlays.append(np.array(Image.open(os.path.join(tmp, 'output', 'segs', 'clip', 'overlay', f'{t:05d}.png'))))
+        pal = Image.open(os.path.join(tmp, 'output', 'segs', 'clip', 'mask', '00001.png')).getpalette()
+        np.savez_compressed(os.path.join(OUT, 'main_loop_120x200.npz'), frames_u8=u8.numpy(), mask=m0.numpy(),
+                            labels=np.packbits(np.stack(labels), axis=-1), shape=np.array(labels[0].shape),
+                            palette=np.array(pal[:768]), overlay1=overlays[1])
+    finally:
+        os.chdir(cwd)
+        shutil.rmtree(tmp, ignore_errors=True)
+
+    with open(os.path.join(OUT, 'meta.json'), 'w') as f:
+        json.dump(meta, f, indent=1)
+    tot = sum(os.path.getsize(os.path.join(OUT, x)) for x in os.listdir(OUT))
+    print('golden written to', OUT, f'({tot / 1e6:.2f} MB)')
+
+
+if __name__ == '__main__':
+    main()

@@ -1,0 +1,143 @@
+"""Host-side logic that needs no GPU: padding, resize rule, tiling choices, weight repacking,
+dataset / palette plumbing, the host connected-components routine."""
+import os
+
+import numpy as np
+import pytest
+import torch
+from torch.nn import functional as F
+
+
+def test_pad_divide_by_matches_oracle():
+    from vfloodnet_amd.engine import pad_divide_by
+    from oracle import afb_urr_ref as O
+    for h, w in [(480, 854), (480, 853), (1080, 1920), (96, 160), (90, 150), (481, 17)]:
+        pad, nh, nw = pad_divide_by(h, w)
+        (x,), pad_ref = O.pad_divide_by([torch.zeros(1, 1, h, w)], 16, (h, w))
+        assert pad == tuple(pad_ref) and (nh, nw) == tuple(x.shape[-2:])
+    assert pad_divide_by(480, 854)[0] == (5, 5, 0, 0)
+
+
+def test_resized_hw_rule():
+    from vfloodnet_amd.video_seg import resized_hw
+    assert resized_hw(480, 854, 480) == (480, 854)
+    assert resized_hw(720, 1280, 480) == (480, 853)
+    assert resized_hw(1080, 1920, 480) == (480, 853)
+    assert resized_hw(1920, 1080, 480) == (853, 480)
+    assert resized_hw(64, 96, 128) == (128, 192)
+
+
+def test_conv_weight_packing_is_a_gemm():
+    """packed[c, (kh,kw,cin)] . im2col(NHWC) == conv2d."""
+    from vfloodnet_amd import weights as W
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(1, 8, 6, 7, generator=g)
+    w = torch.randn(5, 8, 3, 3, generator=g)
+    ref = F.conv2d(x, w, padding=1)
+    wp = W.pack_conv_weight(w)                                   # [5, 72]
+    xp = F.pad(x, (1, 1, 1, 1)).permute(0, 2, 3, 1)              # NHWC
+    cols = torch.stack([xp[0, i:i + 3, j:j + 3, :].reshape(-1) for i in range(6) for j in range(7)])
+    out = (cols @ wp.t()).t().reshape(1, 5, 6, 7)
+    assert (out - ref).abs().max() < 1e-5
+
+
+def test_bn_scale_shift_equals_eval_batchnorm():
+    from vfloodnet_amd import weights as W
+    bn = torch.nn.BatchNorm2d(6).eval()
+    with torch.no_grad():
+        bn.weight.uniform_(0.5, 1.5); bn.bias.normal_(); bn.running_mean.normal_(); bn.running_var.uniform_(0.5, 2)
+    x = torch.randn(2, 6, 4, 4)
+    sc, sh = W.bn_scale_shift(bn)
+    assert (bn(x) - (x * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1))).abs().max() < 1e-5
+
+
+def test_state_dict_names_match_reference_schema():
+    """562 entries with the reference's names (checkpoint schema)."""
+    import vfloodnet_amd
+    m = vfloodnet_amd.AFB_URR('cpu', update_bank=True, _allow_cpu_container=True)
+    sd = m.state_dict()
+    assert len(sd) == 562
+    n_param = sum(v.numel() for k, v in sd.items() if v.dtype.is_floating_point and 'running' not in k and not k.endswith(('.mean', '.std')))
+    assert n_param == 33082660            # 33,082,660 parameters
+    for k in ['encoder_m.conv1_m.weight', 'encoder_m.res4.5.bn3.running_var', 'encoder_q.res3.0.downsample.1.weight',
+              'keyval_r4.Key.bias', 'decoder.RF2.ResFS.conv2.weight', 'decoder.local_pred2.bias', 'encoder_q.mean']:
+        assert k in sd
+    golden = os.path.join(os.path.dirname(__file__), 'golden', 'state_dict_names.txt')
+    if os.path.exists(golden):
+        names = [l.split()[0] for l in open(golden).read().splitlines() if l.strip()]
+        assert names == list(sd.keys())
+
+
+def test_nsplit_and_cfg_choices():
+    from vfloodnet_amd.feature_bank import pick_nsplit
+    from vfloodnet_amd import engine
+    assert pick_nsplit(1620, 2, 100) == 1
+    s = pick_nsplit(1620, 2, 100000)
+    assert 1 <= s <= 16 and (26 * 2 * s) % 256 <= 256
+    engine._CFG_TILES = [(128, 128), (128, 64), (64, 128), (64, 64), (32, 64), (64, 32), (128, 32), (256, 128)]
+    c = engine.choose_cfg(51840, 256, 2304)
+    assert engine._CFG_TILES[c][1] >= 64
+    c = engine.choose_cfg(207360, 2, 288)
+    assert engine._CFG_TILES[c][1] == 32
+
+
+def test_video_ds_and_palette(tmp_path):
+    from PIL import Image
+    from vfloodnet_amd.dataset import Video_DS, to_onehot
+    from vfloodnet_amd.data import save_seg_mask, load_image_in_PIL, color_palette
+    rng = np.random.RandomState(0)
+    paths = []
+    for i in range(3):
+        p = str(tmp_path / f'{i:05d}.png')
+        Image.fromarray(rng.randint(0, 255, (20, 30, 3), dtype=np.uint8)).save(p)
+        paths.append(p)
+    mask = np.zeros((20, 30), np.uint8)
+    mask[5:15, 8:20] = 1
+    mp = str(tmp_path / 'm.png')
+    save_seg_mask(mask, mp, color_palette)
+    im = Image.open(mp)
+    assert im.mode == 'P' and im.getpalette()[:12] == [0, 0, 0, 0, 0, 128, 0, 128, 0, 128, 0, 0]
+    ds = Video_DS(paths, load_image_in_PIL(paths[0]), load_image_in_PIL(mp, 'P'))
+    assert ds.obj_n == 2 and len(ds) == 2
+    assert ds.first_mask.shape == (2, 20, 30) and ds.first_mask.dtype == torch.uint8
+    assert torch.equal(ds.first_mask[1], torch.from_numpy(mask)) and torch.equal(ds.first_mask[0], 1 - ds.first_mask[1])
+    f, name = ds[0]
+    assert f.shape == (3, 20, 30) and f.dtype == torch.float32 and name == '00001' and 0 <= f.min() and f.max() <= 1
+    oh, objs = to_onehot(np.array([[0, 2], [1, 2]]), 3)
+    assert objs == [1, 2] and oh[0].tolist() == [[1, 0], [0, 0]]
+
+
+def test_postprocess_cases():
+    """vfn_postprocess_pred_u8 is a host routine of the HIP library (the reference runs cv2 on the CPU)."""
+    from vfloodnet_amd.data import postprocessing_pred
+    from oracle import afb_urr_ref as O
+    a = np.zeros((20, 30), np.uint8)
+    assert postprocessing_pred(a).min() == 1                     # all background -> all ones (reference quirk)
+    assert postprocessing_pred(np.ones((20, 30), np.uint8)).min() == 1
+    a[2:6, 3:9] = 1
+    a[10:18, 12:28] = 1
+    a[7, 9] = 1
+    assert np.array_equal(postprocessing_pred(a), O.postprocessing_pred(a))
+    b = np.zeros((9, 9), np.uint8)
+    b[1:4, 1:4] = 1
+    assert np.array_equal(postprocessing_pred(b), b)             # single blob: identity
+    rng = np.random.RandomState(0)
+    for thr in (0.45, 0.55, 0.7):
+        c = (rng.rand(64, 80) > thr).astype(np.uint8)
+        assert np.array_equal(postprocessing_pred(c), O.postprocessing_pred(c))
+
+
+def test_overlay_matches_reference_formula():
+    from vfloodnet_amd.data import add_overlay, color_palette
+    from scipy.ndimage import binary_dilation
+    rng = np.random.RandomState(1)
+    img = rng.randint(0, 255, (12, 14, 3)).astype(np.uint8)
+    mask = np.zeros((12, 14), np.uint8)
+    mask[3:8, 4:10] = 1
+    out = add_overlay(img, mask, color_palette)
+    colors = np.reshape(color_palette, (-1, 3))
+    canvas = img * 0.4 + np.ones(img.shape) * 0.6 * np.array(colors[1])[::-1]
+    ref = img.copy()
+    ref[mask == 1] = canvas[mask == 1]
+    ref[binary_dilation(mask == 1) ^ (mask == 1), :] = 0
+    assert np.array_equal(out, ref)

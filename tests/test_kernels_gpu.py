@@ -1,0 +1,209 @@
+"""Each HIP kernel against the plain torch CPU fp32 form of the same operator."""
+import math
+
+import numpy as np
+import pytest
+import torch
+from torch.nn import functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def nhwc(x):
+    return x.permute(0, 2, 3, 1).contiguous()
+
+
+def nchw(x):
+    return x.permute(0, 3, 1, 2).contiguous()
+
+
+@pytest.mark.parametrize('with_mask,H0,W0', [(False, 30, 43), (True, 30, 43), (True, 32, 48), (False, 17, 70)])
+def test_stem(gpu, with_mask, H0, W0):
+    from vfloodnet_amd import ops
+    from vfloodnet_amd.engine import pad_divide_by
+    g = torch.Generator().manual_seed(3)
+    N = 2 if with_mask else 1
+    frame = torch.rand(3, H0, W0, generator=g)
+    mask = torch.rand(N, H0, W0, generator=g) if with_mask else None
+    w = torch.randn(64, 3, 7, 7, generator=g) / 12
+    wm = torch.randn(64, 1, 7, 7, generator=g) / 7
+    wo = torch.randn(64, 1, 7, 7, generator=g) / 7
+    scale = 1 + 0.1 * torch.randn(64, generator=g)
+    shift = 0.1 * torch.randn(64, generator=g)
+    mean = torch.tensor([0.485, 0.456, 0.406]).view(1, 3, 1, 1)
+    std = torch.tensor([0.229, 0.224, 0.225]).view(1, 3, 1, 1)
+    pad, Hp, Wp = pad_divide_by(H0, W0)
+    fp = F.pad(frame.unsqueeze(0), pad)
+    f = (fp - mean) / std
+    x = F.conv2d(f.expand(N, -1, -1, -1), w, stride=2, padding=3)
+    if with_mask:
+        mp = F.pad(mask.unsqueeze(1), pad)
+        x = x + F.conv2d(mp, wm, stride=2, padding=3) + F.conv2d((1 - mp).clamp(0, 1), wo, stride=2, padding=3)
+    ref = F.relu(x * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1))
+    ws = [w, wm, wo] if with_mask else [w]
+    wp = ops.pack_stem_weight(ws).to(gpu)
+    out = torch.empty(N, Hp // 2, Wp // 2, 64, device=gpu)
+    d = ops.make_stem_desc(frame.to(gpu), mask.to(gpu) if with_mask else None, wp, scale.to(gpu), shift.to(gpu), out,
+                           mean.flatten().tolist(), std.flatten().tolist(), N, H0, W0, pad, Hp, Wp)
+    ops.stem_launch(d)
+    torch.cuda.synchronize()
+    err = (nchw(out.cpu()) - ref).abs().max().item()
+    assert err < 2e-4, err
+
+
+def test_maxpool(gpu):
+    from vfloodnet_amd import ops
+    x = torch.randn(2, 64, 13, 18)
+    ref = F.max_pool2d(x, 3, 2, 1)
+    out = torch.empty(2, ref.shape[2], ref.shape[3], 64, device=gpu)
+    ops.maxpool3x3s2(nhwc(x).to(gpu), out)
+    assert torch.equal(nchw(out.cpu()), ref)
+
+
+def test_upsample_add(gpu):
+    from vfloodnet_amd import ops
+    pm = torch.randn(2, 8, 5, 7)
+    s = torch.randn(1, 8, 10, 14)
+    ref = s + F.interpolate(pm, scale_factor=2, mode='bilinear', align_corners=False)
+    out = torch.empty(2, 10, 14, 8, device=gpu)
+    ops.upsample2x_add(nhwc(s).to(gpu), nhwc(pm).to(gpu), out, True)
+    assert (nchw(out.cpu()) - ref).abs().max() < 1e-5
+
+
+def test_decoder_tail(gpu):
+    """rough/uncertainty, local window stats and the final logits against AFB_URR.py:214-237 in torch."""
+    from vfloodnet_amd import ops
+    g = torch.Generator().manual_seed(5)
+    K, h, w = 2, 12, 18           # 1/4-res grid; r1 grid is 2h x 2w; frame is 4h x 4w
+    p = torch.randn(K, 2, h, w, generator=g) * 2
+    r1 = torch.rand(1, 64, 2 * h, 2 * w, generator=g)
+    q = torch.randn(K, 2, 2 * h, 2 * w, generator=g)
+    # reference
+    pu = F.interpolate(p, scale_factor=2, mode='bilinear', align_corners=False)
+    rough = F.softmax(pu, dim=1)[:, 1].view(1, K, 2 * h, 2 * w)
+    rough = F.softmax(rough, dim=1)
+    top, _ = rough.topk(k=2, dim=1)
+    unc = torch.exp(1 - top[:, 0] / (top[:, 1] + 1e-8)).unsqueeze(1)
+    rg = rough.view(K, 1, 2 * h, 2 * w)
+    r1e = r1.expand(K, -1, -1, -1)
+    r1_local = F.avg_pool2d(r1e * rg, 7, 1, 3) / (F.avg_pool2d(rg, 7, 1, 3) + 1e-8)
+    conf = F.max_pool2d(rg, 7, 1, 3)
+    p2 = pu + unc.expand(-1, K, -1, -1).reshape(K, 1, 2 * h, 2 * w) * (conf * q)
+    out = F.softmax(F.interpolate(p2, scale_factor=2, mode='bilinear', align_corners=False), dim=1)[:, 1]
+    out = out.clamp(1e-7, 1 - 1e-7)
+    score = torch.log(out / (1 - out))
+    pad = (3, 2, 1, 2)           # lw, uw, lh, uh
+    H0, W0 = 4 * h - 3, 4 * w - 5
+    score_ref = score[:, pad[2]:pad[2] + H0, pad[0]:pad[0] + W0]
+    # HIP
+    d = lambda t: t.to(gpu)
+    p_up = torch.empty(K, 2 * h, 2 * w, 2, device=gpu)
+    rough_d = torch.empty(K, 2 * h, 2 * w, device=gpu)
+    unc_d = torch.empty(2 * h, 2 * w, device=gpu)
+    ops.rough_uncertainty(d(nhwc(p)), p_up, rough_d, unc_d)
+    assert (nchw(p_up.cpu()) - pu).abs().max() < 1e-5
+    assert (rough_d.cpu() - rough[0]).abs().max() < 1e-6
+    assert (unc_d.cpu() - unc[0, 0]).abs().max() < 1e-5
+    hs = torch.empty(K, 2 * h, 2 * w, 64, device=gpu)
+    hr = torch.empty(K, 2 * h, 2 * w, device=gpu)
+    hm = torch.empty(K, 2 * h, 2 * w, device=gpu)
+    lm = torch.empty(K, 2 * h, 2 * w, 128, device=gpu)
+    cf = torch.empty(K, 2 * h, 2 * w, device=gpu)
+    ops.local_stats(d(nhwc(r1)), rough_d, hs, hr, hm, lm, cf)
+    lmc = nchw(lm.cpu())
+    assert torch.equal(lmc[:, :64], r1e)
+    assert (lmc[:, 64:] - r1_local).abs().max() < 1e-5
+    assert (cf.cpu() - conf[:, 0]).abs().max() < 1e-6
+    sc = torch.empty(1, K, H0, W0, device=gpu)
+    ops.final_logits(p_up, unc_d, cf, d(nhwc(q)), sc, pad, H0, W0)
+    assert (sc.cpu()[0] - score_ref).abs().max() < 2e-4
+
+
+@pytest.mark.parametrize('Hi,Wi,Ho,Wo', [(30, 53, 48, 85), (108, 192, 48, 85), (48, 85, 48, 85)])
+def test_resize_ops(gpu, Hi, Wi, Ho, Wo):
+    from vfloodnet_amd import ops
+    g = torch.Generator().manual_seed(7)
+    x = torch.rand(1, 3, Hi, Wi, generator=g)
+    ref = F.interpolate(x, size=[Ho, Wo], mode='bicubic', align_corners=False)
+    out = ops.resize_bicubic(x.to(gpu), Ho, Wo)
+    assert (out.cpu() - ref).abs().max() < 1e-5
+    refn = F.interpolate(x, size=[Ho, Wo], mode='nearest')
+    outn = ops.resize_nearest(x.to(gpu), Ho, Wo)
+    assert torch.equal(outn.cpu(), refn)
+    score = torch.randn(1, 2, Hi, Wi, generator=g) * 3
+    pm = ops.softmax_objects(score.to(gpu))
+    pref = F.softmax(score, dim=1)
+    assert (pm.cpu() - pref).abs().max() < 1e-6
+    lab = ops.resize_argmax(pm, Ho, Wo).cpu()
+    r = F.interpolate(pref, size=[Ho, Wo], mode='bicubic', align_corners=False)[0]
+    labref = r.argmax(0).to(torch.uint8)
+    margin = (r[0] - r[1]).abs()
+    assert torch.equal(lab[margin > 1e-5], labref[margin > 1e-5])
+
+
+def _bank(gpu, B, HW, seed=0, cap_extra=300):
+    g = torch.Generator().manual_seed(seed)
+    K = torch.randn(2, B, 128, generator=g)
+    V = torch.randn(2, B, 512, generator=g)
+    return K, V
+
+
+@pytest.mark.parametrize('B,HW', [(60, 60), (1000, 150), (5000, 1620)])
+def test_memory_read(gpu, B, HW):
+    """Two-pass fused memory read vs softmax/matmul in torch (AFB_URR.py:144-146,163-174)."""
+    from vfloodnet_amd.feature_bank import FeatureBank
+    from vfloodnet_amd.engine import Engine
+    import types
+    g = torch.Generator().manual_seed(B)
+    keys = [torch.randn(128, B, generator=g) for _ in range(2)]
+    vals = [torch.randn(512, B, generator=g) for _ in range(2)]
+    kvq = torch.randn(1, HW, 640, generator=g)
+    kvq[..., :128] *= 1.5
+    fb = FeatureBank(2, 250000, gpu)
+    fb._hw = HW
+    # init with B columns although HW differs: allocate by hand
+    fb._alloc(HW, B)
+    fb._write_columns([k.to(gpu) for k in keys], [v.to(gpu) for v in vals], [0, 0], 0, 0.0)
+    fb._set_lengths([B, B])
+    fb._ibuf[:, :B, 1] = 0.5
+    plan = types.SimpleNamespace(HW=HW, kv_q=kvq.to(gpu), ml=torch.empty(2, HW, 2, device=gpu),
+                                 ml_part=torch.empty(2, 16, HW, 2, device=gpu),
+                                 o_part=torch.empty(2, 16, HW, 512, device=gpu),
+                                 dec_in=torch.empty(2, HW, 1024, device=gpu))
+    Engine._memory_read(None, plan, fb, True)
+    torch.cuda.synchronize()
+    out = plan.dec_in.cpu()
+    q_in = kvq[0, :, :128].t().unsqueeze(0)
+    for i in range(2):
+        p = torch.matmul(keys[i].t(), q_in) / math.sqrt(128)
+        p = F.softmax(p, dim=1)
+        mem = torch.matmul(vals[i], p)[0]                        # [512, HW]
+        assert (out[i, :, :512].t() - mem).abs().max() < 5e-5 * max(1, mem.abs().max().item())
+        assert torch.equal(out[i, :, 512:], kvq[0, :, 128:])
+        cnt = (p > 1e-3).float().sum(dim=2)[0]
+        info_ref = 0.5 + torch.log(cnt + 1)
+        got = fb.info[i][:, 1].cpu()
+        # a count may differ by one where p is within rounding of the threshold
+        near = ((p[0] - 1e-3).abs() < 1e-7).any(dim=1)
+        assert (got[~near] - info_ref[~near]).abs().max() < 1e-5
+    assert int(fb._cnt.abs().sum()) == 0
+
+
+def test_scatter_mean(gpu):
+    from vfloodnet_amd import scatter_mean
+    g = torch.Generator().manual_seed(11)
+    D, S, B = 128, 200, 50
+    src = torch.randn(D, S, generator=g)
+    idx = torch.randint(0, B, (S,), generator=g)
+    out0 = torch.zeros(D, B)
+    ref = out0.clone()
+    ref.scatter_add_(1, idx.unsqueeze(0).expand(D, -1), src)
+    cnt = torch.zeros(D, B).scatter_add_(1, idx.unsqueeze(0).expand(D, -1), torch.ones(D, S)).clamp_(min=1)
+    ref = ref / cnt
+    out = torch.zeros(D, B, device=gpu)
+    scatter_mean(src.to(gpu), idx.to(gpu).unsqueeze(0).expand(D, -1), dim=1, out=out)
+    assert (out.cpu() - ref).abs().max() < 1e-5
+    # empty selection (all-append frames): no-op
+    out2 = torch.zeros(D, B, device=gpu)
+    scatter_mean(src[:, :0].to(gpu), idx[:0].to(gpu).unsqueeze(0).expand(D, -1), dim=1, out=out2)
+    assert float(out2.abs().sum()) == 0.0

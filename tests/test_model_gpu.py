@@ -1,0 +1,143 @@
+"""The HIP model path against the CPU oracle (oracle/afb_urr_ref.py) on the same seeded inputs.
+
+Tolerances (fp32 on both sides, different summation order): key/value features 1e-4 relative,
+logits atol 1e-3, labels exact wherever the oracle's logit margin exceeds 1e-2.
+"""
+import numpy as np
+import pytest
+import torch
+from torch.nn import functional as F
+
+pytestmark = pytest.mark.gpu
+
+SEED = 20200212
+
+
+@pytest.fixture(scope='module')
+def sd():
+    from vfloodnet_amd import synth
+    return synth.make_state_dict(SEED)
+
+
+@pytest.fixture(scope='module')
+def model(gpu, sd):
+    from vfloodnet_amd import AFB_URR
+    m = AFB_URR(gpu, update_bank=True).to(gpu).eval()
+    m.load_state_dict(sd, strict=True)
+    return m
+
+
+def miou(a, b):
+    v = []
+    for c in (0, 1):
+        inter = ((a == c) & (b == c)).sum().item()
+        union = ((a == c) | (b == c)).sum().item()
+        v.append(1.0 if union == 0 else inter / union)
+    return sum(v) / 2
+
+
+@pytest.mark.parametrize('H,W', [(96, 160), (90, 150)])
+def test_memorize_segment_vs_oracle(gpu, sd, model, H, W):
+    from vfloodnet_amd import synth, FeatureBank
+    from oracle import afb_urr_ref as O
+    frames, m0 = synth.clip(1, 2, H, W)
+    oh = synth.onehot(m0).unsqueeze(0)
+    torch.set_num_threads(8)
+    k_ref, v_ref = O.memorize(sd, frames[0:1], oh)
+    fb_ref = O.FeatureBankRef(2, 250000)
+    fb_ref.init_bank(k_ref, v_ref)
+    score_ref, _ = O.segment(sd, frames[1:2], fb_ref)
+
+    k, v = model.memorize(frames[0:1].to(gpu), oh.to(gpu))
+    for i in range(2):
+        assert k[i].shape == k_ref[i].shape and v[i].shape == v_ref[i].shape
+        assert (k[i].cpu() - k_ref[i]).abs().max() < 1e-4 * max(1, k_ref[i].abs().max().item())
+        assert (v[i].cpu() - v_ref[i]).abs().max() < 1e-4 * max(1, v_ref[i].abs().max().item())
+    fb = FeatureBank(2, 250000, gpu)
+    fb.init_bank(k, v)
+    score, unc = model.segment(frames[1:2].to(gpu), fb)
+    assert unc is None and score.shape == score_ref.shape
+    s = score.cpu()
+    # logit(p) is ill-conditioned near the clamp (one ulp of p at |logit| = 14 is 0.1 logit): accept
+    # |dlogit| < 1e-3 or |dprob| < 5e-7 (a few ulps of the softmax output)
+    dl = (s - score_ref).abs()
+    dp = (torch.sigmoid(s) - torch.sigmoid(score_ref)).abs()
+    assert bool(((dl < 1e-3) | (dp < 5e-7)).all()), (dl.max().item(), dp.max().item())
+    margin = (score_ref[0, 1] - score_ref[0, 0]).abs()
+    lab, lab_ref = s[0].argmax(0), score_ref[0].argmax(0)
+    assert torch.equal(lab[margin > 1e-2], lab_ref[margin > 1e-2])
+    # hit-count side effect on the bank (AFB_URR.py:174)
+    for i in range(2):
+        assert fb.keys[i].shape == fb_ref.keys[i].shape
+        assert (fb.info[i].cpu() - fb_ref.info[i]).abs().max() < 0.02
+
+
+def _rand_feats(g, n, hw):
+    return [torch.randn(128, hw, generator=g) for _ in range(n)], [torch.randn(512, hw, generator=g) for _ in range(n)]
+
+
+@pytest.mark.parametrize('regime', ['append', 'merge', 'mixed', 'evict'])
+def test_bank_update_vs_oracle(gpu, regime):
+    """FeatureBank.update in the three regimes of SURVEY.md 8(c): all-append, all-merge, evict."""
+    from vfloodnet_amd import FeatureBank
+    from oracle import afb_urr_ref as O
+    g = torch.Generator().manual_seed({'append': 1, 'merge': 2, 'mixed': 3, 'evict': 4}[regime])
+    hw = 150
+    budget = 250000 if regime != 'evict' else 1000          # class_budget 0.8*500 = 400
+    thr = 0.95
+    k0, v0 = _rand_feats(g, 2, hw)
+    fb_ref = O.FeatureBankRef(2, budget, 'cpu', 0.1, thr)
+    fb_ref.init_bank([k.clone() for k in k0], [v.clone() for v in v0])
+    fb = FeatureBank(2, budget, gpu, 0.1, thr)
+    fb.init_bank([k.to(gpu) for k in k0], [v.to(gpu) for v in v0])
+    prev_k = k0
+    for t in range(1, 6):
+        if regime == 'append':
+            k1, v1 = _rand_feats(g, 2, hw)
+        elif regime == 'merge':
+            k1 = [1.3 * k + 0.02 * torch.randn(k.shape, generator=g) for k in k0]
+            v1 = [0.7 * v + 0.02 * torch.randn(v.shape, generator=g) for v in v0]
+        else:   # mixed / evict: half near-duplicates (several sources hit the same entry), half new
+            k1, v1 = _rand_feats(g, 2, hw)
+            for i in range(2):
+                src = torch.randint(0, hw // 3, (hw // 2,), generator=g)
+                k1[i][:, :hw // 2] = 0.9 * k0[i][:, src] + 0.03 * torch.randn(128, hw // 2, generator=g)
+        # hit counters differ per entry so the LFU order is well defined
+        bump = [torch.rand(fb_ref.info[i].shape[0], generator=g) * 3 for i in range(2)]
+        for i in range(2):
+            fb_ref.info[i][:, 1] += bump[i]
+            fb.info[i][:, 1] += bump[i].to(gpu)
+        fb_ref.update([k.clone() for k in k1], [v.clone() for v in v1], t)
+        fb.update([k.to(gpu) for k in k1], [v.to(gpu) for v in v1], t)
+        for i in range(2):
+            assert fb.keys[i].shape == fb_ref.keys[i].shape, (regime, t, fb.keys[i].shape, fb_ref.keys[i].shape)
+            assert (fb.keys[i].cpu() - fb_ref.keys[i]).abs().max() < 1e-4
+            assert (fb.values[i].cpu() - fb_ref.values[i]).abs().max() < 1e-4
+            assert (fb.info[i].cpu() - fb_ref.info[i]).abs().max() < 1e-5
+    assert np.array_equal(fb.peak_n, fb_ref.peak_n)
+    assert np.array_equal(fb.replace_n, fb_ref.replace_n)
+    if regime == 'evict':
+        assert fb_ref.replace_n.sum() > 0
+
+
+def test_clip_vs_oracle(gpu, sd, model):
+    """8-frame clip through the whole loop (resize up to short edge 128, memorize+update every frame)."""
+    from vfloodnet_amd import synth
+    from vfloodnet_amd.video_seg import run_clip
+    from oracle import afb_urr_ref as O
+    frames, m0 = synth.clip(3, 8, 64, 96)
+    torch.set_num_threads(8)
+    ref = O.run_clip(sd, frames, m0, size=128)
+    out = run_clip(model, frames.to(gpu), m0, size=128)
+    assert out['bank_sizes'] == ref['bank_sizes']
+    ious = [miou(out['labels'][t], ref['labels'][t]) for t in range(1, 8)]
+    assert min(ious) >= 0.99, ious
+
+
+def test_cpu_device_fails_loudly(sd):
+    from vfloodnet_amd import AFB_URR, FeatureBank
+    m = AFB_URR('cpu', update_bank=True, _allow_cpu_container=True).eval()
+    with pytest.raises(RuntimeError):
+        m.memorize(torch.zeros(1, 3, 32, 32), torch.zeros(1, 2, 32, 32))
+    with pytest.raises(RuntimeError):
+        FeatureBank(2, 1000, 'cpu').init_bank([torch.zeros(128, 4)] * 2, [torch.zeros(512, 4)] * 2)

@@ -25,6 +25,46 @@ class ConvDesc(C.Structure):
                 ('relu_in', C.c_int), ('relu_out', C.c_int), ('M', C.c_int)]
 
 
+class StemDesc(C.Structure):
+    _fields_ = [('frame', c_fp), ('mask', c_fp), ('w', c_fp), ('scale', c_fp), ('shift', c_fp), ('out', c_fp),
+                ('mean', C.c_float * 3), ('std', C.c_float * 3),
+                ('N', C.c_int), ('cin', C.c_int), ('H0', C.c_int), ('W0', C.c_int),
+                ('pad_top', C.c_int), ('pad_left', C.c_int), ('Hp', C.c_int), ('Wp', C.c_int),
+                ('Ho', C.c_int), ('Wo', C.c_int)]
+
+
+class BankScanDesc(C.Structure):
+    _fields_ = [('q', c_fp), ('bank_k', c_fp), ('bank_len', c_fp), ('rowscale', c_fp), ('part', c_fp),
+                ('stride_q', C.c_longlong), ('stride_k', C.c_longlong), ('stride_rs', C.c_longlong),
+                ('scale', C.c_float),
+                ('ldq', C.c_int), ('q_per_obj', C.c_int), ('HW', C.c_int), ('obj_n', C.c_int),
+                ('nsplit', C.c_int), ('mode', C.c_int)]
+
+
+class MemReadDesc(C.Structure):
+    _fields_ = [('q', c_fp), ('qv', c_fp), ('bank_k', c_fp), ('bank_v', c_fp), ('bank_len', c_fp), ('ml', c_fp),
+                ('o_part', c_fp), ('cnt', c_fp), ('info', c_fp), ('out', c_fp),
+                ('stride_k', C.c_longlong), ('stride_v', C.c_longlong), ('stride_cnt', C.c_longlong),
+                ('stride_info', C.c_longlong),
+                ('scale', C.c_float), ('thres', C.c_float),
+                ('ldq', C.c_int), ('ldqv', C.c_int), ('ld_out', C.c_int), ('HW', C.c_int), ('obj_n', C.c_int),
+                ('nsplit', C.c_int)]
+
+
+class BankDesc(C.Structure):
+    _fields_ = [('bank_k', c_fp), ('bank_v', c_fp), ('info', c_fp),
+                ('scratch_k', c_fp), ('scratch_v', c_fp), ('scratch_info', c_fp),
+                ('bank_len', c_fp), ('bank_len_rw', c_fp), ('bank_knorm', c_fp), ('bank_vnorm', c_fp),
+                ('match_idx', c_fp), ('match_corr', c_fp), ('new_k', c_fp), ('new_knorm', c_fp), ('new_vnorm', c_fp),
+                ('app_pos', c_fp), ('keep_dst', c_fp), ('plan', c_fp), ('stats', c_fp),
+                ('stride_k', C.c_longlong), ('stride_v', C.c_longlong), ('stride_info', C.c_longlong),
+                ('stride_n', C.c_longlong), ('stride_new', C.c_longlong),
+                ('class_budget', C.c_double),
+                ('thres_close', C.c_float), ('update_rate', C.c_float), ('new_hit_init', C.c_float),
+                ('frame_idx', C.c_int), ('ld_new', C.c_int), ('voff', C.c_int), ('HW', C.c_int),
+                ('obj_n', C.c_int), ('cap', C.c_int)]
+
+
 def lib():
     """Load the shared library once; raise loudly if it is absent."""
     global _lib
@@ -44,6 +84,12 @@ def _declare(L):
     L.vfn_conv_cfg_count.restype = i
     L.vfn_conv_cfg_tile.argtypes = [i, C.POINTER(i), C.POINTER(i)]
     L.vfn_conv2d_nhwc_f32.argtypes = [C.POINTER(ConvDesc), i, p]
+    L.vfn_stem_conv7x7_f32.argtypes = [C.POINTER(StemDesc), p]
+    L.vfn_bank_scan.argtypes = [C.POINTER(BankScanDesc), p]
+    L.vfn_memread_apply.argtypes = [C.POINTER(MemReadDesc), p]
+    L.vfn_memread_finish.argtypes = [C.POINTER(MemReadDesc), p]
+    L.vfn_bank_merge.argtypes = [C.POINTER(BankDesc), p]
+    L.vfn_bank_append.argtypes = [C.POINTER(BankDesc), p]
     for name, args in SIGNATURES.items():
         fn = getattr(L, name)
         fn.argtypes = args
@@ -52,7 +98,27 @@ def _declare(L):
 
 # name -> argtypes for the plain-argument launchers (kept next to the header order)
 _i, _f, _p = C.c_int, C.c_float, C.c_void_p
-SIGNATURES = {}
+_ll = C.c_longlong
+SIGNATURES = {
+    'vfn_maxpool3x3s2_nhwc_f32': [_p, _p, _i, _i, _i, _i, _p],
+    'vfn_upsample2x_add_nhwc_f32': [_p, _p, _p, _i, _i, _i, _i, _i, _p],
+    'vfn_rough_uncertainty_f32': [_p, _p, _p, _p, _i, _i, _i, _p],
+    'vfn_local_hpass_f32': [_p, _p, _p, _p, _p, _i, _i, _i, _i, _p],
+    'vfn_local_vpass_f32': [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p],
+    'vfn_final_logits_f32': [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p],
+    'vfn_bank_scan_finish': [_p, _i, _i, _i, _i, _p, _p, _p, _p, _p],
+    'vfn_row_norms': [_p, _ll, _i, _i, _p, _i, _i, _p, _p, _ll, _p],
+    'vfn_scatter_mean_f32': [_p, _ll, _ll, _p, _i, _p, _ll, _ll, _i, _p],
+    'vfn_resize_bicubic_f32': [_p, _p, _i, _i, _i, _i, _i, _p],
+    'vfn_resize_nearest_f32': [_p, _p, _i, _i, _i, _i, _i, _p],
+    'vfn_softmax_objects_f32': [_p, _p, _i, _i, _p],
+    'vfn_resize_argmax_u8': [_p, _p, _i, _i, _i, _i, _i, _p],
+    'vfn_postprocess_pred_u8': [_p, _i, _i, _p],
+}
+# every symbol include/vfn_hip.h declares (checked by tests/test_abi.py)
+ALL_SYMBOLS = sorted(list(SIGNATURES) + [
+    'vfn_abi_version', 'vfn_conv_cfg_count', 'vfn_conv_cfg_tile', 'vfn_conv2d_nhwc_f32', 'vfn_stem_conv7x7_f32',
+    'vfn_bank_scan', 'vfn_memread_apply', 'vfn_memread_finish', 'vfn_bank_merge', 'vfn_bank_append'])
 
 
 def check(status, what):

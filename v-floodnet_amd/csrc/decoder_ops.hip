@@ -1,0 +1,257 @@
+// HBM-bound decoder pointwise / window kernels (NHWC fp32).
+//
+//   vfn_upsample2x_add      Refine: m = s + interpolate(pm, x2, bilinear)          AFB_URR.py:124
+//   vfn_rough_uncertainty   interpolate(pred2) -> softmax[:,1] -> object softmax   AFB_URR.py:214-219
+//                           -> calc_uncertainty (top-2 ratio)                        myutils/data.py:40-46
+//   vfn_local_hpass/vpass   r1*rough, 7x7 avg-pools, divide, 7x7 max-pool, concat   AFB_URR.py:226-231
+//   vfn_final_logits        p + unc*(conf*q) -> interpolate x2 -> softmax[:,1]      AFB_URR.py:233-237
+//                           -> clamp -> logit -> un-pad crop                         AFB_URR.py:300,309-316
+//
+// Bilinear x2, align_corners=False (PyTorch): src=(dst+0.5)/2-0.5 clamped at 0,
+// i0=floor(src), i1=min(i0+1,in-1), l1=src-i0, l0=1-l1;
+// out = lh0*(lw0*a + lw1*b) + lh1*(lw0*c + lw1*d).
+#include "common.h"
+#include "../../include/vfn_hip.h"
+
+namespace {
+
+struct Lerp { int i0, i1; float l0, l1; };
+
+__device__ __forceinline__ Lerp lerp2x(int dst, int in_size) {
+    float src = 0.5f * (dst + 0.5f) - 0.5f;
+    if (src < 0.f) src = 0.f;
+    Lerp L;
+    L.i0 = (int)src;
+    L.i1 = L.i0 + (L.i0 < in_size - 1 ? 1 : 0);
+    L.l1 = src - L.i0;
+    L.l0 = 1.f - L.l1;
+    return L;
+}
+
+__global__ void upsample2x_add_kernel(const float* __restrict__ s, const float* __restrict__ pm,
+                                      float* __restrict__ out, int N, int h, int w, int C, int s_bcast) {
+    const int c4n = C / 4;
+    const int hi = h / 2, wi = w / 2;
+    const size_t total = (size_t)N * h * w * c4n;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int c4 = i % c4n;
+        size_t t = i / c4n;
+        const int x = t % w; t /= w;
+        const int y = t % h;
+        const int n = t / h;
+        const Lerp ly = lerp2x(y, hi), lx = lerp2x(x, wi);
+        const float* base = pm + (size_t)n * hi * wi * C + c4 * 4;
+        const f32x4 a = *reinterpret_cast<const f32x4*>(base + ((size_t)ly.i0 * wi + lx.i0) * C);
+        const f32x4 b = *reinterpret_cast<const f32x4*>(base + ((size_t)ly.i0 * wi + lx.i1) * C);
+        const f32x4 c = *reinterpret_cast<const f32x4*>(base + ((size_t)ly.i1 * wi + lx.i0) * C);
+        const f32x4 d = *reinterpret_cast<const f32x4*>(base + ((size_t)ly.i1 * wi + lx.i1) * C);
+        const size_t so = ((size_t)(s_bcast ? 0 : n) * h * w + (size_t)y * w + x) * C + c4 * 4;
+        const f32x4 sv = *reinterpret_cast<const f32x4*>(s + so);
+        f32x4 o;
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            o[k] = sv[k] + (ly.l0 * (lx.l0 * a[k] + lx.l1 * b[k]) + ly.l1 * (lx.l0 * c[k] + lx.l1 * d[k]));
+        *reinterpret_cast<f32x4*>(out + i * 4) = o;
+    }
+}
+
+constexpr int MAX_OBJ = 8;
+
+// p: [obj][h][w][2] (1/4 res) -> p_up [obj][2h][2w][2], rough [obj][2h][2w], unc [2h][2w]
+__global__ void rough_unc_kernel(const float* __restrict__ p, float* __restrict__ p_up, float* __restrict__ rough,
+                                 float* __restrict__ unc, int obj_n, int h, int w) {
+    const int H = 2 * h, W = 2 * w;
+    const int total = H * W;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+        const int y = i / W, x = i - y * W;
+        const Lerp ly = lerp2x(y, h), lx = lerp2x(x, w);
+        float r[MAX_OBJ];
+        float rmax = -INFINITY;
+        for (int n = 0; n < obj_n; ++n) {
+            const float* base = p + (size_t)n * h * w * 2;
+            const float2 a = *reinterpret_cast<const float2*>(base + ((size_t)ly.i0 * w + lx.i0) * 2);
+            const float2 b = *reinterpret_cast<const float2*>(base + ((size_t)ly.i0 * w + lx.i1) * 2);
+            const float2 c = *reinterpret_cast<const float2*>(base + ((size_t)ly.i1 * w + lx.i0) * 2);
+            const float2 d = *reinterpret_cast<const float2*>(base + ((size_t)ly.i1 * w + lx.i1) * 2);
+            const float v0 = ly.l0 * (lx.l0 * a.x + lx.l1 * b.x) + ly.l1 * (lx.l0 * c.x + lx.l1 * d.x);
+            const float v1 = ly.l0 * (lx.l0 * a.y + lx.l1 * b.y) + ly.l1 * (lx.l0 * c.y + lx.l1 * d.y);
+            *reinterpret_cast<float2*>(p_up + ((size_t)n * total + i) * 2) = make_float2(v0, v1);
+            const float m = fmaxf(v0, v1);
+            const float e0 = expf(v0 - m), e1 = expf(v1 - m);
+            r[n] = e1 / (e0 + e1);                       // softmax(p, dim=1)[:, 1]
+            rmax = fmaxf(rmax, r[n]);
+        }
+        float sum = 0.f;
+        for (int n = 0; n < obj_n; ++n) { r[n] = expf(r[n] - rmax); sum += r[n]; }
+        float top1 = -INFINITY, top2 = -INFINITY;
+        for (int n = 0; n < obj_n; ++n) {
+            const float v = r[n] / sum;                  // object-level softmax
+            rough[(size_t)n * total + i] = v;
+            if (v > top1) { top2 = top1; top1 = v; } else if (v > top2) top2 = v;
+        }
+        unc[i] = expf(1.f - top1 / (top2 + 1e-8f));     // calc_uncertainty
+    }
+}
+
+// horizontal 7-tap pass: hs[obj][y][x][C] = sum_dx r1[y][x+dx][c]*rough[obj][y][x+dx]
+//                        hr[obj][y][x]   = sum_dx rough ; hm = max_dx rough (in-bounds only)
+__global__ void local_hpass_kernel(const float* __restrict__ r1, const float* __restrict__ rough,
+                                   float* __restrict__ hs, float* __restrict__ hr, float* __restrict__ hm,
+                                   int obj_n, int h, int w, int C) {
+    const int c4n = C / 4;
+    const size_t total = (size_t)h * w * c4n;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int c4 = i % c4n;
+        const size_t pix = i / c4n;
+        const int x = pix % w;
+        const int y = pix / w;
+        f32x4 v[7];
+        bool ok[7];
+#pragma unroll
+        for (int d = 0; d < 7; ++d) {
+            const int xx = x + d - 3;
+            ok[d] = (unsigned)xx < (unsigned)w;
+            v[d] = ok[d] ? *reinterpret_cast<const f32x4*>(r1 + ((size_t)y * w + xx) * C + c4 * 4)
+                         : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        for (int n = 0; n < obj_n; ++n) {
+            const float* rg = rough + (size_t)n * h * w + (size_t)y * w;
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+            float sr = 0.f, mr = -INFINITY;
+#pragma unroll
+            for (int d = 0; d < 7; ++d) {
+                if (ok[d]) {
+                    const float g = rg[x + d - 3];
+                    acc += v[d] * g;
+                    sr += g;
+                    mr = fmaxf(mr, g);
+                }
+            }
+            *reinterpret_cast<f32x4*>(hs + ((size_t)n * h * w + pix) * C + c4 * 4) = acc;
+            if (c4 == 0) { hr[(size_t)n * h * w + pix] = sr; hm[(size_t)n * h * w + pix] = mr; }
+        }
+    }
+}
+
+// vertical pass + divide; writes local_match [obj][h][w][2C] = cat(r1, r1_local) and conf [obj][h][w]
+__global__ void local_vpass_kernel(const float* __restrict__ r1, const float* __restrict__ hs,
+                                   const float* __restrict__ hr, const float* __restrict__ hm,
+                                   float* __restrict__ lm, float* __restrict__ conf,
+                                   int obj_n, int h, int w, int C) {
+    const int c4n = C / 4;
+    const size_t total = (size_t)obj_n * h * w * c4n;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int c4 = i % c4n;
+        size_t t = i / c4n;
+        const int x = t % w; t /= w;
+        const int y = t % h;
+        const int n = t / h;
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        float sr = 0.f, mr = -INFINITY;
+#pragma unroll
+        for (int d = 0; d < 7; ++d) {
+            const int yy = y + d - 3;
+            if ((unsigned)yy < (unsigned)h) {
+                const size_t pp = (size_t)n * h * w + (size_t)yy * w + x;
+                acc += *reinterpret_cast<const f32x4*>(hs + pp * C + c4 * 4);
+                sr += hr[pp];
+                mr = fmaxf(mr, hm[pp]);
+            }
+        }
+        const float den = sr / 49.f + 1e-8f;                 // AvgPool2d(7,1,3), count_include_pad
+        f32x4 loc;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) loc[k] = (acc[k] / 49.f) / den;
+        const size_t pix = (size_t)y * w + x;
+        float* dst = lm + ((size_t)n * h * w + pix) * (2 * C);
+        *reinterpret_cast<f32x4*>(dst + c4 * 4) = *reinterpret_cast<const f32x4*>(r1 + pix * C + c4 * 4);
+        *reinterpret_cast<f32x4*>(dst + C + c4 * 4) = loc;
+        if (c4 == 0) conf[(size_t)n * h * w + pix] = mr;
+    }
+}
+
+// score[obj][H0][W0] = logit(clamp(softmax(up2(p_up + unc*(conf*q)))[1]))
+__global__ void final_logits_kernel(const float* __restrict__ p_up, const float* __restrict__ unc,
+                                    const float* __restrict__ conf, const float* __restrict__ q,
+                                    float* __restrict__ score, int obj_n, int h, int w,
+                                    int pad_top, int pad_left, int H0, int W0) {
+    const size_t total = (size_t)obj_n * H0 * W0;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int x0 = i % W0;
+        size_t t = i / W0;
+        const int y0 = t % H0;
+        const int n = t / H0;
+        const int y = y0 + pad_top, x = x0 + pad_left;       // coordinates in the padded frame (2h x 2w)
+        const Lerp ly = lerp2x(y, h), lx = lerp2x(x, w);
+        float v[2][4];
+        const int ys[2] = {ly.i0, ly.i1}, xs[2] = {lx.i0, lx.i1};
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b) {
+                const size_t pix = (size_t)ys[a] * w + xs[b];
+                const size_t pn = (size_t)n * h * w + pix;
+                const float2 pv = *reinterpret_cast<const float2*>(p_up + pn * 2);
+                const float2 qv = *reinterpret_cast<const float2*>(q + pn * 2);
+                const float u = unc[pix], cf = conf[pn];
+                v[0][a * 2 + b] = pv.x + u * (cf * qv.x);
+                v[1][a * 2 + b] = pv.y + u * (cf * qv.y);
+            }
+        const float o0 = ly.l0 * (lx.l0 * v[0][0] + lx.l1 * v[0][1]) + ly.l1 * (lx.l0 * v[0][2] + lx.l1 * v[0][3]);
+        const float o1 = ly.l0 * (lx.l0 * v[1][0] + lx.l1 * v[1][1]) + ly.l1 * (lx.l0 * v[1][2] + lx.l1 * v[1][3]);
+        const float m = fmaxf(o0, o1);
+        const float e0 = expf(o0 - m), e1 = expf(o1 - m);
+        float s = e1 / (e0 + e1);
+        s = fminf(fmaxf(s, 1e-7f), 1.f - 1e-7f);
+        score[i] = logf(s / (1.f - s));
+    }
+}
+
+inline int grid_for(size_t total, int block = 256, int cap = 8192) {
+    size_t b = (total + block - 1) / block;
+    return (int)(b < (size_t)cap ? (b ? b : 1) : cap);
+}
+
+}  // namespace
+
+extern "C" int vfn_upsample2x_add_nhwc_f32(const float* s, const float* pm, float* out, int N, int h, int w, int C,
+                                           int s_bcast, void* stream) {
+    if (!s || !pm || !out || C % 4 || h % 2 || w % 2) return VFN_ERR_ARG;
+    const size_t total = (size_t)N * h * w * (C / 4);
+    hipLaunchKernelGGL(upsample2x_add_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream,
+                       s, pm, out, N, h, w, C, s_bcast);
+    return vfn_check_launch();
+}
+
+extern "C" int vfn_rough_uncertainty_f32(const float* p, float* p_up, float* rough, float* unc, int obj_n, int h, int w,
+                                         void* stream) {
+    if (!p || !p_up || !rough || !unc || obj_n < 2 || obj_n > MAX_OBJ) return VFN_ERR_ARG;
+    hipLaunchKernelGGL(rough_unc_kernel, dim3(grid_for((size_t)4 * h * w)), dim3(256), 0, (hipStream_t)stream,
+                       p, p_up, rough, unc, obj_n, h, w);
+    return vfn_check_launch();
+}
+
+extern "C" int vfn_local_hpass_f32(const float* r1, const float* rough, float* hs, float* hr, float* hm, int obj_n,
+                                   int h, int w, int C, void* stream) {
+    if (!r1 || !rough || !hs || !hr || !hm || C % 4) return VFN_ERR_ARG;
+    hipLaunchKernelGGL(local_hpass_kernel, dim3(grid_for((size_t)h * w * (C / 4))), dim3(256), 0, (hipStream_t)stream,
+                       r1, rough, hs, hr, hm, obj_n, h, w, C);
+    return vfn_check_launch();
+}
+
+extern "C" int vfn_local_vpass_f32(const float* r1, const float* hs, const float* hr, const float* hm, float* lm,
+                                   float* conf, int obj_n, int h, int w, int C, void* stream) {
+    if (!r1 || !hs || !hr || !hm || !lm || !conf || C % 4) return VFN_ERR_ARG;
+    hipLaunchKernelGGL(local_vpass_kernel, dim3(grid_for((size_t)obj_n * h * w * (C / 4))), dim3(256), 0,
+                       (hipStream_t)stream, r1, hs, hr, hm, lm, conf, obj_n, h, w, C);
+    return vfn_check_launch();
+}
+
+extern "C" int vfn_final_logits_f32(const float* p_up, const float* unc, const float* conf, const float* q, float* score,
+                                    int obj_n, int h, int w, int pad_top, int pad_left, int H0, int W0, void* stream) {
+    if (!p_up || !unc || !conf || !q || !score) return VFN_ERR_ARG;
+    if (pad_top + H0 > 2 * h || pad_left + W0 > 2 * w) return VFN_ERR_ARG;
+    hipLaunchKernelGGL(final_logits_kernel, dim3(grid_for((size_t)obj_n * H0 * W0)), dim3(256), 0, (hipStream_t)stream,
+                       p_up, unc, conf, q, score, obj_n, h, w, pad_top, pad_left, H0, W0);
+    return vfn_check_launch();
+}

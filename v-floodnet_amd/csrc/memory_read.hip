@@ -1,0 +1,413 @@
+// Feature-bank contractions on the f32 matrix cores.
+//
+// (1) Memory read -- Matcher.forward, AFB_URR.py:136-178, per object:
+//        p   = softmax_over_bank( keys^T q / sqrt(128) )          [B, HW]
+//        mem = values p                                            [512, HW]
+//        info[:,1] += log( sum_hw [p > 1e-3] + 1 )                 (update_bank side effect, :161-174)
+//     The reference materialises p (648 MB at B = 100k) and makes >= 7 elementwise passes over it,
+//     with an out-of-memory -> CPU fallback (:147-157).  Here p is never stored:
+//        pass 1  vfn_memread_stats   per query column: running max m and sum l over the bank
+//        pass 2  vfn_memread_apply   recompute the scores, p = exp(s-m)/l in registers,
+//                                    hit counts by wave ballots, O^T += P^T V on the MFMA
+//        finish  vfn_memread_finish  reduce the bank-split partial O, write it (and the query
+//                                    value) into the decoder input, apply the log(count+1) bump
+//
+// (2) Bank match -- FeatureBank.update, FeatureBank.py:63-68:
+//        corr = normalize(keys)^T normalize(new_keys); argmax over the bank per new feature
+//     Same GEMM with an arg-max epilogue (corr is never stored): vfn_bank_match + vfn_bank_match_finish.
+//
+// Layout: bank entry-major K [cap][128], V [cap][512]; queries / new keys [HW][ld].
+// Tiling: one workgroup = 64 query columns x one slice of the bank, walked in chunks of
+// 128 entries; 4 waves, wave w owns chunk rows 32w..32w+31 for the score GEMM
+// (A = bank rows, B = queries) and value channels 128w..128w+127 for P^T V
+// (A = P^T read back from LDS, B = value rows straight from global memory).
+// Blocks of one bank slice share blockIdx % 8, i.e. one XCD's L2 (speed only).
+#include "common.h"
+#include "../../include/vfn_hip.h"
+
+namespace {
+
+constexpr int DK = 128, DV = 512;
+constexpr int QT = 64;      // query columns per workgroup
+constexpr int CH = 128;     // bank entries per chunk
+
+// [rows][128 floats] LDS image, 16-byte chunk index XOR (row & 15): conflict-free b128 fragment reads
+__device__ __forceinline__ int swz(int row, int chunk) { return row * DK + ((chunk ^ (row & 15)) << 2); }
+
+// stage `rows` x 128 floats (row r from src + r*ld, zero past `valid` rows) into an LDS image
+__device__ __forceinline__ void stage_rows(float* dst, const float* src, size_t ld, int rows, int valid, int tid) {
+    const int c = tid & 31;
+    for (int r = tid >> 5; r < rows; r += 8) {
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (r < valid) v = *reinterpret_cast<const f32x4*>(src + (size_t)r * ld + c * 4);
+        *reinterpret_cast<f32x4*>(dst + swz(r, c)) = v;
+    }
+}
+
+// scores for this wave's 32 chunk rows x 64 query columns: acc[tn][r], row = (r&3)+8*(r>>2)+4*lh
+__device__ __forceinline__ void score_tile(const float* sK, const float* sQ, int wave, int li, int lh, f32x16 (&acc)[2]) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { acc[0][r] = 0.f; acc[1][r] = 0.f; }
+    const int ra = wave * 32 + li;
+#pragma unroll
+    for (int kk = 0; kk < 16; ++kk) {
+        const int lc = 2 * kk + lh;
+        const f32x4 a = *reinterpret_cast<const f32x4*>(sK + swz(ra, lc));
+        const f32x4 b0 = *reinterpret_cast<const f32x4*>(sQ + swz(li, lc));
+        const f32x4 b1 = *reinterpret_cast<const f32x4*>(sQ + swz(32 + li, lc));
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t], b0[t], acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t], b1[t], acc[1], 0, 0, 0);
+        }
+    }
+}
+
+__device__ __forceinline__ void chunk_range(int B, int nsplit, int split, int& c_lo, int& c_hi) {
+    const int nchunks = (B + CH - 1) / CH;
+    const int per = (nchunks + nsplit - 1) / nsplit;
+    c_lo = split * per;
+    c_hi = min(nchunks, c_lo + per);
+}
+
+// ------------------------------------------------------------------ pass 1: softmax statistics
+// MODE 0: (max, sum exp) of scale*s per query.  MODE 1: arg-max of s*rowscale[b] per query.
+template <int MODE>
+__global__ __launch_bounds__(256)
+void bank_scan_kernel(const vfn_bankscan_desc p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* sQ = reinterpret_cast<float*>(smem);      // [64][128]
+    float* sK = sQ + QT * DK;                        // [128][128]
+    float* sRed = sK + CH * DK;                      // [4][64][2]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 31, lh = lane >> 5;
+    const int split = blockIdx.x % p.nsplit;
+    const int qt = blockIdx.x / p.nsplit;
+    const int obj = blockIdx.y;
+    const int q0 = qt * QT;
+    const int B = p.bank_len[obj];
+    const float* K = p.bank_k + (size_t)obj * p.stride_k;
+    const float* Q = p.q + (size_t)(p.q_per_obj ? obj : 0) * p.stride_q;
+
+    stage_rows(sQ, Q + (size_t)q0 * p.ldq, p.ldq, QT, min(QT, p.HW - q0), tid);
+
+    int c_lo, c_hi;
+    chunk_range(B, p.nsplit, split, c_lo, c_hi);
+
+    float run_m[2] = {-INFINITY, -INFINITY};
+    float run_l[2] = {0.f, 0.f};
+    int run_i[2] = {0x7fffffff, 0x7fffffff};
+
+    for (int c = c_lo; c < c_hi; ++c) {
+        const int b0 = c * CH;
+        __syncthreads();                               // previous chunk fully consumed (also covers sQ)
+        stage_rows(sK, K + (size_t)b0 * DK, DK, CH, min(CH, B - b0), tid);
+        __syncthreads();
+        f32x16 acc[2];
+        score_tile(sK, sQ, wave, li, lh, acc);
+        const int rb = b0 + wave * 32 + 4 * lh;
+#pragma unroll
+        for (int tn = 0; tn < 2; ++tn) {
+            if (MODE == 0) {
+                float mx = -INFINITY;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = rb + (r & 3) + 8 * (r >> 2);
+                    const float s = acc[tn][r] * p.scale;
+                    acc[tn][r] = s;
+                    if (row < B) mx = fmaxf(mx, s);
+                }
+                const float mn = fmaxf(run_m[tn], mx);
+                if (mn > -INFINITY) {
+                    float sum = 0.f;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int row = rb + (r & 3) + 8 * (r >> 2);
+                        if (row < B) sum += expf(acc[tn][r] - mn);
+                    }
+                    run_l[tn] = run_l[tn] * expf(run_m[tn] - mn) + sum;   // exp(-inf)=0 on the first chunk
+                    run_m[tn] = mn;
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = rb + (r & 3) + 8 * (r >> 2);
+                    if (row < B) {
+                        const float s = acc[tn][r] * p.rowscale[(size_t)obj * p.stride_rs + row];
+                        if (s > run_m[tn]) { run_m[tn] = s; run_i[tn] = row; }   // ascending rows: first max wins
+                    }
+                }
+            }
+        }
+    }
+
+    // combine the two lane halves, then the four waves
+#pragma unroll
+    for (int tn = 0; tn < 2; ++tn) {
+        const float om = __shfl_xor(run_m[tn], 32, 64);
+        if (MODE == 0) {
+            const float ol = __shfl_xor(run_l[tn], 32, 64);
+            const float mn = fmaxf(run_m[tn], om);
+            float l = 0.f;
+            if (mn > -INFINITY) l = run_l[tn] * expf(run_m[tn] - mn) + ol * expf(om - mn);
+            run_m[tn] = mn; run_l[tn] = l;
+        } else {
+            const int oi = __shfl_xor(run_i[tn], 32, 64);
+            if (om > run_m[tn] || (om == run_m[tn] && oi < run_i[tn])) { run_m[tn] = om; run_i[tn] = oi; }
+        }
+        if (lh == 0) {
+            sRed[(wave * QT + tn * 32 + li) * 2 + 0] = run_m[tn];
+            sRed[(wave * QT + tn * 32 + li) * 2 + 1] = (MODE == 0) ? run_l[tn] : __int_as_float(run_i[tn]);
+        }
+    }
+    __syncthreads();
+    if (tid < QT) {
+        float m = sRed[tid * 2], x = sRed[tid * 2 + 1];
+        for (int w = 1; w < 4; ++w) {
+            const float om = sRed[(w * QT + tid) * 2], ox = sRed[(w * QT + tid) * 2 + 1];
+            if (MODE == 0) {
+                const float mn = fmaxf(m, om);
+                if (mn > -INFINITY) x = x * expf(m - mn) + ox * expf(om - mn);
+                m = mn;
+            } else {
+                const int i0 = __float_as_int(x), i1 = __float_as_int(ox);
+                if (om > m || (om == m && i1 < i0)) { m = om; x = ox; }
+            }
+        }
+        const int q = q0 + tid;
+        if (q < p.HW) {
+            float* dst = p.part + (((size_t)obj * p.nsplit + split) * p.HW + q) * 2;
+            dst[0] = m; dst[1] = x;
+        }
+    }
+}
+
+// combine bank-split partials.  MODE 0 -> ml[obj][q] = (m, l); MODE 1 -> idx[obj][q], corr[obj][q]
+template <int MODE>
+__global__ void bank_scan_finish_kernel(const float* __restrict__ part, int nsplit, int HW, int obj_n,
+                                        float* __restrict__ ml, int* __restrict__ idx, float* __restrict__ corr,
+                                        const float* __restrict__ colscale) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= obj_n * HW) return;
+    const int obj = i / HW, q = i - obj * HW;
+    float m = -INFINITY, x = (MODE == 0) ? 0.f : __int_as_float(0x7fffffff);
+    for (int s = 0; s < nsplit; ++s) {
+        const float* src = part + (((size_t)obj * nsplit + s) * HW + q) * 2;
+        const float om = src[0], ox = src[1];
+        if (MODE == 0) {
+            const float mn = fmaxf(m, om);
+            if (mn > -INFINITY) x = x * expf(m - mn) + ox * expf(om - mn);
+            m = mn;
+        } else {
+            const int i0 = __float_as_int(x), i1 = __float_as_int(ox);
+            if (om > m || (om == m && i1 < i0)) { m = om; x = ox; }
+        }
+    }
+    if (MODE == 0) { ml[(size_t)i * 2] = m; ml[(size_t)i * 2 + 1] = x; }
+    else { idx[i] = __float_as_int(x); corr[i] = m * colscale[i]; }
+}
+
+// ------------------------------------------------------------------ pass 2: P^T V and hit counts
+__global__ __launch_bounds__(256)
+void memread_apply_kernel(const vfn_memread_desc p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* sQ = reinterpret_cast<float*>(smem);      // [64][128]
+    float* sK = sQ + QT * DK;                        // [128][128]
+    float* sP = sK + CH * DK;                        // [64 q][128 b]  (P^T)
+    float* sML = sP + QT * CH;                       // [64][2]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 31, lh = lane >> 5;
+    const int split = blockIdx.x % p.nsplit;
+    const int qt = blockIdx.x / p.nsplit;
+    const int obj = blockIdx.y;
+    const int q0 = qt * QT;
+    const int B = p.bank_len[obj];
+    const float* K = p.bank_k + (size_t)obj * p.stride_k;
+    const float* V = p.bank_v + (size_t)obj * p.stride_v;
+
+    stage_rows(sQ, p.q + (size_t)q0 * p.ldq, p.ldq, QT, min(QT, p.HW - q0), tid);
+    if (tid < QT) {
+        const int q = q0 + tid;
+        float m = 0.f, l = 1.f;
+        if (q < p.HW) { m = p.ml[((size_t)obj * p.HW + q) * 2]; l = p.ml[((size_t)obj * p.HW + q) * 2 + 1]; }
+        sML[tid * 2] = m; sML[tid * 2 + 1] = l;
+    }
+
+    int c_lo, c_hi;
+    chunk_range(B, p.nsplit, split, c_lo, c_hi);
+
+    f32x16 o[2][4];                                  // O^T tiles: [tq][tc], rows = q, cols = value channel
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[a][b][r] = 0.f;
+
+    const float* vcol = V + wave * 128 + li;         // + row*512 + tc*32
+
+    for (int c = c_lo; c < c_hi; ++c) {
+        const int b0 = c * CH;
+        __syncthreads();                             // sK / sP of the previous chunk fully consumed
+        stage_rows(sK, K + (size_t)b0 * DK, DK, CH, min(CH, B - b0), tid);
+        __syncthreads();
+
+        f32x16 acc[2];
+        score_tile(sK, sQ, wave, li, lh, acc);
+
+        // p = exp(s - m) / l; hit counts; P^T -> LDS
+        const int rloc = wave * 32 + 4 * lh;         // chunk-local row of register 0
+        int mycnt = 0;
+#pragma unroll
+        for (int tn = 0; tn < 2; ++tn) {
+            const float m = sML[(tn * 32 + li) * 2], l = sML[(tn * 32 + li) * 2 + 1];
+            const bool qok = (q0 + tn * 32 + li) < p.HW;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int rr = rloc + (r & 3) + 8 * (r >> 2);
+                float pv = 0.f;
+                if (qok && b0 + rr < B) pv = expf(acc[tn][r] * p.scale - m) / l;
+                acc[tn][r] = pv;
+                const unsigned long long hit = __ballot(pv > p.thres);
+                // row of lanes 0-31 is (r&3)+8*(r>>2), of lanes 32-63 that + 4; lane li (lower half) owns row li
+                const int rlo = (r & 3) + 8 * (r >> 2);
+                if (lh == 0) {
+                    if (li == rlo) mycnt += __popcll(hit & 0xffffffffull);
+                    if (li == rlo + 4) mycnt += __popcll(hit >> 32);
+                }
+            }
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {            // registers 4g..4g+3 = 4 consecutive bank rows
+                const int brow = rloc + 8 * g;       // chunk-local row, multiple of 4
+                const f32x4 v = {acc[tn][4 * g], acc[tn][4 * g + 1], acc[tn][4 * g + 2], acc[tn][4 * g + 3]};
+                *reinterpret_cast<f32x4*>(sP + swz(tn * 32 + li, brow >> 2)) = v;
+            }
+        }
+        if (p.cnt && lh == 0 && mycnt > 0) {
+            const int row = b0 + wave * 32 + li;
+            if (row < B) atomicAdd(p.cnt + (size_t)obj * p.stride_cnt + row, mycnt);
+        }
+        __syncthreads();
+
+        // O^T[q][c] += sum_b P^T[q][b] V[b][c];  this wave: channels 128*wave .. +127
+#pragma unroll 2
+        for (int kk = 0; kk < 16; ++kk) {
+            const int lc = 2 * kk + lh;
+            const f32x4 a0 = *reinterpret_cast<const f32x4*>(sP + swz(li, lc));
+            const f32x4 a1 = *reinterpret_cast<const f32x4*>(sP + swz(32 + li, lc));
+            float vb[4][4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const int row = b0 + 8 * kk + 4 * lh + t;
+                const bool ok = row < B;
+#pragma unroll
+                for (int tc = 0; tc < 4; ++tc) vb[t][tc] = ok ? vcol[(size_t)row * DV + tc * 32] : 0.f;
+            }
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int tc = 0; tc < 4; ++tc) {
+                    o[0][tc] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[t], vb[t][tc], o[0][tc], 0, 0, 0);
+                    o[1][tc] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[t], vb[t][tc], o[1][tc], 0, 0, 0);
+                }
+        }
+    }
+
+    // partial O^T -> o_part[obj][split][q][512]
+    float* dst = p.o_part + ((size_t)obj * p.nsplit + split) * p.HW * DV;
+#pragma unroll
+    for (int tq = 0; tq < 2; ++tq)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int q = q0 + tq * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+            if (q < p.HW) {
+#pragma unroll
+                for (int tc = 0; tc < 4; ++tc)
+                    dst[(size_t)q * DV + wave * 128 + tc * 32 + li] = o[tq][tc][r];
+            }
+        }
+}
+
+// out[obj][q][0:512] = sum_split o_part ; out[obj][q][512:1024] = query value; then the hit-count bump
+__global__ void memread_finish_kernel(const vfn_memread_desc p) {
+    const int obj = blockIdx.y;
+    const size_t total = (size_t)p.HW * (DV / 4);
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int c4 = i % (DV / 4);
+        const int q = i / (DV / 4);
+        f32x4 s = {0.f, 0.f, 0.f, 0.f};
+        for (int sp = 0; sp < p.nsplit; ++sp)
+            s += *reinterpret_cast<const f32x4*>(p.o_part + (((size_t)obj * p.nsplit + sp) * p.HW + q) * DV + c4 * 4);
+        float* o = p.out + ((size_t)obj * p.HW + q) * p.ld_out;
+        *reinterpret_cast<f32x4*>(o + c4 * 4) = s;
+        *reinterpret_cast<f32x4*>(o + DV + c4 * 4) = *reinterpret_cast<const f32x4*>(p.qv + (size_t)q * p.ldqv + c4 * 4);
+    }
+    if (p.cnt) {
+        const int B = p.bank_len[obj];
+        int* cnt = p.cnt + (size_t)obj * p.stride_cnt;
+        float* info = p.info + (size_t)obj * p.stride_info;
+        for (int b = blockIdx.x * blockDim.x + threadIdx.x; b < B; b += gridDim.x * blockDim.x) {
+            info[(size_t)b * 2 + 1] += logf((float)cnt[b] + 1.f);
+            cnt[b] = 0;
+        }
+    }
+}
+
+constexpr size_t SCAN_LDS = (size_t)(QT * DK + CH * DK + 4 * QT * 2) * sizeof(float);
+constexpr size_t APPLY_LDS = (size_t)(QT * DK + CH * DK + QT * CH + QT * 2) * sizeof(float);
+
+template <typename K>
+void allow_lds(K kern, size_t bytes) {
+    hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+}
+
+}  // namespace
+
+extern "C" int vfn_bank_scan(const vfn_bankscan_desc* d, void* stream) {
+    if (!d || !d->q || !d->bank_k || !d->bank_len || !d->part) return VFN_ERR_ARG;
+    if (d->nsplit < 1 || d->HW < 1 || d->obj_n < 1 || d->ldq % 4) return VFN_ERR_ARG;
+    if (d->mode == 1 && !d->rowscale) return VFN_ERR_ARG;
+    static bool once = false;
+    if (!once) { allow_lds(bank_scan_kernel<0>, SCAN_LDS); allow_lds(bank_scan_kernel<1>, SCAN_LDS); once = true; }
+    const dim3 grid(cdiv(d->HW, QT) * d->nsplit, d->obj_n);
+    if (d->mode == 0) hipLaunchKernelGGL(bank_scan_kernel<0>, grid, dim3(256), SCAN_LDS, (hipStream_t)stream, *d);
+    else hipLaunchKernelGGL(bank_scan_kernel<1>, grid, dim3(256), SCAN_LDS, (hipStream_t)stream, *d);
+    return vfn_check_launch();
+}
+
+extern "C" int vfn_bank_scan_finish(const float* part, int nsplit, int HW, int obj_n, int mode, float* ml, int* idx,
+                                    float* corr, const float* colscale, void* stream) {
+    if (!part) return VFN_ERR_ARG;
+    const int total = obj_n * HW;
+    if (mode == 0) {
+        if (!ml) return VFN_ERR_ARG;
+        hipLaunchKernelGGL(bank_scan_finish_kernel<0>, dim3(cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream,
+                           part, nsplit, HW, obj_n, ml, idx, corr, colscale);
+    } else {
+        if (!idx || !corr || !colscale) return VFN_ERR_ARG;
+        hipLaunchKernelGGL(bank_scan_finish_kernel<1>, dim3(cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream,
+                           part, nsplit, HW, obj_n, ml, idx, corr, colscale);
+    }
+    return vfn_check_launch();
+}
+
+extern "C" int vfn_memread_apply(const vfn_memread_desc* d, void* stream) {
+    if (!d || !d->q || !d->bank_k || !d->bank_v || !d->bank_len || !d->ml || !d->o_part) return VFN_ERR_ARG;
+    if (d->nsplit < 1 || d->ldq % 4) return VFN_ERR_ARG;
+    static bool once = false;
+    if (!once) { allow_lds(memread_apply_kernel, APPLY_LDS); once = true; }
+    const dim3 grid(cdiv(d->HW, QT) * d->nsplit, d->obj_n);
+    hipLaunchKernelGGL(memread_apply_kernel, grid, dim3(256), APPLY_LDS, (hipStream_t)stream, *d);
+    return vfn_check_launch();
+}
+
+extern "C" int vfn_memread_finish(const vfn_memread_desc* d, void* stream) {
+    if (!d || !d->o_part || !d->out || !d->qv || !d->bank_len) return VFN_ERR_ARG;
+    if (d->cnt && !d->info) return VFN_ERR_ARG;
+    if (d->ld_out % 4 || d->ldqv % 4) return VFN_ERR_ARG;
+    const dim3 grid(256, d->obj_n);
+    hipLaunchKernelGGL(memread_finish_kernel, grid, dim3(256), 0, (hipStream_t)stream, *d);
+    return vfn_check_launch();
+}

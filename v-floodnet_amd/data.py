@@ -1,0 +1,74 @@
+"""Helpers of the reference's ``myutils/data.py`` that the inference loop touches.
+
+``postprocessing_pred`` / ``save_seg_mask`` / ``save_overlay`` / ``color_palette`` /
+``load_image_in_PIL`` / ``pad_divide_by`` / ``calc_uncertainty`` keep the reference's names and
+argument meaning (myutils/data.py:14-90,132-149); OpenCV is not a dependency: the connected
+components come from ``vfn_postprocess_pred_u8`` and the overlay PNG is written with PIL.
+"""
+import numpy as np
+import torch
+from PIL import Image
+
+from . import ops
+from .engine import pad_divide_by as _pad_amounts
+
+color_palette = [0, 0, 0, 0, 0, 128, 0, 128, 0, 128, 0, 0] + [100, 100, 100] * 252     # data.py:14
+
+
+def postprocessing_pred(pred):
+    """data.py:17-37: keep the largest 8-connected water component (all-background -> all ones)."""
+    return ops.postprocess_pred(np.asarray(pred, dtype=np.uint8))
+
+
+def save_seg_mask(pred, seg_path, palette=color_palette):
+    """data.py:49-53: mode-P PNG with the reference palette."""
+    seg_img = Image.fromarray(np.asarray(pred, dtype=np.uint8))
+    seg_img.putpalette(palette)
+    seg_img.save(seg_path)
+
+
+def _binary_dilation_cross(m):
+    """scipy.ndimage.binary_dilation default structure (4-connected cross), border value 0."""
+    out = m.copy()
+    out[1:, :] |= m[:-1, :]
+    out[:-1, :] |= m[1:, :]
+    out[:, 1:] |= m[:, :-1]
+    out[:, :-1] |= m[:, 1:]
+    return out
+
+
+def add_overlay(img, mask, colors=color_palette, alpha=0.4, cscale=1):
+    """data.py:56-75 (img is BGR uint8 [H,W,3])."""
+    ids = np.unique(mask)
+    img_overlay = img.copy()
+    ones_np = np.ones(img.shape) * (1 - alpha)
+    colors = np.reshape(colors, (-1, 3))
+    colors = np.atleast_2d(colors) * cscale
+    for i in ids[1:]:
+        canvas = img * alpha + ones_np * np.array(colors[i])[::-1]
+        binary_mask = mask == i
+        img_overlay[binary_mask] = canvas[binary_mask]
+        contour = _binary_dilation_cross(binary_mask) ^ binary_mask
+        img_overlay[contour, :] = 0
+    return img_overlay
+
+
+def save_overlay(img, mask, overlay_path, colors=[255, 0, 0], alpha=0.4, cscale=1):
+    """data.py:78-84: img float [3,H,W] in [0,1] (any device) -> BGR overlay PNG."""
+    img = (img.permute(1, 2, 0).cpu().numpy() * 255).astype(np.uint8)
+    bgr = np.ascontiguousarray(img[..., ::-1])
+    ov = add_overlay(bgr, mask, colors, alpha, cscale)
+    Image.fromarray(np.ascontiguousarray(ov[..., ::-1])).save(overlay_path)      # cv2.imwrite(BGR) == save(RGB)
+
+
+def load_image_in_PIL(path, mode='RGB'):
+    """data.py:87-90."""
+    img = Image.open(path)
+    img.load()
+    return img.convert(mode)
+
+
+def pad_divide_by(in_list, d, in_size):
+    """data.py:132-149 for callers that want the padded tensors (the engine fuses the padding instead)."""
+    pad, _, _ = _pad_amounts(in_size[0], in_size[1], d)
+    return [torch.nn.functional.pad(x, pad) for x in in_list], pad

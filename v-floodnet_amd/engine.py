@@ -1,0 +1,417 @@
+"""The HIP execution engine behind ``AFB_URR.memorize`` / ``AFB_URR.segment``.
+
+For one frame size the whole forward is a *static* list of kernel launches over
+pre-allocated NHWC buffers (``FramePlan``): descriptors are built once, a frame is
+``for launch in plan: launch()``.  Weights are repacked once per ``load_state_dict``
+(``[Cout][kh][kw][Cin]`` filters, BatchNorm as per-channel scale/shift, the three
+memory-encoder stems as one 5-plane filter bank).
+
+Work the reference does twice is done once (mathematically identical):
+``RF3/RF2.convFS + ResFS`` see the same ``r3`` / ``r2`` for every object
+(``AFB_URR.py:289-295`` only ``expand``s them), so they run at N=1 and are broadcast
+into the per-object ``ResMM`` path by the fused upsample-add kernel.
+
+Call graph per frame (reference lines in brackets):
+  segment   pad+norm+stem [AFB_URR.py:279-285] -> res2..res4 -> KeyValue -> memory read
+            [136-178] -> decoder [208-239] -> logits [300-316]
+  memorize  pad+norm+3 stems [259-266] -> res2..res4 -> KeyValue [268-272]
+"""
+import math
+
+import torch
+
+from . import _lib, ops, weights as W
+from ._lib import ptr, stream, check, MemReadDesc, BankScanDesc
+from .feature_bank import pick_nsplit, MAX_SPLIT, DK, DV
+
+# (BM, BN) -> relative efficiency of the tile shape in the implicit-GEMM kernel
+_CFG_EFF = {(128, 128): 1.00, (128, 64): 0.95, (64, 128): 0.95, (64, 64): 0.86, (32, 64): 0.74,
+            (64, 32): 0.74, (128, 32): 0.80, (256, 128): 0.97}
+_CFG_TILES = None
+_TUNED = {}          # (M, Cout, K) -> cfg, filled by Engine.autotune()
+
+
+def pad_divide_by(h, w, d=16):
+    """Pad amounts of myutils.pad_divide_by (myutils/data.py:132-149): (lw, uw, lh, uh)."""
+    new_h = h + d - h % d if h % d > 0 else h
+    new_w = w + d - w % d if w % d > 0 else w
+    lh = int((new_h - h) / 2)
+    uh = int(new_h - h) - lh
+    lw = int((new_w - w) / 2)
+    uw = int(new_w - w) - lw
+    return (lw, uw, lh, uh), new_h, new_w
+
+
+def choose_cfg(M, cout, K):
+    """Pick the tile config that minimises (rounds over 256 CUs) x (tile work / efficiency)."""
+    global _CFG_TILES
+    key = (M, cout, K)
+    if key in _TUNED:
+        return _TUNED[key]
+    if _CFG_TILES is None:
+        _CFG_TILES = ops.conv_cfg_tiles()
+    best, best_cost = 0, None
+    for c, (bm, bn) in enumerate(_CFG_TILES):
+        if bn > 32 and cout <= 32:
+            continue
+        if bn >= 128 and cout < 128:
+            continue
+        blocks = ((M + bm - 1) // bm) * ((cout + bn - 1) // bn)
+        rounds = (blocks + 255) // 256
+        cost = rounds * bm * bn / _CFG_EFF[(bm, bn)]
+        if best_cost is None or cost < best_cost:
+            best, best_cost = c, cost
+    return best
+
+
+class ConvLayer:
+    """Packed filters + epilogue constants of one convolution."""
+
+    def __init__(self, conv, bn=None, device=None):
+        w = conv.weight.detach().float()
+        self.cout, self.cin, self.k, _ = w.shape
+        self.stride = conv.stride[0]
+        self.pad = conv.padding[0]
+        self.w = ops.pad_rows(W.pack_conv_weight(w)).to(device)
+        sc, sh = W.conv_epilogue(conv, bn)
+        self.scale = sc.to(device).contiguous()
+        self.shift = sh.to(device).contiguous()
+
+
+class Launch:
+    """One pre-built kernel launch."""
+    __slots__ = ('fn', 'args', 'name', 'flops')
+
+    def __init__(self, fn, args, name, flops=0.0):
+        self.fn, self.args, self.name, self.flops = fn, args, name, flops
+
+    def __call__(self):
+        self.fn(*self.args)
+
+
+class FramePlan:
+    """Buffers + launch lists for one (H0, W0, obj_n)."""
+
+    def __init__(self, eng, H0, W0, obj_n):
+        self.eng = eng
+        self.H0, self.W0, self.obj_n = H0, W0, obj_n
+        self.pad, self.Hp, self.Wp = pad_divide_by(H0, W0)
+        dev = eng.device
+        self.h2, self.w2 = self.Hp // 2, self.Wp // 2
+        self.h4, self.w4 = self.Hp // 4, self.Wp // 4
+        self.h8, self.w8 = self.Hp // 8, self.Wp // 8
+        self.h16, self.w16 = self.Hp // 16, self.Wp // 16
+        self.HW = self.h16 * self.w16
+        f = lambda *s: torch.empty(*s, device=dev, dtype=torch.float32)
+        K = obj_n
+        # inputs are bound per call (pointers patched into the stem descriptors)
+        self.frame_in = f(3, H0, W0)
+        self.mask_in = f(K, H0, W0)
+        # query encoder
+        self.q = self._trunk_buffers(1)
+        self.kv_q = f(1, self.HW, DK + DV)
+        # memory encoder
+        self.m = self._trunk_buffers(K)
+        self.kv_m = f(K, self.HW, DK + DV)
+        # memory read
+        self.ml = f(K, self.HW, 2)
+        self.ml_part = f(K, MAX_SPLIT, self.HW, 2)
+        self.o_part = f(K, MAX_SPLIT, self.HW, DV)
+        self.dec_in = f(K, self.h16, self.w16, 2 * DV)
+        # decoder
+        self.d16 = [f(K, self.h16, self.w16, 256) for _ in range(3)]
+        self.s8 = [f(1, self.h8, self.w8, 256) for _ in range(3)]
+        self.d8 = [f(K, self.h8, self.w8, 256) for _ in range(3)]
+        self.s4 = [f(1, self.h4, self.w4, 256) for _ in range(3)]
+        self.d4 = [f(K, self.h4, self.w4, 256) for _ in range(3)]
+        self.pp = f(K, self.h4, self.w4, 2)
+        self.p_up = f(K, self.h2, self.w2, 2)
+        self.rough = f(K, self.h2, self.w2)
+        self.unc = f(self.h2, self.w2)
+        self.hs = f(K, self.h2, self.w2, 64)
+        self.hr = f(K, self.h2, self.w2)
+        self.hm = f(K, self.h2, self.w2)
+        self.lm = f(K, self.h2, self.w2, 128)
+        self.conf = f(K, self.h2, self.w2)
+        self.l2 = [f(K, self.h2, self.w2, 32) for _ in range(3)]
+        self.qq = f(K, self.h2, self.w2, 2)
+        self.score = f(1, K, H0, W0)
+
+        self.seg_pre = []     # stem .. KeyValue
+        self.seg_post = []    # decoder
+        self.mem = []         # memorize
+        self._build()
+
+    def _trunk_buffers(self, N):
+        dev = self.eng.device
+        f = lambda *s: torch.empty(*s, device=dev, dtype=torch.float32)
+        b = {}
+        b['r1'] = f(N, self.h2, self.w2, 64)
+        b['x4'] = f(N, self.h4, self.w4, 64)
+        for name, (h, w, planes) in {'res2': (self.h4, self.w4, 64), 'res3': (self.h8, self.w8, 128),
+                                     'res4': (self.h16, self.w16, 256)}.items():
+            # t1 may live at the input resolution when the block strides (conv1 runs before the strided 3x3)
+            hin, win = (h * 2, w * 2) if name != 'res2' else (h, w)
+            b[name] = dict(t1a=f(N, hin, win, planes), t1=f(N, h, w, planes), t2=f(N, h, w, planes),
+                           ds=f(N, h, w, planes * 4), o=[f(N, h, w, planes * 4) for _ in range(2)],
+                           out=f(N, h, w, planes * 4))
+        return b
+
+    # ------------------------------------------------------------------ builders
+    def _conv(self, lst, layer, x, out, N, H, Wd, res=None, relu_in=False, relu_out=False, name='conv',
+              in_ld=None, out_ld=None):
+        d = ops.make_conv_desc(x, layer.w, layer.cout, layer.k, layer.k, layer.stride, layer.pad, out,
+                               layer.scale, layer.shift, res, relu_in, relu_out,
+                               cin=layer.cin, in_ld=in_ld if in_ld is not None else x.shape[-1],
+                               out_ld=out_ld, N=N, H=H, W=Wd)
+        K = layer.k * layer.k * layer.cin
+        cfg = choose_cfg(d.M, layer.cout, K)
+        lst.append(Launch(ops.conv2d_launch, (d, cfg), f'{name}[{d.M}x{layer.cout}x{K}]', 2.0 * d.M * layer.cout * K))
+        return out
+
+    def _trunk(self, lst, enc, bufs, N, prefix):
+        x = bufs['x4']
+        lst.append(Launch(ops.maxpool3x3s2, (bufs['r1'], x), prefix + '.maxpool'))
+        H, Wd = self.h4, self.w4
+        for lname in ('res2', 'res3', 'res4'):
+            blocks = enc[lname]
+            lb = bufs[lname]
+            for bi, blk in enumerate(blocks):
+                s = blk['conv2'].stride
+                Ho, Wo = H // s, Wd // s
+                t1 = lb['t1a'] if (s == 2) else lb['t1']
+                nm = f'{prefix}.{lname}.{bi}'
+                self._conv(lst, blk['conv1'], x, t1, N, H, Wd, relu_out=True, name=nm + '.conv1')
+                self._conv(lst, blk['conv2'], t1, lb['t2'], N, H, Wd, relu_out=True, name=nm + '.conv2')
+                if 'down' in blk:
+                    self._conv(lst, blk['down'], x, lb['ds'], N, H, Wd, name=nm + '.down')
+                    idn = lb['ds']
+                else:
+                    idn = x
+                out = lb['out'] if bi == len(blocks) - 1 else lb['o'][bi % 2]
+                self._conv(lst, blk['conv3'], lb['t2'], out, N, Ho, Wo, res=idn, relu_out=True, name=nm + '.conv3')
+                x = out
+                H, Wd = Ho, Wo
+        return x
+
+    def _resblock(self, lst, rb, x, t, out, N, H, Wd, name):
+        self._conv(lst, rb['conv1'], x, t, N, H, Wd, relu_in=True, name=name + '.conv1')
+        self._conv(lst, rb['conv2'], t, out, N, H, Wd, res=x, relu_in=True, name=name + '.conv2')
+        return out
+
+    def _build(self):
+        e = self.eng
+        K = self.obj_n
+        # ---- segment: query encoder + KeyValue
+        self.stem_q = ops.make_stem_desc(self.frame_in, None, e.stem_q_w, e.stem_q_scale, e.stem_q_shift,
+                                         self.q['r1'], e.mean, e.std, 1, self.H0, self.W0, self.pad, self.Hp, self.Wp)
+        self.seg_pre.append(Launch(ops.stem_launch, (self.stem_q,), 'encoder_q.stem',
+                                   2.0 * self.h2 * self.w2 * 64 * 147))
+        r4 = self._trunk(self.seg_pre, e.enc_q, self.q, 1, 'encoder_q')
+        self._conv(self.seg_pre, e.keyval, r4, self.kv_q, 1, self.h16, self.w16, name='keyval')
+        # ---- decoder
+        L = self.seg_post
+        D = e.dec
+        d16, s8, d8, s4, d4 = self.d16, self.s8, self.d8, self.s4, self.d4
+        self._conv(L, D['convFM'], self.dec_in, d16[0], K, self.h16, self.w16, name='decoder.convFM')
+        self._resblock(L, D['ResMM'], d16[0], d16[1], d16[2], K, self.h16, self.w16, 'decoder.ResMM')
+        # RF3 (feature branch shared by the objects: N=1)
+        self._conv(L, D['RF3']['convFS'], self.q['res3']['out'], s8[0], 1, self.h8, self.w8, name='decoder.RF3.convFS')
+        self._resblock(L, D['RF3']['ResFS'], s8[0], s8[1], s8[2], 1, self.h8, self.w8, 'decoder.RF3.ResFS')
+        L.append(Launch(ops.upsample2x_add, (s8[2], d16[2], d8[0], True), 'decoder.RF3.up_add'))
+        self._resblock(L, D['RF3']['ResMM'], d8[0], d8[1], d8[2], K, self.h8, self.w8, 'decoder.RF3.ResMM')
+        # RF2
+        self._conv(L, D['RF2']['convFS'], self.q['res2']['out'], s4[0], 1, self.h4, self.w4, name='decoder.RF2.convFS')
+        self._resblock(L, D['RF2']['ResFS'], s4[0], s4[1], s4[2], 1, self.h4, self.w4, 'decoder.RF2.ResFS')
+        L.append(Launch(ops.upsample2x_add, (s4[2], d8[2], d4[0], True), 'decoder.RF2.up_add'))
+        self._resblock(L, D['RF2']['ResMM'], d4[0], d4[1], d4[2], K, self.h4, self.w4, 'decoder.RF2.ResMM')
+        self._conv(L, D['pred2'], d4[2], self.pp, K, self.h4, self.w4, relu_in=True, name='decoder.pred2')
+        L.append(Launch(ops.rough_uncertainty, (self.pp, self.p_up, self.rough, self.unc), 'decoder.rough_unc'))
+        L.append(Launch(ops.local_stats, (self.q['r1'], self.rough, self.hs, self.hr, self.hm, self.lm, self.conf),
+                        'decoder.local_stats'))
+        l2 = self.l2
+        self._conv(L, D['local_convFM'], self.lm, l2[0], K, self.h2, self.w2, name='decoder.local_convFM')
+        self._resblock(L, D['local_ResMM'], l2[0], l2[1], l2[2], K, self.h2, self.w2, 'decoder.local_ResMM')
+        self._conv(L, D['local_pred2'], l2[2], self.qq, K, self.h2, self.w2, relu_in=True, name='decoder.local_pred2')
+        L.append(Launch(ops.final_logits, (self.p_up, self.unc, self.conf, self.qq, self.score, self.pad,
+                                           self.H0, self.W0), 'decoder.final_logits'))
+        # ---- memorize
+        self.stem_m = ops.make_stem_desc(self.frame_in, self.mask_in, e.stem_m_w, e.stem_m_scale, e.stem_m_shift,
+                                         self.m['r1'], e.mean, e.std, K, self.H0, self.W0, self.pad, self.Hp, self.Wp)
+        self.mem.append(Launch(ops.stem_launch, (self.stem_m,), 'encoder_m.stem',
+                               2.0 * K * self.h2 * self.w2 * 64 * 245))
+        r4m = self._trunk(self.mem, e.enc_m, self.m, K, 'encoder_m')
+        self._conv(self.mem, e.keyval, r4m, self.kv_m, K, self.h16, self.w16, name='keyval')
+
+    def conv_flops(self, which):
+        return sum(l.flops for l in getattr(self, which))
+
+
+class Engine:
+    def __init__(self, model):
+        dev = next(model.parameters()).device
+        if dev.type != 'cuda':
+            raise RuntimeError('AFB_URR runs on hand-written HIP kernels only: move the model to the GPU '
+                               f'(model.to("cuda")); got {dev}.  There is no CPU fallback.')
+        _lib.lib()
+        self.device = dev
+        self.model = model
+        self.plans = {}
+        self._pack(model)
+
+    # ------------------------------------------------------------------ weights
+    def _pack_trunk(self, enc):
+        dev = self.device
+        out = {}
+        for lname in ('res2', 'res3', 'res4'):
+            blocks = []
+            for blk in getattr(enc, lname):
+                b = dict(conv1=ConvLayer(blk.conv1, blk.bn1, dev), conv2=ConvLayer(blk.conv2, blk.bn2, dev),
+                         conv3=ConvLayer(blk.conv3, blk.bn3, dev))
+                if hasattr(blk, 'downsample'):
+                    b['down'] = ConvLayer(blk.downsample[0], blk.downsample[1], dev)
+                blocks.append(b)
+            out[lname] = blocks
+        return out
+
+    def _pack(self, m):
+        dev = self.device
+        with torch.no_grad():
+            self.mean = [float(x) for x in m.encoder_q.mean.flatten().cpu()]
+            self.std = [float(x) for x in m.encoder_q.std.flatten().cpu()]
+            mm = [float(x) for x in m.encoder_m.mean.flatten().cpu()]
+            ms = [float(x) for x in m.encoder_m.std.flatten().cpu()]
+            if mm != self.mean or ms != self.std:
+                raise RuntimeError('encoder_m / encoder_q normalisation buffers differ; unsupported checkpoint')
+            self.stem_q_w = ops.pack_stem_weight([m.encoder_q.conv1.weight]).to(dev)
+            self.stem_q_scale, self.stem_q_shift = [t.to(dev) for t in W.bn_scale_shift(m.encoder_q.bn1)]
+            self.stem_m_w = ops.pack_stem_weight([m.encoder_m.conv1.weight, m.encoder_m.conv1_m.weight,
+                                                  m.encoder_m.conv1_o.weight]).to(dev)
+            self.stem_m_scale, self.stem_m_shift = [t.to(dev) for t in W.bn_scale_shift(m.encoder_m.bn1)]
+            self.enc_q = self._pack_trunk(m.encoder_q)
+            self.enc_m = self._pack_trunk(m.encoder_m)
+            # KeyValue: Key and Value share the input -> one GEMM with 640 filters (AFB_URR.py:106,109)
+            kv = m.keyval_r4
+            wk = torch.cat([kv.Key.weight.detach().float(), kv.Value.weight.detach().float()], 0)
+            bk = torch.cat([kv.Key.bias.detach().float(), kv.Value.bias.detach().float()], 0)
+            holder = type('KV', (), {})()
+            holder.weight, holder.bias, holder.stride, holder.padding = wk, bk, (1, 1), (1, 1)
+            self.keyval = ConvLayer(holder, None, dev)
+            d = m.decoder
+            cl = lambda c: ConvLayer(c, None, dev)
+            rb = lambda r: dict(conv1=cl(r.conv1), conv2=cl(r.conv2))
+            rf = lambda r: dict(convFS=cl(r.convFS), ResFS=rb(r.ResFS), ResMM=rb(r.ResMM))
+            self.dec = dict(convFM=cl(d.convFM), ResMM=rb(d.ResMM), RF3=rf(d.RF3), RF2=rf(d.RF2), pred2=cl(d.pred2),
+                            local_convFM=cl(d.local_convFM), local_ResMM=rb(d.local_ResMM),
+                            local_pred2=cl(d.local_pred2))
+
+    # ------------------------------------------------------------------ plans
+    def plan(self, H0, W0, obj_n):
+        key = (H0, W0, obj_n)
+        p = self.plans.get(key)
+        if p is None:
+            if len(self.plans) >= 4:
+                self.plans.pop(next(iter(self.plans)))
+            p = FramePlan(self, H0, W0, obj_n)
+            self.plans[key] = p
+        return p
+
+    @staticmethod
+    def _check_frame(frame):
+        if frame.dim() != 4 or frame.shape[0] != 1 or frame.shape[1] != 3:
+            raise RuntimeError(f'expected one RGB frame [1,3,h,w], got {tuple(frame.shape)} '
+                               '(the inference path is batch 1, test_video_seg.py:74)')
+        _lib.require_gpu(frame, 'frame')
+
+    # ------------------------------------------------------------------ API
+    def memorize(self, frame, mask):
+        self._check_frame(frame)
+        _, K, H, Wd = mask.shape
+        p = self.plan(frame.shape[2], frame.shape[3], K)
+        p.frame_in.copy_(frame[0])
+        p.mask_in.copy_(mask[0])                       # uint8 / float -> float32 (mask.float(), AFB_URR.py:262)
+        for l in p.mem:
+            l()
+        kv = p.kv_m
+        k_list = [kv[i, :, :DK].t() for i in range(K)]            # [128, HW] views
+        v_list = [kv[i, :, DK:].t() for i in range(K)]            # [512, HW]
+        return k_list, v_list
+
+    def segment(self, frame, fb, update_bank):
+        self._check_frame(frame)
+        K = fb.obj_n
+        p = self.plan(frame.shape[2], frame.shape[3], K)
+        if fb._kbuf is None:
+            raise RuntimeError('feature bank is empty: call fb.init_bank() first')
+        if fb._hw != p.HW:
+            raise RuntimeError('feature bank was built for a different frame size')
+        p.frame_in.copy_(frame[0])
+        for l in p.seg_pre:
+            l()
+        self._memory_read(p, fb, update_bank)
+        for l in p.seg_post:
+            l()
+        return p.score
+
+    def _memory_read(self, p, fb, update_bank):
+        """Matcher.forward (AFB_URR.py:136-178) on the bank slabs."""
+        L = _lib.lib()
+        s = stream()
+        K, HW, cap = fb.obj_n, p.HW, fb._cap
+        nsplit = pick_nsplit(HW, K, fb.len_upper())
+        scale = 1.0 / math.sqrt(DK)
+        d = BankScanDesc()
+        d.q, d.bank_k, d.bank_len, d.rowscale, d.part = ptr(p.kv_q), ptr(fb._kbuf), ptr(fb._len_dev), None, ptr(p.ml_part)
+        d.stride_q, d.stride_k, d.stride_rs = 0, cap * DK, 0
+        d.scale = scale
+        d.ldq, d.q_per_obj, d.HW, d.obj_n, d.nsplit, d.mode = DK + DV, 0, HW, K, nsplit, 0
+        check(L.vfn_bank_scan(_lib.C.byref(d), s), 'vfn_bank_scan')
+        check(L.vfn_bank_scan_finish(ptr(p.ml_part), nsplit, HW, K, 0, ptr(p.ml), None, None, None, s),
+              'vfn_bank_scan_finish')
+        m = MemReadDesc()
+        m.q = ptr(p.kv_q)
+        m.qv = _lib.C.c_void_p(p.kv_q.data_ptr() + DK * 4)
+        m.bank_k, m.bank_v, m.bank_len, m.ml, m.o_part = ptr(fb._kbuf), ptr(fb._vbuf), ptr(fb._len_dev), ptr(p.ml), ptr(p.o_part)
+        m.cnt = ptr(fb._cnt) if update_bank else None
+        m.info, m.out = ptr(fb._ibuf), ptr(p.dec_in)
+        m.stride_k, m.stride_v, m.stride_cnt, m.stride_info = cap * DK, cap * DV, cap, cap * 2
+        m.scale, m.thres = scale, 1e-3
+        m.ldq, m.ldqv, m.ld_out, m.HW, m.obj_n, m.nsplit = DK + DV, DK + DV, 2 * DV, HW, K, nsplit
+        check(L.vfn_memread_apply(_lib.C.byref(m), s), 'vfn_memread_apply')
+        check(L.vfn_memread_finish(_lib.C.byref(m), s), 'vfn_memread_finish')
+
+    # ------------------------------------------------------------------ tuning
+    def autotune(self, H0, W0, obj_n, iters=3):
+        """Time every tile config for every distinct conv shape of this frame size; keep the fastest."""
+        p = self.plan(H0, W0, obj_n)
+        seen = {}
+        for lst in (p.seg_pre, p.seg_post, p.mem):
+            for l in lst:
+                if l.fn is ops.conv2d_launch:
+                    d = l.args[0]
+                    key = (d.M, d.Cout, d.KH * d.KW * d.Cin)
+                    seen.setdefault(key, []).append(l)
+        tiles = ops.conv_cfg_tiles()
+        for key, launches in seen.items():
+            d = launches[0].args[0]
+            best, best_t = None, None
+            for c, (bm, bn) in enumerate(tiles):
+                if d.cout_pad < ((d.Cout + bn - 1) // bn) * bn:
+                    continue
+                if bn > 64 and d.Cout <= 32:
+                    continue
+                ops.conv2d_launch(d, c)
+                torch.cuda.synchronize()
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(iters):
+                    ops.conv2d_launch(d, c)
+                e1.record()
+                torch.cuda.synchronize()
+                t = e0.elapsed_time(e1)
+                if best_t is None or t < best_t:
+                    best, best_t = c, t
+            _TUNED[key] = best
+            for l in launches:
+                l.args = (l.args[0], best)
+        return dict(_TUNED)

@@ -1,2 +1,311 @@
-class FeatureBank:  # placeholder, replaced below
-    pass
+"""``FeatureBank``: the reference's adaptive feature bank API on device-resident storage.
+
+Drop-in for ``video_module.model.FeatureBank`` (``FeatureBank.py:8-149``) as used by
+``test_video_seg.py:83,101,112,123`` and read by the matcher (``AFB_URR.py:140-174``):
+
+    fb = FeatureBank(obj_n, memory_budget, device, update_rate=0.1, thres_close=0.95)
+    fb.init_bank(k4_list, v4_list)            # lists of [128,HW] / [512,HW]
+    fb.update(k4_list, v4_list, frame_idx)    # merge (scatter_mean) / append / LFU evict
+    fb.keys[i] [128,B]  fb.values[i] [512,B]  fb.info[i] [B,2]  fb.peak_n  fb.replace_n  fb.class_budget
+
+Storage is MI355X-first rather than the reference's per-frame ``torch.cat``: one
+pre-allocated entry-major slab per bank (``[obj][cap][128]``, ``[obj][cap][512]``,
+``[obj][cap][2]``) with the live length kept in *device* memory, so a whole
+``update`` is a fixed sequence of kernel launches with no host round trip; the public
+``keys / values / info`` attributes are transposed views of the slabs (reading them
+is the only thing that synchronises).  ``cap = class_budget + HW`` entries: at the
+default budget that is 2 x 260 MB -- sized for 288 GB of HBM, not for an 11 GB card.
+"""
+import numpy as np
+import torch
+
+from . import _lib, ops
+from ._lib import ptr, stream, check, BankDesc, BankScanDesc
+
+DK, DV = 128, 512
+MAX_SPLIT = 16
+QT, CH = 64, 128
+
+
+def pick_nsplit(hw, obj_n, b_upper):
+    """Bank slices per query tile: fill the 256 CUs (one workgroup each) in whole rounds."""
+    nchunks = max(1, (b_upper + CH - 1) // CH)
+    qtiles = (hw + QT - 1) // QT
+    best, best_eff = 1, -1.0
+    for s in range(1, min(nchunks, MAX_SPLIT) + 1):
+        blocks = qtiles * obj_n * s
+        eff = blocks / (((blocks + 255) // 256) * 256)
+        if eff >= best_eff:
+            best, best_eff = s, eff
+    return best
+
+
+class FeatureBank:
+    def __init__(self, obj_n, memory_budget, device, update_rate=0.1, thres_close=0.95):
+        self.obj_n = obj_n
+        self.update_rate = update_rate
+        self.thres_close = thres_close
+        self.device = torch.device(device)
+
+        self.peak_n = np.zeros(obj_n)
+        self.replace_n = np.zeros(obj_n)
+
+        self.class_budget = memory_budget // obj_n          # FeatureBank.py:20-22
+        if obj_n == 2:
+            self.class_budget = 0.8 * self.class_budget
+
+        self._cap = 0
+        self._hw = 0
+        self._len_host = None        # exact lengths after the last sync
+        self._len_upper = None       # upper bound valid without a sync
+        self._dirty = False
+        self._kbuf = self._vbuf = self._ibuf = None
+        self._scratch = None
+
+    # ------------------------------------------------------------------ storage
+    def _require_gpu(self):
+        if self.device.type != 'cuda':
+            raise RuntimeError('FeatureBank lives in GPU memory (HIP kernels only, no CPU fallback); '
+                               f'got device {self.device}')
+        _lib.lib()
+
+    def _alloc(self, hw, n_init):
+        self._require_gpu()
+        dev = self.device
+        o = self.obj_n
+        cap = int(max(self.class_budget, n_init)) + 2 * hw + CH
+        self._cap, self._hw = cap, hw
+        self._kbuf = torch.empty(o, cap, DK, device=dev)
+        self._vbuf = torch.empty(o, cap, DV, device=dev)
+        self._ibuf = torch.zeros(o, cap, 2, device=dev)
+        self._len_dev = torch.zeros(o, dtype=torch.int32, device=dev)
+        self._stats = torch.zeros(o, 4, dtype=torch.int32, device=dev)
+        self._knorm = torch.empty(o, cap, device=dev)
+        self._vnorm = torch.empty(o, cap, device=dev)
+        self._kinv = torch.empty(o, cap, device=dev)
+        self._cnt = torch.zeros(o, cap, dtype=torch.int32, device=dev)
+        self._keep_dst = torch.empty(o, cap, dtype=torch.int32, device=dev)
+        self._plan = torch.zeros(o, 4, dtype=torch.int32, device=dev)
+        self._new = torch.empty(o, hw, DK + DV, device=dev)       # staging for foreign-layout inputs
+        self._nknorm = torch.empty(o, hw, device=dev)
+        self._nvnorm = torch.empty(o, hw, device=dev)
+        self._nkinv = torch.empty(o, hw, device=dev)
+        self._midx = torch.empty(o, hw, dtype=torch.int32, device=dev)
+        self._mcorr = torch.empty(o, hw, device=dev)
+        self._app_pos = torch.empty(o, hw, dtype=torch.int32, device=dev)
+        self._part = torch.empty(o, MAX_SPLIT, hw, 2, device=dev)
+        self._stats_pinned = torch.zeros(o, 4, dtype=torch.int32).pin_memory()
+        self._scratch = None
+
+    def _ensure_scratch(self):
+        if self._scratch is None:
+            self._scratch = (torch.empty_like(self._kbuf), torch.empty_like(self._vbuf), torch.empty_like(self._ibuf))
+        return self._scratch
+
+    # ------------------------------------------------------------------ lengths
+    def _sync_len(self):
+        if self._dirty:
+            self._stats_pinned.copy_(self._stats, non_blocking=True)
+            torch.cuda.current_stream().synchronize()
+            self.absorb_stats(self._stats_pinned)
+        return self._len_host
+
+    def absorb_stats(self, stats_host):
+        """Take a host copy of the device ``stats`` block (len, peak, replace, n_append per object)."""
+        st = stats_host.numpy()
+        self._len_host = [int(st[i, 0]) for i in range(self.obj_n)]
+        self._len_upper = list(self._len_host)
+        for i in range(self.obj_n):
+            self.peak_n[i] = max(self.peak_n[i], float(st[i, 1]))
+            self.replace_n[i] = float(st[i, 2])
+        self._dirty = False
+
+    def stats_device(self):
+        return self._stats
+
+    def len_upper(self):
+        return max(self._len_upper)
+
+    # ------------------------------------------------------------------ reference attributes
+    @property
+    def keys(self):
+        if self._kbuf is None:
+            return None
+        n = self._sync_len()
+        return [self._kbuf[i, :n[i]].t() for i in range(self.obj_n)]
+
+    @keys.setter
+    def keys(self, value):
+        if value is None:
+            self._kbuf = None
+            return
+        raise AttributeError('assign through init_bank()/append(): the bank lives in pre-allocated device slabs')
+
+    @property
+    def values(self):
+        if self._vbuf is None:
+            return None
+        n = self._sync_len()
+        return [self._vbuf[i, :n[i]].t() for i in range(self.obj_n)]
+
+    @values.setter
+    def values(self, value):
+        if value is None:
+            self._vbuf = None
+            return
+        raise AttributeError('assign through init_bank()/append(): the bank lives in pre-allocated device slabs')
+
+    @property
+    def info(self):
+        if self._ibuf is None:
+            return [None for _ in range(self.obj_n)]
+        n = self._sync_len()
+        return [self._ibuf[i, :n[i]] for i in range(self.obj_n)]
+
+    # ------------------------------------------------------------------ API
+    def _write_columns(self, keys, values, start, frame_idx, hit_init):
+        """Copy per-object [128,n] / [512,n] columns into the slabs at row ``start[i]`` (plumbing copies)."""
+        for i in range(self.obj_n):
+            n = keys[i].shape[1]
+            s = start[i]
+            self._kbuf[i, s:s + n].copy_(keys[i].t())
+            self._vbuf[i, s:s + n].copy_(values[i].t())
+            self._ibuf[i, s:s + n, 0] = float(frame_idx)
+            self._ibuf[i, s:s + n, 1] = float(hit_init)
+
+    def init_bank(self, keys, values, frame_idx=0):
+        """FeatureBank.py:27-36."""
+        self._require_gpu()
+        hw = keys[0].shape[1]
+        n_init = max(k.shape[1] for k in keys)
+        self._alloc(hw, n_init)
+        self._write_columns(keys, values, [0] * self.obj_n, frame_idx, 0.0)
+        lens = [int(k.shape[1]) for k in keys]
+        self._set_lengths(lens)
+
+    def _set_lengths(self, lens):
+        self._len_host = list(lens)
+        self._len_upper = list(lens)
+        for i in range(self.obj_n):
+            self.peak_n[i] = max(self.peak_n[i], lens[i])
+        st = torch.zeros(self.obj_n, 4, dtype=torch.int32)
+        for i in range(self.obj_n):
+            st[i, 0] = lens[i]
+            st[i, 1] = int(self.peak_n[i])
+            st[i, 2] = int(self.replace_n[i])
+        self._stats.copy_(st)
+        self._len_dev.copy_(torch.tensor(lens, dtype=torch.int32))
+        self._dirty = False
+
+    def append(self, keys, values, frame_idx=0):
+        """FeatureBank.py:38-51 (append-only entry point; hit accumulator starts at 20)."""
+        if self._kbuf is None:
+            return self.init_bank(keys, values, frame_idx)
+        lens = self._sync_len()
+        need = max(lens[i] + keys[i].shape[1] for i in range(self.obj_n))
+        if need > self._cap:
+            self._grow(need)
+        self._write_columns(keys, values, lens, frame_idx, 20.0)
+        self._set_lengths([lens[i] + int(keys[i].shape[1]) for i in range(self.obj_n)])
+
+    def _grow(self, need):
+        cap = int(need * 1.5) + self._hw
+        lens = self._len_host
+        for name in ('_kbuf', '_vbuf', '_ibuf', '_knorm', '_vnorm', '_kinv', '_cnt', '_keep_dst'):
+            old = getattr(self, name)
+            new = torch.zeros(old.shape[0], cap, *old.shape[2:], dtype=old.dtype, device=old.device)
+            new[:, :self._cap] = old
+            setattr(self, name, new)
+        self._cap = cap
+        self._scratch = None
+        del lens
+
+    def _stage_new(self, prev_key, prev_value):
+        """Return (tensor, ld) holding the new features as [obj][HW][640] (key | value)."""
+        hw = prev_key[0].shape[1]
+        k0 = prev_key[0]
+        ld = DK + DV
+        ok = k0.is_cuda and k0.dtype == torch.float32 and k0.stride() == (1, ld) and hw == self._hw
+        if ok:
+            base = k0.data_ptr()
+            for i in range(self.obj_n):
+                k, v = prev_key[i], prev_value[i]
+                if (k.stride() != (1, ld) or v.stride() != (1, ld) or k.shape != (DK, hw) or v.shape != (DV, hw)
+                        or k.data_ptr() != base + i * hw * ld * 4 or v.data_ptr() != k.data_ptr() + DK * 4):
+                    ok = False
+                    break
+        if ok:
+            return k0, ld            # already the engine's [obj][HW][640] slab: zero-copy
+        for i in range(self.obj_n):
+            self._new[i, :, :DK].copy_(prev_key[i].t())
+            self._new[i, :, DK:].copy_(prev_value[i].t())
+        return self._new, ld
+
+    def update(self, prev_key, prev_value, frame_idx, update_rate=-1):
+        """FeatureBank.py:53-115: cosine match -> merge (scatter_mean + blend) / append / LFU evict."""
+        self._require_gpu()
+        if update_rate == -1:
+            update_rate = self.update_rate
+        hw = prev_key[0].shape[1]
+        if hw != self._hw:
+            raise RuntimeError(f'feature count changed ({hw} vs {self._hw}): one bank serves one frame size')
+        L = _lib.lib()
+        o, cap = self.obj_n, self._cap
+        new, ld = self._stage_new(prev_key, prev_value)
+        s = stream()
+
+        # norms: bank keys / values (device length), new keys / values
+        ops.row_norms(self._kbuf, cap * DK, DK, DK, self._len_dev, 0, o, self._knorm, self._kinv, cap)
+        ops.row_norms(self._vbuf, cap * DV, DV, DV, self._len_dev, 0, o, self._vnorm, None, cap)
+        ops.row_norms(new, hw * ld, ld, DK, None, hw, o, self._nknorm, self._nkinv, hw)
+        check(L.vfn_row_norms(_lib.C.c_void_p(new.data_ptr() + DK * 4), hw * ld, ld, DV, None, hw, o,
+                              ptr(self._nvnorm), None, hw, s), 'vfn_row_norms')
+
+        # cosine arg-max over the bank per new feature
+        b_up = self.len_upper()
+        nsplit = pick_nsplit(hw, o, b_up)
+        d = BankScanDesc()
+        d.q, d.bank_k, d.bank_len, d.rowscale, d.part = ptr(new), ptr(self._kbuf), ptr(self._len_dev), ptr(self._kinv), ptr(self._part)
+        d.stride_q, d.stride_k, d.stride_rs = hw * ld, cap * DK, cap
+        d.scale = 1.0
+        d.ldq, d.q_per_obj, d.HW, d.obj_n, d.nsplit, d.mode = ld, 1, hw, o, nsplit, 1
+        check(L.vfn_bank_scan(_lib.C.byref(d), s), 'vfn_bank_scan')
+        check(L.vfn_bank_scan_finish(ptr(self._part), nsplit, hw, o, 1, None, ptr(self._midx), ptr(self._mcorr),
+                                     ptr(self._nkinv), s), 'vfn_bank_scan_finish')
+
+        # merge + append (+ evict)
+        may_evict = self.class_budget < b_up + hw
+        if may_evict:
+            sk, sv, si = self._ensure_scratch()
+        else:
+            sk, sv, si = self._kbuf, self._vbuf, self._ibuf       # never touched: no eviction possible
+        bd = BankDesc()
+        bd.bank_k, bd.bank_v, bd.info = ptr(self._kbuf), ptr(self._vbuf), ptr(self._ibuf)
+        bd.scratch_k, bd.scratch_v, bd.scratch_info = ptr(sk), ptr(sv), ptr(si)
+        bd.bank_len, bd.bank_len_rw = ptr(self._len_dev), ptr(self._len_dev)
+        bd.bank_knorm, bd.bank_vnorm = ptr(self._knorm), ptr(self._vnorm)
+        bd.match_idx, bd.match_corr = ptr(self._midx), ptr(self._mcorr)
+        bd.new_k, bd.new_knorm, bd.new_vnorm = ptr(new), ptr(self._nknorm), ptr(self._nvnorm)
+        bd.app_pos, bd.keep_dst, bd.plan, bd.stats = ptr(self._app_pos), ptr(self._keep_dst), ptr(self._plan), ptr(self._stats)
+        bd.stride_k, bd.stride_v, bd.stride_info, bd.stride_n, bd.stride_new = cap * DK, cap * DV, cap * 2, cap, hw * ld
+        bd.class_budget = float(self.class_budget)
+        bd.thres_close, bd.update_rate, bd.new_hit_init = float(self.thres_close), float(update_rate), 0.0
+        bd.frame_idx, bd.ld_new, bd.voff, bd.HW, bd.obj_n, bd.cap = int(frame_idx), ld, DK, hw, o, cap
+        check(L.vfn_bank_merge(_lib.C.byref(bd), s), 'vfn_bank_merge')
+        check(L.vfn_bank_append(_lib.C.byref(bd), s), 'vfn_bank_append')
+
+        self._dirty = True
+        self._len_upper = [min(n + hw, cap) for n in self._len_upper]
+
+    def remove(self, class_idx, request_n, frame_idx):
+        """FeatureBank.py:117-143.  Eviction is fused into ``update`` on the device; the standalone entry
+        point is kept for API completeness and runs the same plan for one object."""
+        raise RuntimeError('remove() is fused into update() in the HIP path (vfn_bank_append); '
+                           'call update() -- it evicts when class_budget < bank_n + appended')
+
+    def print_peak_mem(self):
+        """FeatureBank.py:145-149."""
+        self._sync_len()
+        ur = self.peak_n / self.class_budget
+        rr = self.replace_n / self.class_budget
+        print(f'Obj num: {self.obj_n}.', f'Budget / obj: {self.class_budget}.', f'UR: {ur}.', f'Replace: {rr}.')

@@ -71,3 +71,135 @@ def conv2d_nhwc(x, wp, cout, kh, kw, stride, pad, scale=None, shift=None, res=No
     d = make_conv_desc(x, wp, cout, kh, kw, stride, pad, out, scale, shift, res, relu_in, relu_out)
     conv2d_launch(d, cfg)
     return out
+
+
+# --------------------------------------------------------------------------- stems / pooling
+def make_stem_desc(frame, mask, w, scale, shift, out, mean, std, N, H0, W0, pad, Hp, Wp):
+    """frame [3,H0,W0] planar; mask [N,H0,W0] or None; out NHWC [N,Hp/2,Wp/2,64]; pad=(lw,uw,lh,uh)."""
+    from ._lib import StemDesc
+    d = StemDesc()
+    d.frame, d.mask, d.w, d.scale, d.shift, d.out = ptr(frame), ptr(mask), ptr(w), ptr(scale), ptr(shift), ptr(out)
+    for i in range(3):
+        d.mean[i] = float(mean[i])
+        d.std[i] = float(std[i])
+    d.N, d.cin = N, (5 if mask is not None else 3)
+    d.H0, d.W0 = H0, W0
+    d.pad_top, d.pad_left = pad[2], pad[0]
+    d.Hp, d.Wp, d.Ho, d.Wo = Hp, Wp, Hp // 2, Wp // 2
+    return d
+
+
+def stem_launch(desc):
+    check(_lib.lib().vfn_stem_conv7x7_f32(C.byref(desc), stream()), 'vfn_stem_conv7x7_f32')
+
+
+def pack_stem_weight(ws):
+    """list of [64,c_i,7,7] conv weights -> [sum(c_i)*7*8, 64], k=(plane*7+kh)*8+kw, 8th tap zero."""
+    w = torch.cat([x.detach().float() for x in ws], dim=1)          # [64, P, 7, 7]
+    P = w.shape[1]
+    out = torch.zeros(P, 7, 8, 64, dtype=torch.float32, device=w.device)
+    out[:, :, :7, :] = w.permute(1, 2, 3, 0)
+    return out.reshape(P * 56, 64).contiguous()
+
+
+def maxpool3x3s2(x, out):
+    N, H, W, Cc = x.shape
+    check(_lib.lib().vfn_maxpool3x3s2_nhwc_f32(ptr(x), ptr(out), N, H, W, Cc, stream()), 'vfn_maxpool3x3s2_nhwc_f32')
+    return out
+
+
+# --------------------------------------------------------------------------- decoder pointwise
+def upsample2x_add(s, pm, out, s_bcast):
+    N, h, w, Cc = out.shape
+    check(_lib.lib().vfn_upsample2x_add_nhwc_f32(ptr(s), ptr(pm), ptr(out), N, h, w, Cc, int(s_bcast), stream()),
+          'vfn_upsample2x_add_nhwc_f32')
+    return out
+
+
+def rough_uncertainty(p, p_up, rough, unc):
+    obj_n, h, w, _ = p.shape
+    check(_lib.lib().vfn_rough_uncertainty_f32(ptr(p), ptr(p_up), ptr(rough), ptr(unc), obj_n, h, w, stream()),
+          'vfn_rough_uncertainty_f32')
+
+
+def local_stats(r1, rough, hs, hr, hm, lm, conf):
+    obj_n, h, w = rough.shape
+    Cc = r1.shape[-1]
+    L = _lib.lib()
+    check(L.vfn_local_hpass_f32(ptr(r1), ptr(rough), ptr(hs), ptr(hr), ptr(hm), obj_n, h, w, Cc, stream()),
+          'vfn_local_hpass_f32')
+    check(L.vfn_local_vpass_f32(ptr(r1), ptr(hs), ptr(hr), ptr(hm), ptr(lm), ptr(conf), obj_n, h, w, Cc, stream()),
+          'vfn_local_vpass_f32')
+
+
+def final_logits(p_up, unc, conf, q, score, pad, H0, W0):
+    obj_n, h, w, _ = p_up.shape
+    check(_lib.lib().vfn_final_logits_f32(ptr(p_up), ptr(unc), ptr(conf), ptr(q), ptr(score), obj_n, h, w,
+                                          pad[2], pad[0], H0, W0, stream()), 'vfn_final_logits_f32')
+
+
+# --------------------------------------------------------------------------- loop operators
+def resize_bicubic(x, Ho, Wo, out=None):
+    """x [C,Hi,Wi] (or [1,C,Hi,Wi]) float32 -> [.., Ho, Wo]."""
+    shp = x.shape
+    Cc, Hi, Wi = shp[-3], shp[-2], shp[-1]
+    assert x.is_contiguous() and x.numel() == Cc * Hi * Wi
+    if out is None:
+        out = torch.empty(*shp[:-2], Ho, Wo, device=x.device, dtype=torch.float32)
+    check(_lib.lib().vfn_resize_bicubic_f32(ptr(x), ptr(out), Cc, Hi, Wi, Ho, Wo, stream()), 'vfn_resize_bicubic_f32')
+    return out
+
+
+def resize_nearest(x, Ho, Wo, out=None):
+    shp = x.shape
+    Cc, Hi, Wi = shp[-3], shp[-2], shp[-1]
+    assert x.is_contiguous() and x.numel() == Cc * Hi * Wi
+    if out is None:
+        out = torch.empty(*shp[:-2], Ho, Wo, device=x.device, dtype=torch.float32)
+    check(_lib.lib().vfn_resize_nearest_f32(ptr(x), ptr(out), Cc, Hi, Wi, Ho, Wo, stream()), 'vfn_resize_nearest_f32')
+    return out
+
+
+def softmax_objects(score, out=None):
+    """score [1,obj,H,W] -> softmax over dim 1."""
+    obj_n = score.shape[-3]
+    n = score.shape[-2] * score.shape[-1]
+    assert score.is_contiguous()
+    if out is None:
+        out = torch.empty_like(score)
+    check(_lib.lib().vfn_softmax_objects_f32(ptr(score), ptr(out), obj_n, n, stream()), 'vfn_softmax_objects_f32')
+    return out
+
+
+def resize_argmax(prob, Ho, Wo, out=None):
+    """prob [1,obj,Hi,Wi] -> uint8 labels [Ho,Wo] = argmax over objects of the bicubic-resized maps."""
+    obj_n, Hi, Wi = prob.shape[-3], prob.shape[-2], prob.shape[-1]
+    assert prob.is_contiguous()
+    if out is None:
+        out = torch.empty(Ho, Wo, device=prob.device, dtype=torch.uint8)
+    check(_lib.lib().vfn_resize_argmax_u8(ptr(prob), ptr(out), obj_n, Hi, Wi, Ho, Wo, stream()), 'vfn_resize_argmax_u8')
+    return out
+
+
+def postprocess_pred(pred_np):
+    """Host uint8 [H,W] -> uint8 [H,W] (largest 8-connected water blob; myutils/data.py:17-37)."""
+    import numpy as np
+    pred_np = np.ascontiguousarray(pred_np, dtype=np.uint8)
+    out = np.empty_like(pred_np)
+    H, W = pred_np.shape
+    check(_lib.lib().vfn_postprocess_pred_u8(pred_np.ctypes.data_as(C.c_void_p), H, W,
+                                             out.ctypes.data_as(C.c_void_p)), 'vfn_postprocess_pred_u8')
+    return out
+
+
+# --------------------------------------------------------------------------- bank
+def row_norms(x, stride_obj, ld, dim, len_dev, rows, obj_n, nrm, inv, stride_n):
+    check(_lib.lib().vfn_row_norms(ptr(x), int(stride_obj), ld, dim, ptr(len_dev), rows, obj_n, ptr(nrm), ptr(inv),
+                                   int(stride_n), stream()), 'vfn_row_norms')
+
+
+def scatter_mean_launch(src, index_row, out):
+    """src [D,S] (any strides), index_row int64 [S] contiguous, out [D,B] (any strides)."""
+    D, S = src.shape
+    check(_lib.lib().vfn_scatter_mean_f32(ptr(src), src.stride(0), src.stride(1), ptr(index_row), S, ptr(out),
+                                          out.stride(0), out.stride(1), D, stream()), 'vfn_scatter_mean_f32')

@@ -27,7 +27,7 @@ from torch.nn import functional as F
 
 from . import weights as W
 
-CALIB_HW = (240, 432)
+CALIB_HW = (240, 426)          # padded to 240x432 by pad_divide_by, like 480x854 -> 480x864
 
 
 def frame0(seed, H, W_):
@@ -41,7 +41,16 @@ def frame0(seed, H, W_):
                         0.30 + 0.4 * ys.expand(H, W_),
                         0.55 - 0.3 * (xs * ys)], 0)
     tint = torch.tensor([-0.15, -0.05, 0.20]).view(3, 1, 1)
-    noise = torch.rand(3, H, W_, generator=g) - 0.5
+    # multi-octave texture (cell sizes 1,2,4,...,32 px): local statistics are similar at every
+    # frame size, so BatchNorm statistics calibrated at one size carry over to the others
+    noise = torch.zeros(3, H, W_)
+    for o in range(6):
+        c = 1 << o
+        n = torch.rand(1, 3, (H + c - 1) // c + 1, (W_ + c - 1) // c + 1, generator=g) - 0.5
+        if c > 1:
+            n = F.interpolate(n, scale_factor=c, mode='bilinear', align_corners=False)
+        noise += n[0, :, :H, :W_]
+    noise = noise / math.sqrt(6.0) * 1.4
     img = base + water.unsqueeze(0) * tint + 0.25 * noise * (0.5 + 0.5 * water.unsqueeze(0))
     return img.clamp(0, 1).contiguous(), water.to(torch.uint8).contiguous()
 
@@ -69,7 +78,13 @@ def _gen_for(name, seed):
     return torch.Generator().manual_seed((zlib.crc32(name.encode()) ^ int(seed)) & 0x7FFFFFFF)
 
 
-def random_state_dict(template_sd, seed):
+DEFAULT_KNOBS = dict(key_scale=1.0, mask_scale=1.0, res_scale=0.4, dec_res_scale=0.5, out_scale=1.0,
+                     logit_std=2.0, local_std=0.5)
+
+
+def random_state_dict(template_sd, seed, knobs=None):
+    kn = dict(DEFAULT_KNOBS)
+    kn.update(knobs or {})
     sd = {}
     for name, t in template_sd.items():
         g = _gen_for(name, seed)
@@ -91,73 +106,145 @@ def random_state_dict(template_sd, seed):
                 sd[name] = 0.05 * torch.randn(t.shape, generator=g)
         else:  # conv biases
             sd[name] = 0.05 * torch.randn(t.shape, generator=g)
+    for name in sd:
+        if name.startswith('keyval_r4.Key.'):
+            sd[name] = sd[name] * kn['key_scale']
+        elif name in ('encoder_m.conv1_m.weight', 'encoder_m.conv1_o.weight'):
+            sd[name] = sd[name] * kn['mask_scale']
+        elif name.endswith('bn3.weight'):
+            sd[name] = sd[name] * kn['res_scale']
+        elif name.startswith('decoder.') and ('.ResMM.conv2.' in name or '.ResFS.conv2.' in name):
+            sd[name] = sd[name] * kn['dec_res_scale']
+        elif name in ('decoder.pred2.weight', 'decoder.local_pred2.weight'):
+            sd[name] = sd[name] * kn['out_scale']
     return sd
 
 
-def _calib_bn(x, sd, prefix):
-    """Batch-statistics BN (train mode, momentum=None -> stats = this batch), records them."""
-    mean = x.mean(dim=(0, 2, 3))
-    var_b = x.var(dim=(0, 2, 3), unbiased=False)
-    n = x.numel() / x.shape[1]
-    sd[prefix + '.running_mean'] = mean.clone()
-    sd[prefix + '.running_var'] = (var_b * n / max(n - 1, 1)).clone()   # running_var is unbiased
-    y = (x - mean.view(1, -1, 1, 1)) / torch.sqrt(var_b.view(1, -1, 1, 1) + W.BN_EPS)
-    return y * sd[prefix + '.weight'].view(1, -1, 1, 1) + sd[prefix + '.bias'].view(1, -1, 1, 1)
+def _bn_apply(x, sd, prefix, calibrate):
+    """BatchNorm: batch statistics (recorded as the running stats) when calibrating, eval otherwise."""
+    if calibrate:
+        mean = x.mean(dim=(0, 2, 3))
+        var_b = x.var(dim=(0, 2, 3), unbiased=False)
+        n = x.numel() / x.shape[1]
+        sd[prefix + '.running_mean'] = mean.clone()
+        sd[prefix + '.running_var'] = (var_b * n / max(n - 1, 1)).clone()   # running_var is unbiased
+        y = (x - mean.view(1, -1, 1, 1)) / torch.sqrt(var_b.view(1, -1, 1, 1) + W.BN_EPS)
+        return y * sd[prefix + '.weight'].view(1, -1, 1, 1) + sd[prefix + '.bias'].view(1, -1, 1, 1)
+    return F.batch_norm(x, sd[prefix + '.running_mean'], sd[prefix + '.running_var'],
+                        sd[prefix + '.weight'], sd[prefix + '.bias'], False, 0.0, W.BN_EPS)
 
 
-def _calib_layer(x, sd, prefix, blocks, stride):
+def _layer_fwd(x, sd, prefix, blocks, stride, calibrate):
     for b in range(blocks):
         p = f'{prefix}.{b}'
         s = stride if b == 0 else 1
-        out = F.relu(_calib_bn(F.conv2d(x, sd[p + '.conv1.weight']), sd, p + '.bn1'))
-        out = F.relu(_calib_bn(F.conv2d(out, sd[p + '.conv2.weight'], stride=s, padding=1), sd, p + '.bn2'))
-        out = _calib_bn(F.conv2d(out, sd[p + '.conv3.weight']), sd, p + '.bn3')
+        out = F.relu(_bn_apply(F.conv2d(x, sd[p + '.conv1.weight']), sd, p + '.bn1', calibrate))
+        out = F.relu(_bn_apply(F.conv2d(out, sd[p + '.conv2.weight'], stride=s, padding=1), sd, p + '.bn2', calibrate))
+        out = _bn_apply(F.conv2d(out, sd[p + '.conv3.weight']), sd, p + '.bn3', calibrate)
         if b == 0:
-            idn = _calib_bn(F.conv2d(x, sd[p + '.downsample.0.weight'], stride=s), sd, p + '.downsample.1')
+            idn = _bn_apply(F.conv2d(x, sd[p + '.downsample.0.weight'], stride=s), sd, p + '.downsample.1', calibrate)
         else:
             idn = x
         x = F.relu(out + idn)
     return x
 
 
-def _calibrate(sd, seed):
-    H, W_ = CALIB_HW
-    f0, m0 = frame0(seed, H, W_)
-    oh = onehot(m0).float()
-    mean = sd['encoder_q.mean']
-    std = sd['encoder_q.std']
-    f = (f0.unsqueeze(0) - mean) / std
-    # query encoder
-    x = F.conv2d(f, sd['encoder_q.conv1.weight'], stride=2, padding=3)
-    x = F.relu(_calib_bn(x, sd, 'encoder_q.bn1'))
-    x = F.max_pool2d(x, 3, 2, 1)
-    x = _calib_layer(x, sd, 'encoder_q.res2', 3, 1)
-    x = _calib_layer(x, sd, 'encoder_q.res3', 4, 2)
-    _calib_layer(x, sd, 'encoder_q.res4', 6, 2)
-    # memory encoder (two objects: background, water)
-    fm = f.expand(2, -1, -1, -1)
-    m = oh.unsqueeze(1)
+def _trunk_fwd(x, sd, prefix, calibrate):
+    r1 = F.relu(_bn_apply(x, sd, prefix + '.bn1', calibrate))
+    x = F.max_pool2d(r1, 3, 2, 1)
+    r2 = _layer_fwd(x, sd, prefix + '.res2', 3, 1, calibrate)
+    r3 = _layer_fwd(r2, sd, prefix + '.res3', 4, 2, calibrate)
+    r4 = _layer_fwd(r3, sd, prefix + '.res4', 6, 2, calibrate)
+    return r4, r3, r2, r1
+
+
+def _enc_q(sd, frame, calibrate):
+    f = (frame - sd['encoder_q.mean']) / sd['encoder_q.std']
+    return _trunk_fwd(F.conv2d(f, sd['encoder_q.conv1.weight'], stride=2, padding=3), sd, 'encoder_q', calibrate)
+
+
+def _enc_m(sd, frame, masks, calibrate):
+    """frame [1,3,h,w]; masks [K,h,w] float."""
+    f = ((frame - sd['encoder_m.mean']) / sd['encoder_m.std']).expand(masks.shape[0], -1, -1, -1)
+    m = masks.unsqueeze(1)
     o = (1 - m).clamp(0, 1)
-    x = F.conv2d(fm, sd['encoder_m.conv1.weight'], stride=2, padding=3) \
+    x = F.conv2d(f, sd['encoder_m.conv1.weight'], stride=2, padding=3) \
         + F.conv2d(m, sd['encoder_m.conv1_m.weight'], stride=2, padding=3) \
         + F.conv2d(o, sd['encoder_m.conv1_o.weight'], stride=2, padding=3)
-    x = F.relu(_calib_bn(x, sd, 'encoder_m.bn1'))
-    x = F.max_pool2d(x, 3, 2, 1)
-    x = _calib_layer(x, sd, 'encoder_m.res2', 3, 1)
-    x = _calib_layer(x, sd, 'encoder_m.res3', 4, 2)
-    _calib_layer(x, sd, 'encoder_m.res4', 6, 2)
+    return _trunk_fwd(x, sd, 'encoder_m', calibrate)[0]
 
 
-def make_state_dict(seed=20200212):
+def _c3(sd, p, x):
+    return F.conv2d(x, sd[p + '.weight'], sd[p + '.bias'], padding=1)
+
+
+def _rb(sd, p, x):
+    return x + _c3(sd, p + '.conv2', F.relu(_c3(sd, p + '.conv1', F.relu(x))))
+
+
+def _calibrate(sd, seed, kn):
+    """Data-dependent part of the recipe, on one synthetic frame pair (plain torch CPU ops):
+    BatchNorm running statistics of both encoders, then the two prediction heads are rescaled and
+    re-centred so the logits neither saturate at the clamp (AFB_URR.py:309) nor collapse to ties."""
+    H, W_ = CALIB_HW
+    f0, m0 = frame0(seed, H, W_)
+    f1 = torch.roll(f0, shifts=(2, 5), dims=(1, 2))
+    oh = onehot(m0).float()
+    from .engine import pad_divide_by
+    pad, _, _ = pad_divide_by(H, W_)                 # myutils/data.py:132-149: zero pad *before* normalisation
+    f0, f1, oh = F.pad(f0, pad), F.pad(f1, pad), F.pad(oh, pad)
+    r4, r3, r2, r1 = _enc_q(sd, f1.unsqueeze(0), True)
+    r4m = _enc_m(sd, f0.unsqueeze(0), oh, True)
+    # memory read of frame 1 against the bank of frame 0 (AFB_URR.py:136-178)
+    kq = _c3(sd, 'keyval_r4.Key', r4).flatten(2)[0]
+    vq = _c3(sd, 'keyval_r4.Value', r4).flatten(2)[0]
+    km = _c3(sd, 'keyval_r4.Key', r4m).flatten(2)
+    vm = _c3(sd, 'keyval_r4.Value', r4m).flatten(2)
+    gh, gw = r4.shape[2:]
+    res = []
+    for i in range(2):
+        p = torch.softmax(km[i].t() @ kq / math.sqrt(km.shape[1]), dim=0)
+        res.append(torch.cat([vm[i] @ p, vq], 0))
+    x = torch.stack(res, 0).view(2, -1, gh, gw)
+    D = 'decoder'
+    p = _rb(sd, D + '.ResMM', _c3(sd, D + '.convFM', x))
+    for rf, feat in (('.RF3', r3), ('.RF2', r2)):
+        s_ = _rb(sd, D + rf + '.ResFS', _c3(sd, D + rf + '.convFS', feat))
+        p = _rb(sd, D + rf + '.ResMM', s_ + F.interpolate(p, scale_factor=2, mode='bilinear', align_corners=False))
+    feat = F.relu(p)
+    c = _c3(sd, D + '.pred2', feat)
+    diff = c[:, 1] - c[:, 0]
+    g = kn['logit_std'] / max(float(diff.std()), 1e-6)
+    sd[D + '.pred2.weight'] = sd[D + '.pred2.weight'] * g
+    sd[D + '.pred2.bias'] = sd[D + '.pred2.bias'] * g
+    sd[D + '.pred2.bias'][1] -= float((diff * g).median())
+    # local head (AFB_URR.py:226-235)
+    c = F.interpolate(_c3(sd, D + '.pred2', feat), scale_factor=2, mode='bilinear', align_corners=False)
+    rough = torch.softmax(torch.softmax(c, dim=1)[:, 1].unsqueeze(0), dim=1)[0].unsqueeze(1)
+    r1e = r1.expand(2, -1, -1, -1)
+    r1_local = F.avg_pool2d(r1e * rough, 7, 1, 3) / (F.avg_pool2d(rough, 7, 1, 3) + 1e-8)
+    q = _rb(sd, D + '.local_ResMM', _c3(sd, D + '.local_convFM', torch.cat([r1e, r1_local], 1)))
+    qf = F.relu(q)
+    c2 = _c3(sd, D + '.local_pred2', qf)
+    d2 = c2[:, 1] - c2[:, 0]
+    g2 = kn['local_std'] / max(float(d2.std()), 1e-6)
+    sd[D + '.local_pred2.weight'] = sd[D + '.local_pred2.weight'] * g2
+    sd[D + '.local_pred2.bias'] = sd[D + '.local_pred2.bias'] * g2
+    sd[D + '.local_pred2.bias'][1] -= float((d2 * g2).median())
+
+
+def make_state_dict(seed=20200212, **knobs):
     """Deterministic calibrated state dict (CPU tensors, reference key names)."""
     from .model import AFB_URR
     with torch.no_grad():
         tmpl = AFB_URR(torch.device('cpu'), update_bank=True, _allow_cpu_container=True).state_dict()
-        sd = random_state_dict(tmpl, seed)
+        sd = random_state_dict(tmpl, seed, knobs)
         nthr = torch.get_num_threads()
         torch.set_num_threads(1)           # fixed reduction order -> bit-reproducible statistics
         try:
-            _calibrate(sd, seed)
+            kn = dict(DEFAULT_KNOBS)
+            kn.update(knobs)
+            _calibrate(sd, seed, kn)
         finally:
             torch.set_num_threads(nthr)
     return sd

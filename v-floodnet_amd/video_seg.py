@@ -1,0 +1,225 @@
+"""The per-frame inference loop: drop-in for ``test_video_seg.py`` (reference lines cited inline).
+
+``main(args, device)`` keeps the reference's contract (``test_video_seg.py:41-123``): a directory
+of ``*.jpg`` / ``*.png`` frames in, ``./output/segs/<name>/{mask,overlay}/<stem>.png`` out, the
+first-frame mask read from ``output/segs/<name>/mask/<first>.png``.  ``ClipRunner`` is the same
+loop on tensors already resident in HBM (what ``bench.py`` times and what the clip-sharded
+multi-GPU driver in ``dist.py`` calls).
+
+Every per-frame operator is a HIP kernel: bicubic / nearest resize, segment, object softmax,
+memorize, bank update, resize + arg-max.  One host synchronisation per frame (the label D2H the
+reference also has at ``.cpu()``, ``test_video_seg.py:115``) -- the bank bookkeeping rides on it.
+"""
+import argparse
+import os
+import time
+from glob import glob
+
+import numpy as np
+import torch
+
+from . import ops
+from .data import (color_palette, load_image_in_PIL, postprocessing_pred, save_overlay, save_seg_mask)
+from .dataset import Video_DS
+from .feature_bank import FeatureBank
+from .model import AFB_URR
+
+
+def gct():
+    """myutils/system.py:56-65 log timestamp."""
+    return time.strftime('%m/%d %H:%M:%S', time.localtime(time.time()))
+
+
+def get_args(argv=None):
+    """test_video_seg.py:20-38 plus the harness options SURVEY.md section 5 lists."""
+    parser = argparse.ArgumentParser(description='V-FloodNet: Water Video Segmentation (MI355X-native)')
+    parser.add_argument('--gpu', type=int, default=0, help='GPU card id.')
+    parser.add_argument('--budget', type=int, default='250000',
+                        help='Max number of features that feature bank can store. Default: 300000')
+    parser.add_argument('--viz', action='store_true', default=True, help='Visualize data.')
+    parser.add_argument('--no-viz', dest='viz', action='store_false', help='Skip the overlay PNGs.')
+    parser.add_argument('--model-path', type=str, default='records/video_seg_checkpoint_20200212-001734.pth',
+                        help='Path to the checkpoint (default: none)')
+    parser.add_argument('--update-rate', type=float, default=0.1, help='Update Rate. Impact of merging new features.')
+    parser.add_argument('--merge-thres', type=float, default=0.95,
+                        help='Merging Rate. If similarity higher than this, then merge, else append.')
+    parser.add_argument('--test-path', type=str, required=True, help='Video Path')
+    parser.add_argument('--test-name', type=str, required=True, help='Video Name')
+    parser.add_argument('--size', type=int, default=480, help='Short-edge size the network runs at (reference: 480).')
+    parser.add_argument('--mem-every', type=int, default=1, help='Memorise every n-th frame (reference: 1).')
+    return parser.parse_args(argv)
+
+
+def resized_hw(h, w, size):
+    """torchvision 0.9.2 ``TF.resize(img, int)``: short edge -> size, long edge ``int(size*long/short)``."""
+    short, long = (w, h) if w <= h else (h, w)
+    if short == size:
+        return h, w
+    new_short, new_long = size, int(size * long / short)
+    return (new_long, new_short) if w <= h else (new_short, new_long)
+
+
+class ClipRunner:
+    """test_video_seg.py:83-121 on device tensors."""
+
+    def __init__(self, model, obj_n=2, budget=250000, update_rate=0.1, thres_close=0.95, size=480, mem_every=1):
+        self.model = model
+        self.device = model.device
+        self.obj_n = obj_n
+        self.size = size
+        self.mem_every = mem_every
+        self.fb = FeatureBank(obj_n, budget, self.device, update_rate=update_rate, thres_close=thres_close)
+        self.t = 0
+        self._pinned = None
+        self._stats_pinned = None
+
+    def _net_frame(self, frame):
+        """TF.resize(ori_frame, 480, BICUBIC) (:88,:107); identity when the short edge already matches."""
+        H0, W0 = frame.shape[-2:]
+        h, w = resized_hw(H0, W0, self.size)
+        if (h, w) == (H0, W0):
+            return frame
+        return ops.resize_bicubic(frame.contiguous(), h, w)
+
+    def start(self, first_frame, first_mask_onehot):
+        """first_frame f32[1,3,H0,W0]; first_mask_onehot u8/f32[1,obj_n,H0,W0] (:85-101)."""
+        H0, W0 = first_frame.shape[-2:]
+        self.ori_size = (H0, W0)
+        f = self._net_frame(first_frame)
+        h, w = f.shape[-2:]
+        m = first_mask_onehot.to(torch.float32).contiguous()
+        if (h, w) != (H0, W0):
+            m = ops.resize_nearest(m, h, w)                      # TF.resize(mask, 480, NEAREST) (:89)
+        k, v = self.model.memorize(f, m)
+        self.fb.init_bank(k, v)
+        self.t = 0
+        self._label_dev = torch.empty(H0, W0, dtype=torch.uint8, device=self.device)
+        self._pinned = torch.empty(H0, W0, dtype=torch.uint8).pin_memory()
+        self._stats_pinned = torch.zeros(self.obj_n, 4, dtype=torch.int32).pin_memory()
+
+    def step(self, frame, want_label=True):
+        """One iteration of the hot loop (:105-115).  frame f32[1,3,H0,W0] on the GPU.
+        Returns the uint8 label map [H0,W0] as a pinned host tensor (valid until the next step)."""
+        self.t += 1
+        f = self._net_frame(frame)
+        score, _ = self.model.segment(f, self.fb)                 # :108
+        pred_mask = ops.softmax_objects(score)                    # :109
+        if self.t % self.mem_every == 0:
+            k, v = self.model.memorize(f, pred_mask)              # :111 (soft masks are memorised)
+            self.fb.update(k, v, self.t)                          # :112
+        H0, W0 = self.ori_size
+        ops.resize_argmax(pred_mask, H0, W0, out=self._label_dev)  # :114-115
+        # single sync point of the frame: labels + bank bookkeeping
+        self._pinned.copy_(self._label_dev, non_blocking=True)
+        self._stats_pinned.copy_(self.fb.stats_device(), non_blocking=True)
+        torch.cuda.current_stream().synchronize()
+        self.fb.absorb_stats(self._stats_pinned)
+        return self._pinned if want_label else None
+
+    def bank_sizes(self):
+        return list(self.fb._len_host)
+
+
+def run_clip(model, frames, first_mask_u8, budget=250000, update_rate=0.1, thres_close=0.95, size=480,
+             mem_every=1, postprocess=False):
+    """frames f32[T,3,H0,W0] on the GPU, first mask u8[H0,W0] (>0 = water).
+    Returns labels u8[T,H0,W0] (host; frame 0 = the given mask) and per-frame bank sizes."""
+    T, _, H0, W0 = frames.shape
+    m = (first_mask_u8 > 0).to(torch.uint8)
+    onehot = torch.stack([1 - m, m], 0).unsqueeze(0).to(frames.device)        # Water_DS.py:93-101
+    runner = ClipRunner(model, 2, budget, update_rate, thres_close, size, mem_every)
+    runner.start(frames[0:1], onehot)
+    labels = torch.empty(T, H0, W0, dtype=torch.uint8)
+    labels[0] = m.cpu()
+    sizes = []
+    for t in range(1, T):
+        lab = runner.step(frames[t:t + 1])
+        if postprocess:
+            labels[t] = torch.from_numpy(postprocessing_pred(lab.numpy()))
+        else:
+            labels[t].copy_(lab)
+        sizes.append(runner.bank_sizes())
+    return dict(labels=labels, bank_sizes=sizes, fb=runner.fb)
+
+
+def main(args, device):
+    """test_video_seg.py:41-123."""
+    model = AFB_URR(device, update_bank=True, load_imagenet_params=False)
+    model = model.to(device)
+    model.eval()
+
+    downsample_size = getattr(args, 'size', 480)
+
+    if os.path.isfile(args.model_path):
+        checkpoint = torch.load(args.model_path, map_location='cpu')
+        end_epoch = checkpoint['epoch']
+        model.load_state_dict(checkpoint['model'], strict=False)
+        train_loss = checkpoint['loss']
+        seed = checkpoint['seed']
+        print(gct(), f'Loaded checkpoint {args.model_path}. (end_epoch: {end_epoch}, train_loss: {train_loss}, seed: {seed})')
+    else:
+        print(gct(), f'No checkpoint found at {args.model_path}')
+        raise IOError
+
+    img_list = sorted(glob(os.path.join(args.test_path, '*.jpg')) + glob(os.path.join(args.test_path, '*.png')))
+    first_frame = load_image_in_PIL(img_list[0])
+    first_name = os.path.basename(img_list[0])[:-4]
+
+    out_dir = './output/segs'
+    mask_dir = os.path.join(out_dir, args.test_name, 'mask')
+    mask_path = os.path.join(mask_dir, first_name + '.png')
+    if not os.path.exists(mask_path):
+        # test_video_seg.py:67-69 bootstraps the mask with the LinkNet image model (test_image_seg.py),
+        # whose weights / package are not part of this path.
+        raise IOError(f'first-frame mask {mask_path} not found: provide it (e.g. from test_image_seg.py)')
+
+    first_mask = load_image_in_PIL(mask_path, 'P')
+    seq_dataset = Video_DS(img_list, first_frame, first_mask)
+    seq_loader = torch.utils.data.DataLoader(seq_dataset, batch_size=1, shuffle=False, num_workers=1)
+
+    seg_dir = os.path.join(out_dir, args.test_name, 'mask')
+    os.makedirs(seg_dir, exist_ok=True)
+    if args.viz:
+        overlay_dir = os.path.join(out_dir, args.test_name, 'overlay')
+        os.makedirs(overlay_dir, exist_ok=True)
+
+    obj_n = seq_dataset.obj_n
+    runner = ClipRunner(model, obj_n, args.budget, update_rate=args.update_rate, thres_close=args.merge_thres,
+                        size=downsample_size, mem_every=getattr(args, 'mem_every', 1))
+
+    ori_first_frame = seq_dataset.first_frame.unsqueeze(0).to(device)
+    ori_first_mask = seq_dataset.first_mask.unsqueeze(0).to(device)
+
+    pred = seq_dataset.first_mask.numpy().argmax(0).astype(np.uint8)          # :91
+    seg_path = os.path.join(seg_dir, f'{first_name}.png')
+    save_seg_mask(pred, seg_path, color_palette)
+    if args.viz:
+        overlay_path = os.path.join(overlay_dir, f'{first_name}.png')
+        save_overlay(ori_first_frame[0], pred, overlay_path, color_palette)
+
+    with torch.no_grad():
+        runner.start(ori_first_frame, ori_first_mask)
+        for idx, (frame, frame_name) in enumerate(seq_loader):
+            ori_frame = frame.to(device)
+            lab = runner.step(ori_frame)
+            pred = postprocessing_pred(lab.numpy())
+            seg_path = os.path.join(seg_dir, f'{frame_name[0]}.png')
+            save_seg_mask(pred, seg_path, color_palette)
+            if args.viz:
+                overlay_path = os.path.join(overlay_dir, f'{frame_name[0]}.png')
+                save_overlay(ori_frame[0], pred, overlay_path, color_palette)
+
+    runner.fb.print_peak_mem()
+    return runner
+
+
+if __name__ == '__main__':
+    args = get_args()
+    print(gct(), 'Args =', args)
+    if args.gpu >= 0 and torch.cuda.is_available():
+        device = torch.device('cuda', args.gpu)
+    else:
+        raise ValueError('CUDA is required. --gpu must be >= 0.')
+    assert os.path.isdir(args.test_path)
+    main(args, device)
+    print(gct(), 'Test video segmentation done.')
