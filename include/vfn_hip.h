@@ -48,6 +48,10 @@ typedef struct vfn_conv_desc {
     int KH, KW, stride, pad;
     int relu_in, relu_out;
     int M;                /* N*Ho*Wo */
+    int ksplit;           /* <= 1: single pass.  > 1: K is cut into ksplit slices (one grid row each), raw
+                             partial sums go to `partial` and a second kernel reduces them in fixed order
+                             and applies the epilogue -- for layers with too few output tiles to fill 256 CUs */
+    float* partial;       /* [ksplit][M][Cout] workspace when ksplit > 1 */
 } vfn_conv_desc;
 
 int vfn_conv_cfg_count(void);

@@ -45,3 +45,14 @@ def test_conv_matches_torch_cpu(gpu, case):
         got = y.permute(0, 3, 1, 2).cpu()
         err = (got - ref).abs().max().item()
         assert err < 2e-4 * max(1.0, ref.abs().max().item()), f'cfg {cfg}: max err {err}'
+    # split-K variants (partial slabs + fixed-order reduce)
+    ws = torch.empty(8 * ref.numel(), device=gpu)
+    y = torch.empty(N, ref.shape[2], ref.shape[3], Cout, device=gpu)
+    d = ops.make_conv_desc(xd, wp, Cout, k, k, s, k // 2, y, scale.to(gpu), shift.to(gpu), resd, relu_in, relu_out)
+    for ks in ops.valid_splits(d, 8)[1:]:
+        y.zero_()
+        ops.set_splitk(d, ks, ws)
+        ops.conv2d_launch(d, 3)
+        torch.cuda.synchronize()
+        err = (y.permute(0, 3, 1, 2).cpu() - ref).abs().max().item()
+        assert err < 2e-4 * max(1.0, ref.abs().max().item()), f'split {ks}: max err {err}'

@@ -22,7 +22,8 @@ class ConvDesc(C.Structure):
                 ('Ho', C.c_int), ('Wo', C.c_int), ('Cout', C.c_int), ('cout_pad', C.c_int),
                 ('out_ld', C.c_int), ('res_ld', C.c_int),
                 ('KH', C.c_int), ('KW', C.c_int), ('stride', C.c_int), ('pad', C.c_int),
-                ('relu_in', C.c_int), ('relu_out', C.c_int), ('M', C.c_int)]
+                ('relu_in', C.c_int), ('relu_out', C.c_int), ('M', C.c_int), ('ksplit', C.c_int),
+                ('partial', c_fp)]
 
 
 class StemDesc(C.Structure):

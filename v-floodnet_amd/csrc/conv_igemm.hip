@@ -57,7 +57,12 @@ void conv_igemm_kernel(const vfn_conv_desc p) {
     const int HoWo = p.Ho * p.Wo;
     const int cblks = p.Cin / BK;
     const int Ktot = p.KH * p.KW * p.Cin;
-    const int nk = p.KH * p.KW * cblks;
+    const int nk_all = p.KH * p.KW * cblks;
+    // split-K: blockIdx.y owns K tiles [kt_begin, kt_begin + nk)
+    const int ksplit = p.ksplit > 1 ? p.ksplit : 1;
+    const int kper = (nk_all + ksplit - 1) / ksplit;
+    const int kt_begin = blockIdx.y * kper;
+    const int nk = min(kper, nk_all - kt_begin);
 
     // per-thread staging coordinates
     const int c16 = tid & 7;               // chunk column (4 floats)
@@ -88,35 +93,43 @@ void conv_igemm_kernel(const vfn_conv_desc p) {
         wrow[j] = p.w + (size_t)(n0 + r0 + j * RSTEP) * Ktot + c16 * 4;
 
     f32x4 ra[AC], rb[BC];
-    int kh = 0, kw = 0, cb = 0;            // tap / channel block of the tile being *loaded*
+    bool a_ok[AC];
+    int kh, kw, cb;                        // tap / channel block of the tile being *loaded*
+    {
+        const int tap = kt_begin / cblks;
+        cb = kt_begin - tap * cblks;
+        kh = tap / p.KW;
+        kw = tap - kh * p.KW;
+    }
 
+    // Loads are unconditional (out-of-image taps read pixel 0 of the image and are zeroed when the
+    // tile is written to LDS): no branch and no s_waitcnt sits between the load issue and the MFMAs.
     auto load_tile = [&](int kt) {
 #pragma unroll
         for (int j = 0; j < AC; ++j) {
             const int hi = a_hi0[j] + kh, wi = a_wi0[j] + kw;
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if ((unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W) {
-                const float* src = p.in + (size_t)(a_base[j] + hi * p.W + wi) * p.in_ld + cb * BK + c16 * 4;
-                v = *reinterpret_cast<const f32x4*>(src);
-                if (p.relu_in) {
-                    v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f);
-                    v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
-                }
-            }
-            ra[j] = v;
+            a_ok[j] = (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;
+            const int pix = a_ok[j] ? a_base[j] + hi * p.W + wi : 0;
+            ra[j] = *reinterpret_cast<const f32x4*>(p.in + (size_t)pix * p.in_ld + cb * BK + c16 * 4);
         }
 #pragma unroll
         for (int j = 0; j < BC; ++j)
             rb[j] = *reinterpret_cast<const f32x4*>(wrow[j] + (size_t)kt * BK);
         if (++cb == cblks) { cb = 0; if (++kw == p.KW) { kw = 0; ++kh; } }
     };
+    const float relu_floor = p.relu_in ? 0.f : -INFINITY;
     auto store_tile = [&](int buf) {
         float* dA = sA + buf * BM * BK;
         float* dB = sB + buf * BN * BK;
 #pragma unroll
         for (int j = 0; j < AC; ++j) {
             const int r = r0 + j * RSTEP;
-            *reinterpret_cast<f32x4*>(dA + r * BK + ((c16 ^ ((r >> 1) & 7)) << 2)) = ra[j];
+            f32x4 v = ra[j];
+            v.x = a_ok[j] ? fmaxf(v.x, relu_floor) : 0.f;
+            v.y = a_ok[j] ? fmaxf(v.y, relu_floor) : 0.f;
+            v.z = a_ok[j] ? fmaxf(v.z, relu_floor) : 0.f;
+            v.w = a_ok[j] ? fmaxf(v.w, relu_floor) : 0.f;
+            *reinterpret_cast<f32x4*>(dA + r * BK + ((c16 ^ ((r >> 1) & 7)) << 2)) = v;
         }
 #pragma unroll
         for (int j = 0; j < BC; ++j) {
@@ -133,41 +146,69 @@ void conv_igemm_kernel(const vfn_conv_desc p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    load_tile(0);
-    store_tile(0);
+    if (nk > 0) {
+        load_tile(kt_begin);
+        store_tile(0);
+    }
     __syncthreads();
 
     for (int kt = 0; kt < nk; ++kt) {
         const int buf = kt & 1;
-        if (kt + 1 < nk) load_tile(kt + 1);
+        if (kt + 1 < nk) load_tile(kt_begin + kt + 1);
 
         const float* cA = sA + buf * BM * BK + (wm * TM * 32) * BK;
         const float* cB = sB + buf * BN * BK + (wn * TN * 32) * BK;
-#pragma unroll
-        for (int kk = 0; kk < 4; ++kk) {
+        // fragment reads run one k-group ahead of the MFMAs that consume them
+        f32x4 a[2][TM], b[2][TN];
+        auto read_frags = [&](int kk, int slot) {
             const int lc = 2 * kk + lh;
-            f32x4 a[TM], b[TN];
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
                 const int r = i * 32 + li;      // (wm*TM*32) is a multiple of 32: swizzle bits unchanged
-                a[i] = *reinterpret_cast<const f32x4*>(cA + r * BK + ((lc ^ ((r >> 1) & 7)) << 2));
+                a[slot][i] = *reinterpret_cast<const f32x4*>(cA + r * BK + ((lc ^ ((r >> 1) & 7)) << 2));
             }
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
                 const int r = j * 32 + li;
-                b[j] = *reinterpret_cast<const f32x4*>(cB + r * BK + ((lc ^ ((r >> 1) & 7)) << 2));
+                b[slot][j] = *reinterpret_cast<const f32x4*>(cB + r * BK + ((lc ^ ((r >> 1) & 7)) << 2));
             }
+        };
+        read_frags(0, 0);
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            const int cur = kk & 1;
+            if (kk + 1 < 4) read_frags(kk + 1, cur ^ 1);
 #pragma unroll
             for (int t = 0; t < 4; ++t)
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
                     for (int j = 0; j < TN; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][t], b[j][t], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[cur][i][t], b[cur][j][t], acc[i][j], 0, 0, 0);
         }
 
         if (kt + 1 < nk) store_tile(buf ^ 1);
         __syncthreads();
+    }
+
+    // split-K: raw partial sums to the workspace slab of this split; vfn_conv_splitk_reduce finishes
+    if (ksplit > 1) {
+        float* part = p.partial + (size_t)blockIdx.y * p.M * p.Cout;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int col = n0 + (wn * TN + j) * 32 + li;
+            if (col >= p.Cout) continue;
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const int rbase = m0 + (wm * TM + i) * 32 + 4 * lh;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = rbase + (r & 3) + 8 * (r >> 2);
+                    if (row < p.M) part[(size_t)row * p.Cout + col] = acc[i][j][r];
+                }
+            }
+        }
+        return;
     }
 
     // epilogue: lane holds filter column (lane&31) for rows (reg&3)+8*(reg>>2)+4*(lane>>5)
@@ -194,6 +235,32 @@ void conv_igemm_kernel(const vfn_conv_desc p) {
     }
 }
 
+// out = act((sum over splits, fixed order) * scale + shift + res)
+__global__ void splitk_reduce_kernel(const vfn_conv_desc p) {
+    const int c4n = p.Cout / 4;
+    const size_t total = (size_t)p.M * c4n;
+    const size_t slab = (size_t)p.M * p.Cout;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int c4 = i % c4n;
+        const size_t row = i / c4n;
+        f32x4 a = *reinterpret_cast<const f32x4*>(p.partial + row * p.Cout + c4 * 4);
+        for (int sp = 1; sp < p.ksplit; ++sp)
+            a += *reinterpret_cast<const f32x4*>(p.partial + sp * slab + row * p.Cout + c4 * 4);
+        f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
+        if (p.scale) sc = *reinterpret_cast<const f32x4*>(p.scale + c4 * 4);
+        if (p.shift) sh = *reinterpret_cast<const f32x4*>(p.shift + c4 * 4);
+        f32x4 v;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[k] = a[k] * sc[k] + sh[k];
+        if (p.res) v += *reinterpret_cast<const f32x4*>(p.res + row * p.res_ld + c4 * 4);
+        if (p.relu_out) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) v[k] = fmaxf(v[k], 0.f);
+        }
+        *reinterpret_cast<f32x4*>(p.out + row * p.out_ld + c4 * 4) = v;
+    }
+}
+
 template <int BM, int BN, int WM, int WN>
 int launch_cfg(const vfn_conv_desc& p, hipStream_t s) {
     constexpr int NT = WM * WN * 64;
@@ -206,7 +273,13 @@ int launch_cfg(const vfn_conv_desc& p, hipStream_t s) {
     }
     const int m_tiles = cdiv(p.M, BM);
     const int n_tiles = cdiv(p.Cout, BN);
-    hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN>), dim3(m_tiles * n_tiles), dim3(NT), lds, s, p);
+    const int ks = p.ksplit > 1 ? p.ksplit : 1;
+    hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN>), dim3(m_tiles * n_tiles, ks), dim3(NT), lds, s, p);
+    if (ks > 1) {
+        const size_t total = (size_t)p.M * (p.Cout / 4);
+        const int blocks = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
+        hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, s, p);
+    }
     return vfn_check_launch();
 }
 
@@ -227,6 +300,11 @@ extern "C" int vfn_conv2d_nhwc_f32(const vfn_conv_desc* d, int cfg, void* stream
     int bm, bn;
     if (vfn_conv_cfg_tile(cfg, &bm, &bn) != VFN_OK) return VFN_ERR_ARG;
     if (d->cout_pad < cdiv(d->Cout, bn) * bn) return VFN_ERR_ARG;
+    if (d->ksplit > 1) {
+        const int nk_all = d->KH * d->KW * (d->Cin / BK);
+        if (!d->partial || d->Cout % 4 || d->out_ld % 4 || (d->res && d->res_ld % 4)) return VFN_ERR_ARG;
+        if (cdiv(nk_all, d->ksplit) * (d->ksplit - 1) >= nk_all) return VFN_ERR_ARG;   // every split non-empty
+    }
     hipStream_t s = (hipStream_t)stream;
     switch (cfg) {
         case 0: return launch_cfg<128, 128, 2, 2>(*d, s);

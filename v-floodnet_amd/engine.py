@@ -42,14 +42,18 @@ def pad_divide_by(h, w, d=16):
     return (lw, uw, lh, uh), new_h, new_w
 
 
+WS_FLOATS = 16 * 1024 * 1024        # split-K workspace (64 MB), shared by all launches of a plan
+
+
 def choose_cfg(M, cout, K):
-    """Pick the tile config that minimises (rounds over 256 CUs) x (tile work / efficiency)."""
+    """(tile config, split-K factor) minimising (rounds over 256 CUs) x (tile work / efficiency)."""
     global _CFG_TILES
     key = (M, cout, K)
     if key in _TUNED:
         return _TUNED[key]
     if _CFG_TILES is None:
         _CFG_TILES = ops.conv_cfg_tiles()
+    nk = K // 32
     best, best_cost = 0, None
     for c, (bm, bn) in enumerate(_CFG_TILES):
         if bn > 32 and cout <= 32:
@@ -61,7 +65,16 @@ def choose_cfg(M, cout, K):
         cost = rounds * bm * bn / _CFG_EFF[(bm, bn)]
         if best_cost is None or cost < best_cost:
             best, best_cost = c, cost
-    return best
+    c = 2 if cout >= 128 else 3                           # 64x128 / 64x64
+    bm, bn = _CFG_TILES[c]
+    blocks = ((M + bm - 1) // bm) * ((cout + bn - 1) // bn)
+    if blocks < 200 and nk >= 16 and cout % 4 == 0 and cout >= 64:
+        # too few output tiles for 256 CUs: cut K (measured on MI355X: 28 -> 60 TFLOP/s at M=1620, K=2304)
+        ks = max(1, min(16, (448 + blocks - 1) // blocks, nk // 4))
+        while ks > 1 and (((nk + ks - 1) // ks) * (ks - 1) >= nk or ks * M * cout > WS_FLOATS):
+            ks -= 1
+        return (c, ks)
+    return (best, 1)
 
 
 class ConvLayer:
@@ -136,6 +149,7 @@ class FramePlan:
         self.l2 = [f(K, self.h2, self.w2, 32) for _ in range(3)]
         self.qq = f(K, self.h2, self.w2, 2)
         self.score = f(1, K, H0, W0)
+        self.ws = f(WS_FLOATS)
 
         self.seg_pre = []     # stem .. KeyValue
         self.seg_post = []    # decoder
@@ -165,7 +179,9 @@ class FramePlan:
                                cin=layer.cin, in_ld=in_ld if in_ld is not None else x.shape[-1],
                                out_ld=out_ld, N=N, H=H, W=Wd)
         K = layer.k * layer.k * layer.cin
-        cfg = choose_cfg(d.M, layer.cout, K)
+        cfg, ks = choose_cfg(d.M, layer.cout, K)
+        if ks > 1 and d.out_ld % 4 == 0 and (res is None or d.res_ld % 4 == 0):
+            ops.set_splitk(d, ks, self.ws)
         lst.append(Launch(ops.conv2d_launch, (d, cfg), f'{name}[{d.M}x{layer.cout}x{K}]', 2.0 * d.M * layer.cout * K))
         return out
 
@@ -392,6 +408,18 @@ class Engine:
                     key = (d.M, d.Cout, d.KH * d.KW * d.Cin)
                     seen.setdefault(key, []).append(l)
         tiles = ops.conv_cfg_tiles()
+
+        def timeit(d, c):
+            ops.conv2d_launch(d, c)
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(iters):
+                ops.conv2d_launch(d, c)
+            e1.record()
+            torch.cuda.synchronize()
+            return e0.elapsed_time(e1)
+
         for key, launches in seen.items():
             d = launches[0].args[0]
             best, best_t = None, None
@@ -400,18 +428,17 @@ class Engine:
                     continue
                 if bn > 64 and d.Cout <= 32:
                     continue
-                ops.conv2d_launch(d, c)
-                torch.cuda.synchronize()
-                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                e0.record()
-                for _ in range(iters):
-                    ops.conv2d_launch(d, c)
-                e1.record()
-                torch.cuda.synchronize()
-                t = e0.elapsed_time(e1)
-                if best_t is None or t < best_t:
-                    best, best_t = c, t
+                blocks = ((d.M + bm - 1) // bm) * ((d.Cout + bn - 1) // bn)
+                splits = [1]
+                if blocks < 256:
+                    splits += [k_ for k_ in ops.valid_splits(d, 16)[1:] if k_ * d.M * d.Cout <= WS_FLOATS]
+                for ks in splits:
+                    ops.set_splitk(d, ks, p.ws)
+                    t = timeit(d, c)
+                    if best_t is None or t < best_t:
+                        best, best_t = (c, ks), t
             _TUNED[key] = best
             for l in launches:
-                l.args = (l.args[0], best)
+                ops.set_splitk(l.args[0], best[1], p.ws)
+                l.args = (l.args[0], best[0])
         return dict(_TUNED)

@@ -52,8 +52,32 @@ def make_conv_desc(x, wp, cout, kh, kw, stride, pad, out, scale=None, shift=None
     d.KH, d.KW, d.stride, d.pad = kh, kw, stride, pad
     d.relu_in, d.relu_out = int(relu_in), int(relu_out)
     d.M = N * Ho * Wo
+    d.ksplit, d.partial = 1, None
     assert wp.shape[1] == kh * kw * cin
     return d
+
+
+def set_splitk(desc, ksplit, workspace):
+    """Cut K into ``ksplit`` slices (``workspace``: float32 tensor with >= ksplit*M*Cout elements)."""
+    if ksplit > 1:
+        assert workspace is not None and workspace.numel() >= ksplit * desc.M * desc.Cout
+        desc.ksplit, desc.partial = int(ksplit), ptr(workspace)
+    else:
+        desc.ksplit, desc.partial = 1, None
+    return desc
+
+
+def valid_splits(desc, max_split=16):
+    """Split factors for which every K slice is non-empty and the epilogue can run vectorised."""
+    nk = desc.KH * desc.KW * (desc.Cin // 32)
+    out = [1]
+    if desc.Cout % 4 or desc.out_ld % 4 or (desc.res and desc.res_ld % 4):
+        return out
+    for s_ in range(2, max_split + 1):
+        per = (nk + s_ - 1) // s_
+        if per * (s_ - 1) < nk and per >= 4:
+            out.append(s_)
+    return out
 
 
 def conv2d_launch(desc, cfg):
