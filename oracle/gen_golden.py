@@ -105,8 +105,8 @@ def main():
         # ---- (c) FeatureBank.update regimes ---------------------------------------------------------
         for regime, rs in {'append': 1, 'merge': 2, 'mixed': 3, 'evict': 4}.items():
             g = torch.Generator().manual_seed(rs)
-            hw = 60
-            budget = 250000 if regime != 'evict' else 400          # class_budget 0.8*200 = 160
+            hw = 24
+            budget = 250000 if regime != 'evict' else 160          # class_budget 0.8*80 = 64
             k0 = [torch.randn(128, hw, generator=g) for _ in range(2)]
             v0 = [torch.randn(512, hw, generator=g) for _ in range(2)]
             fb = ref.FeatureBank(2, budget, cpu, update_rate=0.1, thres_close=0.95)
@@ -134,9 +134,12 @@ def main():
                     steps[f'bump_{t}_{i}'] = bump[i].numpy()
                 fb.update([x.clone() for x in k1], [x.clone() for x in v1], t)
                 for i in range(2):
-                    steps[f'keys_{t}_{i}'] = fb.keys[i].numpy().copy()
-                    steps[f'values_{t}_{i}'] = fb.values[i].numpy().copy()
                     steps[f'info_{t}_{i}'] = fb.info[i].numpy().copy()
+                    steps[f'keysum_{t}_{i}'] = np.array(checksum(fb.keys[i]))
+                    steps[f'valsum_{t}_{i}'] = np.array(checksum(fb.values[i]))
+                    if t == 4:
+                        steps[f'keys_{t}_{i}'] = fb.keys[i].numpy().copy()
+                        steps[f'values_{t}_{i}'] = fb.values[i].numpy().copy()
             np.savez_compressed(os.path.join(OUT, f'bank_{regime}.npz'), k0=torch.stack(k0).numpy(),
                                 v0=torch.stack(v0).numpy(), budget=np.array(budget), peak_n=fb.peak_n,
                                 replace_n=fb.replace_n, **steps)

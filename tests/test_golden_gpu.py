@@ -1,0 +1,112 @@
+"""The HIP path against the reference's golden vectors directly (not through the oracle)."""
+import numpy as np
+import pytest
+import torch
+
+from golden_util import load, state_dict, t, close_logits, miou
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def model(gpu):
+    from vfloodnet_amd import AFB_URR
+    m = AFB_URR(gpu, update_bank=True).to(gpu).eval()
+    m.load_state_dict(state_dict(), strict=True)
+    return m
+
+
+@pytest.mark.parametrize('tag', ['96x160', '90x150'])
+def test_blocks(gpu, model, tag):
+    from vfloodnet_amd import FeatureBank, ops
+    g = load(f'blocks_{tag}.npz')
+    frames, m0 = t(g['frames']).to(gpu), t(g['mask'])
+    H, W = frames.shape[-2:]
+    oh = torch.stack([1 - m0, m0], 0).unsqueeze(0).to(gpu)
+    k, v = model.memorize(frames[0:1], oh)
+    assert (torch.stack([x.cpu() for x in k]) - t(g['key0'])).abs().max() < 5e-4
+    assert (torch.stack([x.cpu() for x in v]) - t(g['val0'])).abs().max() < 5e-4
+    fb = FeatureBank(2, 250000, gpu)
+    fb.init_bank(k, v)
+    score, _ = model.segment(frames[1:2], fb)
+    ok, dl, dp = close_logits(score.cpu(), t(g['score']), 1e-3)
+    assert ok, (dl, dp)
+    p = model.engine().plan(H, W, 2)
+    for n, buf in dict(r1=p.q['r1'], r2=p.q['res2']['out'], r3=p.q['res3']['out'], r4=p.q['res4']['out']).items():
+        x = buf.permute(0, 3, 1, 2).contiguous().cpu()
+        assert (x.flatten()[t(g[n + '_idx'])] - t(g[n + '_val'])).abs().max() < 5e-4, n
+    assert (fb.info[0].cpu() - t(g['info0'])).abs().max() < 0.05
+    pm = ops.softmax_objects(score)
+    k2, v2 = model.memorize(frames[1:2], pm)
+    assert (torch.stack([x.cpu() for x in k2]) - t(g['key1'])).abs().max() < 2e-3
+    ref_lab = t(g['score'])[0].argmax(0)
+    margin = (t(g['score'])[0, 1] - t(g['score'])[0, 0]).abs()
+    assert torch.equal(score.cpu()[0].argmax(0)[margin > 1e-2], ref_lab[margin > 1e-2])
+
+
+@pytest.mark.parametrize('regime', ['append', 'merge', 'mixed', 'evict'])
+def test_bank_update(gpu, regime):
+    from vfloodnet_amd import FeatureBank
+    g = load(f'bank_{regime}.npz')
+    k0, v0 = t(g['k0']).to(gpu), t(g['v0']).to(gpu)
+    fb = FeatureBank(2, int(g['budget']), gpu, 0.1, 0.95)
+    fb.init_bank([k0[i] for i in range(2)], [v0[i] for i in range(2)])
+    for step in range(1, 5):
+        for i in range(2):
+            fb.info[i][:, 1] += t(g[f'bump_{step}_{i}']).to(gpu)
+        k1, v1 = t(g[f'k1_{step}']).to(gpu), t(g[f'v1_{step}']).to(gpu)
+        fb.update([k1[i] for i in range(2)], [v1[i] for i in range(2)], step)
+        for i in range(2):
+            assert tuple(fb.info[i].shape) == g[f'info_{step}_{i}'].shape, (regime, step)
+            assert (fb.info[i].cpu() - t(g[f'info_{step}_{i}'])).abs().max() < 1e-5
+    for i in range(2):
+        assert (fb.keys[i].cpu() - t(g[f'keys_4_{i}'])).abs().max() < 1e-4
+        assert (fb.values[i].cpu() - t(g[f'values_4_{i}'])).abs().max() < 1e-4
+    assert np.array_equal(fb.peak_n, g['peak_n']) and np.array_equal(fb.replace_n, g['replace_n'])
+
+
+def test_main_loop_pngs(gpu, tmp_path, monkeypatch):
+    """vfloodnet_amd.video_seg.main on PNG frames == the PNGs the reference's main() wrote."""
+    import argparse
+    from PIL import Image
+    from vfloodnet_amd import video_seg, synth
+    from vfloodnet_amd.data import save_seg_mask, color_palette
+    g = load('main_loop_120x200.npz')
+    H, W = [int(x) for x in g['shape']]
+    labels = np.unpackbits(g['labels'], axis=-1)[..., :W]
+    fdir = tmp_path / 'frames'
+    fdir.mkdir()
+    for i, fr in enumerate(g['frames_u8']):
+        Image.fromarray(fr.transpose(1, 2, 0)).save(str(fdir / f'{i:05d}.png'))
+    ckpt = str(tmp_path / 'ckpt.pth')
+    torch.save({'epoch': 0, 'model': state_dict(), 'loss': 0.0, 'seed': 20200212}, ckpt)
+    monkeypatch.chdir(tmp_path)
+    (tmp_path / 'output' / 'segs' / 'clip' / 'mask').mkdir(parents=True)
+    save_seg_mask(g['mask'], str(tmp_path / 'output' / 'segs' / 'clip' / 'mask' / '00000.png'), color_palette)
+    args = argparse.Namespace(gpu=0, budget=250000, viz=True, model_path=ckpt, update_rate=0.1, merge_thres=0.95,
+                              test_path=str(fdir), test_name='clip')
+    video_seg.main(args, gpu)
+    for i in range(len(labels)):
+        im = Image.open(str(tmp_path / 'output' / 'segs' / 'clip' / 'mask' / f'{i:05d}.png'))
+        assert im.mode == 'P' and im.getpalette()[:12] == [int(x) for x in g['palette'][:12]]
+        assert miou(torch.from_numpy(np.array(im)), torch.from_numpy(labels[i])) > 0.995, i
+    ov = np.array(Image.open(str(tmp_path / 'output' / 'segs' / 'clip' / 'overlay' / '00001.png')))
+    assert ov.shape == g['overlay1'].shape
+    assert (np.abs(ov.astype(int) - g['overlay1'].astype(int)) > 1).mean() < 0.01
+
+
+def test_full_size_samples(gpu, model):
+    from vfloodnet_amd import synth, FeatureBank
+    g = load('full_480x854.npz')
+    frames, m0 = synth.clip(1, 2, 480, 854)
+    oh = synth.onehot(m0).unsqueeze(0)
+    k, v = model.memorize(frames[0:1].to(gpu), oh.to(gpu))
+    for i in range(2):
+        assert (k[i].cpu().flatten()[t(g['key_idx'])] - t(g['key_val'][i])).abs().max() < 1e-3
+        assert (v[i].cpu().flatten()[t(g['val_idx'])] - t(g['val_val'][i])).abs().max() < 1e-3
+    fb = FeatureBank(2, 250000, gpu)
+    fb.init_bank(k, v)
+    score, _ = model.segment(frames[1:2].to(gpu), fb)
+    ok, dl, dp = close_logits(score.cpu().flatten()[t(g['score_idx'])], t(g['score_val']), 2e-3)
+    assert ok, (dl, dp)
+    assert abs(float((score[0, 1] > score[0, 0]).float().mean()) - float(g['label_water_frac'])) < 2e-3

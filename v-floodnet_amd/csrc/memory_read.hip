@@ -18,9 +18,12 @@
 //
 // Layout: bank entry-major K [cap][128], V [cap][512]; queries / new keys [HW][ld].
 // Tiling: one workgroup = 64 query columns x one slice of the bank, walked in chunks of
-// 128 entries; 4 waves, wave w owns chunk rows 32w..32w+31 for the score GEMM
-// (A = bank rows, B = queries) and value channels 128w..128w+127 for P^T V
-// (A = P^T read back from LDS, B = value rows straight from global memory).
+// 64 entries; 4 waves.  Score GEMM (A = bank rows, B = queries): wave (wr, wq) owns chunk
+// rows 32wr.. x query columns 32wq...  P^T V (A = P^T read back from LDS, B = value rows
+// straight from global memory, prefetched one k-group ahead): wave w owns value channels
+// 128w..128w+127 for all 64 queries.  The next chunk's keys are fetched into registers
+// before the score GEMM and written to LDS behind it, so no load sits on the critical path.
+// 64-80 KB of LDS -> two workgroups per CU (two waves per SIMD cover each other's barriers).
 // Blocks of one bank slice share blockIdx % 8, i.e. one XCD's L2 (speed only).
 #include "common.h"
 #include "../../include/vfn_hip.h"
@@ -29,10 +32,34 @@ namespace {
 
 constexpr int DK = 128, DV = 512;
 constexpr int QT = 64;      // query columns per workgroup
-constexpr int CH = 128;     // bank entries per chunk
+constexpr int CH = 64;      // bank entries per chunk
 
 // [rows][128 floats] LDS image, 16-byte chunk index XOR (row & 15): conflict-free b128 fragment reads
 __device__ __forceinline__ int swz(int row, int chunk) { return row * DK + ((chunk ^ (row & 15)) << 2); }
+
+// [rows][64 floats] image (P^T): chunk index 0..15 XOR (row & 15)
+__device__ __forceinline__ int swz64(int row, int chunk) { return row * CH + ((chunk ^ (row & 15)) << 2); }
+
+// one 64 x 128 chunk = 2048 float4 = 8 per thread: global -> registers, registers -> LDS
+struct ChunkRegs { f32x4 v[8]; };
+__device__ __forceinline__ void chunk_load(ChunkRegs& R, const float* src, int valid, int tid) {
+    const int c = tid & 31;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int r = (tid >> 5) + 8 * j;
+        const int rr = r < valid ? r : 0;                         // clamp: no branch around the load
+        R.v[j] = *reinterpret_cast<const f32x4*>(src + (size_t)rr * DK + c * 4);
+        if (r >= valid) R.v[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+}
+__device__ __forceinline__ void chunk_store(const ChunkRegs& R, float* dst, int tid) {
+    const int c = tid & 31;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int r = (tid >> 5) + 8 * j;
+        *reinterpret_cast<f32x4*>(dst + swz(r, c)) = R.v[j];
+    }
+}
 
 // stage `rows` x 128 floats (row r from src + r*ld, zero past `valid` rows) into an LDS image
 __device__ __forceinline__ void stage_rows(float* dst, const float* src, size_t ld, int rows, int valid, int tid) {
@@ -44,22 +71,24 @@ __device__ __forceinline__ void stage_rows(float* dst, const float* src, size_t 
     }
 }
 
-// scores for this wave's 32 chunk rows x 64 query columns: acc[tn][r], row = (r&3)+8*(r>>2)+4*lh
-__device__ __forceinline__ void score_tile(const float* sK, const float* sQ, int wave, int li, int lh, f32x16 (&acc)[2]) {
+// scores for this wave's 32 chunk rows (32*wr..) x 32 query columns (32*wq..): acc[r], row = (r&3)+8*(r>>2)+4*lh
+__device__ __forceinline__ void score_tile(const float* sK, const float* sQ, int wr, int wq, int li, int lh, f32x16& acc) {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) { acc[0][r] = 0.f; acc[1][r] = 0.f; }
-    const int ra = wave * 32 + li;
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    const int ra = wr * 32 + li, rq = wq * 32 + li;
+    f32x4 a[2], b[2];
+    a[0] = *reinterpret_cast<const f32x4*>(sK + swz(ra, lh));
+    b[0] = *reinterpret_cast<const f32x4*>(sQ + swz(rq, lh));
 #pragma unroll
     for (int kk = 0; kk < 16; ++kk) {
-        const int lc = 2 * kk + lh;
-        const f32x4 a = *reinterpret_cast<const f32x4*>(sK + swz(ra, lc));
-        const f32x4 b0 = *reinterpret_cast<const f32x4*>(sQ + swz(li, lc));
-        const f32x4 b1 = *reinterpret_cast<const f32x4*>(sQ + swz(32 + li, lc));
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t], b0[t], acc[0], 0, 0, 0);
-            acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t], b1[t], acc[1], 0, 0, 0);
+        const int cur = kk & 1;
+        if (kk + 1 < 16) {
+            a[cur ^ 1] = *reinterpret_cast<const f32x4*>(sK + swz(ra, 2 * (kk + 1) + lh));
+            b[cur ^ 1] = *reinterpret_cast<const f32x4*>(sQ + swz(rq, 2 * (kk + 1) + lh));
         }
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[cur][t], b[cur][t], acc, 0, 0, 0);
     }
 }
 
@@ -73,15 +102,16 @@ __device__ __forceinline__ void chunk_range(int B, int nsplit, int split, int& c
 // ------------------------------------------------------------------ pass 1: softmax statistics
 // MODE 0: (max, sum exp) of scale*s per query.  MODE 1: arg-max of s*rowscale[b] per query.
 template <int MODE>
-__global__ __launch_bounds__(256)
+__global__ __launch_bounds__(256, 2)
 void bank_scan_kernel(const vfn_bankscan_desc p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* sQ = reinterpret_cast<float*>(smem);      // [64][128]
-    float* sK = sQ + QT * DK;                        // [128][128]
-    float* sRed = sK + CH * DK;                      // [4][64][2]
+    float* sK = sQ + QT * DK;                        // [64][128]
+    float* sRed = sK;                                // [2][64][2], reused after the last chunk
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 31, lh = lane >> 5;
+    const int wr = wave >> 1, wq = wave & 1;
     const int split = blockIdx.x % p.nsplit;
     const int qt = blockIdx.x / p.nsplit;
     const int obj = blockIdx.y;
@@ -95,85 +125,90 @@ void bank_scan_kernel(const vfn_bankscan_desc p) {
     int c_lo, c_hi;
     chunk_range(B, p.nsplit, split, c_lo, c_hi);
 
-    float run_m[2] = {-INFINITY, -INFINITY};
-    float run_l[2] = {0.f, 0.f};
-    int run_i[2] = {0x7fffffff, 0x7fffffff};
+    float run_m = -INFINITY, run_l = 0.f;
+    int run_i = 0x7fffffff;
+
+    ChunkRegs R;
+    if (c_lo < c_hi) {
+        chunk_load(R, K + (size_t)c_lo * CH * DK, min(CH, B - c_lo * CH), tid);
+        chunk_store(R, sK, tid);
+    }
+    __syncthreads();
 
     for (int c = c_lo; c < c_hi; ++c) {
         const int b0 = c * CH;
-        __syncthreads();                               // previous chunk fully consumed (also covers sQ)
-        stage_rows(sK, K + (size_t)b0 * DK, DK, CH, min(CH, B - b0), tid);
-        __syncthreads();
-        f32x16 acc[2];
-        score_tile(sK, sQ, wave, li, lh, acc);
-        const int rb = b0 + wave * 32 + 4 * lh;
+        const bool more = c + 1 < c_hi;
+        if (more) chunk_load(R, K + (size_t)(b0 + CH) * DK, min(CH, B - b0 - CH), tid);   // in flight behind the MFMAs
+        f32x16 acc;
+        score_tile(sK, sQ, wr, wq, li, lh, acc);
+        __syncthreads();                               // every wave is done reading sK
+        if (more) chunk_store(R, sK, tid);
+        const int rb = b0 + wr * 32 + 4 * lh;
+        if (MODE == 0) {
+            float mx = -INFINITY;
 #pragma unroll
-        for (int tn = 0; tn < 2; ++tn) {
-            if (MODE == 0) {
-                float mx = -INFINITY;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int row = rb + (r & 3) + 8 * (r >> 2);
-                    const float s = acc[tn][r] * p.scale;
-                    acc[tn][r] = s;
-                    if (row < B) mx = fmaxf(mx, s);
-                }
-                const float mn = fmaxf(run_m[tn], mx);
-                if (mn > -INFINITY) {
-                    float sum = 0.f;
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int row = rb + (r & 3) + 8 * (r >> 2);
-                        if (row < B) sum += expf(acc[tn][r] - mn);
-                    }
-                    run_l[tn] = run_l[tn] * expf(run_m[tn] - mn) + sum;   // exp(-inf)=0 on the first chunk
-                    run_m[tn] = mn;
-                }
-            } else {
+            for (int r = 0; r < 16; ++r) {
+                const int row = rb + (r & 3) + 8 * (r >> 2);
+                const float s_ = acc[r] * p.scale;
+                acc[r] = s_;
+                if (row < B) mx = fmaxf(mx, s_);
+            }
+            const float mn = fmaxf(run_m, mx);
+            if (mn > -INFINITY) {
+                float sum = 0.f;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int row = rb + (r & 3) + 8 * (r >> 2);
-                    if (row < B) {
-                        const float s = acc[tn][r] * p.rowscale[(size_t)obj * p.stride_rs + row];
-                        if (s > run_m[tn]) { run_m[tn] = s; run_i[tn] = row; }   // ascending rows: first max wins
-                    }
+                    if (row < B) sum += expf(acc[r] - mn);
+                }
+                run_l = run_l * expf(run_m - mn) + sum;       // exp(-inf)=0 on the first chunk
+                run_m = mn;
+            }
+        } else {
+            const float* rs = p.rowscale + (size_t)obj * p.stride_rs;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = rb + (r & 3) + 8 * (r >> 2);
+                if (row < B) {
+                    const float s_ = acc[r] * rs[row];
+                    if (s_ > run_m) { run_m = s_; run_i = row; }       // ascending rows: first max wins
                 }
             }
         }
+        __syncthreads();                               // next chunk visible
     }
 
-    // combine the two lane halves, then the four waves
-#pragma unroll
-    for (int tn = 0; tn < 2; ++tn) {
-        const float om = __shfl_xor(run_m[tn], 32, 64);
+    // combine the two lane halves, then the two row-halves (waves wr = 0, 1) of each query half
+    {
+        const float om = __shfl_xor(run_m, 32, 64);
         if (MODE == 0) {
-            const float ol = __shfl_xor(run_l[tn], 32, 64);
-            const float mn = fmaxf(run_m[tn], om);
+            const float ol = __shfl_xor(run_l, 32, 64);
+            const float mn = fmaxf(run_m, om);
             float l = 0.f;
-            if (mn > -INFINITY) l = run_l[tn] * expf(run_m[tn] - mn) + ol * expf(om - mn);
-            run_m[tn] = mn; run_l[tn] = l;
+            if (mn > -INFINITY) l = run_l * expf(run_m - mn) + ol * expf(om - mn);
+            run_m = mn; run_l = l;
         } else {
-            const int oi = __shfl_xor(run_i[tn], 32, 64);
-            if (om > run_m[tn] || (om == run_m[tn] && oi < run_i[tn])) { run_m[tn] = om; run_i[tn] = oi; }
+            const int oi = __shfl_xor(run_i, 32, 64);
+            if (om > run_m || (om == run_m && oi < run_i)) { run_m = om; run_i = oi; }
         }
-        if (lh == 0) {
-            sRed[(wave * QT + tn * 32 + li) * 2 + 0] = run_m[tn];
-            sRed[(wave * QT + tn * 32 + li) * 2 + 1] = (MODE == 0) ? run_l[tn] : __int_as_float(run_i[tn]);
-        }
+    }
+    __syncthreads();                                   // sK is free: reuse as sRed
+    if (lh == 0) {
+        sRed[(wr * QT + wq * 32 + li) * 2 + 0] = run_m;
+        sRed[(wr * QT + wq * 32 + li) * 2 + 1] = (MODE == 0) ? run_l : __int_as_float(run_i);
     }
     __syncthreads();
     if (tid < QT) {
         float m = sRed[tid * 2], x = sRed[tid * 2 + 1];
-        for (int w = 1; w < 4; ++w) {
-            const float om = sRed[(w * QT + tid) * 2], ox = sRed[(w * QT + tid) * 2 + 1];
-            if (MODE == 0) {
-                const float mn = fmaxf(m, om);
-                if (mn > -INFINITY) x = x * expf(m - mn) + ox * expf(om - mn);
-                m = mn;
-            } else {
-                const int i0 = __float_as_int(x), i1 = __float_as_int(ox);
-                if (om > m || (om == m && i1 < i0)) { m = om; x = ox; }
-            }
+        const float om = sRed[(QT + tid) * 2], ox = sRed[(QT + tid) * 2 + 1];
+        if (MODE == 0) {
+            const float mn = fmaxf(m, om);
+            if (mn > -INFINITY) x = x * expf(m - mn) + ox * expf(om - mn);
+            else x = 0.f;
+            m = mn;
+        } else {
+            const int i0 = __float_as_int(x), i1 = __float_as_int(ox);
+            if (om > m || (om == m && i1 < i0)) { m = om; x = ox; }
         }
         const int q = q0 + tid;
         if (q < p.HW) {
@@ -209,16 +244,16 @@ __global__ void bank_scan_finish_kernel(const float* __restrict__ part, int nspl
 }
 
 // ------------------------------------------------------------------ pass 2: P^T V and hit counts
-__global__ __launch_bounds__(256)
+__global__ __launch_bounds__(256, 2)
 void memread_apply_kernel(const vfn_memread_desc p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* sQ = reinterpret_cast<float*>(smem);      // [64][128]
-    float* sK = sQ + QT * DK;                        // [128][128]
-    float* sP = sK + CH * DK;                        // [64 q][128 b]  (P^T)
-    float* sML = sP + QT * CH;                       // [64][2]
+    float* sK = sQ + QT * DK;                        // [64][128]
+    float* sP = sK + CH * DK;                        // [64 q][64 b]  (P^T)
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 31, lh = lane >> 5;
+    const int wr = wave >> 1, wq = wave & 1;
     const int split = blockIdx.x % p.nsplit;
     const int qt = blockIdx.x / p.nsplit;
     const int obj = blockIdx.y;
@@ -228,12 +263,6 @@ void memread_apply_kernel(const vfn_memread_desc p) {
     const float* V = p.bank_v + (size_t)obj * p.stride_v;
 
     stage_rows(sQ, p.q + (size_t)q0 * p.ldq, p.ldq, QT, min(QT, p.HW - q0), tid);
-    if (tid < QT) {
-        const int q = q0 + tid;
-        float m = 0.f, l = 1.f;
-        if (q < p.HW) { m = p.ml[((size_t)obj * p.HW + q) * 2]; l = p.ml[((size_t)obj * p.HW + q) * 2 + 1]; }
-        sML[tid * 2] = m; sML[tid * 2 + 1] = l;
-    }
 
     int c_lo, c_hi;
     chunk_range(B, p.nsplit, split, c_lo, c_hi);
@@ -248,71 +277,91 @@ void memread_apply_kernel(const vfn_memread_desc p) {
 
     const float* vcol = V + wave * 128 + li;         // + row*512 + tc*32
 
+    ChunkRegs R;
+    if (c_lo < c_hi) {
+        chunk_load(R, K + (size_t)c_lo * CH * DK, min(CH, B - c_lo * CH), tid);
+        chunk_store(R, sK, tid);
+    }
+    __syncthreads();
+
+    const int qcol = wq * 32 + li;                   // this lane's query column in the score tile
+    const bool qok = (q0 + qcol) < p.HW;
+    float qm = 0.f, ql = 1.f;                        // softmax statistics of this lane's query (pass 1)
+    if (qok) {
+        qm = p.ml[((size_t)obj * p.HW + q0 + qcol) * 2];
+        ql = p.ml[((size_t)obj * p.HW + q0 + qcol) * 2 + 1];
+    }
+
     for (int c = c_lo; c < c_hi; ++c) {
         const int b0 = c * CH;
-        __syncthreads();                             // sK / sP of the previous chunk fully consumed
-        stage_rows(sK, K + (size_t)b0 * DK, DK, CH, min(CH, B - b0), tid);
-        __syncthreads();
+        const bool more = c + 1 < c_hi;
+        if (more) chunk_load(R, K + (size_t)(b0 + CH) * DK, min(CH, B - b0 - CH), tid);
 
-        f32x16 acc[2];
-        score_tile(sK, sQ, wave, li, lh, acc);
+        f32x16 acc;
+        score_tile(sK, sQ, wr, wq, li, lh, acc);
 
         // p = exp(s - m) / l; hit counts; P^T -> LDS
-        const int rloc = wave * 32 + 4 * lh;         // chunk-local row of register 0
+        const int rloc = wr * 32 + 4 * lh;           // chunk-local row of register 0
         int mycnt = 0;
 #pragma unroll
-        for (int tn = 0; tn < 2; ++tn) {
-            const float m = sML[(tn * 32 + li) * 2], l = sML[(tn * 32 + li) * 2 + 1];
-            const bool qok = (q0 + tn * 32 + li) < p.HW;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int rr = rloc + (r & 3) + 8 * (r >> 2);
-                float pv = 0.f;
-                if (qok && b0 + rr < B) pv = expf(acc[tn][r] * p.scale - m) / l;
-                acc[tn][r] = pv;
-                const unsigned long long hit = __ballot(pv > p.thres);
-                // row of lanes 0-31 is (r&3)+8*(r>>2), of lanes 32-63 that + 4; lane li (lower half) owns row li
-                const int rlo = (r & 3) + 8 * (r >> 2);
-                if (lh == 0) {
-                    if (li == rlo) mycnt += __popcll(hit & 0xffffffffull);
-                    if (li == rlo + 4) mycnt += __popcll(hit >> 32);
-                }
+        for (int r = 0; r < 16; ++r) {
+            const int rr = rloc + (r & 3) + 8 * (r >> 2);
+            float pv = 0.f;
+            if (qok && b0 + rr < B) pv = expf(acc[r] * p.scale - qm) / ql;
+            acc[r] = pv;
+            const unsigned long long hit = __ballot(pv > p.thres);
+            // lanes 0-31 hold row (r&3)+8*(r>>2), lanes 32-63 that + 4; lane li of the lower half owns row li
+            const int rlo = (r & 3) + 8 * (r >> 2);
+            if (lh == 0) {
+                if (li == rlo) mycnt += __popcll(hit & 0xffffffffull);
+                if (li == rlo + 4) mycnt += __popcll(hit >> 32);
             }
+        }
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {            // registers 4g..4g+3 = 4 consecutive bank rows
-                const int brow = rloc + 8 * g;       // chunk-local row, multiple of 4
-                const f32x4 v = {acc[tn][4 * g], acc[tn][4 * g + 1], acc[tn][4 * g + 2], acc[tn][4 * g + 3]};
-                *reinterpret_cast<f32x4*>(sP + swz(tn * 32 + li, brow >> 2)) = v;
-            }
+        for (int g = 0; g < 4; ++g) {                // registers 4g..4g+3 = 4 consecutive bank rows
+            const int brow = rloc + 8 * g;           // chunk-local row, multiple of 4
+            const f32x4 v = {acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]};
+            *reinterpret_cast<f32x4*>(sP + swz64(qcol, brow >> 2)) = v;
         }
         if (p.cnt && lh == 0 && mycnt > 0) {
-            const int row = b0 + wave * 32 + li;
+            const int row = b0 + wr * 32 + li;
             if (row < B) atomicAdd(p.cnt + (size_t)obj * p.stride_cnt + row, mycnt);
         }
-        __syncthreads();
+        __syncthreads();                             // P^T visible; every wave is done reading sK
+        if (more) chunk_store(R, sK, tid);
 
-        // O^T[q][c] += sum_b P^T[q][b] V[b][c];  this wave: channels 128*wave .. +127
-#pragma unroll 2
-        for (int kk = 0; kk < 16; ++kk) {
-            const int lc = 2 * kk + lh;
-            const f32x4 a0 = *reinterpret_cast<const f32x4*>(sP + swz(li, lc));
-            const f32x4 a1 = *reinterpret_cast<const f32x4*>(sP + swz(32 + li, lc));
-            float vb[4][4];
+        // O^T[q][c] += sum_b P^T[q][b] V[b][c];  this wave: channels 128*wave .. +127, value rows
+        // prefetched one k-group (8 bank rows) ahead of the MFMAs that use them
+        float vb[2][4][4];
+        auto load_v = [&](int kk, int slot) {
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
                 const int row = b0 + 8 * kk + 4 * lh + t;
-                const bool ok = row < B;
+                const int rr = row < B ? row : 0;
 #pragma unroll
-                for (int tc = 0; tc < 4; ++tc) vb[t][tc] = ok ? vcol[(size_t)row * DV + tc * 32] : 0.f;
+                for (int tc = 0; tc < 4; ++tc) {
+                    const float x = vcol[(size_t)rr * DV + tc * 32];
+                    vb[slot][t][tc] = row < B ? x : 0.f;
+                }
             }
+        };
+        load_v(0, 0);
+#pragma unroll
+        for (int kk = 0; kk < CH / 8; ++kk) {
+            const int cur = kk & 1;
+            if (kk + 1 < CH / 8) load_v(kk + 1, cur ^ 1);
+            const int lc = 2 * kk + lh;
+            const f32x4 a0 = *reinterpret_cast<const f32x4*>(sP + swz64(li, lc));
+            const f32x4 a1 = *reinterpret_cast<const f32x4*>(sP + swz64(32 + li, lc));
 #pragma unroll
             for (int t = 0; t < 4; ++t)
 #pragma unroll
                 for (int tc = 0; tc < 4; ++tc) {
-                    o[0][tc] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[t], vb[t][tc], o[0][tc], 0, 0, 0);
-                    o[1][tc] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[t], vb[t][tc], o[1][tc], 0, 0, 0);
+                    o[0][tc] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[t], vb[cur][t][tc], o[0][tc], 0, 0, 0);
+                    o[1][tc] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[t], vb[cur][t][tc], o[1][tc], 0, 0, 0);
                 }
         }
+        __syncthreads();                             // next chunk's keys visible; sP free again
     }
 
     // partial O^T -> o_part[obj][split][q][512]
@@ -355,8 +404,8 @@ __global__ void memread_finish_kernel(const vfn_memread_desc p) {
     }
 }
 
-constexpr size_t SCAN_LDS = (size_t)(QT * DK + CH * DK + 4 * QT * 2) * sizeof(float);
-constexpr size_t APPLY_LDS = (size_t)(QT * DK + CH * DK + QT * CH + QT * 2) * sizeof(float);
+constexpr size_t SCAN_LDS = (size_t)(QT * DK + CH * DK) * sizeof(float);
+constexpr size_t APPLY_LDS = (size_t)(QT * DK + CH * DK + QT * CH) * sizeof(float);   // 80 KB: two per CU
 
 template <typename K>
 void allow_lds(K kern, size_t bytes) {

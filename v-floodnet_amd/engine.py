@@ -28,7 +28,26 @@ from .feature_bank import pick_nsplit, MAX_SPLIT, DK, DV
 _CFG_EFF = {(128, 128): 1.00, (128, 64): 0.95, (64, 128): 0.95, (64, 64): 0.86, (32, 64): 0.74,
             (64, 32): 0.74, (128, 32): 0.80, (256, 128): 0.97}
 _CFG_TILES = None
-_TUNED = {}          # (M, Cout, K) -> cfg, filled by Engine.autotune()
+_TUNED = {}          # (M, Cout, K) -> (cfg, ksplit): measured choices (Engine.autotune / tuned_gfx950.json)
+_TUNED_PATH = __import__('os').path.join(__import__('os').path.dirname(__import__('os').path.abspath(__file__)),
+                                         'tuned_gfx950.json')
+
+
+def _load_tuned():
+    import json
+    import os
+    if os.path.isfile(_TUNED_PATH) and os.environ.get('VFN_IGNORE_TUNED') != '1':
+        for k, v in json.load(open(_TUNED_PATH)).items():
+            _TUNED[tuple(int(x) for x in k.split(','))] = (int(v[0]), int(v[1]))
+
+
+def save_tuned(path=_TUNED_PATH):
+    import json
+    with open(path, 'w') as f:
+        json.dump({','.join(str(x) for x in k): list(v) for k, v in sorted(_TUNED.items())}, f, indent=0)
+
+
+_load_tuned()
 
 
 def pad_divide_by(h, w, d=16):

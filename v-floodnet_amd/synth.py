@@ -79,7 +79,7 @@ def _gen_for(name, seed):
 
 
 DEFAULT_KNOBS = dict(key_scale=1.0, mask_scale=1.0, res_scale=0.4, dec_res_scale=0.5, out_scale=1.0,
-                     logit_std=2.0, local_std=0.5)
+                     logit_std=1.0, local_std=0.25)
 
 
 def random_state_dict(template_sd, seed, knobs=None):
