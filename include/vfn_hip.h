@@ -48,10 +48,13 @@ typedef struct vfn_conv_desc {
     int KH, KW, stride, pad;
     int relu_in, relu_out;
     int M;                /* N*Ho*Wo */
-    int ksplit;           /* <= 1: single pass.  > 1: K is cut into ksplit slices (one grid row each), raw
-                             partial sums go to `partial` and a second kernel reduces them in fixed order
-                             and applies the epilogue -- for layers with too few output tiles to fill 256 CUs */
-    float* partial;       /* [ksplit][M][Cout] workspace when ksplit > 1 */
+    int ksplit;           /* <= 1: single pass.  > 1: output tiles with index >= split_from are cut along K into
+                             ksplit slices (one workgroup each); their raw partial sums go to `partial` and a
+                             second kernel reduces them in fixed order and applies the epilogue.  split_from = 0
+                             cuts every tile (layers with fewer tiles than CUs); split_from = a multiple of 256
+                             cuts only the last, partial round of tiles so that all 256 CUs finish together */
+    int split_from;       /* tile index (multiple of the number of filter tiles), used when ksplit > 1 */
+    float* partial;       /* [ksplit][M - m_start][Cout] workspace, m_start = first row of tile split_from */
 } vfn_conv_desc;
 
 int vfn_conv_cfg_count(void);

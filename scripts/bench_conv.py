@@ -38,6 +38,26 @@ for (N, H, W, Cin, Cout, k, s) in SHAPES:
         us = e0.elapsed_time(e1) * 100
         line += f'{bm}x{bn}: {fl / us / 1e6:5.1f}  '
     print(line)
+    ws = torch.empty(64 * 1024 * 1024, device=dev)
+    for c in (0, 2, 7, 8, 10):
+        bm, bn = tiles[c]
+        line = f'     tail-split cfg{c} {bm}x{bn}: '
+        for (full, ks, rows) in ops.tail_split_options(d, bm, bn, 8):
+            if ks * rows * Cout > ws.numel():
+                continue
+            ops.set_splitk(d, ks, ws, full, rows)
+            for _ in range(2):
+                ops.conv2d_launch(d, c)
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(10):
+                ops.conv2d_launch(d, c)
+            e1.record(); torch.cuda.synchronize()
+            us = e0.elapsed_time(e1) * 100
+            line += f'f{full}/s{ks}: {fl / us / 1e6:5.1f}  '
+        ops.set_splitk(d, 1, None)
+        print(line)
     if d.M <= 8192:
         ws = torch.empty(16 * d.M * Cout, device=dev)
         for c in (0, 1, 2, 3):

@@ -56,3 +56,17 @@ def test_conv_matches_torch_cpu(gpu, case):
         torch.cuda.synchronize()
         err = (y.permute(0, 3, 1, 2).cpu() - ref).abs().max().item()
         assert err < 2e-4 * max(1.0, ref.abs().max().item()), f'split {ks}: max err {err}'
+    # tail split: only the tiles from an n-tile-aligned index on are cut along K
+    tiles = ops.conv_cfg_tiles()
+    bm, bn = tiles[3]
+    n_t = (Cout + bn - 1) // bn
+    m_t = (d.M + bm - 1) // bm
+    for full_m in {1, m_t // 2, m_t - 1}:
+        if 0 < full_m < m_t and len(ops.valid_splits(d, 4)) > 1:
+            ks = ops.valid_splits(d, 4)[-1]
+            y.zero_()
+            ops.set_splitk(d, ks, ws, split_from=full_m * n_t, rows=d.M - full_m * bm)
+            ops.conv2d_launch(d, 3)
+            torch.cuda.synchronize()
+            err = (y.permute(0, 3, 1, 2).cpu() - ref).abs().max().item()
+            assert err < 2e-4 * max(1.0, ref.abs().max().item()), f'tail split from {full_m}: max err {err}'

@@ -74,13 +74,16 @@ def test_nsplit_and_cfg_choices():
     assert pick_nsplit(1620, 2, 100) == 1
     s = pick_nsplit(1620, 2, 100000)
     assert 1 <= s <= 16 and (26 * 2 * s) % 256 <= 256
-    engine._CFG_TILES = [(128, 128), (128, 64), (64, 128), (64, 64), (32, 64), (64, 32), (128, 32), (256, 128)]
-    c, ks = engine.choose_cfg(51840, 256, 2304)
+    engine._CFG_TILES = [(128, 128), (128, 64), (64, 128), (64, 64), (32, 64), (64, 32), (128, 32), (256, 128),
+                         (128, 128), (128, 128), (64, 128)]
+    engine._TUNED.clear()                                  # exercise the heuristic, not the measured table
+    c, ks, sf = engine.choose_cfg(51840, 256, 2304)
     assert engine._CFG_TILES[c][1] >= 64 and ks == 1
-    c, ks = engine.choose_cfg(207360, 2, 288)
+    c, ks, sf = engine.choose_cfg(207360, 2, 288)
     assert engine._CFG_TILES[c][1] == 32 and ks == 1
-    c, ks = engine.choose_cfg(1620, 256, 2304)              # 1/16-resolution layer: too few tiles -> split K
-    assert ks > 1 and ((72 + ks - 1) // ks) * (ks - 1) < 72
+    c, ks, sf = engine.choose_cfg(1620, 256, 2304)          # 1/16-resolution layer: too few tiles -> split K
+    assert ks > 1 and sf == 0 and ((72 + ks - 1) // ks) * (ks - 1) < 72
+    engine._load_tuned()
 
 
 def test_video_ds_and_palette(tmp_path):

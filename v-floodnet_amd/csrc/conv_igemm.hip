@@ -50,7 +50,18 @@ void conv_igemm_kernel(const vfn_conv_desc p) {
 
     // tile id -> (m tile, n tile); n fastest so blocks sharing input rows are neighbours
     const int n_tiles = (p.Cout + BN - 1) / BN;
-    const int tile = blockIdx.x;
+    // blocks [0, split_from) own whole tiles; the rest are (tile, K slice) pairs: the last, partial round
+    // of tiles is cut along K so that every CU still gets an equal share (and layers with fewer tiles than
+    // CUs are cut entirely: split_from = 0)
+    const int ksplit = p.ksplit > 1 ? p.ksplit : 1;
+    int tile = blockIdx.x, kz = 0;
+    bool split_tile = false;
+    if (ksplit > 1 && tile >= p.split_from) {
+        const int r = tile - p.split_from;
+        tile = p.split_from + r / ksplit;
+        kz = r - (r / ksplit) * ksplit;
+        split_tile = true;
+    }
     const int mt = tile / n_tiles, nt = tile % n_tiles;
     const int m0 = mt * BM, n0 = nt * BN;
 
@@ -58,10 +69,9 @@ void conv_igemm_kernel(const vfn_conv_desc p) {
     const int cblks = p.Cin / BK;
     const int Ktot = p.KH * p.KW * p.Cin;
     const int nk_all = p.KH * p.KW * cblks;
-    // split-K: blockIdx.y owns K tiles [kt_begin, kt_begin + nk)
-    const int ksplit = p.ksplit > 1 ? p.ksplit : 1;
-    const int kper = (nk_all + ksplit - 1) / ksplit;
-    const int kt_begin = blockIdx.y * kper;
+    // a split tile's slice kz owns K tiles [kt_begin, kt_begin + nk)
+    const int kper = split_tile ? (nk_all + ksplit - 1) / ksplit : nk_all;
+    const int kt_begin = kz * kper;
     const int nk = min(kper, nk_all - kt_begin);
 
     // per-thread staging coordinates
@@ -192,8 +202,9 @@ void conv_igemm_kernel(const vfn_conv_desc p) {
     }
 
     // split-K: raw partial sums to the workspace slab of this split; vfn_conv_splitk_reduce finishes
-    if (ksplit > 1) {
-        float* part = p.partial + (size_t)blockIdx.y * p.M * p.Cout;
+    if (split_tile) {
+        const int m_start = (p.split_from / n_tiles) * BM;          // first row covered by split tiles
+        float* part = p.partial + ((long long)kz * (p.M - m_start) - m_start) * (long long)p.Cout;
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
             const int col = n0 + (wn * TN + j) * 32 + li;
@@ -236,16 +247,18 @@ void conv_igemm_kernel(const vfn_conv_desc p) {
 }
 
 // out = act((sum over splits, fixed order) * scale + shift + res)
-__global__ void splitk_reduce_kernel(const vfn_conv_desc p) {
+__global__ void splitk_reduce_kernel(const vfn_conv_desc p, int m_start) {
     const int c4n = p.Cout / 4;
-    const size_t total = (size_t)p.M * c4n;
-    const size_t slab = (size_t)p.M * p.Cout;
+    const size_t rows = (size_t)(p.M - m_start);
+    const size_t total = rows * c4n;
+    const size_t slab = rows * p.Cout;
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
         const int c4 = i % c4n;
-        const size_t row = i / c4n;
-        f32x4 a = *reinterpret_cast<const f32x4*>(p.partial + row * p.Cout + c4 * 4);
+        const size_t lrow = i / c4n;
+        const size_t row = lrow + m_start;
+        f32x4 a = *reinterpret_cast<const f32x4*>(p.partial + lrow * p.Cout + c4 * 4);
         for (int sp = 1; sp < p.ksplit; ++sp)
-            a += *reinterpret_cast<const f32x4*>(p.partial + sp * slab + row * p.Cout + c4 * 4);
+            a += *reinterpret_cast<const f32x4*>(p.partial + sp * slab + lrow * p.Cout + c4 * 4);
         f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
         if (p.scale) sc = *reinterpret_cast<const f32x4*>(p.scale + c4 * 4);
         if (p.shift) sh = *reinterpret_cast<const f32x4*>(p.shift + c4 * 4);
@@ -274,22 +287,28 @@ int launch_cfg(const vfn_conv_desc& p, hipStream_t s) {
     const int m_tiles = cdiv(p.M, BM);
     const int n_tiles = cdiv(p.Cout, BN);
     const int ks = p.ksplit > 1 ? p.ksplit : 1;
-    hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN>), dim3(m_tiles * n_tiles, ks), dim3(NT), lds, s, p);
-    if (ks > 1) {
-        const size_t total = (size_t)p.M * (p.Cout / 4);
+    const int tiles = m_tiles * n_tiles;
+    if (ks > 1 && (p.split_from < 0 || p.split_from > tiles || p.split_from % n_tiles)) return VFN_ERR_ARG;
+    const int grid = ks > 1 ? p.split_from + (tiles - p.split_from) * ks : tiles;
+    hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN>), dim3(grid), dim3(NT), lds, s, p);
+    if (ks > 1 && p.split_from < tiles) {
+        const int m_start = (p.split_from / n_tiles) * BM;
+        const size_t total = (size_t)(p.M - m_start) * (p.Cout / 4);
         const int blocks = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
-        hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, s, p);
+        hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, s, p, m_start);
     }
     return vfn_check_launch();
 }
 
 }  // namespace
 
-extern "C" int vfn_conv_cfg_count(void) { return 8; }
+extern "C" int vfn_conv_cfg_count(void) { return 11; }
 
 extern "C" int vfn_conv_cfg_tile(int cfg, int* bm, int* bn) {
-    static const int t[8][2] = {{128, 128}, {128, 64}, {64, 128}, {64, 64}, {32, 64}, {64, 32}, {128, 32}, {256, 128}};
-    if (cfg < 0 || cfg >= 8) return VFN_ERR_ARG;
+    // 8..10: same tiles as 0 / 0 / 2 with twice the waves (smaller per-wave tiles, 4 waves per SIMD at 2 blocks/CU)
+    static const int t[11][2] = {{128, 128}, {128, 64}, {64, 128}, {64, 64}, {32, 64}, {64, 32}, {128, 32}, {256, 128},
+                                 {128, 128}, {128, 128}, {64, 128}};
+    if (cfg < 0 || cfg >= 11) return VFN_ERR_ARG;
     *bm = t[cfg][0]; *bn = t[cfg][1];
     return VFN_OK;
 }
@@ -315,6 +334,9 @@ extern "C" int vfn_conv2d_nhwc_f32(const vfn_conv_desc* d, int cfg, void* stream
         case 5: return launch_cfg<64, 32, 2, 1>(*d, s);
         case 6: return launch_cfg<128, 32, 4, 1>(*d, s);
         case 7: return launch_cfg<256, 128, 4, 2>(*d, s);
+        case 8: return launch_cfg<128, 128, 2, 4>(*d, s);
+        case 9: return launch_cfg<128, 128, 4, 2>(*d, s);
+        case 10: return launch_cfg<64, 128, 2, 4>(*d, s);
     }
     return VFN_ERR_ARG;
 }

@@ -38,7 +38,7 @@ def _load_tuned():
     import os
     if os.path.isfile(_TUNED_PATH) and os.environ.get('VFN_IGNORE_TUNED') != '1':
         for k, v in json.load(open(_TUNED_PATH)).items():
-            _TUNED[tuple(int(x) for x in k.split(','))] = (int(v[0]), int(v[1]))
+            _TUNED[tuple(int(x) for x in k.split(','))] = (int(v[0]), int(v[1]), int(v[2]) if len(v) > 2 else 0)
 
 
 def save_tuned(path=_TUNED_PATH):
@@ -64,17 +64,37 @@ def pad_divide_by(h, w, d=16):
 WS_FLOATS = 16 * 1024 * 1024        # split-K workspace (64 MB), shared by all launches of a plan
 
 
+def _tiles():
+    global _CFG_TILES
+    if _CFG_TILES is None:
+        _CFG_TILES = ops.conv_cfg_tiles()
+    return _CFG_TILES
+
+
+def apply_choice(desc, choice, ws):
+    """Configure a conv descriptor for a (cfg, ksplit, split_from) choice; returns the cfg index."""
+    cfg, ks, split_from = choice
+    if ks > 1:
+        bm, bn = _tiles()[cfg]
+        n_tiles = (desc.Cout + bn - 1) // bn
+        rows = desc.M - (split_from // n_tiles) * bm
+        ops.set_splitk(desc, ks, ws, split_from, rows)
+    else:
+        ops.set_splitk(desc, 1, None)
+    return cfg
+
+
 def choose_cfg(M, cout, K):
-    """(tile config, split-K factor) minimising (rounds over 256 CUs) x (tile work / efficiency)."""
+    """(tile config, split-K factor, first split tile): the measured table if the shape is in it, otherwise
+    minimise (rounds over 256 CUs) x (tile work / efficiency), cutting K when there are too few tiles."""
     global _CFG_TILES
     key = (M, cout, K)
     if key in _TUNED:
         return _TUNED[key]
-    if _CFG_TILES is None:
-        _CFG_TILES = ops.conv_cfg_tiles()
+    _tiles()
     nk = K // 32
     best, best_cost = 0, None
-    for c, (bm, bn) in enumerate(_CFG_TILES):
+    for c, (bm, bn) in enumerate(_CFG_TILES[:8]):
         if bn > 32 and cout <= 32:
             continue
         if bn >= 128 and cout < 128:
@@ -92,8 +112,8 @@ def choose_cfg(M, cout, K):
         ks = max(1, min(16, (448 + blocks - 1) // blocks, nk // 4))
         while ks > 1 and (((nk + ks - 1) // ks) * (ks - 1) >= nk or ks * M * cout > WS_FLOATS):
             ks -= 1
-        return (c, ks)
-    return (best, 1)
+        return (c, ks, 0)
+    return (best, 1, 0)
 
 
 class ConvLayer:
@@ -198,9 +218,10 @@ class FramePlan:
                                cin=layer.cin, in_ld=in_ld if in_ld is not None else x.shape[-1],
                                out_ld=out_ld, N=N, H=H, W=Wd)
         K = layer.k * layer.k * layer.cin
-        cfg, ks = choose_cfg(d.M, layer.cout, K)
-        if ks > 1 and d.out_ld % 4 == 0 and (res is None or d.res_ld % 4 == 0):
-            ops.set_splitk(d, ks, self.ws)
+        choice = choose_cfg(d.M, layer.cout, K)
+        if choice[1] > 1 and (d.out_ld % 4 or (res is not None and d.res_ld % 4)):
+            choice = (choice[0], 1, 0)
+        cfg = apply_choice(d, choice, self.ws)
         lst.append(Launch(ops.conv2d_launch, (d, cfg), f'{name}[{d.M}x{layer.cout}x{K}]', 2.0 * d.M * layer.cout * K))
         return out
 
@@ -448,16 +469,18 @@ class Engine:
                 if bn > 64 and d.Cout <= 32:
                     continue
                 blocks = ((d.M + bm - 1) // bm) * ((d.Cout + bn - 1) // bn)
-                splits = [1]
+                options = [(c, 1, 0)]
                 if blocks < 256:
-                    splits += [k_ for k_ in ops.valid_splits(d, 16)[1:] if k_ * d.M * d.Cout <= WS_FLOATS]
-                for ks in splits:
-                    ops.set_splitk(d, ks, p.ws)
+                    options += [(c, k_, 0) for k_ in ops.valid_splits(d, 16)[1:] if k_ * d.M * d.Cout <= WS_FLOATS]
+                else:
+                    options += [(c, k_, full) for (full, k_, rows) in ops.tail_split_options(d, bm, bn, 8)
+                                if k_ * rows * d.Cout <= WS_FLOATS and k_ in (2, 3, 4, 5, 6, 8)]
+                for opt in options:
+                    apply_choice(d, opt, p.ws)
                     t = timeit(d, c)
                     if best_t is None or t < best_t:
-                        best, best_t = (c, ks), t
+                        best, best_t = opt, t
             _TUNED[key] = best
             for l in launches:
-                ops.set_splitk(l.args[0], best[1], p.ws)
-                l.args = (l.args[0], best[0])
+                l.args = (l.args[0], apply_choice(l.args[0], best, p.ws))
         return dict(_TUNED)

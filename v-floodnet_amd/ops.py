@@ -52,19 +52,38 @@ def make_conv_desc(x, wp, cout, kh, kw, stride, pad, out, scale=None, shift=None
     d.KH, d.KW, d.stride, d.pad = kh, kw, stride, pad
     d.relu_in, d.relu_out = int(relu_in), int(relu_out)
     d.M = N * Ho * Wo
-    d.ksplit, d.partial = 1, None
+    d.ksplit, d.split_from, d.partial = 1, 0, None
     assert wp.shape[1] == kh * kw * cin
     return d
 
 
-def set_splitk(desc, ksplit, workspace):
-    """Cut K into ``ksplit`` slices (``workspace``: float32 tensor with >= ksplit*M*Cout elements)."""
+def set_splitk(desc, ksplit, workspace, split_from=0, rows=None):
+    """Cut the tiles from index ``split_from`` on along K into ``ksplit`` slices.  ``rows`` = output rows
+    those tiles cover (default: all M); ``workspace``: float32 tensor with >= ksplit*rows*Cout elements."""
     if ksplit > 1:
-        assert workspace is not None and workspace.numel() >= ksplit * desc.M * desc.Cout
-        desc.ksplit, desc.partial = int(ksplit), ptr(workspace)
+        rows = desc.M if rows is None else rows
+        assert workspace is not None and workspace.numel() >= ksplit * rows * desc.Cout
+        desc.ksplit, desc.split_from, desc.partial = int(ksplit), int(split_from), ptr(workspace)
     else:
-        desc.ksplit, desc.partial = 1, None
+        desc.ksplit, desc.split_from, desc.partial = 1, 0, None
     return desc
+
+
+def tail_split_options(desc, bm, bn, max_split=8):
+    """(split_from, ksplit, rows) candidates that cut only the last partial round of tiles."""
+    m_tiles = (desc.M + bm - 1) // bm
+    n_tiles = (desc.Cout + bn - 1) // bn
+    tiles = m_tiles * n_tiles
+    out = []
+    for unit in (256, 512):
+        full = (tiles // unit) * unit
+        full -= full % n_tiles
+        if full <= 0 or full >= tiles:
+            continue
+        rows = desc.M - (full // n_tiles) * bm
+        for ks in valid_splits(desc, max_split)[1:]:
+            out.append((full, ks, rows))
+    return out
 
 
 def valid_splits(desc, max_split=16):
