@@ -61,6 +61,20 @@ __device__ __forceinline__ void chunk_store(const ChunkRegs& R, float* dst, int 
     }
 }
 
+// One 64 x 128 key chunk straight into its swizzled LDS image with LDS-DMA (no VGPRs): a wave
+// instruction writes 1 KB = two image rows linearly, so the XOR swizzle goes on the per-lane SOURCE
+// address.  Rows past `valid` re-read the last valid row (finite data; masked by the caller).
+__device__ __forceinline__ void chunk_load_async(float* sK, const float* src, int valid, int wave, int lane) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int r = (wave * 8 + j) * 2 + (lane >> 5);
+        const int pc = lane & 31;
+        const int rr = min(r, valid - 1);
+        const float* g = src + (size_t)rr * DK + ((pc ^ (r & 15)) << 2);
+        __builtin_amdgcn_global_load_lds(g, sK + (wave * 8 + j) * 2 * DK, 16, 0, 0);
+    }
+}
+
 // stage `rows` x 128 floats (row r from src + r*ld, zero past `valid` rows) into an LDS image
 __device__ __forceinline__ void stage_rows(float* dst, const float* src, size_t ld, int rows, int valid, int tid) {
     const int c = tid & 31;
@@ -101,48 +115,66 @@ __device__ __forceinline__ void chunk_range(int B, int nsplit, int split, int& c
 
 // ------------------------------------------------------------------ pass 1: softmax statistics
 // MODE 0: (max, sum exp) of scale*s per query.  MODE 1: arg-max of s*rowscale[b] per query.
+// Query fragments live in registers (64 VGPRs), key chunks are double-buffered in LDS by LDS-DMA:
+// 64 KB of LDS -> two workgroups per CU, one barrier per chunk, the next chunk lands behind the MFMAs.
 template <int MODE>
 __global__ __launch_bounds__(256, 2)
 void bank_scan_kernel(const vfn_bankscan_desc p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    float* sQ = reinterpret_cast<float*>(smem);      // [64][128]
-    float* sK = sQ + QT * DK;                        // [64][128]
-    float* sRed = sK;                                // [2][64][2], reused after the last chunk
+    float* sKb = reinterpret_cast<float*>(smem);     // [2][64][128]
+    float* sRed = sKb;                               // [2][64][2], reused after the last chunk
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 31, lh = lane >> 5;
     const int wr = wave >> 1, wq = wave & 1;
-    const int split = blockIdx.x % p.nsplit;
-    const int qt = blockIdx.x / p.nsplit;
+    const int sstride = p.nsplit;                    // nsplit % 8 == 0 -> one bank slice per XCD
+    const int split = blockIdx.x % sstride;
+    const int qt = blockIdx.x / sstride;
+    if (split >= p.nsplit) return;
     const int obj = blockIdx.y;
     const int q0 = qt * QT;
     const int B = p.bank_len[obj];
     const float* K = p.bank_k + (size_t)obj * p.stride_k;
     const float* Q = p.q + (size_t)(p.q_per_obj ? obj : 0) * p.stride_q;
 
-    stage_rows(sQ, Q + (size_t)q0 * p.ldq, p.ldq, QT, min(QT, p.HW - q0), tid);
-
     int c_lo, c_hi;
     chunk_range(B, p.nsplit, split, c_lo, c_hi);
+    if (c_lo < c_hi) chunk_load_async(sKb, K + (size_t)c_lo * CH * DK, min(CH, B - c_lo * CH), wave, lane);
+
+    // B operand: this lane's query column, k = 8kk + 4lh + t
+    f32x4 qf[16];
+    {
+        const int q = min(q0 + wq * 32 + li, p.HW - 1);          // columns past HW are never written out
+        const float* qrow = Q + (size_t)q * p.ldq + 4 * lh;
+#pragma unroll
+        for (int kk = 0; kk < 16; ++kk) qf[kk] = *reinterpret_cast<const f32x4*>(qrow + 8 * kk);
+    }
 
     float run_m = -INFINITY, run_l = 0.f;
     int run_i = 0x7fffffff;
-
-    ChunkRegs R;
-    if (c_lo < c_hi) {
-        chunk_load(R, K + (size_t)c_lo * CH * DK, min(CH, B - c_lo * CH), tid);
-        chunk_store(R, sK, tid);
-    }
-    __syncthreads();
+    __syncthreads();                                   // chunk c_lo landed (the barrier drains the LDS-DMA)
 
     for (int c = c_lo; c < c_hi; ++c) {
         const int b0 = c * CH;
-        const bool more = c + 1 < c_hi;
-        if (more) chunk_load(R, K + (size_t)(b0 + CH) * DK, min(CH, B - b0 - CH), tid);   // in flight behind the MFMAs
+        const float* sK = sKb + ((c - c_lo) & 1) * CH * DK;
+        if (c + 1 < c_hi)
+            chunk_load_async(sKb + ((c + 1 - c_lo) & 1) * CH * DK, K + (size_t)(b0 + CH) * DK, min(CH, B - b0 - CH), wave, lane);
         f32x16 acc;
-        score_tile(sK, sQ, wr, wq, li, lh, acc);
-        __syncthreads();                               // every wave is done reading sK
-        if (more) chunk_store(R, sK, tid);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+        {
+            const int ra = wr * 32 + li;
+            f32x4 a[2];
+            a[0] = *reinterpret_cast<const f32x4*>(sK + swz(ra, lh));
+#pragma unroll
+            for (int kk = 0; kk < 16; ++kk) {
+                const int cur = kk & 1;
+                if (kk + 1 < 16) a[cur ^ 1] = *reinterpret_cast<const f32x4*>(sK + swz(ra, 2 * (kk + 1) + lh));
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[cur][t], qf[kk][t], acc, 0, 0, 0);
+            }
+        }
         const int rb = b0 + wr * 32 + 4 * lh;
         if (MODE == 0) {
             float mx = -INFINITY;
@@ -175,7 +207,7 @@ void bank_scan_kernel(const vfn_bankscan_desc p) {
                 }
             }
         }
-        __syncthreads();                               // next chunk visible
+        __syncthreads();                               // next chunk landed; this buffer is free again
     }
 
     // combine the two lane halves, then the two row-halves (waves wr = 0, 1) of each query half
@@ -192,7 +224,6 @@ void bank_scan_kernel(const vfn_bankscan_desc p) {
             if (om > run_m || (om == run_m && oi < run_i)) { run_m = om; run_i = oi; }
         }
     }
-    __syncthreads();                                   // sK is free: reuse as sRed
     if (lh == 0) {
         sRed[(wr * QT + wq * 32 + li) * 2 + 0] = run_m;
         sRed[(wr * QT + wq * 32 + li) * 2 + 1] = (MODE == 0) ? run_l : __int_as_float(run_i);
@@ -254,8 +285,10 @@ void memread_apply_kernel(const vfn_memread_desc p) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 31, lh = lane >> 5;
     const int wr = wave >> 1, wq = wave & 1;
-    const int split = blockIdx.x % p.nsplit;
-    const int qt = blockIdx.x / p.nsplit;
+    const int sstride = p.nsplit;
+    const int split = blockIdx.x % sstride;
+    const int qt = blockIdx.x / sstride;
+    if (split >= p.nsplit) return;
     const int obj = blockIdx.y;
     const int q0 = qt * QT;
     const int B = p.bank_len[obj];
@@ -277,12 +310,8 @@ void memread_apply_kernel(const vfn_memread_desc p) {
 
     const float* vcol = V + wave * 128 + li;         // + row*512 + tc*32
 
-    ChunkRegs R;
-    if (c_lo < c_hi) {
-        chunk_load(R, K + (size_t)c_lo * CH * DK, min(CH, B - c_lo * CH), tid);
-        chunk_store(R, sK, tid);
-    }
-    __syncthreads();
+    if (c_lo < c_hi) chunk_load_async(sK, K + (size_t)c_lo * CH * DK, min(CH, B - c_lo * CH), wave, lane);
+    __syncthreads();                                 // (drains the LDS-DMA: it is a pending LDS write)
 
     const int qcol = wq * 32 + li;                   // this lane's query column in the score tile
     const bool qok = (q0 + qcol) < p.HW;
@@ -295,7 +324,6 @@ void memread_apply_kernel(const vfn_memread_desc p) {
     for (int c = c_lo; c < c_hi; ++c) {
         const int b0 = c * CH;
         const bool more = c + 1 < c_hi;
-        if (more) chunk_load(R, K + (size_t)(b0 + CH) * DK, min(CH, B - b0 - CH), tid);
 
         f32x16 acc;
         score_tile(sK, sQ, wr, wq, li, lh, acc);
@@ -328,28 +356,30 @@ void memread_apply_kernel(const vfn_memread_desc p) {
             if (row < B) atomicAdd(p.cnt + (size_t)obj * p.stride_cnt + row, mycnt);
         }
         __syncthreads();                             // P^T visible; every wave is done reading sK
-        if (more) chunk_store(R, sK, tid);
+        if (more) chunk_load_async(sK, K + (size_t)(b0 + CH) * DK, min(CH, B - b0 - CH), wave, lane);   // lands behind P^T V
 
         // O^T[q][c] += sum_b P^T[q][b] V[b][c];  this wave: channels 128*wave .. +127, value rows
         // prefetched one k-group (8 bank rows) ahead of the MFMAs that use them
-        float vb[2][4][4];
+        float vb[3][4][4];                           // ring: value rows two k-groups ahead of their MFMAs
         auto load_v = [&](int kk, int slot) {
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
-                const int row = b0 + 8 * kk + 4 * lh + t;
-                const int rr = row < B ? row : 0;
+                // rows past the bank end are clamped to the last entry: their P is exactly 0 (masked in
+                // the softmax above) and the clamped value is a finite bank entry, so no select is needed
+                // -- a select would force a wait right behind every load
+                const int rr = min(b0 + 8 * kk + 4 * lh + t, B - 1);
 #pragma unroll
-                for (int tc = 0; tc < 4; ++tc) {
-                    const float x = vcol[(size_t)rr * DV + tc * 32];
-                    vb[slot][t][tc] = row < B ? x : 0.f;
-                }
+                for (int tc = 0; tc < 4; ++tc) vb[slot][t][tc] = vcol[(size_t)rr * DV + tc * 32];
             }
         };
         load_v(0, 0);
+        load_v(1, 1);
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int kk = 0; kk < CH / 8; ++kk) {
-            const int cur = kk & 1;
-            if (kk + 1 < CH / 8) load_v(kk + 1, cur ^ 1);
+            const int cur = kk % 3;
+            if (kk + 2 < CH / 8) load_v(kk + 2, (kk + 2) % 3);
+            __builtin_amdgcn_sched_barrier(0);       // keep the prefetch ahead of this k-group's MFMAs
             const int lc = 2 * kk + lh;
             const f32x4 a0 = *reinterpret_cast<const f32x4*>(sP + swz64(li, lc));
             const f32x4 a1 = *reinterpret_cast<const f32x4*>(sP + swz64(32 + li, lc));
@@ -404,7 +434,7 @@ __global__ void memread_finish_kernel(const vfn_memread_desc p) {
     }
 }
 
-constexpr size_t SCAN_LDS = (size_t)(QT * DK + CH * DK) * sizeof(float);
+constexpr size_t SCAN_LDS = (size_t)(2 * CH * DK) * sizeof(float);
 constexpr size_t APPLY_LDS = (size_t)(QT * DK + CH * DK + QT * CH) * sizeof(float);   // 80 KB: two per CU
 
 template <typename K>

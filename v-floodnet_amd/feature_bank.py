@@ -24,13 +24,16 @@ from ._lib import ptr, stream, check, BankDesc, BankScanDesc
 
 DK, DV = 128, 512
 MAX_SPLIT = 16
-QT, CH = 64, 128
+QT, CH = 64, 64
 
 
 def pick_nsplit(hw, obj_n, b_upper):
-    """Bank slices per query tile: fill the 256 CUs (one workgroup each) in whole rounds."""
+    """Bank slices per query tile: fill the 256 CUs x 2 resident workgroups in whole rounds."""
     nchunks = max(1, (b_upper + CH - 1) // CH)
     qtiles = (hw + QT - 1) // QT
+    import os
+    if os.environ.get('VFN_NSPLIT'):
+        return min(int(os.environ['VFN_NSPLIT']), nchunks)
     best, best_eff = 1, -1.0
     for s in range(1, min(nchunks, MAX_SPLIT) + 1):
         blocks = qtiles * obj_n * s
