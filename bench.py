@@ -88,7 +88,9 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-frames', type=int, default=4)
     ap.add_argument('--no-autotune', action='store_true')
-    ap.add_argument('--sample-every', type=int, default=8, help='time the conv launches on every n-th frame')
+    ap.add_argument('--no-overlap', action='store_true',
+                    help="do not run the next frame's query encoder on a side stream under memorize/update")
+    ap.add_argument('--sample-every', type=int, default=16, help='time the conv launches on every n-th frame')
     args = ap.parse_args()
 
     import vfloodnet_amd
@@ -146,7 +148,11 @@ def main():
     for t in range(1, K + 1):
         idx = ((t - 1) % (n_frames - 1)) + 1
         timer.active = (t % args.sample_every == 0)
-        runner.step(frames[idx:idx + 1], want_label=False)
+        # no prefetch into / out of a sampled frame: its kernels are timed alone on the device
+        sampled_next = ((t + 1) % args.sample_every == 0)
+        nxt = ((t % (n_frames - 1)) + 1) if (t < K and not args.no_overlap and not timer.active and not sampled_next) else None
+        runner.step(frames[idx:idx + 1], want_label=False,
+                    next_frame=frames[nxt:nxt + 1] if nxt is not None else None)
         timer.active = False
         labels[t].copy_(runner._label_dev, non_blocking=True)
         bank_sum += sum(runner.bank_sizes())

@@ -54,12 +54,17 @@ typedef struct vfn_conv_desc {
                              cuts every tile (layers with fewer tiles than CUs); split_from = a multiple of 256
                              cuts only the last, partial round of tiles so that all 256 CUs finish together */
     int split_from;       /* tile index (multiple of the number of filter tiles), used when ksplit > 1 */
+    int res_mod;          /* > 0: the residual is shared by the images of the batch: row m reads res[m % res_mod]
+                             (a term computed once for all objects, e.g. the query-value half of convFM) */
     float* partial;       /* [ksplit][M - m_start][Cout] workspace, m_start = first row of tile split_from */
 } vfn_conv_desc;
 
 int vfn_conv_cfg_count(void);
 int vfn_conv_cfg_tile(int cfg, int* bm, int* bn);
 int vfn_conv2d_nhwc_f32(const vfn_conv_desc* d, int cfg, void* stream);
+/* 3x3/s1/p1 convolution with Cout == 2 and Cin in {32, 256} (Decoder.pred2 / local_pred2, AFB_URR.py:195,202,
+ * 213,234): bandwidth-bound reduction kernel; same descriptor, w = [2][9*Cin]. */
+int vfn_conv3x3_cout2_f32(const vfn_conv_desc* d, void* stream);
 
 /* ------------------------------------------------------------------ encoder stems
  * vfn_stem_conv7x7_f32: pad_divide_by (myutils/data.py:132-149) + (x-mean)/std + conv1
@@ -92,9 +97,9 @@ int vfn_maxpool3x3s2_nhwc_f32(const float* in, float* out, int N, int H, int W, 
  * vfn_rough_uncertainty_f32     AFB_URR.py:214-223 + myutils/data.py:40-46
  *     p: [obj][h][w][2] -> p_up [obj][2h][2w][2], rough [obj][2h][2w], unc [2h][2w]
  * vfn_local_hpass_f32 / vfn_local_vpass_f32   AFB_URR.py:226-231 (r1*rough, AvgPool2d(7,1,3) x2,
- *     divide, MaxPool2d(7,1,3), cat([r1, r1_local])) as a separable window
+ *     divide, MaxPool2d(7,1,3)) as a separable window; cat([r1, r1_local]) (:231) is not materialised
  *     r1: [h][w][C] (shared by the objects), rough: [obj][h][w]
- *     scratch hs [obj][h][w][C], hr/hm [obj][h][w]; lm: [obj][h][w][2C], conf: [obj][h][w]
+ *     scratch hs [obj][h][w][C], hr/hm [obj][h][w]; lm = r1_local: [obj][h][w][C], conf: [obj][h][w]
  * vfn_final_logits_f32          AFB_URR.py:233-237,300,309-316
  *     score[obj][H0][W0] = logit(clamp(softmax(bilinear_x2(p_up + unc*(conf*q)))[1], 1e-7, 1-1e-7)), un-padded
  */
@@ -104,7 +109,7 @@ int vfn_rough_uncertainty_f32(const float* p, float* p_up, float* rough, float* 
                               void* stream);
 int vfn_local_hpass_f32(const float* r1, const float* rough, float* hs, float* hr, float* hm, int obj_n,
                         int h, int w, int C, void* stream);
-int vfn_local_vpass_f32(const float* r1, const float* hs, const float* hr, const float* hm, float* lm,
+int vfn_local_vpass_f32(const float* hs, const float* hr, const float* hm, float* lm,
                         float* conf, int obj_n, int h, int w, int C, void* stream);
 int vfn_final_logits_f32(const float* p_up, const float* unc, const float* conf, const float* q, float* score,
                          int obj_n, int h, int w, int pad_top, int pad_left, int H0, int W0, void* stream);
@@ -137,7 +142,8 @@ typedef struct vfn_bankscan_desc {
 
 typedef struct vfn_memread_desc {
     const float* q;        /* [HW][ldq] query keys */
-    const float* qv;       /* [HW][ldqv] query values (copied into out[..][512:1024]) */
+    const float* qv;       /* [HW][ldqv] query values, copied into out[..][512:1024]; NULL: no copy (the caller
+                              applies convFM to the two halves of torch.cat([mem, q_out]) separately) */
     const float* bank_k;   /* [obj][cap][128] */
     const float* bank_v;   /* [obj][cap][512] */
     const int* bank_len;   /* [obj], device */
@@ -145,7 +151,7 @@ typedef struct vfn_memread_desc {
     float* o_part;         /* [obj][nsplit][HW][512] scratch */
     int* cnt;              /* [obj][stride_cnt] zero-initialised hit counters, or NULL (update_bank=False) */
     float* info;           /* [obj][cap][2] */
-    float* out;            /* [obj][HW][ld_out] decoder input, ld_out >= 1024 */
+    float* out;            /* [obj][HW][ld_out] decoder input, ld_out >= 1024 (>= 512 when qv is NULL) */
     long long stride_k, stride_v, stride_cnt, stride_info;
     float scale, thres;
     int ldq, ldqv, ld_out, HW, obj_n, nsplit;

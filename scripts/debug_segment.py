@@ -36,7 +36,7 @@ rep('k4', p.kv_q[0, :, :128].t().cpu(), k4[0]); rep('v4', p.kv_q[0, :, 128:].t()
 res = O.matcher(fb_ref, k4, v4, True)
 gh, gw = r4.shape[2:]
 res = res.reshape(2, 1024, gh, gw)
-rep('dec_in', nchw(p.dec_in), res)
+rep('dec_in', nchw(p.dec_in), res[:, :512])
 r3e, r2e, r1e = r3.expand(2, -1, -1, -1), r2.expand(2, -1, -1, -1), r1.expand(2, -1, -1, -1)
 out, parts = O.decoder(sd, res, r3e, r2e, r1e, (1, 2, r1.shape[2], r1.shape[3]), return_parts=True)
 D = 'decoder'
@@ -48,7 +48,7 @@ pr = O._conv3(sd, D + '.pred2', F.relu(pp2)); rep('pred2', nchw(p.pp), pr)
 rep('p_up', nchw(p.p_up), parts['p_up'])
 rep('rough', p.rough.cpu(), parts['rough'][:, 0])
 rep('unc', p.unc.cpu(), parts['unc'][0, 0])
-rep('r1_local', nchw(p.lm)[:, 64:], parts['r1_local'])
+rep('r1_local', nchw(p.lm), parts['r1_local'])
 rep('conf', p.conf.cpu(), parts['r1_conf'][:, 0])
 qraw = parts['q'] / parts['r1_conf']
 rep('q*conf', nchw(p.qq) * p.conf.cpu().unsqueeze(1), parts['q'])

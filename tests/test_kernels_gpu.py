@@ -107,12 +107,10 @@ def test_decoder_tail(gpu):
     hs = torch.empty(K, 2 * h, 2 * w, 64, device=gpu)
     hr = torch.empty(K, 2 * h, 2 * w, device=gpu)
     hm = torch.empty(K, 2 * h, 2 * w, device=gpu)
-    lm = torch.empty(K, 2 * h, 2 * w, 128, device=gpu)
+    lm = torch.empty(K, 2 * h, 2 * w, 64, device=gpu)
     cf = torch.empty(K, 2 * h, 2 * w, device=gpu)
     ops.local_stats(d(nhwc(r1)), rough_d, hs, hr, hm, lm, cf)
-    lmc = nchw(lm.cpu())
-    assert torch.equal(lmc[:, :64], r1e)
-    assert (lmc[:, 64:] - r1_local).abs().max() < 1e-5
+    assert (nchw(lm.cpu()) - r1_local).abs().max() < 1e-5
     assert (cf.cpu() - conf[:, 0]).abs().max() < 1e-6
     sc = torch.empty(1, K, H0, W0, device=gpu)
     ops.final_logits(p_up, unc_d, cf, d(nhwc(q)), sc, pad, H0, W0)
@@ -169,7 +167,7 @@ def test_memory_read(gpu, B, HW):
     plan = types.SimpleNamespace(HW=HW, kv_q=kvq.to(gpu), ml=torch.empty(2, HW, 2, device=gpu),
                                  ml_part=torch.empty(2, 16, HW, 2, device=gpu),
                                  o_part=torch.empty(2, 16, HW, 512, device=gpu),
-                                 dec_in=torch.empty(2, HW, 1024, device=gpu))
+                                 dec_in=torch.empty(2, HW, 512, device=gpu))
     Engine._memory_read(None, plan, fb, True)
     torch.cuda.synchronize()
     out = plan.dec_in.cpu()
@@ -179,7 +177,6 @@ def test_memory_read(gpu, B, HW):
         p = F.softmax(p, dim=1)
         mem = torch.matmul(vals[i], p)[0]                        # [512, HW]
         assert (out[i, :, :512].t() - mem).abs().max() < 5e-5 * max(1, mem.abs().max().item())
-        assert torch.equal(out[i, :, 512:], kvq[0, :, 128:])
         cnt = (p > 1e-3).float().sum(dim=2)[0]
         info_ref = 0.5 + torch.log(cnt + 1)
         got = fb.info[i][:, 1].cpu()

@@ -23,7 +23,7 @@ class ConvDesc(C.Structure):
                 ('out_ld', C.c_int), ('res_ld', C.c_int),
                 ('KH', C.c_int), ('KW', C.c_int), ('stride', C.c_int), ('pad', C.c_int),
                 ('relu_in', C.c_int), ('relu_out', C.c_int), ('M', C.c_int), ('ksplit', C.c_int),
-                ('split_from', C.c_int), ('partial', c_fp)]
+                ('split_from', C.c_int), ('res_mod', C.c_int), ('partial', c_fp)]
 
 
 class StemDesc(C.Structure):
@@ -85,6 +85,7 @@ def _declare(L):
     L.vfn_conv_cfg_count.restype = i
     L.vfn_conv_cfg_tile.argtypes = [i, C.POINTER(i), C.POINTER(i)]
     L.vfn_conv2d_nhwc_f32.argtypes = [C.POINTER(ConvDesc), i, p]
+    L.vfn_conv3x3_cout2_f32.argtypes = [C.POINTER(ConvDesc), p]
     L.vfn_stem_conv7x7_f32.argtypes = [C.POINTER(StemDesc), p]
     L.vfn_bank_scan.argtypes = [C.POINTER(BankScanDesc), p]
     L.vfn_memread_apply.argtypes = [C.POINTER(MemReadDesc), p]
@@ -105,7 +106,7 @@ SIGNATURES = {
     'vfn_upsample2x_add_nhwc_f32': [_p, _p, _p, _i, _i, _i, _i, _i, _p],
     'vfn_rough_uncertainty_f32': [_p, _p, _p, _p, _i, _i, _i, _p],
     'vfn_local_hpass_f32': [_p, _p, _p, _p, _p, _i, _i, _i, _i, _p],
-    'vfn_local_vpass_f32': [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p],
+    'vfn_local_vpass_f32': [_p, _p, _p, _p, _p, _i, _i, _i, _i, _p],
     'vfn_final_logits_f32': [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p],
     'vfn_bank_scan_finish': [_p, _i, _i, _i, _i, _p, _p, _p, _p, _p],
     'vfn_row_norms': [_p, _ll, _i, _i, _p, _i, _i, _p, _p, _ll, _p],
@@ -118,7 +119,8 @@ SIGNATURES = {
 }
 # every symbol include/vfn_hip.h declares (checked by tests/test_abi.py)
 ALL_SYMBOLS = sorted(list(SIGNATURES) + [
-    'vfn_abi_version', 'vfn_conv_cfg_count', 'vfn_conv_cfg_tile', 'vfn_conv2d_nhwc_f32', 'vfn_stem_conv7x7_f32',
+    'vfn_abi_version', 'vfn_conv_cfg_count', 'vfn_conv_cfg_tile', 'vfn_conv2d_nhwc_f32', 'vfn_conv3x3_cout2_f32',
+    'vfn_stem_conv7x7_f32',
     'vfn_bank_scan', 'vfn_memread_apply', 'vfn_memread_finish', 'vfn_bank_merge', 'vfn_bank_append'])
 
 

@@ -3,7 +3,7 @@
 //   vfn_upsample2x_add      Refine: m = s + interpolate(pm, x2, bilinear)          AFB_URR.py:124
 //   vfn_rough_uncertainty   interpolate(pred2) -> softmax[:,1] -> object softmax   AFB_URR.py:214-219
 //                           -> calc_uncertainty (top-2 ratio)                        myutils/data.py:40-46
-//   vfn_local_hpass/vpass   r1*rough, 7x7 avg-pools, divide, 7x7 max-pool, concat   AFB_URR.py:226-231
+//   vfn_local_hpass/vpass   r1*rough, 7x7 avg-pools, divide, 7x7 max-pool            AFB_URR.py:226-229
 //   vfn_final_logits        p + unc*(conf*q) -> interpolate x2 -> softmax[:,1]      AFB_URR.py:233-237
 //                           -> clamp -> logit -> un-pad crop                         AFB_URR.py:300,309-316
 //
@@ -133,8 +133,9 @@ __global__ void local_hpass_kernel(const float* __restrict__ r1, const float* __
     }
 }
 
-// vertical pass + divide; writes local_match [obj][h][w][2C] = cat(r1, r1_local) and conf [obj][h][w]
-__global__ void local_vpass_kernel(const float* __restrict__ r1, const float* __restrict__ hs,
+// vertical pass + divide; writes r1_local [obj][h][w][C] and conf [obj][h][w].  (torch.cat([r1, r1_local]),
+// AFB_URR.py:231, is never materialised: local_convFM is applied to the two halves separately.)
+__global__ void local_vpass_kernel(const float* __restrict__ hs,
                                    const float* __restrict__ hr, const float* __restrict__ hm,
                                    float* __restrict__ lm, float* __restrict__ conf,
                                    int obj_n, int h, int w, int C) {
@@ -163,9 +164,7 @@ __global__ void local_vpass_kernel(const float* __restrict__ r1, const float* __
 #pragma unroll
         for (int k = 0; k < 4; ++k) loc[k] = (acc[k] / 49.f) / den;
         const size_t pix = (size_t)y * w + x;
-        float* dst = lm + ((size_t)n * h * w + pix) * (2 * C);
-        *reinterpret_cast<f32x4*>(dst + c4 * 4) = *reinterpret_cast<const f32x4*>(r1 + pix * C + c4 * 4);
-        *reinterpret_cast<f32x4*>(dst + C + c4 * 4) = loc;
+        *reinterpret_cast<f32x4*>(lm + ((size_t)n * h * w + pix) * C + c4 * 4) = loc;
         if (c4 == 0) conf[(size_t)n * h * w + pix] = mr;
     }
 }
@@ -239,11 +238,11 @@ extern "C" int vfn_local_hpass_f32(const float* r1, const float* rough, float* h
     return vfn_check_launch();
 }
 
-extern "C" int vfn_local_vpass_f32(const float* r1, const float* hs, const float* hr, const float* hm, float* lm,
+extern "C" int vfn_local_vpass_f32(const float* hs, const float* hr, const float* hm, float* lm,
                                    float* conf, int obj_n, int h, int w, int C, void* stream) {
-    if (!r1 || !hs || !hr || !hm || !lm || !conf || C % 4) return VFN_ERR_ARG;
+    if (!hs || !hr || !hm || !lm || !conf || C % 4) return VFN_ERR_ARG;
     hipLaunchKernelGGL(local_vpass_kernel, dim3(grid_for((size_t)obj_n * h * w * (C / 4))), dim3(256), 0,
-                       (hipStream_t)stream, r1, hs, hr, hm, lm, conf, obj_n, h, w, C);
+                       (hipStream_t)stream, hs, hr, hm, lm, conf, obj_n, h, w, C);
     return vfn_check_launch();
 }
 

@@ -421,7 +421,7 @@ __global__ void memread_finish_kernel(const vfn_memread_desc p) {
             s += *reinterpret_cast<const f32x4*>(p.o_part + (((size_t)obj * p.nsplit + sp) * p.HW + q) * DV + c4 * 4);
         float* o = p.out + ((size_t)obj * p.HW + q) * p.ld_out;
         *reinterpret_cast<f32x4*>(o + c4 * 4) = s;
-        *reinterpret_cast<f32x4*>(o + DV + c4 * 4) = *reinterpret_cast<const f32x4*>(p.qv + (size_t)q * p.ldqv + c4 * 4);
+        if (p.qv) *reinterpret_cast<f32x4*>(o + DV + c4 * 4) = *reinterpret_cast<const f32x4*>(p.qv + (size_t)q * p.ldqv + c4 * 4);
     }
     if (p.cnt) {
         const int B = p.bank_len[obj];
@@ -483,7 +483,7 @@ extern "C" int vfn_memread_apply(const vfn_memread_desc* d, void* stream) {
 }
 
 extern "C" int vfn_memread_finish(const vfn_memread_desc* d, void* stream) {
-    if (!d || !d->o_part || !d->out || !d->qv || !d->bank_len) return VFN_ERR_ARG;
+    if (!d || !d->o_part || !d->out || !d->bank_len) return VFN_ERR_ARG;
     if (d->cnt && !d->info) return VFN_ERR_ARG;
     if (d->ld_out % 4 || d->ldqv % 4) return VFN_ERR_ARG;
     const dim3 grid(256, d->obj_n);

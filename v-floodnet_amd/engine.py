@@ -117,15 +117,20 @@ def choose_cfg(M, cout, K):
 
 
 class ConvLayer:
-    """Packed filters + epilogue constants of one convolution."""
+    """Packed filters + epilogue constants of one convolution (optionally of a slice of its input channels:
+    a conv over torch.cat([a, b]) is conv_a(a) + conv_b(b), which lets a shared half be computed once)."""
 
-    def __init__(self, conv, bn=None, device=None):
+    def __init__(self, conv, bn=None, device=None, cin_range=None, with_bias=True):
         w = conv.weight.detach().float()
+        if cin_range is not None:
+            w = w[:, cin_range[0]:cin_range[1]].contiguous()
         self.cout, self.cin, self.k, _ = w.shape
         self.stride = conv.stride[0]
         self.pad = conv.padding[0]
         self.w = ops.pad_rows(W.pack_conv_weight(w)).to(device)
         sc, sh = W.conv_epilogue(conv, bn)
+        if not with_bias:
+            sh = torch.zeros_like(sh)
         self.scale = sc.to(device).contiguous()
         self.shift = sh.to(device).contiguous()
 
@@ -157,8 +162,9 @@ class FramePlan:
         f = lambda *s: torch.empty(*s, device=dev, dtype=torch.float32)
         K = obj_n
         # inputs are bound per call (pointers patched into the stem descriptors)
-        self.frame_in = f(3, H0, W0)
-        self.mask_in = f(K, H0, W0)
+        self.frame_in = f(3, H0, W0)          # memorize() input
+        self.frame_q = f(3, H0, W0)           # segment() input (own buffer: the query encoder of frame t+1 may
+        self.mask_in = f(K, H0, W0)           #  run on a side stream while memorize() works on frame t)
         # query encoder
         self.q = self._trunk_buffers(1)
         self.kv_q = f(1, self.HW, DK + DV)
@@ -169,7 +175,8 @@ class FramePlan:
         self.ml = f(K, self.HW, 2)
         self.ml_part = f(K, MAX_SPLIT, self.HW, 2)
         self.o_part = f(K, MAX_SPLIT, self.HW, DV)
-        self.dec_in = f(K, self.h16, self.w16, 2 * DV)
+        self.dec_in = f(K, self.h16, self.w16, DV)          # memory read-out only; the query-value half of
+        self.fm_q = f(1, self.h16, self.w16, 256)            # cat([mem, q_out]) goes through its own conv (fm_q)
         # decoder
         self.d16 = [f(K, self.h16, self.w16, 256) for _ in range(3)]
         self.s8 = [f(1, self.h8, self.w8, 256) for _ in range(3)]
@@ -183,12 +190,15 @@ class FramePlan:
         self.hs = f(K, self.h2, self.w2, 64)
         self.hr = f(K, self.h2, self.w2)
         self.hm = f(K, self.h2, self.w2)
-        self.lm = f(K, self.h2, self.w2, 128)
+        self.lm = f(K, self.h2, self.w2, 64)                 # r1_local
+        self.lq = f(1, self.h2, self.w2, 32)                 # local_convFM over the shared r1 half
         self.conf = f(K, self.h2, self.w2)
         self.l2 = [f(K, self.h2, self.w2, 32) for _ in range(3)]
         self.qq = f(K, self.h2, self.w2, 2)
         self.score = f(1, K, H0, W0)
         self.ws = f(WS_FLOATS)
+        self.ws_q = f(WS_FLOATS)              # split-K workspace of the query-encoder list (side stream)
+        self._ws_cur = self.ws
 
         self.seg_pre = []     # stem .. KeyValue
         self.seg_post = []    # decoder
@@ -212,16 +222,20 @@ class FramePlan:
 
     # ------------------------------------------------------------------ builders
     def _conv(self, lst, layer, x, out, N, H, Wd, res=None, relu_in=False, relu_out=False, name='conv',
-              in_ld=None, out_ld=None):
+              in_ld=None, out_ld=None, res_mod=0):
         d = ops.make_conv_desc(x, layer.w, layer.cout, layer.k, layer.k, layer.stride, layer.pad, out,
                                layer.scale, layer.shift, res, relu_in, relu_out,
                                cin=layer.cin, in_ld=in_ld if in_ld is not None else x.shape[-1],
                                out_ld=out_ld, N=N, H=H, W=Wd)
+        d.res_mod = int(res_mod)
         K = layer.k * layer.k * layer.cin
+        if layer.cout == 2 and layer.k == 3 and layer.cin in (32, 256) and res is None:
+            lst.append(Launch(ops.conv_cout2_launch, (d,), f'{name}[{d.M}x2x{K}]', 2.0 * d.M * 2 * K))
+            return out
         choice = choose_cfg(d.M, layer.cout, K)
         if choice[1] > 1 and (d.out_ld % 4 or (res is not None and d.res_ld % 4)):
             choice = (choice[0], 1, 0)
-        cfg = apply_choice(d, choice, self.ws)
+        cfg = apply_choice(d, choice, self._ws_cur)
         lst.append(Launch(ops.conv2d_launch, (d, cfg), f'{name}[{d.M}x{layer.cout}x{K}]', 2.0 * d.M * layer.cout * K))
         return out
 
@@ -259,17 +273,25 @@ class FramePlan:
         e = self.eng
         K = self.obj_n
         # ---- segment: query encoder + KeyValue
-        self.stem_q = ops.make_stem_desc(self.frame_in, None, e.stem_q_w, e.stem_q_scale, e.stem_q_shift,
+        self._ws_cur = self.ws_q
+        self.stem_q = ops.make_stem_desc(self.frame_q, None, e.stem_q_w, e.stem_q_scale, e.stem_q_shift,
                                          self.q['r1'], e.mean, e.std, 1, self.H0, self.W0, self.pad, self.Hp, self.Wp)
         self.seg_pre.append(Launch(ops.stem_launch, (self.stem_q,), 'encoder_q.stem',
                                    2.0 * self.h2 * self.w2 * 64 * 147))
         r4 = self._trunk(self.seg_pre, e.enc_q, self.q, 1, 'encoder_q')
         self._conv(self.seg_pre, e.keyval, r4, self.kv_q, 1, self.h16, self.w16, name='keyval')
+        self._ws_cur = self.ws
         # ---- decoder
         L = self.seg_post
         D = e.dec
         d16, s8, d8, s4, d4 = self.d16, self.s8, self.d8, self.s4, self.d4
-        self._conv(L, D['convFM'], self.dec_in, d16[0], K, self.h16, self.w16, name='decoder.convFM')
+        # convFM(cat([mem_i, q_out])) = convFM[:, :512](mem_i) + convFM[:, 512:](q_out): the second term is the
+        # same for every object (AFB_URR.py:159,176) -> computed once (with the bias) and added as a shared residual
+        kvq_val = self.kv_q[:, :, DK:]                          # [1, HW, 512] view, pixel stride 640
+        self._conv(L, D['convFM_q'], kvq_val, self.fm_q, 1, self.h16, self.w16, name='decoder.convFM.q',
+                   in_ld=DK + DV)
+        self._conv(L, D['convFM_m'], self.dec_in, d16[0], K, self.h16, self.w16, res=self.fm_q, res_mod=self.HW,
+                   name='decoder.convFM.mem')
         self._resblock(L, D['ResMM'], d16[0], d16[1], d16[2], K, self.h16, self.w16, 'decoder.ResMM')
         # RF3 (feature branch shared by the objects: N=1)
         self._conv(L, D['RF3']['convFS'], self.q['res3']['out'], s8[0], 1, self.h8, self.w8, name='decoder.RF3.convFS')
@@ -286,7 +308,10 @@ class FramePlan:
         L.append(Launch(ops.local_stats, (self.q['r1'], self.rough, self.hs, self.hr, self.hm, self.lm, self.conf),
                         'decoder.local_stats'))
         l2 = self.l2
-        self._conv(L, D['local_convFM'], self.lm, l2[0], K, self.h2, self.w2, name='decoder.local_convFM')
+        # local_convFM(cat([r1, r1_local])) likewise: the r1 half is shared by the objects (AFB_URR.py:231-232)
+        self._conv(L, D['local_convFM_r1'], self.q['r1'], self.lq, 1, self.h2, self.w2, name='decoder.local_convFM.r1')
+        self._conv(L, D['local_convFM_loc'], self.lm, l2[0], K, self.h2, self.w2, res=self.lq,
+                   res_mod=self.h2 * self.w2, name='decoder.local_convFM.local')
         self._resblock(L, D['local_ResMM'], l2[0], l2[1], l2[2], K, self.h2, self.w2, 'decoder.local_ResMM')
         self._conv(L, D['local_pred2'], l2[2], self.qq, K, self.h2, self.w2, relu_in=True, name='decoder.local_pred2')
         L.append(Launch(ops.final_logits, (self.p_up, self.unc, self.conf, self.qq, self.score, self.pad,
@@ -313,6 +338,8 @@ class Engine:
         self.device = dev
         self.model = model
         self.plans = {}
+        self._side = None            # side stream for the next frame's query encoder
+        self._prefetched = None
         self._pack(model)
 
     # ------------------------------------------------------------------ weights
@@ -357,8 +384,12 @@ class Engine:
             cl = lambda c: ConvLayer(c, None, dev)
             rb = lambda r: dict(conv1=cl(r.conv1), conv2=cl(r.conv2))
             rf = lambda r: dict(convFS=cl(r.convFS), ResFS=rb(r.ResFS), ResMM=rb(r.ResMM))
-            self.dec = dict(convFM=cl(d.convFM), ResMM=rb(d.ResMM), RF3=rf(d.RF3), RF2=rf(d.RF2), pred2=cl(d.pred2),
-                            local_convFM=cl(d.local_convFM), local_ResMM=rb(d.local_ResMM),
+            self.dec = dict(convFM_m=ConvLayer(d.convFM, None, dev, (0, DV), with_bias=False),
+                            convFM_q=ConvLayer(d.convFM, None, dev, (DV, 2 * DV)),
+                            local_convFM_r1=ConvLayer(d.local_convFM, None, dev, (0, 64)),
+                            local_convFM_loc=ConvLayer(d.local_convFM, None, dev, (64, 128), with_bias=False),
+                            ResMM=rb(d.ResMM), RF3=rf(d.RF3), RF2=rf(d.RF2), pred2=cl(d.pred2),
+                            local_ResMM=rb(d.local_ResMM),
                             local_pred2=cl(d.local_pred2))
 
     # ------------------------------------------------------------------ plans
@@ -401,13 +432,38 @@ class Engine:
             raise RuntimeError('feature bank is empty: call fb.init_bank() first')
         if fb._hw != p.HW:
             raise RuntimeError('feature bank was built for a different frame size')
-        p.frame_in.copy_(frame[0])
-        for l in p.seg_pre:
-            l()
+        pre = self._prefetched
+        if pre is not None and pre[0] is p and pre[1] == frame.data_ptr():
+            torch.cuda.current_stream().wait_event(pre[2])       # query encoder already ran on the side stream
+        else:
+            p.frame_q.copy_(frame[0])
+            for l in p.seg_pre:
+                l()
+        self._prefetched = None
         self._memory_read(p, fb, update_bank)
         for l in p.seg_post:
             l()
         return p.score
+
+    def prefetch_query(self, frame, obj_n):
+        """Run the query encoder + KeyValue of ``frame`` (the *next* frame of the clip) on a side stream.
+        It depends only on that frame, so it may overlap ``memorize`` / ``FeatureBank.update`` of the
+        current frame; the next ``segment(frame, ...)`` call picks the result up.  Call it after the
+        current frame's ``segment`` (the decoder reads the query encoder's skip features)."""
+        self._check_frame(frame)
+        p = self.plan(frame.shape[2], frame.shape[3], obj_n)
+        if self._side is None:
+            self._side = torch.cuda.Stream(device=self.device)
+        ready = torch.cuda.Event()
+        ready.record()                                           # decoder of the current frame is enqueued
+        with torch.cuda.stream(self._side):
+            self._side.wait_event(ready)
+            p.frame_q.copy_(frame[0])
+            for l in p.seg_pre:
+                l()
+            done = torch.cuda.Event()
+            done.record()
+        self._prefetched = (p, frame.data_ptr(), done)
 
     def _memory_read(self, p, fb, update_bank):
         """Matcher.forward (AFB_URR.py:136-178) on the bank slabs."""
@@ -426,13 +482,13 @@ class Engine:
               'vfn_bank_scan_finish')
         m = MemReadDesc()
         m.q = ptr(p.kv_q)
-        m.qv = _lib.C.c_void_p(p.kv_q.data_ptr() + DK * 4)
+        m.qv = None                       # the query value joins through decoder.convFM.q instead of a concat
         m.bank_k, m.bank_v, m.bank_len, m.ml, m.o_part = ptr(fb._kbuf), ptr(fb._vbuf), ptr(fb._len_dev), ptr(p.ml), ptr(p.o_part)
         m.cnt = ptr(fb._cnt) if update_bank else None
         m.info, m.out = ptr(fb._ibuf), ptr(p.dec_in)
         m.stride_k, m.stride_v, m.stride_cnt, m.stride_info = cap * DK, cap * DV, cap, cap * 2
         m.scale, m.thres = scale, 1e-3
-        m.ldq, m.ldqv, m.ld_out, m.HW, m.obj_n, m.nsplit = DK + DV, DK + DV, 2 * DV, HW, K, nsplit
+        m.ldq, m.ldqv, m.ld_out, m.HW, m.obj_n, m.nsplit = DK + DV, DK + DV, p.dec_in.shape[-1], HW, K, nsplit
         check(L.vfn_memread_apply(_lib.C.byref(m), s), 'vfn_memread_apply')
         check(L.vfn_memread_finish(_lib.C.byref(m), s), 'vfn_memread_finish')
 

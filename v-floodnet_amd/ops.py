@@ -53,6 +53,7 @@ def make_conv_desc(x, wp, cout, kh, kw, stride, pad, out, scale=None, shift=None
     d.relu_in, d.relu_out = int(relu_in), int(relu_out)
     d.M = N * Ho * Wo
     d.ksplit, d.split_from, d.partial = 1, 0, None
+    d.res_mod = 0
     assert wp.shape[1] == kh * kw * cin
     return d
 
@@ -97,6 +98,10 @@ def valid_splits(desc, max_split=16):
         if per * (s_ - 1) < nk and per >= 4:
             out.append(s_)
     return out
+
+
+def conv_cout2_launch(desc):
+    check(_lib.lib().vfn_conv3x3_cout2_f32(C.byref(desc), stream()), 'vfn_conv3x3_cout2_f32')
 
 
 def conv2d_launch(desc, cfg):
@@ -171,7 +176,7 @@ def local_stats(r1, rough, hs, hr, hm, lm, conf):
     L = _lib.lib()
     check(L.vfn_local_hpass_f32(ptr(r1), ptr(rough), ptr(hs), ptr(hr), ptr(hm), obj_n, h, w, Cc, stream()),
           'vfn_local_hpass_f32')
-    check(L.vfn_local_vpass_f32(ptr(r1), ptr(hs), ptr(hr), ptr(hm), ptr(lm), ptr(conf), obj_n, h, w, Cc, stream()),
+    check(L.vfn_local_vpass_f32(ptr(hs), ptr(hr), ptr(hm), ptr(lm), ptr(conf), obj_n, h, w, Cc, stream()),
           'vfn_local_vpass_f32')
 
 

@@ -72,6 +72,8 @@ class ClipRunner:
         self.t = 0
         self._pinned = None
         self._stats_pinned = None
+        self._next_net = None
+        self._next_src = None
 
     def _net_frame(self, frame):
         """TF.resize(ori_frame, 480, BICUBIC) (:88,:107); identity when the short edge already matches."""
@@ -97,13 +99,25 @@ class ClipRunner:
         self._pinned = torch.empty(H0, W0, dtype=torch.uint8).pin_memory()
         self._stats_pinned = torch.zeros(self.obj_n, 4, dtype=torch.int32).pin_memory()
 
-    def step(self, frame, want_label=True):
+    def step(self, frame, want_label=True, next_frame=None):
         """One iteration of the hot loop (:105-115).  frame f32[1,3,H0,W0] on the GPU.
-        Returns the uint8 label map [H0,W0] as a pinned host tensor (valid until the next step)."""
+        Returns the uint8 label map [H0,W0] as a pinned host tensor (valid until the next step).
+
+        ``next_frame`` (optional, already on the GPU): lets the query encoder of frame t+1 -- which depends
+        on nothing but that frame -- run on a side stream underneath memorize/update of frame t.  Results
+        are identical with or without it."""
         self.t += 1
-        f = self._net_frame(frame)
+        if self._next_net is not None and self._next_src == frame.data_ptr():
+            f = self._next_net                                    # resized when it was prefetched
+        else:
+            f = self._net_frame(frame)
+        self._next_net = None
         score, _ = self.model.segment(f, self.fb)                 # :108
         pred_mask = ops.softmax_objects(score)                    # :109
+        if next_frame is not None:
+            self._next_net = self._net_frame(next_frame)
+            self._next_src = next_frame.data_ptr()
+            self.model.engine().prefetch_query(self._next_net, self.obj_n)
         if self.t % self.mem_every == 0:
             k, v = self.model.memorize(f, pred_mask)              # :111 (soft masks are memorised)
             self.fb.update(k, v, self.t)                          # :112
@@ -121,7 +135,7 @@ class ClipRunner:
 
 
 def run_clip(model, frames, first_mask_u8, budget=250000, update_rate=0.1, thres_close=0.95, size=480,
-             mem_every=1, postprocess=False):
+             mem_every=1, postprocess=False, overlap=True):
     """frames f32[T,3,H0,W0] on the GPU, first mask u8[H0,W0] (>0 = water).
     Returns labels u8[T,H0,W0] (host; frame 0 = the given mask) and per-frame bank sizes."""
     T, _, H0, W0 = frames.shape
@@ -133,7 +147,7 @@ def run_clip(model, frames, first_mask_u8, budget=250000, update_rate=0.1, thres
     labels[0] = m.cpu()
     sizes = []
     for t in range(1, T):
-        lab = runner.step(frames[t:t + 1])
+        lab = runner.step(frames[t:t + 1], next_frame=frames[t + 1:t + 2] if (overlap and t + 1 < T) else None)
         if postprocess:
             labels[t] = torch.from_numpy(postprocessing_pred(lab.numpy()))
         else:
