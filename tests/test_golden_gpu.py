@@ -110,3 +110,31 @@ def test_full_size_samples(gpu, model):
     ok, dl, dp = close_logits(score.cpu().flatten()[t(g['score_idx'])], t(g['score_val']), 2e-3)
     assert ok, (dl, dp)
     assert abs(float((score[0, 1] > score[0, 0]).float().mean()) - float(g['label_water_frac'])) < 2e-3
+
+
+def test_c2_full_clip_vs_reference(gpu, model):
+    """BASELINE config C2: the whole 100-frame 480x854 fp32 clip, free-running (segment -> softmax -> memorize ->
+    bank update every frame, eviction at the budget), against the label maps produced by the reference's own
+    model + FeatureBank on CPU (oracle/gen_c2_golden.py).  Target: mIoU >= 0.99 on every frame."""
+    import os
+    from golden_util import GOLDEN
+    from vfloodnet_amd import synth
+    from vfloodnet_amd.video_seg import run_clip
+    path = os.path.join(GOLDEN, 'c2_480x854_100.npz')
+    if not os.path.exists(path):
+        pytest.skip('c2 golden not generated')
+    g = np.load(path)
+    H, W = [int(x) for x in g['shape']]
+    ref = np.unpackbits(g['labels'], axis=-1)[..., :W]
+    T = ref.shape[0]
+    frames, m0 = synth.clip(int(g['seed']), T, H, W)
+    out = run_clip(model, frames.to(gpu), m0)
+    lab = out['labels'].numpy()
+    assert np.array_equal(lab[0], ref[0])
+    ious = [miou(torch.from_numpy(lab[t]), torch.from_numpy(ref[t])) for t in range(1, T)]
+    sizes = np.array(out['bank_sizes'])
+    drift = np.abs(sizes - g['bank_sizes']).max()
+    print('C2 mIoU min %.5f mean %.5f; bank size max drift %d; peak %s replace %s (ref %s %s)' % (
+        min(ious), sum(ious) / len(ious), drift, out['fb'].peak_n, out['fb'].replace_n, g['peak_n'], g['replace_n']))
+    assert min(ious) >= 0.99, (min(ious), int(np.argmin(ious)) + 1)
+    assert drift <= max(8, 0.001 * sizes.max())        # merge/append decisions sit on a float threshold

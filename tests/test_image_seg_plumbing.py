@@ -1,0 +1,44 @@
+"""BASELINE config C1: one 480x854 frame through the test_image_seg.py plumbing on CPU with a stand-in
+``.predict`` (the LinkNet weights / package are not available; only the contract around it is in scope)."""
+import numpy as np
+import torch
+from PIL import Image
+
+
+class StandIn:
+    """predict(x[1,3,416,416]) -> prob[1,1,416,416]: brightness threshold of the de-normalised image."""
+
+    def predict(self, x):
+        assert tuple(x.shape) == (1, 3, 416, 416) and x.dtype == torch.float32
+        g = (x * torch.tensor([0.229, 0.224, 0.225]).view(1, 3, 1, 1) + torch.tensor([0.485, 0.456, 0.406]).view(1, 3, 1, 1))
+        return (g.mean(1, keepdim=True) > 0.5).float() * 0.9
+
+
+def test_c1_single_frame(tmp_path):
+    import vfloodnet_amd  # noqa: F401
+    from vfloodnet_amd import image_seg, synth
+    frames, m0 = synth.clip(1, 1, 480, 854)
+    src = tmp_path / 'frame.png'
+    Image.fromarray((frames[0] * 255).round().to(torch.uint8).permute(1, 2, 0).numpy()).save(str(src))
+    image_seg.test_waterseg('unused.pth', str(src), 'clip', str(tmp_path / 'out'), torch.device('cpu'), model=StandIn())
+    mask = Image.open(str(tmp_path / 'out' / 'clip' / 'mask' / 'frame.png'))
+    assert mask.mode == 'P' and mask.size == (854, 480)
+    assert mask.getpalette()[:12] == [0, 0, 0, 0, 0, 128, 0, 128, 0, 128, 0, 0]
+    lab = np.array(mask)
+    assert set(np.unique(lab)) <= {0, 1} and 0 < lab.mean() < 1
+    # the output is one 8-connected blob (postprocessing_pred)
+    from scipy import ndimage
+    assert ndimage.label(lab, structure=np.ones((3, 3)))[1] == 1
+    ov = Image.open(str(tmp_path / 'out' / 'clip' / 'overlay' / 'frame.png'))
+    assert ov.size == (854, 480) and ov.mode == 'RGB'
+
+
+def test_norm_imagenet_matches_definition():
+    import vfloodnet_amd  # noqa: F401
+    from vfloodnet_amd import image_seg
+    rng = np.random.RandomState(0)
+    img = Image.fromarray(rng.randint(0, 255, (60, 90, 3), dtype=np.uint8))
+    t = image_seg.norm_imagenet(img, (416, 416))
+    ref = torch.from_numpy(np.asarray(img.resize((416, 416), Image.BILINEAR)).transpose(2, 0, 1).copy()).float() / 255
+    ref = (ref - torch.tensor([0.485, 0.456, 0.406]).view(3, 1, 1)) / torch.tensor([0.229, 0.224, 0.225]).view(3, 1, 1)
+    assert t.shape == (3, 416, 416) and torch.equal(t, ref)

@@ -183,9 +183,13 @@ def main(args, device):
     mask_dir = os.path.join(out_dir, args.test_name, 'mask')
     mask_path = os.path.join(mask_dir, first_name + '.png')
     if not os.path.exists(mask_path):
-        # test_video_seg.py:67-69 bootstraps the mask with the LinkNet image model (test_image_seg.py),
-        # whose weights / package are not part of this path.
-        raise IOError(f'first-frame mask {mask_path} not found: provide it (e.g. from test_image_seg.py)')
+        # test_video_seg.py:67-69: bootstrap the first mask with the image model (plumbing in image_seg.py;
+        # the pickled LinkNet itself is outside this path)
+        image_model_path = './records/link_efficientb4_model.pth'
+        if not os.path.isfile(image_model_path):
+            raise IOError(f'first-frame mask {mask_path} not found and no image model at {image_model_path}')
+        from .image_seg import test_waterseg
+        test_waterseg(image_model_path, img_list[0], args.test_name, out_dir, device)
 
     first_mask = load_image_in_PIL(mask_path, 'P')
     seq_dataset = Video_DS(img_list, first_frame, first_mask)
