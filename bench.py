@@ -29,6 +29,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 PEAK_F32_MATRIX_TFLOPS = 157.3        # MI355X_MICROARCH.md, v_mfma_f32_32x32x2_f32
+WAVES = [(2, 2), (2, 2), (2, 2), (2, 2), (1, 2), (2, 1), (4, 1), (4, 2), (2, 4), (4, 2), (2, 4)]   # per conv cfg
 H0, W0 = 480, 854
 
 
@@ -183,9 +184,17 @@ def main():
         tot_ms = sum(v[1] for v in per.values())
         fl, ms, n = per[dom]
         ach = fl / (ms * 1e-3) / 1e12
-        roof = {'bound': 'mfma', 'kernel': f'conv_igemm_kernel<{tiles[dom][0]},{tiles[dom][1]}>',
+        kname = f'conv_igemm_kernel<{tiles[dom][0]}, {tiles[dom][1]}, {WAVES[dom][0]}, {WAVES[dom][1]}>'
+        traffic = None                      # HBM bytes per launch of this kernel from the committed PMC passes
+        tpath = os.path.join(ROOT, 'profiles', 'r01_pmc_traffic.json')
+        if os.path.isfile(tpath):
+            for k_, v_ in json.load(open(tpath)).items():
+                if kname in k_:
+                    traffic = round(v_['hbm_bytes_per_launch'])
+        roof = {'bound': 'mfma', 'kernel': kname,
                 'achieved': round(ach, 2), 'peak': PEAK_F32_MATRIX_TFLOPS, 'unit': 'TFLOP/s',
-                'frac': round(ach / PEAK_F32_MATRIX_TFLOPS, 4), 'traffic': None,
+                'frac': round(ach / PEAK_F32_MATRIX_TFLOPS, 4), 'traffic': traffic,
+                'traffic_source': 'profiles/r01_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, FETCH doubled per MI355X_MICROARCH.md)',
                 'launches_timed': n, 'avg_launch_us': round(ms * 1e3 / n, 2),
                 'all_conv_achieved': round(tot_fl / (tot_ms * 1e-3) / 1e12, 2),
                 'all_conv_frac': round(tot_fl / (tot_ms * 1e-3) / 1e12 / PEAK_F32_MATRIX_TFLOPS, 4)}
@@ -215,6 +224,19 @@ def main():
         parity = {'frames': n_cpu,
                   'miou_vs_oracle': round(min(miou(lab[t], ref['labels'][t]) for t in range(1, n_cpu + 1)), 5),
                   'bank_sizes_equal': bank_sizes[:n_cpu] == ref['bank_sizes']}
+
+    gpath = os.path.join(ROOT, 'tests', 'golden', 'c2_480x854_100.npz')
+    if world == 1 and K == 99 and os.path.isfile(gpath):
+        import numpy as np
+        g = np.load(gpath)
+        refl = torch.from_numpy(np.unpackbits(g['labels'], axis=-1)[..., :W0])
+        lab = labels.cpu()
+        ious = [miou(lab[t], refl[t]) for t in range(1, K + 1)]
+        parity = dict(parity or {})
+        parity.update({'full_clip_frames': K, 'full_clip_miou_min': round(min(ious), 5),
+                       'full_clip_miou_mean': round(sum(ious) / len(ious), 5),
+                       'full_clip_reference': 'tests/golden/c2_480x854_100.npz (reference model + FeatureBank on CPU, '
+                                              'oracle/gen_c2_golden.py)'})
 
     out = {'metric': 'segmented frames/sec at 480p', 'value': round(fps, 3), 'unit': 'frames/s', 'n_gpus': world,
            'steps': K, 'warmup': Wm, 'ms_per_step': round(1e3 * elapsed / K, 3), 'higher_is_better': True,
