@@ -162,9 +162,14 @@ void conv_igemm_kernel(const vfn_conv_desc p) {
     }
     __syncthreads();
 
+#ifdef VFN_ABLATE
+    const bool ab_noload = p.relu_out & 256, ab_nobar = p.relu_out & 512;
+#else
+    constexpr bool ab_noload = false, ab_nobar = false;
+#endif
     for (int kt = 0; kt < nk; ++kt) {
         const int buf = kt & 1;
-        if (kt + 1 < nk) load_tile(kt_begin + kt + 1);
+        if (kt + 1 < nk && !ab_noload) load_tile(kt_begin + kt + 1);
 
         const float* cA = sA + buf * BM * BK + (wm * TM * 32) * BK;
         const float* cB = sB + buf * BN * BK + (wn * TN * 32) * BK;
@@ -197,8 +202,8 @@ void conv_igemm_kernel(const vfn_conv_desc p) {
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[cur][i][t], b[cur][j][t], acc[i][j], 0, 0, 0);
         }
 
-        if (kt + 1 < nk) store_tile(buf ^ 1);
-        __syncthreads();
+        if (kt + 1 < nk && !ab_noload) store_tile(buf ^ 1);
+        if (!ab_nobar) __syncthreads();
     }
 
     // split-K: raw partial sums to the workspace slab of this split; vfn_conv_splitk_reduce finishes
@@ -223,6 +228,201 @@ void conv_igemm_kernel(const vfn_conv_desc p) {
     }
 
     // epilogue: lane holds filter column (lane&31) for rows (reg&3)+8*(reg>>2)+4*(lane>>5)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int col = n0 + (wn * TN + j) * 32 + li;
+        if (col >= p.Cout) continue;
+        const float sc = p.scale ? p.scale[col] : 1.f;
+        const float sh = p.shift ? p.shift[col] : 0.f;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const int rbase = m0 + (wm * TM + i) * 32 + 4 * lh;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = rbase + (r & 3) + 8 * (r >> 2);
+                if (row < p.M) {
+                    float v = acc[i][j][r] * sc + sh;
+                    if (p.res) v += p.res[(size_t)(p.res_mod > 0 ? row % p.res_mod : row) * p.res_ld + col];
+                    if (p.relu_out) v = fmaxf(v, 0.f);
+                    p.out[(size_t)row * p.out_ld + col] = v;
+                }
+            }
+        }
+    }
+}
+
+// 128 bytes of zeros: the LDS-DMA source of every filter tap that falls outside the image
+__device__ __attribute__((aligned(128))) float vfn_zero_page[32];
+
+// (device-only helper: the builtin has no host form, and the host pass must still be able to emit the stub)
+__device__ __forceinline__ void lds_dma16(const float* src, float* lds_dst) {
+    __builtin_amdgcn_global_load_lds(src, lds_dst, 16, 0, 0);
+}
+__device__ __forceinline__ int wave_uniform(int x) { return __builtin_amdgcn_readfirstlane(x); }
+
+// Same GEMM, operands staged by LDS-DMA (global_load_lds_dwordx4): no staging VGPRs, no ds_write, no
+// select/ReLU VALU on the load path -- the ablation of the register-staged kernel shows that path costs
+// 15-30 % of the MFMA rate.  One wave instruction writes 1 KB = 8 image rows x 128 B linearly, so the XOR
+// swizzle is applied to the per-lane SOURCE address; out-of-image taps read vfn_zero_page; ReLU-on-input
+// moves to the fragment registers.
+template <int BM, int BN, int WM, int WN>
+__global__ __launch_bounds__(WM * WN * 64)
+void conv_igemm_dma_kernel(const vfn_conv_desc p) {
+    constexpr int NW = WM * WN;
+    constexpr int TM = BM / WM / 32;
+    constexpr int TN = BN / WN / 32;
+    constexpr int APW = BM / 8 / NW;       // A wave-instructions per wave per K tile
+    constexpr int BPW = BN / 8 / NW;
+    static_assert(APW >= 1 && BPW >= 1, "tile too small for the wave count");
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* sA = reinterpret_cast<float*>(smem);          // [2][BM][32]
+    float* sB = sA + 2 * BM * BK;                        // [2][BN][32]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = wave_uniform(tid >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+    const int li = lane & 31, lh = lane >> 5;
+    const int lr = lane >> 3, pc = lane & 7;             // row within a wave instruction / physical chunk
+
+    const int n_tiles = (p.Cout + BN - 1) / BN;
+    const int ksplit = p.ksplit > 1 ? p.ksplit : 1;
+    int tile = blockIdx.x, kz = 0;
+    bool split_tile = false;
+    if (ksplit > 1 && tile >= p.split_from) {
+        const int r = tile - p.split_from;
+        tile = p.split_from + r / ksplit;
+        kz = r - (r / ksplit) * ksplit;
+        split_tile = true;
+    }
+    const int mt = tile / n_tiles, nt = tile % n_tiles;
+    const int m0 = mt * BM, n0 = nt * BN;
+
+    const int HoWo = p.Ho * p.Wo;
+    const int cblks = p.Cin / BK;
+    const int Ktot = p.KH * p.KW * p.Cin;
+    const int nk_all = p.KH * p.KW * cblks;
+    const int kper = split_tile ? (nk_all + ksplit - 1) / ksplit : nk_all;
+    const int kt_begin = kz * kper;
+    const int nk = min(kper, nk_all - kt_begin);
+
+    // per-lane source description of its A rows (one row per wave instruction)
+    int a_base[APW], a_hi0[APW], a_wi0[APW], a_c[APW];
+#pragma unroll
+    for (int j = 0; j < APW; ++j) {
+        const int r = (wave * APW + j) * 8 + lr;
+        a_c[j] = (pc ^ ((r >> 1) & 7)) << 2;
+        const int m = m0 + r;
+        if (m < p.M) {
+            const int n = m / HoWo;
+            const int rem = m - n * HoWo;
+            const int ho = rem / p.Wo;
+            const int wo = rem - ho * p.Wo;
+            a_base[j] = n * p.H * p.W;
+            a_hi0[j] = ho * p.stride - p.pad;
+            a_wi0[j] = wo * p.stride - p.pad;
+        } else {
+            a_base[j] = 0;
+            a_hi0[j] = -100000;
+            a_wi0[j] = 0;
+        }
+    }
+    const float* wsrc[BPW];
+#pragma unroll
+    for (int j = 0; j < BPW; ++j) {
+        const int r = (wave * BPW + j) * 8 + lr;
+        wsrc[j] = p.w + (size_t)(n0 + r) * Ktot + ((pc ^ ((r >> 1) & 7)) << 2);
+    }
+
+    int kh, kw, cb;
+    {
+        const int tap = kt_begin / cblks;
+        cb = kt_begin - tap * cblks;
+        kh = tap / p.KW;
+        kw = tap - kh * p.KW;
+    }
+    auto issue_tile = [&](int kt, int buf) {
+        float* dA = sA + buf * BM * BK + (wave * APW) * 8 * BK;
+        float* dB = sB + buf * BN * BK + (wave * BPW) * 8 * BK;
+#pragma unroll
+        for (int j = 0; j < APW; ++j) {
+            const int hi = a_hi0[j] + kh, wi = a_wi0[j] + kw;
+            const bool ok = (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;
+            const float* src = ok ? p.in + (size_t)(a_base[j] + hi * p.W + wi) * p.in_ld + cb * BK + a_c[j]
+                                  : vfn_zero_page + a_c[j];
+            lds_dma16(src, dA + j * 8 * BK);
+        }
+#pragma unroll
+        for (int j = 0; j < BPW; ++j)
+            lds_dma16(wsrc[j] + (size_t)kt * BK, dB + j * 8 * BK);
+        if (++cb == cblks) { cb = 0; if (++kw == p.KW) { kw = 0; ++kh; } }
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    if (nk > 0) issue_tile(kt_begin, 0);
+    __syncthreads();                                   // (drains the LDS-DMA)
+    const float relu_floor = p.relu_in ? 0.f : -INFINITY;
+
+    for (int kt = 0; kt < nk; ++kt) {
+        const int buf = kt & 1;
+        if (kt + 1 < nk) issue_tile(kt_begin + kt + 1, buf ^ 1);     // lands behind this tile's MFMAs
+
+        const float* cA = sA + buf * BM * BK + (wm * TM * 32) * BK;
+        const float* cB = sB + buf * BN * BK + (wn * TN * 32) * BK;
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            const int lc = 2 * kk + lh;
+            f32x4 a[TM], b[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const int r = i * 32 + li;
+                a[i] = *reinterpret_cast<const f32x4*>(cA + r * BK + ((lc ^ ((r >> 1) & 7)) << 2));
+                a[i].x = fmaxf(a[i].x, relu_floor); a[i].y = fmaxf(a[i].y, relu_floor);
+                a[i].z = fmaxf(a[i].z, relu_floor); a[i].w = fmaxf(a[i].w, relu_floor);
+            }
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int r = j * 32 + li;
+                b[j] = *reinterpret_cast<const f32x4*>(cB + r * BK + ((lc ^ ((r >> 1) & 7)) << 2));
+            }
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][t], b[j][t], acc[i][j], 0, 0, 0);
+        }
+        __syncthreads();                               // next tile landed; this buffer may be refilled
+    }
+
+    if (split_tile) {
+        const int m_start = (p.split_from / n_tiles) * BM;
+        float* part = p.partial + ((long long)kz * (p.M - m_start) - m_start) * (long long)p.Cout;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int col = n0 + (wn * TN + j) * 32 + li;
+            if (col >= p.Cout) continue;
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const int rbase = m0 + (wm * TM + i) * 32 + 4 * lh;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = rbase + (r & 3) + 8 * (r >> 2);
+                    if (row < p.M) part[(size_t)row * p.Cout + col] = acc[i][j][r];
+                }
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
         const int col = n0 + (wn * TN + j) * 32 + li;
@@ -330,14 +530,18 @@ void conv3x3_cout2_kernel(const vfn_conv_desc p) {
     }
 }
 
-template <int BM, int BN, int WM, int WN>
+template <int BM, int BN, int WM, int WN, bool DMA = false>
 int launch_cfg(const vfn_conv_desc& p, hipStream_t s) {
     constexpr int NT = WM * WN * 64;
     const size_t lds = 2 * (size_t)(BM + BN) * BK * sizeof(float);
     static bool attr_set = false;
     if (!attr_set && lds > 64 * 1024) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel<BM, BN, WM, WN>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if constexpr (DMA)
+            hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_dma_kernel<BM, BN, WM, WN>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        else
+            hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel<BM, BN, WM, WN>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = true;
     }
     const int m_tiles = cdiv(p.M, BM);
@@ -346,7 +550,8 @@ int launch_cfg(const vfn_conv_desc& p, hipStream_t s) {
     const int tiles = m_tiles * n_tiles;
     if (ks > 1 && (p.split_from < 0 || p.split_from > tiles || p.split_from % n_tiles)) return VFN_ERR_ARG;
     const int grid = ks > 1 ? p.split_from + (tiles - p.split_from) * ks : tiles;
-    hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN>), dim3(grid), dim3(NT), lds, s, p);
+    if constexpr (DMA) hipLaunchKernelGGL((conv_igemm_dma_kernel<BM, BN, WM, WN>), dim3(grid), dim3(NT), lds, s, p);
+    else hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN>), dim3(grid), dim3(NT), lds, s, p);
     if (ks > 1 && p.split_from < tiles) {
         const int m_start = (p.split_from / n_tiles) * BM;
         const size_t total = (size_t)(p.M - m_start) * (p.Cout / 4);
@@ -358,13 +563,15 @@ int launch_cfg(const vfn_conv_desc& p, hipStream_t s) {
 
 }  // namespace
 
-extern "C" int vfn_conv_cfg_count(void) { return 11; }
+extern "C" int vfn_conv_cfg_count(void) { return 17; }
 
 extern "C" int vfn_conv_cfg_tile(int cfg, int* bm, int* bn) {
     // 8..10: same tiles as 0 / 0 / 2 with twice the waves (smaller per-wave tiles, 4 waves per SIMD at 2 blocks/CU)
-    static const int t[11][2] = {{128, 128}, {128, 64}, {64, 128}, {64, 64}, {32, 64}, {64, 32}, {128, 32}, {256, 128},
-                                 {128, 128}, {128, 128}, {64, 128}};
-    if (cfg < 0 || cfg >= 11) return VFN_ERR_ARG;
+    // 11..16: LDS-DMA staging variants of 8 / 10 / 3 / 7 / 6 / 2
+    static const int t[17][2] = {{128, 128}, {128, 64}, {64, 128}, {64, 64}, {32, 64}, {64, 32}, {128, 32}, {256, 128},
+                                 {128, 128}, {128, 128}, {64, 128},
+                                 {128, 128}, {64, 128}, {64, 64}, {256, 128}, {128, 32}, {64, 128}};
+    if (cfg < 0 || cfg >= 17) return VFN_ERR_ARG;
     *bm = t[cfg][0]; *bn = t[cfg][1];
     return VFN_OK;
 }
@@ -403,6 +610,12 @@ extern "C" int vfn_conv2d_nhwc_f32(const vfn_conv_desc* d, int cfg, void* stream
         case 8: return launch_cfg<128, 128, 2, 4>(*d, s);
         case 9: return launch_cfg<128, 128, 4, 2>(*d, s);
         case 10: return launch_cfg<64, 128, 2, 4>(*d, s);
+        case 11: return launch_cfg<128, 128, 2, 4, true>(*d, s);
+        case 12: return launch_cfg<64, 128, 2, 4, true>(*d, s);
+        case 13: return launch_cfg<64, 64, 2, 2, true>(*d, s);
+        case 14: return launch_cfg<256, 128, 4, 2, true>(*d, s);
+        case 15: return launch_cfg<128, 32, 4, 1, true>(*d, s);
+        case 16: return launch_cfg<64, 128, 2, 2, true>(*d, s);
     }
     return VFN_ERR_ARG;
 }
