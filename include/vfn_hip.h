@@ -200,12 +200,17 @@ typedef struct vfn_bank_desc {
     double class_budget;       /* FeatureBank.py:20-22: float 0.8*(budget//obj_n) when obj_n == 2 */
     float thres_close, update_rate, new_hit_init;
     int frame_idx, ld_new, voff, HW, obj_n, cap;
+    int rm_class;              /* -1 for update(); >= 0: vfn_bank_remove evicts from this object only */
+    int rm_request;            /* remove(class_idx, request_n, frame_idx): room to make (FeatureBank.py:117-143) */
 } vfn_bank_desc;
 
 int vfn_row_norms(const float* x, long long stride_obj, int ld, int dim, const int* len_dev, int rows,
                   int obj_n, float* nrm, float* inv /* 1/max(nrm,1e-12) or NULL */, long long stride_n, void* stream);
 int vfn_bank_merge(const vfn_bank_desc* d, void* stream);
 int vfn_bank_append(const vfn_bank_desc* d, void* stream);
+/* FeatureBank.remove(class_idx, request_n, frame_idx) on its own (update() fuses it into vfn_bank_append):
+ * LFU threshold loop + order-preserving compaction of one object; stats[obj] = {len, peak, replace_n, -}. */
+int vfn_bank_remove(const vfn_bank_desc* d, void* stream);
 int vfn_scatter_mean_f32(const float* src, long long src_s0, long long src_s1, const long long* index,
                          int S, float* out, long long out_s0, long long out_s1, int D, void* stream);
 

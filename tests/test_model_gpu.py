@@ -141,3 +141,53 @@ def test_cpu_device_fails_loudly(sd):
         m.memorize(torch.zeros(1, 3, 32, 32), torch.zeros(1, 2, 32, 32))
     with pytest.raises(RuntimeError):
         FeatureBank(2, 1000, 'cpu').init_bank([torch.zeros(128, 4)] * 2, [torch.zeros(512, 4)] * 2)
+
+
+def test_c3_shape_720p_mem_every_5(gpu, sd, model):
+    """BASELINE config C3's shape at reference semantics: a 1280x720 clip is resized (bicubic, HIP kernel) to
+    853x480, padded to 864x480, the bank is updated every 5th frame (harness option; the reference memorises every
+    frame) -- fp32 here; the bf16 variant of C3 is not built yet."""
+    from vfloodnet_amd import synth
+    from vfloodnet_amd.video_seg import run_clip
+    from oracle import afb_urr_ref as O
+    frames, m0 = synth.clip(5, 7, 720, 1280)
+    torch.set_num_threads(16)
+    ref = O.run_clip(sd, frames, m0, size=480, mem_every=5)
+    out = run_clip(model, frames.to(gpu), m0, size=480, mem_every=5)
+    assert out['bank_sizes'] == ref['bank_sizes']
+    assert ref['bank_sizes'][3] == ref['bank_sizes'][0] and ref['bank_sizes'][4] != ref['bank_sizes'][3]
+    ious = [miou(out['labels'][t], ref['labels'][t]) for t in range(1, 7)]
+    assert min(ious) >= 0.995, ious
+    assert out['labels'].shape == (7, 720, 1280)
+
+
+def test_bank_remove_and_append_api(gpu):
+    """FeatureBank.remove / .append as standalone calls (FeatureBank.py:38-51,117-143) vs the oracle."""
+    from vfloodnet_amd import FeatureBank
+    from oracle import afb_urr_ref as O
+    g = torch.Generator().manual_seed(9)
+    hw = 40
+    k0, v0 = _rand_feats(g, 2, hw)
+    fb_ref = O.FeatureBankRef(2, 300, 'cpu')                      # class_budget 0.8 * 150 = 120
+    fb = FeatureBank(2, 300, gpu)
+    fb_ref.init_bank([k.clone() for k in k0], [v.clone() for v in v0])
+    fb.init_bank([k.to(gpu) for k in k0], [v.to(gpu) for v in v0])
+    for t in (1, 2):
+        k1, v1 = _rand_feats(g, 2, hw)
+        fb_ref.append([k.clone() for k in k1], [v.clone() for v in v1], t)
+        fb.append([k.to(gpu) for k in k1], [v.to(gpu) for v in v1], t)
+    for i in range(2):
+        assert fb.keys[i].shape == fb_ref.keys[i].shape == (128, 120)
+        assert torch.equal(fb.info[i].cpu(), fb_ref.info[i])
+        bump = torch.rand(120, generator=g) * 40
+        fb_ref.info[i][:, 1] += bump
+        fb.info[i][:, 1] += bump.to(gpu)
+    for cls, req in ((0, 30), (1, 55)):
+        bal_ref = fb_ref.remove(cls, req, 5)
+        bal = fb.remove(cls, req, 5)
+        assert bal == bal_ref and bal >= 0
+    for i in range(2):
+        assert fb.keys[i].shape == fb_ref.keys[i].shape
+        assert torch.equal(fb.keys[i].cpu(), fb_ref.keys[i]) and torch.equal(fb.values[i].cpu(), fb_ref.values[i])
+        assert torch.equal(fb.info[i].cpu(), fb_ref.info[i])
+    assert np.array_equal(fb.replace_n, fb_ref.replace_n) and fb_ref.replace_n.min() > 0

@@ -63,7 +63,7 @@ class BankDesc(C.Structure):
                 ('class_budget', C.c_double),
                 ('thres_close', C.c_float), ('update_rate', C.c_float), ('new_hit_init', C.c_float),
                 ('frame_idx', C.c_int), ('ld_new', C.c_int), ('voff', C.c_int), ('HW', C.c_int),
-                ('obj_n', C.c_int), ('cap', C.c_int)]
+                ('obj_n', C.c_int), ('cap', C.c_int), ('rm_class', C.c_int), ('rm_request', C.c_int)]
 
 
 def lib():
@@ -92,6 +92,7 @@ def _declare(L):
     L.vfn_memread_finish.argtypes = [C.POINTER(MemReadDesc), p]
     L.vfn_bank_merge.argtypes = [C.POINTER(BankDesc), p]
     L.vfn_bank_append.argtypes = [C.POINTER(BankDesc), p]
+    L.vfn_bank_remove.argtypes = [C.POINTER(BankDesc), p]
     for name, args in SIGNATURES.items():
         fn = getattr(L, name)
         fn.argtypes = args
@@ -121,7 +122,7 @@ SIGNATURES = {
 ALL_SYMBOLS = sorted(list(SIGNATURES) + [
     'vfn_abi_version', 'vfn_conv_cfg_count', 'vfn_conv_cfg_tile', 'vfn_conv2d_nhwc_f32', 'vfn_conv3x3_cout2_f32',
     'vfn_stem_conv7x7_f32',
-    'vfn_bank_scan', 'vfn_memread_apply', 'vfn_memread_finish', 'vfn_bank_merge', 'vfn_bank_append'])
+    'vfn_bank_scan', 'vfn_memread_apply', 'vfn_memread_finish', 'vfn_bank_merge', 'vfn_bank_append', 'vfn_bank_remove'])
 
 
 def check(status, what):

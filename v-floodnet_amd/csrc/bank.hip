@@ -154,10 +154,15 @@ void bank_plan_kernel(const vfn_bank_desc p) {
     int* pos = p.app_pos + (size_t)obj * p.HW;
     int* plan = p.plan + obj * 4;
     const int B = p.bank_len[obj];
+    const bool remove_only = p.rm_class >= 0;        // FeatureBank.remove() called on its own
+    if (remove_only && obj != p.rm_class) {
+        if (tid == 0) { plan[0] = 0; plan[1] = 0; plan[2] = B; plan[3] = 0; }
+        return;
+    }
 
     // append set, positions in ascending source order (nonzero())
     int carry = 0;
-    for (int base = 0; base < p.HW; base += 1024) {
+    for (int base = 0; base < (remove_only ? 0 : p.HW); base += 1024) {
         const int j = base + tid;
         const int f = (j < p.HW) && (corr[j] <= p.thres_close);
         int tot;
@@ -166,10 +171,10 @@ void bank_plan_kernel(const vfn_bank_desc p) {
         carry += tot;
         __syncthreads();
     }
-    const int n_app = carry;
+    const int n_app = remove_only ? p.rm_request : carry;
 
     int evict = 0, kept = B;
-    if ((double)p.class_budget < (double)B + (double)n_app) {
+    if (remove_only || (double)p.class_budget < (double)B + (double)n_app) {
         // FeatureBank.remove: LFU = info[:,1] / (frame_idx - info[:,0]); thr = int(min)+1; loop
         evict = 1;
         const float* info = p.info + (size_t)obj * p.stride_info;
@@ -212,7 +217,7 @@ void bank_plan_kernel(const vfn_bank_desc p) {
         kept = c2;
     }
     if (tid == 0) {
-        plan[0] = n_app; plan[1] = evict; plan[2] = kept; plan[3] = B - kept;
+        plan[0] = remove_only ? 0 : n_app; plan[1] = evict; plan[2] = kept; plan[3] = B - kept;
         (void)s_carry;
     }
 }
@@ -277,15 +282,16 @@ __global__ void bank_finalize_kernel(const vfn_bank_desc p) {
     int newlen = plan[2] + plan[0];
     if (newlen > p.cap) newlen = p.cap;
     float* I = p.info + (size_t)obj * p.stride_info;
-    for (int b = blockIdx.x * blockDim.x + threadIdx.x; b < newlen; b += gridDim.x * blockDim.x)
-        I[(size_t)b * 2 + 1] = fminf(fmaxf(I[(size_t)b * 2 + 1], 0.f), 1e5f);
+    if (p.rm_class < 0)                                // the clamp belongs to update() (FeatureBank.py:115), not to remove()
+        for (int b = blockIdx.x * blockDim.x + threadIdx.x; b < newlen; b += gridDim.x * blockDim.x)
+            I[(size_t)b * 2 + 1] = fminf(fmaxf(I[(size_t)b * 2 + 1], 0.f), 1e5f);
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         // stats[obj] = {len, peak_n, replace_n_total, last_n_append}
         int* st = p.stats + obj * 4;
         st[0] = newlen;
         if (newlen > st[1]) st[1] = newlen;
         st[2] += plan[3];
-        st[3] = plan[0];
+        if (p.rm_class < 0) st[3] = plan[0];
     }
 }
 
@@ -335,7 +341,7 @@ static int bank_desc_ok(const vfn_bank_desc* d) {
 }
 
 extern "C" int vfn_bank_merge(const vfn_bank_desc* d, void* stream) {
-    if (!bank_desc_ok(d) || d->HW > 12000) return VFN_ERR_ARG;
+    if (!bank_desc_ok(d) || d->HW > 12000 || d->rm_class >= 0) return VFN_ERR_ARG;
     if (!d->match_idx || !d->match_corr || !d->new_k || !d->new_knorm || !d->new_vnorm || !d->bank_knorm || !d->bank_vnorm)
         return VFN_ERR_ARG;
     hipLaunchKernelGGL(bank_merge_kernel, dim3(d->HW, d->obj_n), dim3(256), (size_t)d->HW * 5 + 16, (hipStream_t)stream, *d);
@@ -343,7 +349,7 @@ extern "C" int vfn_bank_merge(const vfn_bank_desc* d, void* stream) {
 }
 
 extern "C" int vfn_bank_append(const vfn_bank_desc* d, void* stream) {
-    if (!bank_desc_ok(d)) return VFN_ERR_ARG;
+    if (!bank_desc_ok(d) || d->rm_class >= 0) return VFN_ERR_ARG;
     if (!d->match_corr || !d->app_pos || !d->plan || !d->keep_dst || !d->new_k || !d->stats || !d->bank_len_rw ||
         !d->scratch_k || !d->scratch_v || !d->scratch_info)
         return VFN_ERR_ARG;
@@ -352,6 +358,20 @@ extern "C" int vfn_bank_append(const vfn_bank_desc* d, void* stream) {
     hipLaunchKernelGGL(bank_compact_kernel, dim3(1024, d->obj_n), dim3(256), 0, s, *d, 0);
     hipLaunchKernelGGL(bank_compact_kernel, dim3(1024, d->obj_n), dim3(256), 0, s, *d, 1);
     hipLaunchKernelGGL(bank_append_kernel, dim3(cdiv(d->HW, 4), d->obj_n), dim3(256), 0, s, *d);
+    hipLaunchKernelGGL(bank_finalize_kernel, dim3(256, d->obj_n), dim3(256), 0, s, *d);
+    hipLaunchKernelGGL(bank_commit_len_kernel, dim3(1), dim3(64), 0, s, *d);
+    return vfn_check_launch();
+}
+
+extern "C" int vfn_bank_remove(const vfn_bank_desc* d, void* stream) {
+    if (!bank_desc_ok(d) || d->rm_class < 0 || d->rm_class >= d->obj_n || d->rm_request < 0) return VFN_ERR_ARG;
+    if (!d->app_pos || !d->plan || !d->keep_dst || !d->stats || !d->bank_len_rw || !d->scratch_k || !d->scratch_v ||
+        !d->scratch_info || !d->match_corr)
+        return VFN_ERR_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(bank_plan_kernel, dim3(d->obj_n), dim3(1024), 0, s, *d);
+    hipLaunchKernelGGL(bank_compact_kernel, dim3(1024, d->obj_n), dim3(256), 0, s, *d, 0);
+    hipLaunchKernelGGL(bank_compact_kernel, dim3(1024, d->obj_n), dim3(256), 0, s, *d, 1);
     hipLaunchKernelGGL(bank_finalize_kernel, dim3(256, d->obj_n), dim3(256), 0, s, *d);
     hipLaunchKernelGGL(bank_commit_len_kernel, dim3(1), dim3(64), 0, s, *d);
     return vfn_check_launch();

@@ -294,6 +294,7 @@ class FeatureBank:
         bd.class_budget = float(self.class_budget)
         bd.thres_close, bd.update_rate, bd.new_hit_init = float(self.thres_close), float(update_rate), 0.0
         bd.frame_idx, bd.ld_new, bd.voff, bd.HW, bd.obj_n, bd.cap = int(frame_idx), ld, DK, hw, o, cap
+        bd.rm_class, bd.rm_request = -1, 0
         check(L.vfn_bank_merge(_lib.C.byref(bd), s), 'vfn_bank_merge')
         check(L.vfn_bank_append(_lib.C.byref(bd), s), 'vfn_bank_append')
 
@@ -301,10 +302,29 @@ class FeatureBank:
         self._len_upper = [min(n + hw, cap) for n in self._len_upper]
 
     def remove(self, class_idx, request_n, frame_idx):
-        """FeatureBank.py:117-143.  Eviction is fused into ``update`` on the device; the standalone entry
-        point is kept for API completeness and runs the same plan for one object."""
-        raise RuntimeError('remove() is fused into update() in the HIP path (vfn_bank_append); '
-                           'call update() -- it evicts when class_budget < bank_n + appended')
+        """FeatureBank.py:117-143: LFU eviction of one object until ``class_budget - bank_n - request_n >= 0``;
+        returns that balance.  (``update`` runs the same plan fused with the append; this entry point is the
+        reference's public method.)"""
+        self._require_gpu()
+        L = _lib.lib()
+        o, cap, hw = self.obj_n, self._cap, self._hw
+        self._sync_len()
+        sk, sv, si = self._ensure_scratch()
+        bd = BankDesc()
+        bd.bank_k, bd.bank_v, bd.info = ptr(self._kbuf), ptr(self._vbuf), ptr(self._ibuf)
+        bd.scratch_k, bd.scratch_v, bd.scratch_info = ptr(sk), ptr(sv), ptr(si)
+        bd.bank_len, bd.bank_len_rw = ptr(self._len_dev), ptr(self._len_dev)
+        bd.match_corr = ptr(self._mcorr)
+        bd.app_pos, bd.keep_dst, bd.plan, bd.stats = ptr(self._app_pos), ptr(self._keep_dst), ptr(self._plan), ptr(self._stats)
+        bd.stride_k, bd.stride_v, bd.stride_info, bd.stride_n, bd.stride_new = cap * DK, cap * DV, cap * 2, cap, 0
+        bd.class_budget = float(self.class_budget)
+        bd.thres_close, bd.update_rate, bd.new_hit_init = float(self.thres_close), float(self.update_rate), 0.0
+        bd.frame_idx, bd.ld_new, bd.voff, bd.HW, bd.obj_n, bd.cap = int(frame_idx), DK + DV, DK, hw, o, cap
+        bd.rm_class, bd.rm_request = int(class_idx), int(request_n)
+        check(L.vfn_bank_remove(_lib.C.byref(bd), stream()), 'vfn_bank_remove')
+        self._dirty = True
+        n = self._sync_len()
+        return (self.class_budget - n[class_idx]) - request_n
 
     def print_peak_mem(self):
         """FeatureBank.py:145-149."""
