@@ -24,7 +24,7 @@ for (N, H, W, Cin, Cout, k, s) in SHAPES:
     fl = 2.0 * d.M * Cout * k * k * Cin
     line = f'M={d.M:6d} Cout={Cout:4d} K={k*k*Cin:5d} | '
     for c, (bm, bn) in enumerate(tiles):
-        if bn > 64 and Cout <= 32:
+        if (bn > 64 and Cout <= 32) or (bn > 128 and Cout < 256):
             line += f'{bm}x{bn}: --   '
             continue
         for _ in range(2):
@@ -39,7 +39,7 @@ for (N, H, W, Cin, Cout, k, s) in SHAPES:
         line += f'{bm}x{bn}: {fl / us / 1e6:5.1f}  '
     print(line)
     ws = torch.empty(64 * 1024 * 1024, device=dev)
-    for c in (0, 2, 7, 8, 10):
+    for c in (8, 10, 17, 18, 19):
         bm, bn = tiles[c]
         line = f'     tail-split cfg{c} {bm}x{bn}: '
         for (full, ks, rows) in ops.tail_split_options(d, bm, bn, 8):

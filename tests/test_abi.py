@@ -29,7 +29,7 @@ def test_library_exports_every_declared_symbol():
     for s in declared_symbols():
         assert hasattr(L, s), s
     assert L.vfn_abi_version() == 1
-    assert L.vfn_conv_cfg_count() == 17
+    assert L.vfn_conv_cfg_count() == 20
 
 
 def test_missing_library_fails_loudly(monkeypatch):

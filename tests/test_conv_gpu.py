@@ -38,7 +38,9 @@ def test_conv_matches_torch_cpu(gpu, case):
     xd = x.permute(0, 2, 3, 1).contiguous().to(gpu)
     wp = ops.pad_rows(weights.pack_conv_weight(w)).to(gpu)
     resd = res.permute(0, 2, 3, 1).contiguous().to(gpu) if use_res else None
-    for cfg in range(len(ops.conv_cfg_tiles())):
+    for cfg, (bm_, bn_) in enumerate(ops.conv_cfg_tiles()):
+        if wp.shape[0] < ((Cout + bn_ - 1) // bn_) * bn_:
+            continue
         y = ops.conv2d_nhwc(xd, wp, Cout, k, k, s, k // 2, scale.to(gpu), shift.to(gpu), resd,
                             relu_in, relu_out, cfg=cfg)
         torch.cuda.synchronize()

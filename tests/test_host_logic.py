@@ -75,7 +75,7 @@ def test_nsplit_and_cfg_choices():
     s = pick_nsplit(1620, 2, 100000)
     assert 1 <= s <= 16 and (26 * 2 * s) % 256 <= 256
     engine._CFG_TILES = [(128, 128), (128, 64), (64, 128), (64, 64), (32, 64), (64, 32), (128, 32), (256, 128),
-                         (128, 128), (128, 128), (64, 128), (128, 128), (64, 128), (64, 64), (256, 128), (128, 32), (64, 128)]
+                         (128, 128), (128, 128), (64, 128), (128, 128), (64, 128), (64, 64), (256, 128), (128, 32), (64, 128), (128, 256), (128, 256), (64, 256)]
     engine._TUNED.clear()                                  # exercise the heuristic, not the measured table
     c, ks, sf = engine.choose_cfg(51840, 256, 2304)
     assert engine._CFG_TILES[c][1] >= 64 and ks == 1

@@ -56,8 +56,19 @@ void conv_igemm_kernel(const vfn_conv_desc p) {
     const int ksplit = p.ksplit > 1 ? p.ksplit : 1;
     int tile = blockIdx.x, kz = 0;
     bool split_tile = false;
-    if (ksplit > 1 && tile >= p.split_from) {
-        const int r = tile - p.split_from;
+    {
+        // Workgroups are dealt round-robin over the 8 XCDs (private L2 each): give every XCD one contiguous
+        // run of tiles so that neighbours (same input rows, overlapping filter taps) share an L2.  Bijective
+        // for any tile count; affects speed only.
+        const int nfull = (ksplit > 1) ? p.split_from : (int)gridDim.x;
+        if (tile < nfull && nfull >= 16) {
+            const int q = nfull >> 3, r = nfull & 7;
+            const int xcd = tile & 7, loc = tile >> 3;
+            tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
+        }
+    }
+    if (ksplit > 1 && blockIdx.x >= (unsigned)p.split_from) {
+        const int r = (int)blockIdx.x - p.split_from;
         tile = p.split_from + r / ksplit;
         kz = r - (r / ksplit) * ksplit;
         split_tile = true;
@@ -260,12 +271,13 @@ __device__ __forceinline__ void lds_dma16(const float* src, float* lds_dst) {
 }
 __device__ __forceinline__ int wave_uniform(int x) { return __builtin_amdgcn_readfirstlane(x); }
 
+
 // Same GEMM, operands staged by LDS-DMA (global_load_lds_dwordx4): no staging VGPRs, no ds_write, no
 // select/ReLU VALU on the load path -- the ablation of the register-staged kernel shows that path costs
 // 15-30 % of the MFMA rate.  One wave instruction writes 1 KB = 8 image rows x 128 B linearly, so the XOR
 // swizzle is applied to the per-lane SOURCE address; out-of-image taps read vfn_zero_page; ReLU-on-input
 // moves to the fragment registers.
-template <int BM, int BN, int WM, int WN>
+template <int BM, int BN, int WM, int WN, int STAGES>
 __global__ __launch_bounds__(WM * WN * 64)
 void conv_igemm_dma_kernel(const vfn_conv_desc p) {
     constexpr int NW = WM * WN;
@@ -276,8 +288,8 @@ void conv_igemm_dma_kernel(const vfn_conv_desc p) {
     static_assert(APW >= 1 && BPW >= 1, "tile too small for the wave count");
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    float* sA = reinterpret_cast<float*>(smem);          // [2][BM][32]
-    float* sB = sA + 2 * BM * BK;                        // [2][BN][32]
+    float* sA = reinterpret_cast<float*>(smem);          // [STAGES][BM][32]
+    float* sB = sA + STAGES * BM * BK;                   // [STAGES][BN][32]
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -290,8 +302,19 @@ void conv_igemm_dma_kernel(const vfn_conv_desc p) {
     const int ksplit = p.ksplit > 1 ? p.ksplit : 1;
     int tile = blockIdx.x, kz = 0;
     bool split_tile = false;
-    if (ksplit > 1 && tile >= p.split_from) {
-        const int r = tile - p.split_from;
+    {
+        // Workgroups are dealt round-robin over the 8 XCDs (private L2 each): give every XCD one contiguous
+        // run of tiles so that neighbours (same input rows, overlapping filter taps) share an L2.  Bijective
+        // for any tile count; affects speed only.
+        const int nfull = (ksplit > 1) ? p.split_from : (int)gridDim.x;
+        if (tile < nfull && nfull >= 16) {
+            const int q = nfull >> 3, r = nfull & 7;
+            const int xcd = tile & 7, loc = tile >> 3;
+            tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
+        }
+    }
+    if (ksplit > 1 && blockIdx.x >= (unsigned)p.split_from) {
+        const int r = (int)blockIdx.x - p.split_from;
         tile = p.split_from + r / ksplit;
         kz = r - (r / ksplit) * ksplit;
         split_tile = true;
@@ -367,14 +390,8 @@ void conv_igemm_dma_kernel(const vfn_conv_desc p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    if (nk > 0) issue_tile(kt_begin, 0);
-    __syncthreads();                                   // (drains the LDS-DMA)
     const float relu_floor = p.relu_in ? 0.f : -INFINITY;
-
-    for (int kt = 0; kt < nk; ++kt) {
-        const int buf = kt & 1;
-        if (kt + 1 < nk) issue_tile(kt_begin + kt + 1, buf ^ 1);     // lands behind this tile's MFMAs
-
+    auto compute_tile = [&](int buf) {
         const float* cA = sA + buf * BM * BK + (wm * TM * 32) * BK;
         const float* cB = sB + buf * BN * BK + (wn * TN * 32) * BK;
 #pragma unroll
@@ -401,6 +418,17 @@ void conv_igemm_dma_kernel(const vfn_conv_desc p) {
                     for (int j = 0; j < TN; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][t], b[j][t], acc[i][j], 0, 0, 0);
         }
+    };
+
+    // Two-stage ring.  (A three-stage ring with counted vmcnt + raw s_barrier, i.e. the DMA of tile kt+2 in
+    // flight across the barrier, was built and measured: 106 vs 124 TFLOP/s on the balanced 128x128 case --
+    // it costs the second resident workgroup per CU and the loads were not the exposed latency.)
+    if (nk > 0) issue_tile(kt_begin, 0);
+    __syncthreads();                                   // (drains the LDS-DMA)
+    for (int kt = 0; kt < nk; ++kt) {
+        const int buf = kt & 1;
+        if (kt + 1 < nk) issue_tile(kt_begin + kt + 1, buf ^ 1);     // lands behind this tile's MFMAs
+        compute_tile(buf);
         __syncthreads();                               // next tile landed; this buffer may be refilled
     }
 
@@ -530,14 +558,14 @@ void conv3x3_cout2_kernel(const vfn_conv_desc p) {
     }
 }
 
-template <int BM, int BN, int WM, int WN, bool DMA = false>
+template <int BM, int BN, int WM, int WN, int DMA = 0>     // DMA: 0 = register staged, 2 / 3 = LDS-DMA ring depth
 int launch_cfg(const vfn_conv_desc& p, hipStream_t s) {
     constexpr int NT = WM * WN * 64;
-    const size_t lds = 2 * (size_t)(BM + BN) * BK * sizeof(float);
+    const size_t lds = (DMA == 3 ? 3 : 2) * (size_t)(BM + BN) * BK * sizeof(float);
     static bool attr_set = false;
     if (!attr_set && lds > 64 * 1024) {
-        if constexpr (DMA)
-            hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_dma_kernel<BM, BN, WM, WN>),
+        if constexpr (DMA != 0)
+            hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_dma_kernel<BM, BN, WM, WN, DMA>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         else
             hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel<BM, BN, WM, WN>),
@@ -550,7 +578,7 @@ int launch_cfg(const vfn_conv_desc& p, hipStream_t s) {
     const int tiles = m_tiles * n_tiles;
     if (ks > 1 && (p.split_from < 0 || p.split_from > tiles || p.split_from % n_tiles)) return VFN_ERR_ARG;
     const int grid = ks > 1 ? p.split_from + (tiles - p.split_from) * ks : tiles;
-    if constexpr (DMA) hipLaunchKernelGGL((conv_igemm_dma_kernel<BM, BN, WM, WN>), dim3(grid), dim3(NT), lds, s, p);
+    if constexpr (DMA != 0) hipLaunchKernelGGL((conv_igemm_dma_kernel<BM, BN, WM, WN, DMA>), dim3(grid), dim3(NT), lds, s, p);
     else hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN>), dim3(grid), dim3(NT), lds, s, p);
     if (ks > 1 && p.split_from < tiles) {
         const int m_start = (p.split_from / n_tiles) * BM;
@@ -563,15 +591,17 @@ int launch_cfg(const vfn_conv_desc& p, hipStream_t s) {
 
 }  // namespace
 
-extern "C" int vfn_conv_cfg_count(void) { return 17; }
+extern "C" int vfn_conv_cfg_count(void) { return 20; }
 
 extern "C" int vfn_conv_cfg_tile(int cfg, int* bm, int* bn) {
     // 8..10: same tiles as 0 / 0 / 2 with twice the waves (smaller per-wave tiles, 4 waves per SIMD at 2 blocks/CU)
     // 11..16: LDS-DMA staging variants of 8 / 10 / 3 / 7 / 6 / 2
-    static const int t[17][2] = {{128, 128}, {128, 64}, {64, 128}, {64, 64}, {32, 64}, {64, 32}, {128, 32}, {256, 128},
+    // 17..19: 256-filter-wide tiles (input tile read once for all 256 filters): 128x256 and 64x256, 8 waves
+    static const int t[20][2] = {{128, 128}, {128, 64}, {64, 128}, {64, 64}, {32, 64}, {64, 32}, {128, 32}, {256, 128},
                                  {128, 128}, {128, 128}, {64, 128},
-                                 {128, 128}, {64, 128}, {64, 64}, {256, 128}, {128, 32}, {64, 128}};
-    if (cfg < 0 || cfg >= 17) return VFN_ERR_ARG;
+                                 {128, 128}, {64, 128}, {64, 64}, {256, 128}, {128, 32}, {64, 128},
+                                 {128, 256}, {128, 256}, {64, 256}};
+    if (cfg < 0 || cfg >= 20) return VFN_ERR_ARG;
     *bm = t[cfg][0]; *bn = t[cfg][1];
     return VFN_OK;
 }
@@ -610,12 +640,15 @@ extern "C" int vfn_conv2d_nhwc_f32(const vfn_conv_desc* d, int cfg, void* stream
         case 8: return launch_cfg<128, 128, 2, 4>(*d, s);
         case 9: return launch_cfg<128, 128, 4, 2>(*d, s);
         case 10: return launch_cfg<64, 128, 2, 4>(*d, s);
-        case 11: return launch_cfg<128, 128, 2, 4, true>(*d, s);
-        case 12: return launch_cfg<64, 128, 2, 4, true>(*d, s);
-        case 13: return launch_cfg<64, 64, 2, 2, true>(*d, s);
-        case 14: return launch_cfg<256, 128, 4, 2, true>(*d, s);
-        case 15: return launch_cfg<128, 32, 4, 1, true>(*d, s);
-        case 16: return launch_cfg<64, 128, 2, 2, true>(*d, s);
+        case 11: return launch_cfg<128, 128, 2, 4, 2>(*d, s);
+        case 12: return launch_cfg<64, 128, 2, 4, 2>(*d, s);
+        case 13: return launch_cfg<64, 64, 2, 2, 2>(*d, s);
+        case 14: return launch_cfg<256, 128, 4, 2, 2>(*d, s);
+        case 15: return launch_cfg<128, 32, 4, 1, 2>(*d, s);
+        case 16: return launch_cfg<64, 128, 2, 2, 2>(*d, s);
+        case 17: return launch_cfg<128, 256, 2, 4>(*d, s);
+        case 18: return launch_cfg<128, 256, 2, 4, 2>(*d, s);
+        case 19: return launch_cfg<64, 256, 2, 4>(*d, s);
     }
     return VFN_ERR_ARG;
 }

@@ -522,7 +522,7 @@ class Engine:
             for c, (bm, bn) in enumerate(tiles):
                 if d.cout_pad < ((d.Cout + bn - 1) // bn) * bn:
                     continue
-                if bn > 64 and d.Cout <= 32:
+                if (bn > 64 and d.Cout <= 32) or (bn > 128 and d.Cout < 256):
                     continue
                 blocks = ((d.M + bm - 1) // bm) * ((d.Cout + bn - 1) // bn)
                 options = [(c, 1, 0)]
