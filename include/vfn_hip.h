@@ -57,6 +57,8 @@ typedef struct vfn_conv_desc {
     int res_mod;          /* > 0: the residual is shared by the images of the batch: row m reads res[m % res_mod]
                              (a term computed once for all objects, e.g. the query-value half of convFM) */
     float* partial;       /* [ksplit][M - m_start][Cout] workspace, m_start = first row of tile split_from */
+    int* tile_counters;   /* one int per split tile, zero at rest: the slice workgroup that arrives last reduces the
+                             tile inside the same launch (agent-scope release/acquire); NULL: a second kernel reduces */
 } vfn_conv_desc;
 
 int vfn_conv_cfg_count(void);

@@ -35,13 +35,14 @@ def test_conv_matches_torch_cpu(gpu, case):
         ref = ref + res
     if relu_out:
         ref = F.relu(ref)
+    scale_d, shift_d = scale.to(gpu), shift.to(gpu)      # descriptors hold raw pointers: keep the tensors alive
     xd = x.permute(0, 2, 3, 1).contiguous().to(gpu)
     wp = ops.pad_rows(weights.pack_conv_weight(w)).to(gpu)
     resd = res.permute(0, 2, 3, 1).contiguous().to(gpu) if use_res else None
     for cfg, (bm_, bn_) in enumerate(ops.conv_cfg_tiles()):
         if wp.shape[0] < ((Cout + bn_ - 1) // bn_) * bn_:
             continue
-        y = ops.conv2d_nhwc(xd, wp, Cout, k, k, s, k // 2, scale.to(gpu), shift.to(gpu), resd,
+        y = ops.conv2d_nhwc(xd, wp, Cout, k, k, s, k // 2, scale_d, shift_d, resd,
                             relu_in, relu_out, cfg=cfg)
         torch.cuda.synchronize()
         got = y.permute(0, 3, 1, 2).cpu()
@@ -50,14 +51,21 @@ def test_conv_matches_torch_cpu(gpu, case):
     # split-K variants (partial slabs + fixed-order reduce)
     ws = torch.empty(8 * ref.numel(), device=gpu)
     y = torch.empty(N, ref.shape[2], ref.shape[3], Cout, device=gpu)
-    d = ops.make_conv_desc(xd, wp, Cout, k, k, s, k // 2, y, scale.to(gpu), shift.to(gpu), resd, relu_in, relu_out)
+    d = ops.make_conv_desc(xd, wp, Cout, k, k, s, k // 2, y, scale_d, shift_d, resd, relu_in, relu_out)
+    cnt = torch.zeros(4096, dtype=torch.int32, device=gpu)
     for ks in ops.valid_splits(d, 8)[1:]:
-        y.zero_()
-        ops.set_splitk(d, ks, ws)
-        ops.conv2d_launch(d, 3)
-        torch.cuda.synchronize()
-        err = (y.permute(0, 3, 1, 2).cpu() - ref).abs().max().item()
-        assert err < 2e-4 * max(1.0, ref.abs().max().item()), f'split {ks}: max err {err}'
+        outs = []
+        for counters in (None, cnt if Cout % 64 == 0 else None):       # separate reduce launch / in-launch finish
+            y.zero_()
+            ops.set_splitk(d, ks, ws, counters=counters)
+            for _ in range(2):                                          # twice: the counters must return to rest
+                ops.conv2d_launch(d, 3)
+            torch.cuda.synchronize()
+            err = (y.permute(0, 3, 1, 2).cpu() - ref).abs().max().item()
+            assert err < 2e-4 * max(1.0, ref.abs().max().item()), f'split {ks}: max err {err}'
+            outs.append(y.clone())
+        assert torch.equal(outs[0], outs[1]), 'in-launch finish must be bit-identical to the reduce launch'
+        assert int(cnt.abs().sum()) == 0
     # tail split: only the tiles from an n-tile-aligned index on are cut along K
     tiles = ops.conv_cfg_tiles()
     bm, bn = tiles[3]

@@ -28,6 +28,59 @@ namespace {
 
 constexpr int BK = 32;
 
+// In-launch finish of a K-split tile (replaces the separate reduce launch): every slice workgroup stores its
+// raw partial tile, then takes a ticket on the tile's arrival counter; the workgroup that draws the last
+// ticket sums the slices IN SLICE ORDER (bit-reproducible whichever workgroup arrives last) and applies the
+// epilogue.  Hand-off = agent-scope release by the producers / acquire by the last arriver
+// (cdna_hip_programming.md guideline 16, counter form): results do not depend on dispatch order or XCD
+// placement.  `flag` is one int of the (now idle) dynamic LDS; counters are zero at rest.
+template <int BM, int BN, int NT>
+__device__ __forceinline__ void splitk_finish(const vfn_conv_desc& p, int* flag, int tile, int m0, int n0, int n_tiles) {
+    const int tid = threadIdx.x;
+    const int ksplit = p.ksplit;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // this wave's partial stores have left
+    __syncthreads();
+    if (tid == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        int* cnt = p.tile_counters + (tile - p.split_from);
+        const int prev = __hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int last = (prev == ksplit - 1);
+        if (last) {
+            __hip_atomic_store(cnt, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // at rest again for the next launch
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        *flag = last;
+    }
+    __syncthreads();
+    if (!*flag) return;
+
+    const int m_start = (p.split_from / n_tiles) * BM;
+    const size_t slab = (size_t)(p.M - m_start) * p.Cout;
+    constexpr int C4 = BN / 4;
+    for (int i = tid; i < BM * C4; i += NT) {
+        const int row = m0 + i / C4;
+        const int col = n0 + (i % C4) * 4;
+        if (row >= p.M || col >= p.Cout) continue;
+        const float* src = p.partial + (size_t)(row - m_start) * p.Cout + col;
+        f32x4 a = *reinterpret_cast<const f32x4*>(src);
+        for (int sp = 1; sp < ksplit; ++sp) a += *reinterpret_cast<const f32x4*>(src + sp * slab);
+        f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
+        if (p.scale) sc = *reinterpret_cast<const f32x4*>(p.scale + col);
+        if (p.shift) sh = *reinterpret_cast<const f32x4*>(p.shift + col);
+        f32x4 v;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[k] = a[k] * sc[k] + sh[k];
+        if (p.res) v += *reinterpret_cast<const f32x4*>(p.res + (size_t)(p.res_mod > 0 ? row % p.res_mod : row) * p.res_ld + col);
+        if (p.relu_out) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) v[k] = fmaxf(v[k], 0.f);
+        }
+        *reinterpret_cast<f32x4*>(p.out + (size_t)row * p.out_ld + col) = v;
+    }
+}
+
 template <int BM, int BN, int WM, int WN>
 __global__ __launch_bounds__(WM * WN * 64)
 void conv_igemm_kernel(const vfn_conv_desc p) {
@@ -235,6 +288,7 @@ void conv_igemm_kernel(const vfn_conv_desc p) {
                 }
             }
         }
+        if (p.tile_counters) splitk_finish<BM, BN, WM * WN * 64>(p, reinterpret_cast<int*>(smem), tile, m0, n0, n_tiles);
         return;
     }
 
@@ -449,6 +503,7 @@ void conv_igemm_dma_kernel(const vfn_conv_desc p) {
                 }
             }
         }
+        if (p.tile_counters) splitk_finish<BM, BN, WM * WN * 64>(p, reinterpret_cast<int*>(smem), tile, m0, n0, n_tiles);
         return;
     }
 #pragma unroll
@@ -580,7 +635,7 @@ int launch_cfg(const vfn_conv_desc& p, hipStream_t s) {
     const int grid = ks > 1 ? p.split_from + (tiles - p.split_from) * ks : tiles;
     if constexpr (DMA != 0) hipLaunchKernelGGL((conv_igemm_dma_kernel<BM, BN, WM, WN, DMA>), dim3(grid), dim3(NT), lds, s, p);
     else hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN>), dim3(grid), dim3(NT), lds, s, p);
-    if (ks > 1 && p.split_from < tiles) {
+    if (ks > 1 && p.split_from < tiles && !p.tile_counters) {
         const int m_start = (p.split_from / n_tiles) * BM;
         const size_t total = (size_t)(p.M - m_start) * (p.Cout / 4);
         const int blocks = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
@@ -625,6 +680,7 @@ extern "C" int vfn_conv2d_nhwc_f32(const vfn_conv_desc* d, int cfg, void* stream
     if (d->ksplit > 1) {
         const int nk_all = d->KH * d->KW * (d->Cin / BK);
         if (!d->partial || d->Cout % 4 || d->out_ld % 4 || (d->res && d->res_ld % 4)) return VFN_ERR_ARG;
+        if (d->tile_counters && d->Cout % bn) return VFN_ERR_ARG;      // in-launch finish works on whole filter tiles
         if (cdiv(nk_all, d->ksplit) * (d->ksplit - 1) >= nk_all) return VFN_ERR_ARG;   // every split non-empty
     }
     hipStream_t s = (hipStream_t)stream;

@@ -62,6 +62,7 @@ def pad_divide_by(h, w, d=16):
 
 
 WS_FLOATS = 16 * 1024 * 1024        # split-K workspace (64 MB), shared by all launches of a plan
+_INLAUNCH_SPLITK = __import__('os').environ.get('VFN_INLAUNCH_SPLITK') == '1'
 
 
 def _tiles():
@@ -71,14 +72,19 @@ def _tiles():
     return _CFG_TILES
 
 
-def apply_choice(desc, choice, ws):
+def apply_choice(desc, choice, ws, counters=None):
     """Configure a conv descriptor for a (cfg, ksplit, split_from) choice; returns the cfg index."""
     cfg, ks, split_from = choice
     if ks > 1:
         bm, bn = _tiles()[cfg]
         n_tiles = (desc.Cout + bn - 1) // bn
         rows = desc.M - (split_from // n_tiles) * bm
-        ops.set_splitk(desc, ks, ws, split_from, rows)
+        # In-launch finish (last-arriving slice reduces the tile) is built and bit-identical, but measured SLOWER
+        # on MI355X (C2: 93 vs 100 frames/s): every slice workgroup pays an agent-scope release (L2 write-back),
+        # more than the ~2 us kernel boundary it removes.  Off unless VFN_INLAUNCH_SPLITK=1.
+        if desc.Cout % bn or not _INLAUNCH_SPLITK:
+            counters = None
+        ops.set_splitk(desc, ks, ws, split_from, rows, counters)
     else:
         ops.set_splitk(desc, 1, None)
     return cfg
@@ -198,7 +204,9 @@ class FramePlan:
         self.score = f(1, K, H0, W0)
         self.ws = f(WS_FLOATS)
         self.ws_q = f(WS_FLOATS)              # split-K workspace of the query-encoder list (side stream)
-        self._ws_cur = self.ws
+        self.cnt = torch.zeros(4096, dtype=torch.int32, device=dev)      # split-tile arrival counters (zero at rest)
+        self.cnt_q = torch.zeros(4096, dtype=torch.int32, device=dev)
+        self._ws_cur, self._cnt_cur = self.ws, self.cnt
 
         self.seg_pre = []     # stem .. KeyValue
         self.seg_post = []    # decoder
@@ -235,7 +243,7 @@ class FramePlan:
         choice = choose_cfg(d.M, layer.cout, K)
         if choice[1] > 1 and (d.out_ld % 4 or (res is not None and d.res_ld % 4)):
             choice = (choice[0], 1, 0)
-        cfg = apply_choice(d, choice, self._ws_cur)
+        cfg = apply_choice(d, choice, self._ws_cur, self._cnt_cur)
         lst.append(Launch(ops.conv2d_launch, (d, cfg), f'{name}[{d.M}x{layer.cout}x{K}]', 2.0 * d.M * layer.cout * K))
         return out
 
@@ -273,14 +281,14 @@ class FramePlan:
         e = self.eng
         K = self.obj_n
         # ---- segment: query encoder + KeyValue
-        self._ws_cur = self.ws_q
+        self._ws_cur, self._cnt_cur = self.ws_q, self.cnt_q
         self.stem_q = ops.make_stem_desc(self.frame_q, None, e.stem_q_w, e.stem_q_scale, e.stem_q_shift,
                                          self.q['r1'], e.mean, e.std, 1, self.H0, self.W0, self.pad, self.Hp, self.Wp)
         self.seg_pre.append(Launch(ops.stem_launch, (self.stem_q,), 'encoder_q.stem',
                                    2.0 * self.h2 * self.w2 * 64 * 147))
         r4 = self._trunk(self.seg_pre, e.enc_q, self.q, 1, 'encoder_q')
         self._conv(self.seg_pre, e.keyval, r4, self.kv_q, 1, self.h16, self.w16, name='keyval')
-        self._ws_cur = self.ws
+        self._ws_cur, self._cnt_cur = self.ws, self.cnt
         # ---- decoder
         L = self.seg_post
         D = e.dec
@@ -532,11 +540,12 @@ class Engine:
                     options += [(c, k_, full) for (full, k_, rows) in ops.tail_split_options(d, bm, bn, 8)
                                 if k_ * rows * d.Cout <= WS_FLOATS and k_ in (2, 3, 4, 5, 6, 8)]
                 for opt in options:
-                    apply_choice(d, opt, p.ws)
+                    apply_choice(d, opt, p.ws, p.cnt)
                     t = timeit(d, c)
                     if best_t is None or t < best_t:
                         best, best_t = opt, t
             _TUNED[key] = best
             for l in launches:
-                l.args = (l.args[0], apply_choice(l.args[0], best, p.ws))
+                in_q = l in p.seg_pre
+                l.args = (l.args[0], apply_choice(l.args[0], best, p.ws_q if in_q else p.ws, p.cnt_q if in_q else p.cnt))
         return dict(_TUNED)

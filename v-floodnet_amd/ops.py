@@ -53,20 +53,24 @@ def make_conv_desc(x, wp, cout, kh, kw, stride, pad, out, scale=None, shift=None
     d.relu_in, d.relu_out = int(relu_in), int(relu_out)
     d.M = N * Ho * Wo
     d.ksplit, d.split_from, d.partial = 1, 0, None
+    d.tile_counters = None
     d.res_mod = 0
     assert wp.shape[1] == kh * kw * cin
     return d
 
 
-def set_splitk(desc, ksplit, workspace, split_from=0, rows=None):
+def set_splitk(desc, ksplit, workspace, split_from=0, rows=None, counters=None):
     """Cut the tiles from index ``split_from`` on along K into ``ksplit`` slices.  ``rows`` = output rows
-    those tiles cover (default: all M); ``workspace``: float32 tensor with >= ksplit*rows*Cout elements."""
+    those tiles cover (default: all M); ``workspace``: float32 tensor with >= ksplit*rows*Cout elements;
+    ``counters``: zeroed int32 tensor (one per split tile) -> the tile is reduced inside the same launch."""
     if ksplit > 1:
         rows = desc.M if rows is None else rows
         assert workspace is not None and workspace.numel() >= ksplit * rows * desc.Cout
         desc.ksplit, desc.split_from, desc.partial = int(ksplit), int(split_from), ptr(workspace)
+        desc.tile_counters = ptr(counters) if counters is not None else None
     else:
         desc.ksplit, desc.split_from, desc.partial = 1, 0, None
+        desc.tile_counters = None
     return desc
 
 
