@@ -3,8 +3,7 @@
     python bench.py --gpus N --steps K --warmup W
 
 One *step* = one frame of ``test_video_seg.py:105-115``: bicubic resize (identity at 480p) ->
-``segment`` -> object softmax -> ``memorize`` -> ``FeatureBank.update`` -> resize+argmax -> label
-D2H, on a synthetic 480x854 clip (BASELINE.json config C2, fp32) that is resident in HBM when
+``segment`` -> object softmax -> ``memorize`` -> ``FeatureBank.update`` -> resize+argmax -> largest-component filter -> label D2H, on a synthetic 480x854 clip (BASELINE.json config C2, fp32) that is resident in HBM when
 the timed region starts.  For N > 1 every rank runs its own clip (seed = rank + 1, weak
 scaling, no collective on the data path) and the per-clip label masks are exchanged with one
 RCCL all-gather inside the timed bracket (BASELINE.json config C4).
@@ -136,7 +135,7 @@ def main():
     del warm
 
     # ---- timed region: exactly K steps
-    runner = ClipRunner(model, 2, args.budget)
+    runner = ClipRunner(model, 2, args.budget, postprocess=True)     # largest-blob filter (:116) on the device too
     runner.start(frames[0:1], onehot)
     labels = torch.empty(K + 1, H0, W0, dtype=torch.uint8, device=dev)
     labels[0] = m0.to(dev)
@@ -242,7 +241,7 @@ def main():
            'steps': K, 'warmup': Wm, 'ms_per_step': round(1e3 * elapsed / K, 3), 'higher_is_better': True,
            'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
            'config': {'workload': f'C2: {K + 1}-frame 480x854 synthetic clip per GPU through the test_video_seg.py loop '
-                                  f'(segment+softmax+memorize+bank update+argmax), fp32, budget {args.budget}',
+                                  f'(segment+softmax+memorize+bank update+argmax+CCL), fp32, budget {args.budget}',
                       'mean_bank_entries_per_object': round(b_mean, 1),
                       'frame_mfma_frac_Fmin': round(frame_frac, 4)},
            'roofline': roof, 'cpu_baseline': cpu, 'parity': parity}

@@ -230,6 +230,10 @@ int vfn_softmax_objects_f32(const float* score, float* prob, int obj_n, int n, v
 int vfn_resize_argmax_u8(const float* prob, unsigned char* label, int obj_n, int Hi, int Wi, int Ho, int Wo,
                          void* stream);
 int vfn_postprocess_pred_u8(const unsigned char* pred_host, int H, int W, unsigned char* out_host);
+/* The same on DEVICE buffers (union-find CCL with atomicMin, largest component, reference special cases), so the
+ * label map leaves the GPU already post-processed.  scratch: int32[2*H*W + 8]. */
+int vfn_postprocess_pred_device_u8(const unsigned char* pred, unsigned char* out, int* scratch, int H, int W,
+                                   void* stream);
 
 #ifdef __cplusplus
 }

@@ -204,3 +204,33 @@ def test_scatter_mean(gpu):
     out2 = torch.zeros(D, B, device=gpu)
     scatter_mean(src[:, :0].to(gpu), idx[:0].to(gpu).unsqueeze(0).expand(D, -1), dim=1, out=out2)
     assert float(out2.abs().sum()) == 0.0
+
+
+def test_device_ccl_matches_host_and_oracle(gpu):
+    """vfn_postprocess_pred_device_u8 == the host routine == the oracle's postprocessing_pred."""
+    from vfloodnet_amd import ops
+    from vfloodnet_amd.data import postprocessing_pred
+    from oracle import afb_urr_ref as O
+    rng = np.random.RandomState(3)
+    cases = [np.zeros((20, 30), np.uint8), np.ones((20, 30), np.uint8)]
+    a = np.zeros((24, 40), np.uint8); a[2:6, 3:9] = 1; a[10:20, 12:30] = 1; a[7, 9] = 1
+    cases.append(a)
+    b = np.zeros((9, 9), np.uint8); b[1:4, 1:4] = 1
+    cases.append(b)
+    # two blobs of EQUAL size: the first in raster order wins
+    c = np.zeros((12, 12), np.uint8); c[1:3, 1:3] = 1; c[8:10, 5:7] = 1
+    cases.append(c)
+    for thr in (0.3, 0.45, 0.55, 0.62, 0.7):
+        cases.append((rng.rand(96, 130) > thr).astype(np.uint8))
+    cases.append((rng.rand(480, 854) > 0.58).astype(np.uint8))
+    # spiral / snake: long dependency chains for the union-find
+    s_ = np.zeros((64, 64), np.uint8)
+    for r in range(0, 64, 4):
+        s_[r, :] = 1
+        s_[r:r + 4, 63 if (r // 4) % 2 == 0 else 0] = 1
+    cases.append(s_)
+    for x in cases:
+        ref = O.postprocessing_pred(x.copy())
+        assert np.array_equal(postprocessing_pred(x), ref)
+        out = ops.postprocess_pred_device(torch.from_numpy(x).to(gpu)).cpu().numpy()
+        assert np.array_equal(out, ref), x.shape

@@ -117,6 +117,7 @@ SIGNATURES = {
     'vfn_softmax_objects_f32': [_p, _p, _i, _i, _p],
     'vfn_resize_argmax_u8': [_p, _p, _i, _i, _i, _i, _i, _p],
     'vfn_postprocess_pred_u8': [_p, _i, _i, _p],
+    'vfn_postprocess_pred_device_u8': [_p, _p, _p, _i, _i, _p],
 }
 # every symbol include/vfn_hip.h declares (checked by tests/test_abi.py)
 ALL_SYMBOLS = sorted(list(SIGNATURES) + [

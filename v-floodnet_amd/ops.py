@@ -244,6 +244,18 @@ def postprocess_pred(pred_np):
     return out
 
 
+def postprocess_pred_device(label, out=None, scratch=None):
+    """Device uint8 [H,W] -> uint8 [H,W]: postprocessing_pred on the GPU (union-find CCL, largest blob)."""
+    H, W = label.shape
+    if out is None:
+        out = torch.empty_like(label)
+    if scratch is None:
+        scratch = torch.empty(2 * H * W + 8, dtype=torch.int32, device=label.device)
+    check(_lib.lib().vfn_postprocess_pred_device_u8(ptr(label), ptr(out), ptr(scratch), H, W, stream()),
+          'vfn_postprocess_pred_device_u8')
+    return out
+
+
 # --------------------------------------------------------------------------- bank
 def row_norms(x, stride_obj, ld, dim, len_dev, rows, obj_n, nrm, inv, stride_n):
     check(_lib.lib().vfn_row_norms(ptr(x), int(stride_obj), ld, dim, ptr(len_dev), rows, obj_n, ptr(nrm), ptr(inv),

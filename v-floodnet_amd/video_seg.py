@@ -19,7 +19,7 @@ import numpy as np
 import torch
 
 from . import ops
-from .data import (color_palette, load_image_in_PIL, postprocessing_pred, save_overlay, save_seg_mask)
+from .data import color_palette, load_image_in_PIL, save_overlay, save_seg_mask
 from .dataset import Video_DS
 from .feature_bank import FeatureBank
 from .model import AFB_URR
@@ -62,8 +62,10 @@ def resized_hw(h, w, size):
 class ClipRunner:
     """test_video_seg.py:83-121 on device tensors."""
 
-    def __init__(self, model, obj_n=2, budget=250000, update_rate=0.1, thres_close=0.95, size=480, mem_every=1):
+    def __init__(self, model, obj_n=2, budget=250000, update_rate=0.1, thres_close=0.95, size=480, mem_every=1,
+                 postprocess=False):
         self.model = model
+        self.postprocess = postprocess       # run postprocessing_pred (:116) on the device before the D2H
         self.device = model.device
         self.obj_n = obj_n
         self.size = size
@@ -96,6 +98,8 @@ class ClipRunner:
         self.fb.init_bank(k, v)
         self.t = 0
         self._label_dev = torch.empty(H0, W0, dtype=torch.uint8, device=self.device)
+        self._post_dev = torch.empty(H0, W0, dtype=torch.uint8, device=self.device)
+        self._ccl_scratch = torch.empty(2 * H0 * W0 + 8, dtype=torch.int32, device=self.device)
         self._pinned = torch.empty(H0, W0, dtype=torch.uint8).pin_memory()
         self._stats_pinned = torch.zeros(self.obj_n, 4, dtype=torch.int32).pin_memory()
 
@@ -123,8 +127,11 @@ class ClipRunner:
             self.fb.update(k, v, self.t)                          # :112
         H0, W0 = self.ori_size
         ops.resize_argmax(pred_mask, H0, W0, out=self._label_dev)  # :114-115
+        src = self._label_dev
+        if self.postprocess:                                       # :116, largest 8-connected water blob
+            src = ops.postprocess_pred_device(self._label_dev, self._post_dev, self._ccl_scratch)
         # single sync point of the frame: labels + bank bookkeeping
-        self._pinned.copy_(self._label_dev, non_blocking=True)
+        self._pinned.copy_(src, non_blocking=True)
         self._stats_pinned.copy_(self.fb.stats_device(), non_blocking=True)
         torch.cuda.current_stream().synchronize()
         self.fb.absorb_stats(self._stats_pinned)
@@ -141,17 +148,14 @@ def run_clip(model, frames, first_mask_u8, budget=250000, update_rate=0.1, thres
     T, _, H0, W0 = frames.shape
     m = (first_mask_u8 > 0).to(torch.uint8)
     onehot = torch.stack([1 - m, m], 0).unsqueeze(0).to(frames.device)        # Water_DS.py:93-101
-    runner = ClipRunner(model, 2, budget, update_rate, thres_close, size, mem_every)
+    runner = ClipRunner(model, 2, budget, update_rate, thres_close, size, mem_every, postprocess=postprocess)
     runner.start(frames[0:1], onehot)
     labels = torch.empty(T, H0, W0, dtype=torch.uint8)
     labels[0] = m.cpu()
     sizes = []
     for t in range(1, T):
         lab = runner.step(frames[t:t + 1], next_frame=frames[t + 1:t + 2] if (overlap and t + 1 < T) else None)
-        if postprocess:
-            labels[t] = torch.from_numpy(postprocessing_pred(lab.numpy()))
-        else:
-            labels[t].copy_(lab)
+        labels[t].copy_(lab)
         sizes.append(runner.bank_sizes())
     return dict(labels=labels, bank_sizes=sizes, fb=runner.fb)
 
@@ -203,7 +207,7 @@ def main(args, device):
 
     obj_n = seq_dataset.obj_n
     runner = ClipRunner(model, obj_n, args.budget, update_rate=args.update_rate, thres_close=args.merge_thres,
-                        size=downsample_size, mem_every=getattr(args, 'mem_every', 1))
+                        size=downsample_size, mem_every=getattr(args, 'mem_every', 1), postprocess=True)
 
     ori_first_frame = seq_dataset.first_frame.unsqueeze(0).to(device)
     ori_first_mask = seq_dataset.first_mask.unsqueeze(0).to(device)
@@ -219,8 +223,7 @@ def main(args, device):
         runner.start(ori_first_frame, ori_first_mask)
         for idx, (frame, frame_name) in enumerate(seq_loader):
             ori_frame = frame.to(device)
-            lab = runner.step(ori_frame)
-            pred = postprocessing_pred(lab.numpy())
+            pred = runner.step(ori_frame).numpy().copy()          # postprocessing_pred (:116) already ran on the GPU
             seg_path = os.path.join(seg_dir, f'{frame_name[0]}.png')
             save_seg_mask(pred, seg_path, color_palette)
             if args.viz:
