@@ -191,3 +191,41 @@ def test_bank_remove_and_append_api(gpu):
         assert torch.equal(fb.keys[i].cpu(), fb_ref.keys[i]) and torch.equal(fb.values[i].cpu(), fb_ref.values[i])
         assert torch.equal(fb.info[i].cpu(), fb_ref.info[i])
     assert np.array_equal(fb.replace_n, fb_ref.replace_n) and fb_ref.replace_n.min() > 0
+
+
+def test_three_objects_vs_oracle(gpu, sd, model):
+    """obj_n = 3 (background + two regions): the kernels are not specialised to the video path's obj_n = 2
+    (class_budget is then budget // 3 without the 0.8 factor, FeatureBank.py:20-22)."""
+    from vfloodnet_amd import synth, FeatureBank, ops
+    from oracle import afb_urr_ref as O
+    H, W = 96, 160
+    frames, m0 = synth.clip(4, 2, H, W)
+    lab = m0.clone()
+    lab[:, W // 2:] *= 2                                     # split the water into two objects (labels 1 and 2)
+    oh = synth.onehot(lab, 3).unsqueeze(0)
+    assert oh.shape == (1, 3, H, W) and int(oh.sum(1).min()) == 1
+    torch.set_num_threads(8)
+    k_ref, v_ref = O.memorize(sd, frames[0:1], oh)
+    fb_ref = O.FeatureBankRef(3, 3000)
+    fb_ref.init_bank(k_ref, v_ref)
+    score_ref, _ = O.segment(sd, frames[1:2], fb_ref)
+    pm_ref = torch.softmax(score_ref, dim=1)
+    k2r, v2r = O.memorize(sd, frames[1:2], pm_ref)
+    fb_ref.update(k2r, v2r, 1)
+
+    k, v = model.memorize(frames[0:1].to(gpu), oh.to(gpu))
+    fb = FeatureBank(3, 3000, gpu)
+    assert fb.class_budget == fb_ref.class_budget == 1000
+    fb.init_bank(k, v)
+    score, _ = model.segment(frames[1:2].to(gpu), fb)
+    assert score.shape == (1, 3, H, W)
+    pm = ops.softmax_objects(score)
+    assert (pm.cpu() - pm_ref).abs().max() < 1e-3
+    k2, v2 = model.memorize(frames[1:2].to(gpu), pm)
+    fb.update(k2, v2, 1)
+    for i in range(3):
+        assert fb.keys[i].shape == fb_ref.keys[i].shape
+        assert (fb.keys[i].cpu() - fb_ref.keys[i]).abs().max() < 2e-3
+    margin = pm_ref[0].topk(2, dim=0).values
+    margin = margin[0] - margin[1]
+    assert torch.equal(pm.cpu()[0].argmax(0)[margin > 1e-3], pm_ref[0].argmax(0)[margin > 1e-3])
