@@ -71,7 +71,7 @@ def test_state_dict_names_match_reference_schema():
 def test_nsplit_and_cfg_choices():
     from vfloodnet_amd.feature_bank import pick_nsplit
     from vfloodnet_amd import engine
-    assert pick_nsplit(1620, 2, 64) == 1                    # one 64-entry chunk cannot be split
+    assert pick_nsplit(1620, 2, 100) == 1                   # two 64-entry chunks are not worth splitting
     s = pick_nsplit(1620, 2, 100000)
     assert 1 <= s <= 16 and (26 * 2 * s) % 256 <= 256
     engine._CFG_TILES = [(128, 128), (128, 64), (64, 128), (64, 64), (32, 64), (64, 32), (128, 32), (256, 128),

@@ -199,11 +199,17 @@ void bank_scan_kernel(const vfn_bankscan_desc p) {
         } else {
             const float* rs = p.rowscale + (size_t)obj * p.stride_rs;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = rb + (r & 3) + 8 * (r >> 2);
-                if (row < B) {
-                    const float s_ = acc[r] * rs[row];
-                    if (s_ > run_m) { run_m = s_; run_i = row; }       // ascending rows: first max wins
+            for (int g = 0; g < 4; ++g) {                // registers 4g..4g+3 = rows rb+8g .. +3: one 16-byte load
+                const int row0 = rb + 8 * g;
+                f32x4 sc = {0.f, 0.f, 0.f, 0.f};
+                if (row0 < B) sc = *reinterpret_cast<const f32x4*>(rs + row0);     // (slab rows past B are finite scratch)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int row = row0 + j;
+                    if (row < B) {
+                        const float s_ = acc[4 * g + j] * sc[j];
+                        if (s_ > run_m) { run_m = s_; run_i = row; }   // ascending rows: first max wins
+                    }
                 }
             }
         }
@@ -308,7 +314,9 @@ void memread_apply_kernel(const vfn_memread_desc p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) o[a][b][r] = 0.f;
 
-    const float* vcol = V + wave * 128 + li;         // + row*512 + tc*32
+    // value channels of this wave: 128*wave .. +127; lane li owns the 4 consecutive channels 4*li..4*li+3, one per
+    // 32-wide MFMA tile (tile tc, column li <-> channel 4*li + tc): 16-byte loads of V and 16-byte stores of O^T
+    const float* vcol = V + wave * 128 + li * 4;     // + row*512
 
     if (c_lo < c_hi) chunk_load_async(sK, K + (size_t)c_lo * CH * DK, min(CH, B - c_lo * CH), wave, lane);
     __syncthreads();                                 // (drains the LDS-DMA: it is a pending LDS write)
@@ -360,7 +368,7 @@ void memread_apply_kernel(const vfn_memread_desc p) {
 
         // O^T[q][c] += sum_b P^T[q][b] V[b][c];  this wave: channels 128*wave .. +127, value rows
         // prefetched one k-group (8 bank rows) ahead of the MFMAs that use them
-        float vb[3][4][4];                           // ring: value rows two k-groups ahead of their MFMAs
+        f32x4 vb[3][4];                              // ring: value rows two k-groups ahead of their MFMAs
         auto load_v = [&](int kk, int slot) {
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
@@ -368,8 +376,7 @@ void memread_apply_kernel(const vfn_memread_desc p) {
                 // the softmax above) and the clamped value is a finite bank entry, so no select is needed
                 // -- a select would force a wait right behind every load
                 const int rr = min(b0 + 8 * kk + 4 * lh + t, B - 1);
-#pragma unroll
-                for (int tc = 0; tc < 4; ++tc) vb[slot][t][tc] = vcol[(size_t)rr * DV + tc * 32];
+                vb[slot][t] = *reinterpret_cast<const f32x4*>(vcol + (size_t)rr * DV);
             }
         };
         load_v(0, 0);
@@ -402,9 +409,8 @@ void memread_apply_kernel(const vfn_memread_desc p) {
         for (int r = 0; r < 16; ++r) {
             const int q = q0 + tq * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
             if (q < p.HW) {
-#pragma unroll
-                for (int tc = 0; tc < 4; ++tc)
-                    dst[(size_t)q * DV + wave * 128 + tc * 32 + li] = o[tq][tc][r];
+                const f32x4 v = {o[tq][0][r], o[tq][1][r], o[tq][2][r], o[tq][3][r]};
+                *reinterpret_cast<f32x4*>(dst + (size_t)q * DV + wave * 128 + li * 4) = v;
             }
         }
 }
@@ -447,7 +453,7 @@ void allow_lds(K kern, size_t bytes) {
 extern "C" int vfn_bank_scan(const vfn_bankscan_desc* d, void* stream) {
     if (!d || !d->q || !d->bank_k || !d->bank_len || !d->part) return VFN_ERR_ARG;
     if (d->nsplit < 1 || d->HW < 1 || d->obj_n < 1 || d->ldq % 4) return VFN_ERR_ARG;
-    if (d->mode == 1 && !d->rowscale) return VFN_ERR_ARG;
+    if (d->mode == 1 && (!d->rowscale || d->stride_rs % 4)) return VFN_ERR_ARG;
     static bool once = false;
     if (!once) { allow_lds(bank_scan_kernel<0>, SCAN_LDS); allow_lds(bank_scan_kernel<1>, SCAN_LDS); once = true; }
     const dim3 grid(cdiv(d->HW, QT) * d->nsplit, d->obj_n);

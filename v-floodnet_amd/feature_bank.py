@@ -35,7 +35,7 @@ def pick_nsplit(hw, obj_n, b_upper):
     if os.environ.get('VFN_NSPLIT'):
         return min(int(os.environ['VFN_NSPLIT']), nchunks)
     best, best_eff = 1, -1.0
-    for s in range(1, min(nchunks, MAX_SPLIT) + 1):
+    for s in range(1, max(1, min(nchunks // 3, MAX_SPLIT)) + 1):      # >= 3 chunks per slice
         blocks = qtiles * obj_n * s
         eff = blocks / (((blocks + 255) // 256) * 256)
         if eff >= best_eff:
@@ -76,7 +76,7 @@ class FeatureBank:
         self._require_gpu()
         dev = self.device
         o = self.obj_n
-        cap = int(max(self.class_budget, n_init)) + 2 * hw + CH
+        cap = (int(max(self.class_budget, n_init)) + 2 * hw + 2 * CH + 63) // 64 * 64
         self._cap, self._hw = cap, hw
         self._kbuf = torch.empty(o, cap, DK, device=dev)
         self._vbuf = torch.empty(o, cap, DV, device=dev)
@@ -212,7 +212,7 @@ class FeatureBank:
         self._set_lengths([lens[i] + int(keys[i].shape[1]) for i in range(self.obj_n)])
 
     def _grow(self, need):
-        cap = int(need * 1.5) + self._hw
+        cap = (int(need * 1.5) + self._hw + 63) // 64 * 64
         lens = self._len_host
         for name in ('_kbuf', '_vbuf', '_ibuf', '_knorm', '_vnorm', '_kinv', '_cnt', '_keep_dst'):
             old = getattr(self, name)
