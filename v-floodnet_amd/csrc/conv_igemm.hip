@@ -161,13 +161,23 @@ void conv_igemm_kernel(const vfn_conv_desc p) {
             a_wi0[j] = 0;
         }
     }
-    const float* wrow[BC];
+    // Operands come in through raw buffer loads: the descriptor carries the tensor size, so a tap that falls
+    // outside the image (or a row past M) is given an out-of-range offset and the hardware returns zeros --
+    // no select, no branch, and the only per-tile VALU work is two range checks and one add per 16 bytes.
+    const __amdgpu_buffer_rsrc_t rsrc_in = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(p.in), 0, (int)((size_t)p.N * p.H * p.W * p.in_ld * sizeof(float)), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrc_w = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(p.w), 0, (int)((size_t)p.cout_pad * Ktot * sizeof(float)), 0x00020000);
+    int a_off[AC];                         // byte offset of tap (0,0), channel block 0, this lane's chunk
+#pragma unroll
+    for (int j = 0; j < AC; ++j)
+        a_off[j] = ((a_base[j] + a_hi0[j] * p.W + a_wi0[j]) * p.in_ld + c16 * 4) * (int)sizeof(float);
+    int w_off[BC];
 #pragma unroll
     for (int j = 0; j < BC; ++j)
-        wrow[j] = p.w + (size_t)(n0 + r0 + j * RSTEP) * Ktot + c16 * 4;
+        w_off[j] = ((n0 + r0 + j * RSTEP) * Ktot + c16 * 4) * (int)sizeof(float);
 
     f32x4 ra[AC], rb[BC];
-    bool a_ok[AC];
     int kh, kw, cb;                        // tap / channel block of the tile being *loaded*
     {
         const int tap = kt_begin / cblks;
@@ -175,36 +185,36 @@ void conv_igemm_kernel(const vfn_conv_desc p) {
         kh = tap / p.KW;
         kw = tap - kh * p.KW;
     }
-
-    // Loads are unconditional (out-of-image taps read pixel 0 of the image and are zeroed when the
-    // tile is written to LDS): no branch and no s_waitcnt sits between the load issue and the MFMAs.
-    auto load_tile = [&](int kt) {
+    auto load_a = [&]() {
+        const int tap_off = ((kh * p.W + kw) * p.in_ld + cb * BK) * (int)sizeof(float);     // wave-uniform
 #pragma unroll
         for (int j = 0; j < AC; ++j) {
-            const int hi = a_hi0[j] + kh, wi = a_wi0[j] + kw;
-            a_ok[j] = (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;
-            const int pix = a_ok[j] ? a_base[j] + hi * p.W + wi : 0;
-            ra[j] = *reinterpret_cast<const f32x4*>(p.in + (size_t)pix * p.in_ld + cb * BK + c16 * 4);
+            const bool ok = (unsigned)(a_hi0[j] + kh) < (unsigned)p.H && (unsigned)(a_wi0[j] + kw) < (unsigned)p.W;
+            const int off = ok ? a_off[j] + tap_off : 0x7ffffff0;
+            ra[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_in, off, 0, 0));
         }
+    };
+    auto load_b = [&](int kt) {
+        const int k_off = kt * BK * (int)sizeof(float);
 #pragma unroll
         for (int j = 0; j < BC; ++j)
-            rb[j] = *reinterpret_cast<const f32x4*>(wrow[j] + (size_t)kt * BK);
+            rb[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_w, w_off[j] + k_off, 0, 0));
         if (++cb == cblks) { cb = 0; if (++kw == p.KW) { kw = 0; ++kh; } }
     };
     const float relu_floor = p.relu_in ? 0.f : -INFINITY;
-    auto store_tile = [&](int buf) {
+    auto store_a = [&](int buf) {
         float* dA = sA + buf * BM * BK;
-        float* dB = sB + buf * BN * BK;
 #pragma unroll
         for (int j = 0; j < AC; ++j) {
             const int r = r0 + j * RSTEP;
             f32x4 v = ra[j];
-            v.x = a_ok[j] ? fmaxf(v.x, relu_floor) : 0.f;
-            v.y = a_ok[j] ? fmaxf(v.y, relu_floor) : 0.f;
-            v.z = a_ok[j] ? fmaxf(v.z, relu_floor) : 0.f;
-            v.w = a_ok[j] ? fmaxf(v.w, relu_floor) : 0.f;
+            v.x = fmaxf(v.x, relu_floor); v.y = fmaxf(v.y, relu_floor);
+            v.z = fmaxf(v.z, relu_floor); v.w = fmaxf(v.w, relu_floor);
             *reinterpret_cast<f32x4*>(dA + r * BK + ((c16 ^ ((r >> 1) & 7)) << 2)) = v;
         }
+    };
+    auto store_b = [&](int buf) {
+        float* dB = sB + buf * BN * BK;
 #pragma unroll
         for (int j = 0; j < BC; ++j) {
             const int r = r0 + j * RSTEP;
@@ -221,53 +231,49 @@ void conv_igemm_kernel(const vfn_conv_desc p) {
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     if (nk > 0) {
-        load_tile(kt_begin);
-        store_tile(0);
+        load_a();
+        load_b(kt_begin);
+        store_a(0);
+        store_b(0);
     }
     __syncthreads();
 
-#ifdef VFN_ABLATE
-    const bool ab_noload = p.relu_out & 256, ab_nobar = p.relu_out & 512;
-#else
-    constexpr bool ab_noload = false, ab_nobar = false;
-#endif
     for (int kt = 0; kt < nk; ++kt) {
         const int buf = kt & 1;
-        if (kt + 1 < nk && !ab_noload) load_tile(kt_begin + kt + 1);
-
+        const bool more = kt + 1 < nk;
         const float* cA = sA + buf * BM * BK + (wm * TM * 32) * BK;
         const float* cB = sB + buf * BN * BK + (wn * TN * 32) * BK;
-        // fragment reads run one k-group ahead of the MFMAs that consume them
-        f32x4 a[2][TM], b[2][TN];
-        auto read_frags = [&](int kk, int slot) {
+        // the staging of tile kt+1 is spread over the four k-groups of tile kt (loads first, LDS writes in
+        // the second half) so that no long MFMA-free stretch sits at either end of the iteration
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            if (more) {
+                if (kk == 0) load_a();
+                if (kk == 1) load_b(kt_begin + kt + 1);
+                if (kk == 2) store_a(buf ^ 1);
+                if (kk == 3) store_b(buf ^ 1);
+            }
             const int lc = 2 * kk + lh;
+            f32x4 a[TM], b[TN];
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
                 const int r = i * 32 + li;      // (wm*TM*32) is a multiple of 32: swizzle bits unchanged
-                a[slot][i] = *reinterpret_cast<const f32x4*>(cA + r * BK + ((lc ^ ((r >> 1) & 7)) << 2));
+                a[i] = *reinterpret_cast<const f32x4*>(cA + r * BK + ((lc ^ ((r >> 1) & 7)) << 2));
             }
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
                 const int r = j * 32 + li;
-                b[slot][j] = *reinterpret_cast<const f32x4*>(cB + r * BK + ((lc ^ ((r >> 1) & 7)) << 2));
+                b[j] = *reinterpret_cast<const f32x4*>(cB + r * BK + ((lc ^ ((r >> 1) & 7)) << 2));
             }
-        };
-        read_frags(0, 0);
-#pragma unroll
-        for (int kk = 0; kk < 4; ++kk) {
-            const int cur = kk & 1;
-            if (kk + 1 < 4) read_frags(kk + 1, cur ^ 1);
 #pragma unroll
             for (int t = 0; t < 4; ++t)
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
                     for (int j = 0; j < TN; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[cur][i][t], b[cur][j][t], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][t], b[j][t], acc[i][j], 0, 0, 0);
         }
-
-        if (kt + 1 < nk && !ab_noload) store_tile(buf ^ 1);
-        if (!ab_nobar) __syncthreads();
+        __syncthreads();
     }
 
     // split-K: raw partial sums to the workspace slab of this split; vfn_conv_splitk_reduce finishes

@@ -376,7 +376,11 @@ void memread_apply_kernel(const vfn_memread_desc p) {
                 // the softmax above) and the clamped value is a finite bank entry, so no select is needed
                 // -- a select would force a wait right behind every load
                 const int rr = min(b0 + 8 * kk + 4 * lh + t, B - 1);
+#ifdef VFN_ABLATE_V
+                vb[slot][t] = f32x4{1.f * rr, 2.f, 3.f, 4.f};
+#else
                 vb[slot][t] = *reinterpret_cast<const f32x4*>(vcol + (size_t)rr * DV);
+#endif
             }
         };
         load_v(0, 0);
