@@ -35,83 +35,77 @@ void stem_kernel(const vfn_stem_desc p) {
 
     const int tiles_x = (p.Wo + TW - 1) / TW;
     const int tiles_y = (p.Ho + TH - 1) / TH;
-    const int tiles = tiles_x * tiles_y * p.N;
+    int b = blockIdx.x;
+    const int n = b / (tiles_x * tiles_y);
+    b -= n * tiles_x * tiles_y;
+    const int ty = b / tiles_x, tx = b - ty * tiles_x;
+    const int oy0 = ty * TH, ox0 = tx * TW;
 
-    // filters -> LDS once per workgroup (already packed [KP][64] with zero 8th taps); the workgroup then walks
-    // several output tiles, so the 38-63 KB filter bank is amortised over TPB x 128 pixels
+    // filters -> LDS (already packed [KP][64] with zero 8th taps)
     for (int i = tid * 4; i < KP * 64; i += 256 * 4)
         *reinterpret_cast<f32x4*>(sW + i) = *reinterpret_cast<const f32x4*>(p.w + i);
 
-    for (int b = blockIdx.x; b < tiles; b += gridDim.x) {
-        int rem = b;
-        const int n = rem / (tiles_x * tiles_y);
-        rem -= n * tiles_x * tiles_y;
-        const int ty = rem / tiles_x, tx = rem - ty * tiles_x;
-        const int oy0 = ty * TH, ox0 = tx * TW;
-
-        // input patch -> LDS, with pad + normalisation semantics
-        __syncthreads();                                    // previous tile's MFMAs are done with sP
-        const int gy0 = oy0 * 2 - 3, gx0 = ox0 * 2 - 3;     // padded-frame coordinates
-        for (int i = tid; i < CIN * PH * PW; i += 256) {
-            const int c = i / (PH * PW);
-            const int r = i - c * PH * PW;
-            const int y = r / PW, x = r - y * PW;
-            const int gy = gy0 + y, gx = gx0 + x;
-            float v = 0.f;
-            if (x < PW - 1 && (unsigned)gy < (unsigned)p.Hp && (unsigned)gx < (unsigned)p.Wp) {
-                const int ry = gy - p.pad_top, rx = gx - p.pad_left;
-                const bool inside = (unsigned)ry < (unsigned)p.H0 && (unsigned)rx < (unsigned)p.W0;
-                if (c < 3) {
-                    const float raw = inside ? p.frame[((size_t)c * p.H0 + ry) * p.W0 + rx] : 0.f;
-                    v = (raw - p.mean[c]) / p.std[c];
-                } else {
-                    const float m = inside ? p.mask[((size_t)n * p.H0 + ry) * p.W0 + rx] : 0.f;
-                    v = (c == 3) ? m : fminf(fmaxf(1.f - m, 0.f), 1.f);
-                }
-            }
-            sP[i] = v;
-        }
-        __syncthreads();
-
-        // this wave: 32 pixels = tile rows 2*wave, 2*wave+1; lane's pixel for the A operand
-        const int py = 2 * wave + (li >> 4), px = li & 15;
-        const float* pa = sP + (2 * py) * PW + 2 * px + lh;      // + (c*PH+kh)*PW + 2*q
-        const float* pb = sW + lh * 64 + li;                     // + (2*s)*64 + 32*tn
-
-        f32x16 acc0, acc1;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
-
-#pragma unroll
-        for (int c = 0; c < CIN; ++c) {
-#pragma unroll
-            for (int kh = 0; kh < 7; ++kh) {
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const int s = (c * 7 + kh) * 4 + q;          // k-step: k = 2s + lh
-                    const float a = pa[(c * PH + kh) * PW + 2 * q];
-                    const float b0 = pb[(2 * s) * 64];
-                    const float b1 = pb[(2 * s) * 64 + 32];
-                    acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b0, acc0, 0, 0, 0);
-                    acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b1, acc1, 0, 0, 0);
-                }
+    // input patch -> LDS, with pad + normalisation semantics
+    const int gy0 = oy0 * 2 - 3, gx0 = ox0 * 2 - 3;     // padded-frame coordinates
+    for (int i = tid; i < CIN * PH * PW; i += 256) {
+        const int c = i / (PH * PW);
+        const int r = i - c * PH * PW;
+        const int y = r / PW, x = r - y * PW;
+        const int gy = gy0 + y, gx = gx0 + x;
+        float v = 0.f;
+        if (x < PW - 1 && (unsigned)gy < (unsigned)p.Hp && (unsigned)gx < (unsigned)p.Wp) {
+            const int ry = gy - p.pad_top, rx = gx - p.pad_left;
+            const bool inside = (unsigned)ry < (unsigned)p.H0 && (unsigned)rx < (unsigned)p.W0;
+            if (c < 3) {
+                const float raw = inside ? p.frame[((size_t)c * p.H0 + ry) * p.W0 + rx] : 0.f;
+                v = (raw - p.mean[c]) / p.std[c];
+            } else {
+                const float m = inside ? p.mask[((size_t)n * p.H0 + ry) * p.W0 + rx] : 0.f;
+                v = (c == 3) ? m : fminf(fmaxf(1.f - m, 0.f), 1.f);
             }
         }
+        sP[i] = v;
+    }
+    __syncthreads();
 
-        // epilogue: BN + ReLU, NHWC store
+    // this wave: 32 pixels = tile rows 2*wave, 2*wave+1; lane's pixel for the A operand
+    const int py = 2 * wave + (li >> 4), px = li & 15;
+    const float* pa = sP + (2 * py) * PW + 2 * px + lh;      // + (c*PH+kh)*PW + 2*q
+    const float* pb = sW + lh * 64 + li;                     // + (2*s)*64 + 32*tn
+
+    f32x16 acc0, acc1;
 #pragma unroll
-        for (int tn = 0; tn < 2; ++tn) {
-            const int col = tn * 32 + li;
-            const float sc = p.scale[col], sh = p.shift[col];
+    for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
+
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int pix = (r & 3) + 8 * (r >> 2) + 4 * lh;       // 0..31 within the wave tile
-                const int oy = oy0 + 2 * wave + (pix >> 4), ox = ox0 + (pix & 15);
-                if (oy < p.Ho && ox < p.Wo) {
-                    const float a = tn == 0 ? acc0[r] : acc1[r];
-                    const float v = fmaxf(a * sc + sh, 0.f);
-                    p.out[(((size_t)n * p.Ho + oy) * p.Wo + ox) * 64 + col] = v;
-                }
+    for (int c = 0; c < CIN; ++c) {
+#pragma unroll
+        for (int kh = 0; kh < 7; ++kh) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int s = (c * 7 + kh) * 4 + q;          // k-step: k = 2s + lh
+                const float a = pa[(c * PH + kh) * PW + 2 * q];
+                const float b0 = pb[(2 * s) * 64];
+                const float b1 = pb[(2 * s) * 64 + 32];
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b0, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b1, acc1, 0, 0, 0);
+            }
+        }
+    }
+
+    // epilogue: BN + ReLU, NHWC store
+#pragma unroll
+    for (int tn = 0; tn < 2; ++tn) {
+        const int col = tn * 32 + li;
+        const float sc = p.scale[col], sh = p.shift[col];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int pix = (r & 3) + 8 * (r >> 2) + 4 * lh;       // 0..31 within the wave tile
+            const int oy = oy0 + 2 * wave + (pix >> 4), ox = ox0 + (pix & 15);
+            if (oy < p.Ho && ox < p.Wo) {
+                const float a = tn == 0 ? acc0[r] : acc1[r];
+                const float v = fmaxf(a * sc + sh, 0.f);
+                p.out[(((size_t)n * p.Ho + oy) * p.Wo + ox) * 64 + col] = v;
             }
         }
     }
@@ -155,9 +149,7 @@ int launch_stem(const vfn_stem_desc& d, hipStream_t s) {
         attr_set = true;
     }
     const int tiles = cdiv(d.Wo, TW) * cdiv(d.Ho, TH) * d.N;
-    const int per = cdiv(tiles, 512);                           // <= 2 resident workgroups per CU, equal tile counts
-    const int grid = cdiv(tiles, per);
-    hipLaunchKernelGGL((stem_kernel<CIN>), dim3(grid), dim3(256), lds, s, d);
+    hipLaunchKernelGGL((stem_kernel<CIN>), dim3(tiles), dim3(256), lds, s, d);
     return vfn_check_launch();
 }
 
