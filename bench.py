@@ -187,7 +187,7 @@ def main():
         traffic = None                      # HBM bytes per launch of this kernel from the committed PMC passes
         tpath = os.path.join(ROOT, 'profiles', 'r01_pmc_traffic.json')
         if os.path.isfile(tpath):
-            for k_, v_ in json.load(open(tpath)).items():
+            for k_, v_ in json.load(open(tpath)).get('kernels', {}).items():
                 if kname in k_:
                     traffic = round(v_['hbm_bytes_per_launch'])
         roof = {'bound': 'mfma', 'kernel': kname,
