@@ -101,7 +101,8 @@ def main():
     rank, local_rank, world = vdist.init()
     if not torch.cuda.is_available():
         raise RuntimeError('bench.py needs a GPU: the hot path is HIP-only')
-    dev = torch.device('cuda', local_rank)
+    # VFN_SINGLE_DEVICE=1 (+ VFN_DIST_BACKEND=gloo): smoke-run the N > 1 code path on a 1-GPU box
+    dev = torch.device('cuda', 0 if os.environ.get('VFN_SINGLE_DEVICE') == '1' else local_rank)
     torch.cuda.set_device(dev)
 
     K, Wm = args.steps, args.warmup
@@ -163,7 +164,7 @@ def main():
     if world > 1:
         dist.barrier()
     t1 = time.perf_counter()
-    elapsed = torch.tensor([t1 - t0], dtype=torch.float64, device=dev)
+    elapsed = torch.tensor([t1 - t0], dtype=torch.float64, device=dev if (world == 1 or dist.get_backend() == 'nccl') else 'cpu')
     if world > 1:
         dist.all_reduce(elapsed, op=dist.ReduceOp.MAX)
     elapsed = float(elapsed.item())

@@ -23,7 +23,7 @@ def init(backend=None):
     rank, local_rank, world = env_rank_world()
     if world > 1 and not dist.is_initialized():
         if backend is None:
-            backend = 'nccl' if torch.cuda.is_available() else 'gloo'
+            backend = os.environ.get('VFN_DIST_BACKEND') or ('nccl' if torch.cuda.is_available() else 'gloo')
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
         if backend == 'nccl':
@@ -53,9 +53,11 @@ def gather_masks(local_labels, n_clips, rank, world):
     recv = torch.empty(world * per, T, H, W, dtype=torch.uint8, device=local_labels.device)
     if dist.get_backend() == 'nccl':
         dist.all_gather_into_tensor(recv, send)
-    else:
-        parts = list(recv.view(world, per, T, H, W).unbind(0))
-        dist.all_gather(parts, send)
+    else:                                   # gloo (CPU tests, or a 1-GPU smoke run of the N > 1 code path)
+        send_h = send.cpu()
+        parts = [torch.empty_like(send_h) for _ in range(world)]
+        dist.all_gather(parts, send_h)
+        recv.copy_(torch.stack(parts, 0).view_as(recv))
     recv = recv.view(world, per, T, H, W)
     out = torch.empty(n_clips, T, H, W, dtype=torch.uint8, device=local_labels.device)
     for c in range(n_clips):
