@@ -55,13 +55,13 @@ class ConvTimer:
     def install(self):
         ops = self.ops
 
-        def timed(desc, cfg):
+        def timed(desc, cfg, mode=0):
             if not self.active:
-                return self.orig(desc, cfg)
+                return self.orig(desc, cfg, mode)
             e0 = torch.cuda.Event(enable_timing=True)
             e1 = torch.cuda.Event(enable_timing=True)
             e0.record()
-            self.orig(desc, cfg)
+            self.orig(desc, cfg, mode)
             e1.record()
             self.records.append((cfg, 2.0 * desc.M * desc.Cout * desc.KH * desc.KW * desc.Cin, e0, e1))
         ops.conv2d_launch = timed

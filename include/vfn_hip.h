@@ -64,6 +64,15 @@ typedef struct vfn_conv_desc {
 int vfn_conv_cfg_count(void);
 int vfn_conv_cfg_tile(int cfg, int* bm, int* bn);
 int vfn_conv2d_nhwc_f32(const vfn_conv_desc* d, int cfg, void* stream);
+/* Same convolution with both operands rounded to bf16 (nearest-even) as they are staged into LDS and multiplied
+ * on v_mfma_f32_32x32x16_bf16 with f32 accumulation; tensors stay f32 in HBM.  Cin must be a multiple of 64;
+ * register-staged tile configurations only (cfg 0-10, 17, 19); split-K slices are 64-channel tiles.
+ * For BASELINE.json configs C3 / C5 (the reference itself has no reduced-precision path). */
+int vfn_conv2d_nhwc_bf16(const vfn_conv_desc* d, int cfg, void* stream);
+/* "bf16x3": every operand is split into two bf16 (x = hi + lo, 16 significant bits) as it is staged and each product
+ * is hi*hi + hi*lo + lo*hi on the bf16 matrix cores, f32 accumulation: relative error ~2^-16 per product (bf16: 2^-9,
+ * f32: 2^-24).  Cin multiple of 32, split-K slices are 32-channel tiles (as the f32 kernel); cfg as for _bf16. */
+int vfn_conv2d_nhwc_bf16x3(const vfn_conv_desc* d, int cfg, void* stream);
 /* 3x3/s1/p1 convolution with Cout == 2 and Cin in {32, 256} (Decoder.pred2 / local_pred2, AFB_URR.py:195,202,
  * 213,234): bandwidth-bound reduction kernel; same descriptor, w = [2][9*Cin]. */
 int vfn_conv3x3_cout2_f32(const vfn_conv_desc* d, void* stream);

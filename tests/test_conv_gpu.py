@@ -80,3 +80,79 @@ def test_conv_matches_torch_cpu(gpu, case):
             torch.cuda.synchronize()
             err = (y.permute(0, 3, 1, 2).cpu() - ref).abs().max().item()
             assert err < 2e-4 * max(1.0, ref.abs().max().item()), f'tail split from {full_m}: max err {err}'
+
+
+BF16_CASES = [
+    (1, 12, 20, 64, 64, 1, 1, False, True, False),
+    (2, 12, 20, 64, 256, 1, 1, False, False, True),
+    (1, 13, 19, 128, 128, 3, 2, False, True, False),
+    (2, 9, 14, 256, 256, 3, 1, True, False, True),
+    (2, 7, 11, 1024, 640, 3, 1, False, False, False),
+    (1, 33, 47, 64, 96, 3, 1, False, True, True),
+]
+
+
+def _rb(t):
+    return t.bfloat16().float()
+
+
+def _reduced_reference(x, w, stride, pad, mode):
+    """What the reduced-precision kernels compute, in f64: mode 1 = product of the bf16-rounded operands;
+    mode 2 (bf16x3) = (xh+xl)*(wh+wl) - xl*wl with x = xh + xl + eps split into two bf16."""
+    if mode == 1:
+        return F.conv2d(_rb(x).double(), _rb(w).double(), stride=stride, padding=pad).float()
+    xh, wh = _rb(x), _rb(w)
+    xl, wl = _rb(x - xh), _rb(w - wh)
+    full = F.conv2d((xh.double() + xl.double()), (wh.double() + wl.double()), stride=stride, padding=pad)
+    return (full - F.conv2d(xl.double(), wl.double(), stride=stride, padding=pad)).float()
+
+
+@pytest.mark.parametrize('mode', [1, 2])
+@pytest.mark.parametrize('case', BF16_CASES)
+def test_conv_reduced_precision_matches_emulation(gpu, case, mode):
+    """bf16 / bf16x3 kernels against an f64 evaluation of exactly the products they form (operands rounded /
+    split on the host the same way, nearest-even): only the f32 summation order differs."""
+    from vfloodnet_amd import ops, weights
+    N, H, W, Cin, Cout, k, s, relu_in, relu_out, use_res = case
+    g = torch.Generator().manual_seed(hash(case) & 0xFFFF)
+    x = torch.randn(N, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, k, k, generator=g) / (Cin * k * k) ** 0.5
+    scale = 1 + 0.1 * torch.randn(Cout, generator=g)
+    shift = 0.1 * torch.randn(Cout, generator=g)
+    xin = F.relu(x) if relu_in else x
+    ref = _reduced_reference(xin, w, s, k // 2, mode) * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1)
+    exact = F.conv2d(xin, w, stride=s, padding=k // 2) * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1)
+    res = torch.randn(ref.shape, generator=g) if use_res else None
+    if use_res:
+        ref = ref + res
+        exact = exact + res
+    if relu_out:
+        ref = F.relu(ref)
+        exact = F.relu(exact)
+    scale_d, shift_d = scale.to(gpu), shift.to(gpu)
+    xd = x.permute(0, 2, 3, 1).contiguous().to(gpu)
+    wp = ops.pad_rows(weights.pack_conv_weight(w)).to(gpu)
+    resd = res.permute(0, 2, 3, 1).contiguous().to(gpu) if use_res else None
+    tiles = ops.conv_cfg_tiles()
+    tol = 2e-4 * max(1.0, ref.abs().max().item())
+    for cfg in ops.BF16_CFGS:
+        if wp.shape[0] < ((Cout + tiles[cfg][1] - 1) // tiles[cfg][1]) * tiles[cfg][1]:
+            continue
+        y = ops.conv2d_nhwc(xd, wp, Cout, k, k, s, k // 2, scale_d, shift_d, resd, relu_in, relu_out, cfg=cfg, mode=mode)
+        torch.cuda.synchronize()
+        got = y.permute(0, 3, 1, 2).cpu()
+        err = (got - ref).abs().max().item()
+        assert err < tol, f'cfg {cfg}: max err {err}'
+    # distance from the exact f32 convolution: what the mode costs (bf16x3 ~2^-16 per product, bf16 ~2^-9)
+    dev_exact = (got - exact).abs().max().item() / max(1.0, exact.abs().max().item())
+    assert dev_exact < (2e-2 if mode == 1 else 1e-4), dev_exact
+    ws = torch.empty(8 * ref.numel(), device=gpu)
+    y = torch.empty(N, ref.shape[2], ref.shape[3], Cout, device=gpu)
+    d = ops.make_conv_desc(xd, wp, Cout, k, k, s, k // 2, y, scale_d, shift_d, resd, relu_in, relu_out)
+    for ks in ops.valid_splits(d, 8, mode=mode)[1:]:
+        y.zero_()
+        ops.set_splitk(d, ks, ws)
+        ops.conv2d_launch(d, 3, mode=mode)
+        torch.cuda.synchronize()
+        err = (y.permute(0, 3, 1, 2).cpu() - ref).abs().max().item()
+        assert err < tol, f'split {ks}: max err {err}'

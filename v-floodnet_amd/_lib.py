@@ -85,6 +85,8 @@ def _declare(L):
     L.vfn_conv_cfg_count.restype = i
     L.vfn_conv_cfg_tile.argtypes = [i, C.POINTER(i), C.POINTER(i)]
     L.vfn_conv2d_nhwc_f32.argtypes = [C.POINTER(ConvDesc), i, p]
+    L.vfn_conv2d_nhwc_bf16.argtypes = [C.POINTER(ConvDesc), i, p]
+    L.vfn_conv2d_nhwc_bf16x3.argtypes = [C.POINTER(ConvDesc), i, p]
     L.vfn_conv3x3_cout2_f32.argtypes = [C.POINTER(ConvDesc), p]
     L.vfn_stem_conv7x7_f32.argtypes = [C.POINTER(StemDesc), p]
     L.vfn_bank_scan.argtypes = [C.POINTER(BankScanDesc), p]
@@ -121,7 +123,7 @@ SIGNATURES = {
 }
 # every symbol include/vfn_hip.h declares (checked by tests/test_abi.py)
 ALL_SYMBOLS = sorted(list(SIGNATURES) + [
-    'vfn_abi_version', 'vfn_conv_cfg_count', 'vfn_conv_cfg_tile', 'vfn_conv2d_nhwc_f32', 'vfn_conv3x3_cout2_f32',
+    'vfn_abi_version', 'vfn_conv_cfg_count', 'vfn_conv_cfg_tile', 'vfn_conv2d_nhwc_f32', 'vfn_conv2d_nhwc_bf16', 'vfn_conv2d_nhwc_bf16x3', 'vfn_conv3x3_cout2_f32',
     'vfn_stem_conv7x7_f32',
     'vfn_bank_scan', 'vfn_memread_apply', 'vfn_memread_finish', 'vfn_bank_merge', 'vfn_bank_append', 'vfn_bank_remove'])
 

@@ -26,7 +26,18 @@
 
 namespace {
 
-constexpr int BK = 32;
+constexpr int BK = 32;         // floats per LDS image row (128 bytes)
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+
+// x = hi + lo with hi = bf16(x), lo = bf16(x - hi): 16 significant bits in two bf16 (the "bf16x3" operands)
+__device__ __forceinline__ void split_bf16(const f32x4& v, bf16x4& h, bf16x4& l) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        h[e] = (__bf16)v[e];
+        l[e] = (__bf16)(v[e] - (float)h[e]);
+    }
+}
 
 // In-launch finish of a K-split tile (replaces the separate reduce launch): every slice workgroup stores its
 // raw partial tile, then takes a ticket on the tile's arrival counter; the workgroup that draws the last
@@ -81,14 +92,23 @@ __device__ __forceinline__ void splitk_finish(const vfn_conv_desc& p, int* flag,
     }
 }
 
-template <int BM, int BN, int WM, int WN>
+template <int BM, int BN, int WM, int WN, int MODE = 0>
 __global__ __launch_bounds__(WM * WN * 64)
 void conv_igemm_kernel(const vfn_conv_desc p) {
     constexpr int NT = WM * WN * 64;
     constexpr int TM = BM / WM / 32;
     constexpr int TN = BN / WN / 32;
-    constexpr int AC = BM * 8 / NT;   // 16-byte chunks of the A tile per thread
-    constexpr int BC = BN * 8 / NT;
+    // MODE 0: exact f32 (v_mfma_f32_32x32x2_f32).
+    // MODE 1: operands rounded to bf16 (RNE) as they are staged, v_mfma_f32_32x32x16_bf16, f32 accumulate; a K tile
+    //         is 64 channels, so that an LDS row is 128 bytes in every mode.
+    // MODE 2: "bf16x3" -- every operand is split x = hi + lo (two bf16, 16 significant bits together) and the product
+    //         is hi*hi + hi*lo + lo*hi on the bf16 matrix cores (lo*lo, relative 2^-16, is dropped); an LDS row holds
+    //         the 32 hi values in its first 64 bytes and the 32 lo values in the second.
+    constexpr bool BF = (MODE == 1);
+    constexpr int BKT = BF ? 64 : 32;  // K elements per tile
+    constexpr int CPR = BKT / 4;       // float4 chunks per operand row in global memory
+    constexpr int AC = BM * CPR / NT;  // 16-byte global chunks of the A tile per thread
+    constexpr int BC = BN * CPR / NT;
     static_assert(AC >= 1 && BC >= 1, "tile too small for the thread count");
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -130,7 +150,7 @@ void conv_igemm_kernel(const vfn_conv_desc p) {
     const int m0 = mt * BM, n0 = nt * BN;
 
     const int HoWo = p.Ho * p.Wo;
-    const int cblks = p.Cin / BK;
+    const int cblks = p.Cin / BKT;
     const int Ktot = p.KH * p.KW * p.Cin;
     const int nk_all = p.KH * p.KW * cblks;
     // a split tile's slice kz owns K tiles [kt_begin, kt_begin + nk)
@@ -139,9 +159,9 @@ void conv_igemm_kernel(const vfn_conv_desc p) {
     const int nk = min(kper, nk_all - kt_begin);
 
     // per-thread staging coordinates
-    const int c16 = tid & 7;               // chunk column (4 floats)
-    const int r0 = tid >> 3;               // first row this thread stages
-    constexpr int RSTEP = NT / 8;
+    const int c16 = tid % CPR;             // chunk column (4 floats)
+    const int r0 = tid / CPR;              // first row this thread stages
+    constexpr int RSTEP = NT / CPR;
 
     int a_base[AC], a_hi0[AC], a_wi0[AC];
 #pragma unroll
@@ -186,7 +206,7 @@ void conv_igemm_kernel(const vfn_conv_desc p) {
         kw = tap - kh * p.KW;
     }
     auto load_a = [&]() {
-        const int tap_off = ((kh * p.W + kw) * p.in_ld + cb * BK) * (int)sizeof(float);     // wave-uniform
+        const int tap_off = ((kh * p.W + kw) * p.in_ld + cb * BKT) * (int)sizeof(float);     // wave-uniform
 #pragma unroll
         for (int j = 0; j < AC; ++j) {
             const bool ok = (unsigned)(a_hi0[j] + kh) < (unsigned)p.H && (unsigned)(a_wi0[j] + kw) < (unsigned)p.W;
@@ -195,7 +215,7 @@ void conv_igemm_kernel(const vfn_conv_desc p) {
         }
     };
     auto load_b = [&](int kt) {
-        const int k_off = kt * BK * (int)sizeof(float);
+        const int k_off = kt * BKT * (int)sizeof(float);
 #pragma unroll
         for (int j = 0; j < BC; ++j)
             rb[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_w, w_off[j] + k_off, 0, 0));
@@ -210,7 +230,18 @@ void conv_igemm_kernel(const vfn_conv_desc p) {
             f32x4 v = ra[j];
             v.x = fmaxf(v.x, relu_floor); v.y = fmaxf(v.y, relu_floor);
             v.z = fmaxf(v.z, relu_floor); v.w = fmaxf(v.w, relu_floor);
-            *reinterpret_cast<f32x4*>(dA + r * BK + ((c16 ^ ((r >> 1) & 7)) << 2)) = v;
+            if constexpr (MODE == 1) {
+                const bf16x4 h = {(__bf16)v.x, (__bf16)v.y, (__bf16)v.z, (__bf16)v.w};
+                *reinterpret_cast<bf16x4*>(dA + r * BK + ((((c16 >> 1) ^ ((r >> 1) & 7)) << 2) | ((c16 & 1) << 1))) = h;
+            } else if constexpr (MODE == 2) {
+                bf16x4 h, l;
+                split_bf16(v, h, l);
+                const int sw = (r >> 1) & 7, half = (c16 & 1) << 1;
+                *reinterpret_cast<bf16x4*>(dA + r * BK + ((((c16 >> 1) ^ sw) << 2) | half)) = h;
+                *reinterpret_cast<bf16x4*>(dA + r * BK + ((((4 + (c16 >> 1)) ^ sw) << 2) | half)) = l;
+            } else {
+                *reinterpret_cast<f32x4*>(dA + r * BK + ((c16 ^ ((r >> 1) & 7)) << 2)) = v;
+            }
         }
     };
     auto store_b = [&](int buf) {
@@ -218,7 +249,19 @@ void conv_igemm_kernel(const vfn_conv_desc p) {
 #pragma unroll
         for (int j = 0; j < BC; ++j) {
             const int r = r0 + j * RSTEP;
-            *reinterpret_cast<f32x4*>(dB + r * BK + ((c16 ^ ((r >> 1) & 7)) << 2)) = rb[j];
+            if constexpr (MODE == 1) {
+                const f32x4 v = rb[j];
+                const bf16x4 h = {(__bf16)v.x, (__bf16)v.y, (__bf16)v.z, (__bf16)v.w};
+                *reinterpret_cast<bf16x4*>(dB + r * BK + ((((c16 >> 1) ^ ((r >> 1) & 7)) << 2) | ((c16 & 1) << 1))) = h;
+            } else if constexpr (MODE == 2) {
+                bf16x4 h, l;
+                split_bf16(rb[j], h, l);
+                const int sw = (r >> 1) & 7, half = (c16 & 1) << 1;
+                *reinterpret_cast<bf16x4*>(dB + r * BK + ((((c16 >> 1) ^ sw) << 2) | half)) = h;
+                *reinterpret_cast<bf16x4*>(dB + r * BK + ((((4 + (c16 >> 1)) ^ sw) << 2) | half)) = l;
+            } else {
+                *reinterpret_cast<f32x4*>(dB + r * BK + ((c16 ^ ((r >> 1) & 7)) << 2)) = rb[j];
+            }
         }
     };
 
@@ -243,6 +286,38 @@ void conv_igemm_kernel(const vfn_conv_desc p) {
         const bool more = kt + 1 < nk;
         const float* cA = sA + buf * BM * BK + (wm * TM * 32) * BK;
         const float* cB = sB + buf * BN * BK + (wn * TN * 32) * BK;
+        if constexpr (MODE == 2) {
+            // two 16-channel steps per tile: hi chunk 2s+h and lo chunk 4+2s+h of every row; three MFMAs per tile pair
+#pragma unroll
+            for (int st = 0; st < 2; ++st) {
+                if (more) {
+                    if (st == 0) { load_a(); load_b(kt_begin + kt + 1); }
+                    else { store_a(buf ^ 1); store_b(buf ^ 1); }
+                }
+                const int lc = 2 * st + lh;
+                bf16x8 ah[TM], al[TM], bh[TN], bl[TN];
+#pragma unroll
+                for (int i = 0; i < TM; ++i) {
+                    const int r = i * 32 + li, sw = (r >> 1) & 7;
+                    ah[i] = *reinterpret_cast<const bf16x8*>(cA + r * BK + ((lc ^ sw) << 2));
+                    al[i] = *reinterpret_cast<const bf16x8*>(cA + r * BK + (((4 + lc) ^ sw) << 2));
+                }
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    const int r = j * 32 + li, sw = (r >> 1) & 7;
+                    bh[j] = *reinterpret_cast<const bf16x8*>(cB + r * BK + ((lc ^ sw) << 2));
+                    bl[j] = *reinterpret_cast<const bf16x8*>(cB + r * BK + (((4 + lc) ^ sw) << 2));
+                }
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) {
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+                    }
+            }
+        } else {
         // the staging of tile kt+1 is spread over the four k-groups of tile kt (loads first, LDS writes in
         // the second half) so that no long MFMA-free stretch sits at either end of the iteration
 #pragma unroll
@@ -265,13 +340,24 @@ void conv_igemm_kernel(const vfn_conv_desc p) {
                 const int r = j * 32 + li;
                 b[j] = *reinterpret_cast<const f32x4*>(cB + r * BK + ((lc ^ ((r >> 1) & 7)) << 2));
             }
-#pragma unroll
-            for (int t = 0; t < 4; ++t)
+            if constexpr (BF) {
+                // the 16 bytes are 8 bf16 = k 16*kk + 8*h .. +7: one 32x32x16 step per tile pair
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
                     for (int j = 0; j < TN; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][t], b[j][t], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[i]), __builtin_bit_cast(bf16x8, b[j]),
+                                                                            acc[i][j], 0, 0, 0);
+            } else {
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+#pragma unroll
+                    for (int i = 0; i < TM; ++i)
+#pragma unroll
+                        for (int j = 0; j < TN; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][t], b[j][t], acc[i][j], 0, 0, 0);
+            }
+        }
         }
         __syncthreads();
     }
@@ -619,7 +705,7 @@ void conv3x3_cout2_kernel(const vfn_conv_desc p) {
     }
 }
 
-template <int BM, int BN, int WM, int WN, int DMA = 0>     // DMA: 0 = register staged, 2 / 3 = LDS-DMA ring depth
+template <int BM, int BN, int WM, int WN, int DMA = 0, int MODE = 0>     // DMA: 0 = register staged, 2 / 3 = LDS-DMA ring depth
 int launch_cfg(const vfn_conv_desc& p, hipStream_t s) {
     constexpr int NT = WM * WN * 64;
     const size_t lds = (DMA == 3 ? 3 : 2) * (size_t)(BM + BN) * BK * sizeof(float);
@@ -629,7 +715,7 @@ int launch_cfg(const vfn_conv_desc& p, hipStream_t s) {
             hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_dma_kernel<BM, BN, WM, WN, DMA>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         else
-            hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel<BM, BN, WM, WN>),
+            hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel<BM, BN, WM, WN, MODE>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = true;
     }
@@ -640,7 +726,7 @@ int launch_cfg(const vfn_conv_desc& p, hipStream_t s) {
     if (ks > 1 && (p.split_from < 0 || p.split_from > tiles || p.split_from % n_tiles)) return VFN_ERR_ARG;
     const int grid = ks > 1 ? p.split_from + (tiles - p.split_from) * ks : tiles;
     if constexpr (DMA != 0) hipLaunchKernelGGL((conv_igemm_dma_kernel<BM, BN, WM, WN, DMA>), dim3(grid), dim3(NT), lds, s, p);
-    else hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN>), dim3(grid), dim3(NT), lds, s, p);
+    else hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN, MODE>), dim3(grid), dim3(NT), lds, s, p);
     if (ks > 1 && p.split_from < tiles && !p.tile_counters) {
         const int m_start = (p.split_from / n_tiles) * BM;
         const size_t total = (size_t)(p.M - m_start) * (p.Cout / 4);
@@ -711,6 +797,73 @@ extern "C" int vfn_conv2d_nhwc_f32(const vfn_conv_desc* d, int cfg, void* stream
         case 17: return launch_cfg<128, 256, 2, 4>(*d, s);
         case 18: return launch_cfg<128, 256, 2, 4, 2>(*d, s);
         case 19: return launch_cfg<64, 256, 2, 4>(*d, s);
+    }
+    return VFN_ERR_ARG;
+}
+
+// Same convolution with bf16 operands (rounded to nearest-even as they are staged; f32 accumulate, f32
+// tensors in HBM): BASELINE configs C3 / C5.  Register-staged tile configurations only (LDS-DMA cannot convert).
+extern "C" int vfn_conv2d_nhwc_bf16(const vfn_conv_desc* d, int cfg, void* stream) {
+    if (!d || !d->in || !d->w || !d->out) return VFN_ERR_ARG;
+    if (d->Cin % 64 != 0 || d->in_ld % 4 != 0 || d->M <= 0) return VFN_ERR_ARG;
+    int bm, bn;
+    if (vfn_conv_cfg_tile(cfg, &bm, &bn) != VFN_OK) return VFN_ERR_ARG;
+    if (d->cout_pad < cdiv(d->Cout, bn) * bn) return VFN_ERR_ARG;
+    if (d->tile_counters) return VFN_ERR_ARG;
+    if (d->ksplit > 1) {
+        const int nk_all = d->KH * d->KW * (d->Cin / 64);
+        if (!d->partial || d->Cout % 4 || d->out_ld % 4 || (d->res && d->res_ld % 4)) return VFN_ERR_ARG;
+        if (cdiv(nk_all, d->ksplit) * (d->ksplit - 1) >= nk_all) return VFN_ERR_ARG;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    switch (cfg) {
+        case 0: return launch_cfg<128, 128, 2, 2, 0, 1>(*d, s);
+        case 1: return launch_cfg<128, 64, 2, 2, 0, 1>(*d, s);
+        case 2: return launch_cfg<64, 128, 2, 2, 0, 1>(*d, s);
+        case 3: return launch_cfg<64, 64, 2, 2, 0, 1>(*d, s);
+        case 4: return launch_cfg<32, 64, 1, 2, 0, 1>(*d, s);
+        case 5: return launch_cfg<64, 32, 2, 1, 0, 1>(*d, s);
+        case 6: return launch_cfg<128, 32, 4, 1, 0, 1>(*d, s);
+        case 7: return launch_cfg<256, 128, 4, 2, 0, 1>(*d, s);
+        case 8: return launch_cfg<128, 128, 2, 4, 0, 1>(*d, s);
+        case 9: return launch_cfg<128, 128, 4, 2, 0, 1>(*d, s);
+        case 10: return launch_cfg<64, 128, 2, 4, 0, 1>(*d, s);
+        case 17: return launch_cfg<128, 256, 2, 4, 0, 1>(*d, s);
+        case 19: return launch_cfg<64, 256, 2, 4, 0, 1>(*d, s);
+    }
+    return VFN_ERR_ARG;
+}
+
+// "bf16x3": operands split into hi + lo bf16 halves as they are staged (16 significant bits), three bf16 MFMAs per
+// product (hi*hi + hi*lo + lo*hi), f32 accumulate: relative error ~2^-16 per product, against 2^-9 for plain bf16
+// and 2^-24 for f32.  Same tile configurations and K tiling (32 channels) as the f32 kernel's register-staged ones.
+extern "C" int vfn_conv2d_nhwc_bf16x3(const vfn_conv_desc* d, int cfg, void* stream) {
+    if (!d || !d->in || !d->w || !d->out) return VFN_ERR_ARG;
+    if (d->Cin % BK != 0 || d->in_ld % 4 != 0 || d->M <= 0) return VFN_ERR_ARG;
+    int bm, bn;
+    if (vfn_conv_cfg_tile(cfg, &bm, &bn) != VFN_OK) return VFN_ERR_ARG;
+    if (d->cout_pad < cdiv(d->Cout, bn) * bn) return VFN_ERR_ARG;
+    if (d->tile_counters) return VFN_ERR_ARG;
+    if (d->ksplit > 1) {
+        const int nk_all = d->KH * d->KW * (d->Cin / BK);
+        if (!d->partial || d->Cout % 4 || d->out_ld % 4 || (d->res && d->res_ld % 4)) return VFN_ERR_ARG;
+        if (cdiv(nk_all, d->ksplit) * (d->ksplit - 1) >= nk_all) return VFN_ERR_ARG;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    switch (cfg) {
+        case 0: return launch_cfg<128, 128, 2, 2, 0, 2>(*d, s);
+        case 1: return launch_cfg<128, 64, 2, 2, 0, 2>(*d, s);
+        case 2: return launch_cfg<64, 128, 2, 2, 0, 2>(*d, s);
+        case 3: return launch_cfg<64, 64, 2, 2, 0, 2>(*d, s);
+        case 4: return launch_cfg<32, 64, 1, 2, 0, 2>(*d, s);
+        case 5: return launch_cfg<64, 32, 2, 1, 0, 2>(*d, s);
+        case 6: return launch_cfg<128, 32, 4, 1, 0, 2>(*d, s);
+        case 7: return launch_cfg<256, 128, 4, 2, 0, 2>(*d, s);
+        case 8: return launch_cfg<128, 128, 2, 4, 0, 2>(*d, s);
+        case 9: return launch_cfg<128, 128, 4, 2, 0, 2>(*d, s);
+        case 10: return launch_cfg<64, 128, 2, 4, 0, 2>(*d, s);
+        case 17: return launch_cfg<128, 256, 2, 4, 0, 2>(*d, s);
+        case 19: return launch_cfg<64, 256, 2, 4, 0, 2>(*d, s);
     }
     return VFN_ERR_ARG;
 }

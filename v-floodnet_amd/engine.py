@@ -31,20 +31,30 @@ _CFG_TILES = None
 _TUNED = {}          # (M, Cout, K) -> (cfg, ksplit): measured choices (Engine.autotune / tuned_gfx950.json)
 _TUNED_PATH = __import__('os').path.join(__import__('os').path.dirname(__import__('os').path.abspath(__file__)),
                                          'tuned_gfx950.json')
+_TUNED_BF16 = {}     # the same table for the bf16-operand kernel (64-channel K tiles: its own split factors)
+_TUNED_BF16_PATH = _TUNED_PATH.replace('tuned_gfx950.json', 'tuned_gfx950_bf16.json')
+_TUNED_BF16X3 = {}   # ... and for the bf16x3 kernel
+_TUNED_BF16X3_PATH = _TUNED_PATH.replace('tuned_gfx950.json', 'tuned_gfx950_bf16x3.json')
+_TABLES = (_TUNED, _TUNED_BF16, _TUNED_BF16X3)                 # by ops.MODES value
+_TABLE_PATHS = (_TUNED_PATH, _TUNED_BF16_PATH, _TUNED_BF16X3_PATH)
 
 
 def _load_tuned():
     import json
     import os
-    if os.path.isfile(_TUNED_PATH) and os.environ.get('VFN_IGNORE_TUNED') != '1':
-        for k, v in json.load(open(_TUNED_PATH)).items():
-            _TUNED[tuple(int(x) for x in k.split(','))] = (int(v[0]), int(v[1]), int(v[2]) if len(v) > 2 else 0)
+    if os.environ.get('VFN_IGNORE_TUNED') == '1':
+        return
+    for path, table in zip(_TABLE_PATHS, _TABLES):
+        if os.path.isfile(path):
+            for k, v in json.load(open(path)).items():
+                table[tuple(int(x) for x in k.split(','))] = (int(v[0]), int(v[1]), int(v[2]) if len(v) > 2 else 0)
 
 
-def save_tuned(path=_TUNED_PATH):
+def save_tuned(path=None, mode=0):
     import json
-    with open(path, 'w') as f:
-        json.dump({','.join(str(x) for x in k): list(v) for k, v in sorted(_TUNED.items())}, f, indent=0)
+    table = _TABLES[mode]
+    with open(path or _TABLE_PATHS[mode], 'w') as f:
+        json.dump({','.join(str(x) for x in k): list(v) for k, v in sorted(table.items())}, f, indent=0)
 
 
 _load_tuned()
@@ -90,15 +100,16 @@ def apply_choice(desc, choice, ws, counters=None):
     return cfg
 
 
-def choose_cfg(M, cout, K):
+def choose_cfg(M, cout, K, mode=0):
     """(tile config, split-K factor, first split tile): the measured table if the shape is in it, otherwise
     minimise (rounds over 256 CUs) x (tile work / efficiency), cutting K when there are too few tiles."""
     global _CFG_TILES
     key = (M, cout, K)
-    if key in _TUNED:
-        return _TUNED[key]
+    table = _TABLES[mode]
+    if key in table:
+        return table[key]
     _tiles()
-    nk = K // 32
+    nk = K // (64 if mode == 1 else 32)
     best, best_cost = 0, None
     for c, (bm, bn) in enumerate(_CFG_TILES[:8]):
         if bn > 32 and cout <= 32:
@@ -240,11 +251,14 @@ class FramePlan:
         if layer.cout == 2 and layer.k == 3 and layer.cin in (32, 256) and res is None:
             lst.append(Launch(ops.conv_cout2_launch, (d,), f'{name}[{d.M}x2x{K}]', 2.0 * d.M * 2 * K))
             return out
-        choice = choose_cfg(d.M, layer.cout, K)
+        bf = self.eng.mode
+        if bf == 1 and layer.cin % 64:                     # (the 32-channel local head: no 64-channel K tile)
+            bf = 2
+        choice = choose_cfg(d.M, layer.cout, K, bf)
         if choice[1] > 1 and (d.out_ld % 4 or (res is not None and d.res_ld % 4)):
             choice = (choice[0], 1, 0)
         cfg = apply_choice(d, choice, self._ws_cur, self._cnt_cur)
-        lst.append(Launch(ops.conv2d_launch, (d, cfg), f'{name}[{d.M}x{layer.cout}x{K}]', 2.0 * d.M * layer.cout * K))
+        lst.append(Launch(ops.conv2d_launch, (d, cfg, bf), f'{name}[{d.M}x{layer.cout}x{K}]', 2.0 * d.M * layer.cout * K))
         return out
 
     def _trunk(self, lst, enc, bufs, N, prefix):
@@ -346,6 +360,10 @@ class Engine:
         self.device = dev
         self.model = model
         self.plans = {}
+        self.precision = getattr(model, 'precision', 'fp32')
+        if self.precision not in ops.MODES:
+            raise ValueError(f"precision must be one of {sorted(ops.MODES)}, got {self.precision!r}")
+        self.mode = ops.MODES[self.precision]
         self._side = None            # side stream for the next frame's query encoder
         self._prefetched = None
         self._pack(model)
@@ -509,25 +527,28 @@ class Engine:
             for l in lst:
                 if l.fn is ops.conv2d_launch:
                     d = l.args[0]
-                    key = (d.M, d.Cout, d.KH * d.KW * d.Cin)
+                    key = (d.M, d.Cout, d.KH * d.KW * d.Cin, int(l.args[2]))
                     seen.setdefault(key, []).append(l)
         tiles = ops.conv_cfg_tiles()
 
-        def timeit(d, c):
-            ops.conv2d_launch(d, c)
+        def timeit(d, c, bf):
+            ops.conv2d_launch(d, c, bf)
             torch.cuda.synchronize()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             for _ in range(iters):
-                ops.conv2d_launch(d, c)
+                ops.conv2d_launch(d, c, bf)
             e1.record()
             torch.cuda.synchronize()
             return e0.elapsed_time(e1)
 
         for key, launches in seen.items():
             d = launches[0].args[0]
+            bf = key[3]
             best, best_t = None, None
             for c, (bm, bn) in enumerate(tiles):
+                if bf and c not in ops.BF16_CFGS:              # no LDS-DMA variants (the DMA cannot convert)
+                    continue
                 if d.cout_pad < ((d.Cout + bn - 1) // bn) * bn:
                     continue
                 if (bn > 64 and d.Cout <= 32) or (bn > 128 and d.Cout < 256):
@@ -535,17 +556,17 @@ class Engine:
                 blocks = ((d.M + bm - 1) // bm) * ((d.Cout + bn - 1) // bn)
                 options = [(c, 1, 0)]
                 if blocks < 256:
-                    options += [(c, k_, 0) for k_ in ops.valid_splits(d, 16)[1:] if k_ * d.M * d.Cout <= WS_FLOATS]
+                    options += [(c, k_, 0) for k_ in ops.valid_splits(d, 16, bf)[1:] if k_ * d.M * d.Cout <= WS_FLOATS]
                 else:
-                    options += [(c, k_, full) for (full, k_, rows) in ops.tail_split_options(d, bm, bn, 8)
+                    options += [(c, k_, full) for (full, k_, rows) in ops.tail_split_options(d, bm, bn, 8, bf)
                                 if k_ * rows * d.Cout <= WS_FLOATS and k_ in (2, 3, 4, 5, 6, 8)]
                 for opt in options:
                     apply_choice(d, opt, p.ws, p.cnt)
-                    t = timeit(d, c)
+                    t = timeit(d, c, bf)
                     if best_t is None or t < best_t:
                         best, best_t = opt, t
-            _TUNED[key] = best
+            _TABLES[bf][key[:3]] = best
             for l in launches:
                 in_q = l in p.seg_pre
-                l.args = (l.args[0], apply_choice(l.args[0], best, p.ws_q if in_q else p.ws, p.cnt_q if in_q else p.cnt))
-        return dict(_TUNED)
+                l.args = (l.args[0], apply_choice(l.args[0], best, p.ws_q if in_q else p.ws, p.cnt_q if in_q else p.cnt), bf)
+        return dict(_TABLES[self.mode])

@@ -22,8 +22,14 @@ from . import weights as W
 
 
 class AFB_URR(nn.Module):
-    def __init__(self, device, update_bank, load_imagenet_params=False, _allow_cpu_container=False):
+    def __init__(self, device, update_bank, load_imagenet_params=False, _allow_cpu_container=False, precision=None):
         super().__init__()
+        # 'fp32' (default; exact-f32 matrix cores, the parity configuration), 'bf16x3' (operands split into two bf16,
+        # three bf16 MFMAs per product: ~2^-16 relative) or 'bf16' (operands rounded to bf16: 2^-9); f32 accumulation
+        # and f32 tensors in every mode.  For BASELINE configs C3 / C5; the reference has no reduced-precision mode.
+        # VFN_PRECISION sets the default.
+        import os
+        self.precision = precision or os.environ.get('VFN_PRECISION', 'fp32')
         if load_imagenet_params:
             # AFB_URR.py:39,69 would download torchvision ImageNet weights; inference always
             # overwrites them from a checkpoint (test_video_seg.py:51) and there is no network.

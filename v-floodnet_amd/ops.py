@@ -74,7 +74,7 @@ def set_splitk(desc, ksplit, workspace, split_from=0, rows=None, counters=None):
     return desc
 
 
-def tail_split_options(desc, bm, bn, max_split=8):
+def tail_split_options(desc, bm, bn, max_split=8, mode=0):
     """(split_from, ksplit, rows) candidates that cut only the last partial round of tiles."""
     m_tiles = (desc.M + bm - 1) // bm
     n_tiles = (desc.Cout + bn - 1) // bn
@@ -86,14 +86,14 @@ def tail_split_options(desc, bm, bn, max_split=8):
         if full <= 0 or full >= tiles:
             continue
         rows = desc.M - (full // n_tiles) * bm
-        for ks in valid_splits(desc, max_split)[1:]:
+        for ks in valid_splits(desc, max_split, mode)[1:]:
             out.append((full, ks, rows))
     return out
 
 
-def valid_splits(desc, max_split=16):
+def valid_splits(desc, max_split=16, mode=0):
     """Split factors for which every K slice is non-empty and the epilogue can run vectorised."""
-    nk = desc.KH * desc.KW * (desc.Cin // 32)
+    nk = desc.KH * desc.KW * (desc.Cin // (64 if mode == 1 else 32))
     out = [1]
     if desc.Cout % 4 or desc.out_ld % 4 or (desc.res and desc.res_ld % 4):
         return out
@@ -108,12 +108,21 @@ def conv_cout2_launch(desc):
     check(_lib.lib().vfn_conv3x3_cout2_f32(C.byref(desc), stream()), 'vfn_conv3x3_cout2_f32')
 
 
-def conv2d_launch(desc, cfg):
-    check(_lib.lib().vfn_conv2d_nhwc_f32(C.byref(desc), int(cfg), stream()), 'vfn_conv2d_nhwc_f32')
+# arithmetic of the matrix kernels: 0 exact f32, 1 bf16 operands, 2 bf16x3 (hi/lo split operands, 3 MFMAs per product)
+MODES = {'fp32': 0, 'bf16': 1, 'bf16x3': 2}
+_CONV_FN = ('vfn_conv2d_nhwc_f32', 'vfn_conv2d_nhwc_bf16', 'vfn_conv2d_nhwc_bf16x3')
+
+
+def conv2d_launch(desc, cfg, mode=0):
+    name = _CONV_FN[int(mode)]
+    check(getattr(_lib.lib(), name)(C.byref(desc), int(cfg), stream()), name)
+
+
+BF16_CFGS = (0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 17, 19)
 
 
 def conv2d_nhwc(x, wp, cout, kh, kw, stride, pad, scale=None, shift=None, res=None,
-                relu_in=False, relu_out=False, cfg=3, out=None):
+                relu_in=False, relu_out=False, cfg=3, out=None, mode=0):
     """Convenience form for tests: allocates the output."""
     N, H, W, _ = x.shape
     Ho = (H + 2 * pad - kh) // stride + 1
@@ -121,7 +130,7 @@ def conv2d_nhwc(x, wp, cout, kh, kw, stride, pad, scale=None, shift=None, res=No
     if out is None:
         out = torch.empty(N, Ho, Wo, cout, device=x.device, dtype=torch.float32)
     d = make_conv_desc(x, wp, cout, kh, kw, stride, pad, out, scale, shift, res, relu_in, relu_out)
-    conv2d_launch(d, cfg)
+    conv2d_launch(d, cfg, mode)
     return out
 
 
