@@ -149,6 +149,8 @@ typedef struct vfn_bankscan_desc {
     long long stride_q, stride_k, stride_rs;   /* elements between objects */
     float scale;           /* mode 0: 1/sqrt(128) */
     int ldq, q_per_obj, HW, obj_n, nsplit, mode;
+    int precision;         /* arithmetic of the contraction: 0 exact f32, 1 bf16 operands, 2 bf16x3 (see
+                              vfn_conv2d_nhwc_bf16 / _bf16x3); tensors are f32 in every case */
 } vfn_bankscan_desc;
 
 typedef struct vfn_memread_desc {
@@ -166,6 +168,7 @@ typedef struct vfn_memread_desc {
     long long stride_k, stride_v, stride_cnt, stride_info;
     float scale, thres;
     int ldq, ldqv, ld_out, HW, obj_n, nsplit;
+    int precision;         /* as vfn_bankscan_desc.precision (scores, P and value operands); softmax in f32 */
 } vfn_memread_desc;
 
 int vfn_bank_scan(const vfn_bankscan_desc* d, void* stream);

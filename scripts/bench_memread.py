@@ -7,6 +7,8 @@ from vfloodnet_amd.engine import Engine
 from vfloodnet_amd import _lib
 dev = torch.device('cuda', 0)
 HW = 1620
+MODE = int(os.environ.get('MODE', '0'))
+eng = types.SimpleNamespace(mode=MODE)
 for B in [int(x) for x in (sys.argv[1:] or ['1620', '25000', '100000'])]:
     fb = FeatureBank(2, 250000, dev)
     fb._hw = HW
@@ -17,14 +19,14 @@ for B in [int(x) for x in (sys.argv[1:] or ['1620', '25000', '100000'])]:
                                  ml_part=torch.empty(2, 16, HW, 2, device=dev), o_part=torch.empty(2, 16, HW, 512, device=dev),
                                  dec_in=torch.empty(2, HW, 512, device=dev))
     for _ in range(2):
-        Engine._memory_read(None, plan, fb, True)
+        Engine._memory_read(eng, plan, fb, True)
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(5):
-        Engine._memory_read(None, plan, fb, True)
+        Engine._memory_read(eng, plan, fb, True)
     e1.record(); torch.cuda.synchronize()
     us = e0.elapsed_time(e1) * 200
     fl = 2 * (2 * 2 * 128 + 2 * 512) * B * HW
     newk = [torch.randn(128, HW, device=dev) for _ in range(2)]; newv = [torch.randn(512, HW, device=dev) for _ in range(2)]
-    print(f'B={B:6d} nsplit={pick_nsplit(HW, 2, B)}: memory read (scan+apply+finish) {us:8.1f} us  {fl / us / 1e6:6.1f} TF')
+    print(f'mode {MODE} B={B:6d} nsplit={pick_nsplit(HW, 2, B)}: memory read (scan+apply+finish) {us:8.1f} us  {fl / us / 1e6:6.1f} TF')

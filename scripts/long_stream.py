@@ -10,7 +10,7 @@ from vfloodnet_amd.video_seg import ClipRunner
 T = int(sys.argv[1]) if len(sys.argv) > 1 else 400
 dev = torch.device('cuda', 0)
 sd = synth.make_state_dict(20200212)
-model = AFB_URR(dev, update_bank=True).to(dev).eval(); model.load_state_dict(sd)
+model = AFB_URR(dev, update_bank=True, precision=os.environ.get('VFN_PRECISION', 'fp32')).to(dev).eval(); model.load_state_dict(sd)
 f0, m0 = synth.frame0(1, 1080, 1920)
 f0 = f0.to(dev)
 onehot = synth.onehot(m0).unsqueeze(0).to(dev)
@@ -29,5 +29,5 @@ for t in range(1, T + 1):
         print(curve[-1], flush=True)
         t_prev, n_prev = now, t
 os.makedirs('gpurun_out', exist_ok=True)
-json.dump({'config': f'C5 shape: {T} frames 1920x1080 -> 853x480 (bicubic on device), fp32, no eviction (budget {budget})',
-           'curve': curve}, open('gpurun_out/r01_c5_long_stream.json', 'w'), indent=1)
+json.dump({'config': f'C5 shape: {T} frames 1920x1080 -> 853x480 (bicubic on device), {os.environ.get("VFN_PRECISION", "fp32")}, no eviction (budget {budget})',
+           'curve': curve}, open('gpurun_out/r01_c5_long_stream_%s.json' % os.environ.get('VFN_PRECISION', 'fp32'), 'w'), indent=1)

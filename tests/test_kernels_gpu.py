@@ -168,7 +168,7 @@ def test_memory_read(gpu, B, HW):
                                  ml_part=torch.empty(2, 16, HW, 2, device=gpu),
                                  o_part=torch.empty(2, 16, HW, 512, device=gpu),
                                  dec_in=torch.empty(2, HW, 512, device=gpu))
-    Engine._memory_read(None, plan, fb, True)
+    Engine._memory_read(types.SimpleNamespace(mode=0), plan, fb, True)
     torch.cuda.synchronize()
     out = plan.dec_in.cpu()
     q_in = kvq[0, :, :128].t().unsqueeze(0)
@@ -184,6 +184,56 @@ def test_memory_read(gpu, B, HW):
         near = ((p[0] - 1e-3).abs() < 1e-7).any(dim=1)
         assert (got[~near] - info_ref[~near]).abs().max() < 1e-5
     assert int(fb._cnt.abs().sum()) == 0
+
+
+def _rb(t):
+    return t.bfloat16().float()
+
+
+def _mm_reduced(a, b, mode):
+    """f64 value of what the reduced-precision contraction forms: mode 1 = bf16-rounded operands;
+    mode 2 (bf16x3) = (ah+al)(bh+bl) - al*bl."""
+    if mode == 1:
+        return torch.matmul(_rb(a).double(), _rb(b).double())
+    ah, bh = _rb(a), _rb(b)
+    al, bl = _rb(a - ah), _rb(b - bh)
+    return torch.matmul(ah.double() + al.double(), bh.double() + bl.double()) - torch.matmul(al.double(), bl.double())
+
+
+@pytest.mark.parametrize('mode', [1, 2])
+@pytest.mark.parametrize('B,HW', [(60, 60), (1000, 150), (5000, 1620)])
+def test_memory_read_reduced_precision(gpu, B, HW, mode):
+    """bf16 / bf16x3 memory read against an f64 evaluation of the same rounded / split operands (scores,
+    then P and V); softmax in between as the kernel does it (f32 statistics of the reduced-precision scores)."""
+    from vfloodnet_amd.feature_bank import FeatureBank
+    from vfloodnet_amd.engine import Engine
+    import types
+    g = torch.Generator().manual_seed(B + mode)
+    keys = [torch.randn(128, B, generator=g) for _ in range(2)]
+    vals = [torch.randn(512, B, generator=g) for _ in range(2)]
+    kvq = torch.randn(1, HW, 640, generator=g)
+    fb = FeatureBank(2, 250000, gpu)
+    fb._hw = HW
+    fb._alloc(HW, B)
+    fb._write_columns([k.to(gpu) for k in keys], [v.to(gpu) for v in vals], [0, 0], 0, 0.0)
+    fb._set_lengths([B, B])
+    plan = types.SimpleNamespace(HW=HW, kv_q=kvq.to(gpu), ml=torch.empty(2, HW, 2, device=gpu),
+                                 ml_part=torch.empty(2, 16, HW, 2, device=gpu),
+                                 o_part=torch.empty(2, 16, HW, 512, device=gpu),
+                                 dec_in=torch.empty(2, HW, 512, device=gpu))
+    Engine._memory_read(types.SimpleNamespace(mode=mode), plan, fb, True)
+    torch.cuda.synchronize()
+    out = plan.dec_in.cpu()
+    q_in = kvq[0, :, :128].t()
+    for i in range(2):
+        s_ = _mm_reduced(keys[i].t(), q_in, mode) / math.sqrt(128)
+        p = F.softmax(s_, dim=0).float()
+        mem = _mm_reduced(vals[i], p, mode).float()             # [512, HW]
+        exact = torch.matmul(vals[i].double(), F.softmax(torch.matmul(keys[i].t().double(), q_in.double()) / math.sqrt(128), dim=0)).float()
+        err = (out[i].t() - mem).abs().max().item()
+        assert err < 1e-4 * max(1, mem.abs().max().item()), err
+        dev_exact = (out[i].t() - exact).abs().max().item() / max(1, exact.abs().max().item())
+        assert dev_exact < (5e-2 if mode == 1 else 2e-4), dev_exact
 
 
 def test_scatter_mean(gpu):

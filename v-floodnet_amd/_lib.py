@@ -39,7 +39,7 @@ class BankScanDesc(C.Structure):
                 ('stride_q', C.c_longlong), ('stride_k', C.c_longlong), ('stride_rs', C.c_longlong),
                 ('scale', C.c_float),
                 ('ldq', C.c_int), ('q_per_obj', C.c_int), ('HW', C.c_int), ('obj_n', C.c_int),
-                ('nsplit', C.c_int), ('mode', C.c_int)]
+                ('nsplit', C.c_int), ('mode', C.c_int), ('precision', C.c_int)]
 
 
 class MemReadDesc(C.Structure):
@@ -49,7 +49,7 @@ class MemReadDesc(C.Structure):
                 ('stride_info', C.c_longlong),
                 ('scale', C.c_float), ('thres', C.c_float),
                 ('ldq', C.c_int), ('ldqv', C.c_int), ('ld_out', C.c_int), ('HW', C.c_int), ('obj_n', C.c_int),
-                ('nsplit', C.c_int)]
+                ('nsplit', C.c_int), ('precision', C.c_int)]
 
 
 class BankDesc(C.Structure):

@@ -106,6 +106,35 @@ __device__ __forceinline__ void score_tile(const float* sK, const float* sQ, int
     }
 }
 
+// ---- reduced-precision operands (BASELINE configs C3 / C5; precision 1 = bf16, 2 = bf16x3)
+// 8 consecutive k of one operand row -> one v_mfma_f32_32x32x16_bf16 fragment.  bf16x3: x = hi + lo (two bf16,
+// 16 significant bits); a product is hi*hi + hi*lo + lo*hi, the 2^-16 lo*lo term is dropped.
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+
+__device__ __forceinline__ bf16x8 cvt8(const f32x4& a, const f32x4& b) {
+    bf16x8 r;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { r[e] = (__bf16)a[e]; r[4 + e] = (__bf16)b[e]; }
+    return r;
+}
+__device__ __forceinline__ void split8(const f32x4& a, const f32x4& b, bf16x8& h, bf16x8& l) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const __bf16 x = (__bf16)a[e], y = (__bf16)b[e];
+        h[e] = x; h[4 + e] = y;
+        l[e] = (__bf16)(a[e] - (float)x); l[4 + e] = (__bf16)(b[e] - (float)y);
+    }
+}
+template <bool X3>
+__device__ __forceinline__ void mfma_lp(f32x16& acc, const bf16x8& ah, const bf16x8& al, const bf16x8& bh, const bf16x8& bl) {
+    if constexpr (X3) {
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc, 0, 0, 0);
+    }
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc, 0, 0, 0);
+}
+
 __device__ __forceinline__ void chunk_range(int B, int nsplit, int split, int& c_lo, int& c_hi) {
     const int nchunks = (B + CH - 1) / CH;
     const int per = (nchunks + nsplit - 1) / nsplit;
@@ -117,7 +146,7 @@ __device__ __forceinline__ void chunk_range(int B, int nsplit, int split, int& c
 // MODE 0: (max, sum exp) of scale*s per query.  MODE 1: arg-max of s*rowscale[b] per query.
 // Query fragments live in registers (64 VGPRs), key chunks are double-buffered in LDS by LDS-DMA:
 // 64 KB of LDS -> two workgroups per CU, one barrier per chunk, the next chunk lands behind the MFMAs.
-template <int MODE>
+template <int MODE, int PREC = 0>
 __global__ __launch_bounds__(256, 2)
 void bank_scan_kernel(const vfn_bankscan_desc p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -141,13 +170,25 @@ void bank_scan_kernel(const vfn_bankscan_desc p) {
     chunk_range(B, p.nsplit, split, c_lo, c_hi);
     if (c_lo < c_hi) chunk_load_async(sKb, K + (size_t)c_lo * CH * DK, min(CH, B - c_lo * CH), wave, lane);
 
-    // B operand: this lane's query column, k = 8kk + 4lh + t
-    f32x4 qf[16];
+    // B operand: this lane's query column, k = 8kk + 4lh + t (f32) / k = 16g + 8lh + j (bf16 fragments)
+    f32x4 qf[PREC == 0 ? 16 : 1];
+    bf16x8 qh[PREC == 0 ? 1 : 8], ql[PREC == 2 ? 8 : 1];
     {
         const int q = min(q0 + wq * 32 + li, p.HW - 1);          // columns past HW are never written out
-        const float* qrow = Q + (size_t)q * p.ldq + 4 * lh;
+        if constexpr (PREC == 0) {
+            const float* qrow = Q + (size_t)q * p.ldq + 4 * lh;
 #pragma unroll
-        for (int kk = 0; kk < 16; ++kk) qf[kk] = *reinterpret_cast<const f32x4*>(qrow + 8 * kk);
+            for (int kk = 0; kk < 16; ++kk) qf[kk] = *reinterpret_cast<const f32x4*>(qrow + 8 * kk);
+        } else {
+            const float* qrow = Q + (size_t)q * p.ldq + 8 * lh;
+#pragma unroll
+            for (int g = 0; g < 8; ++g) {
+                const f32x4 x0 = *reinterpret_cast<const f32x4*>(qrow + 16 * g);
+                const f32x4 x1 = *reinterpret_cast<const f32x4*>(qrow + 16 * g + 4);
+                if constexpr (PREC == 2) split8(x0, x1, qh[g], ql[g]);
+                else qh[g] = cvt8(x0, x1);
+            }
+        }
     }
 
     float run_m = -INFINITY, run_l = 0.f;
@@ -162,7 +203,7 @@ void bank_scan_kernel(const vfn_bankscan_desc p) {
         f32x16 acc;
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-        {
+        if constexpr (PREC == 0) {
             const int ra = wr * 32 + li;
             f32x4 a[2];
             a[0] = *reinterpret_cast<const f32x4*>(sK + swz(ra, lh));
@@ -173,6 +214,24 @@ void bank_scan_kernel(const vfn_bankscan_desc p) {
 #pragma unroll
                 for (int t = 0; t < 4; ++t)
                     acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[cur][t], qf[kk][t], acc, 0, 0, 0);
+            }
+        } else {
+            // key fragments: two 16-byte reads (f32 chunks 4g+2h, 4g+2h+1 = k 16g+8h .. +7), converted in registers
+            const int ra = wr * 32 + li;
+            f32x4 a[2][2];
+            a[0][0] = *reinterpret_cast<const f32x4*>(sK + swz(ra, 2 * lh));
+            a[0][1] = *reinterpret_cast<const f32x4*>(sK + swz(ra, 2 * lh + 1));
+#pragma unroll
+            for (int g = 0; g < 8; ++g) {
+                const int cur = g & 1;
+                if (g + 1 < 8) {
+                    a[cur ^ 1][0] = *reinterpret_cast<const f32x4*>(sK + swz(ra, 4 * (g + 1) + 2 * lh));
+                    a[cur ^ 1][1] = *reinterpret_cast<const f32x4*>(sK + swz(ra, 4 * (g + 1) + 2 * lh + 1));
+                }
+                bf16x8 ah, al;
+                if constexpr (PREC == 2) split8(a[cur][0], a[cur][1], ah, al);
+                else { ah = cvt8(a[cur][0], a[cur][1]); al = ah; }
+                mfma_lp<PREC == 2>(acc, ah, al, qh[g], ql[PREC == 2 ? g : 0]);
             }
         }
         const int rb = b0 + wr * 32 + 4 * lh;
@@ -419,6 +478,198 @@ void memread_apply_kernel(const vfn_memread_desc p) {
         }
 }
 
+
+// ------------------------------------------------------------------ pass 2 with bf16 / bf16x3 operands
+// Same tiling as memread_apply_kernel.  LDS (80 KB): query image as bf16 hi / lo [64 q][128] (converted once),
+// key chunk f32 [64][128] by LDS-DMA (fragments converted in registers), P^T as bf16 hi / lo [64 q][64 b]
+// (converted once by the wave that computed it, read by all four).  Value rows go global -> registers ->
+// bf16 fragments, one 16-row step ahead of their MFMAs.  k is in natural order everywhere: step g of a
+// 32x32x16 MFMA takes k = 16g + 8*(lane>>5) + j.
+__device__ __forceinline__ int swzq(int row, int chunk) { return row * 256 + ((chunk ^ (row & 15)) << 4); }          // bytes
+__device__ __forceinline__ int swzp(int row, int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); }    // bytes
+
+template <bool X3>
+__global__ __launch_bounds__(256, 2)
+void memread_apply_lp_kernel(const vfn_memread_desc p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* sQh = smem;                                        // [64][128] bf16
+    char* sQl = sQh + QT * DK * 2;
+    float* sK = reinterpret_cast<float*>(sQl + QT * DK * 2); // [64][128] f32
+    char* sPh = reinterpret_cast<char*>(sK + CH * DK);       // [64 q][64 b] bf16
+    char* sPl = sPh + QT * CH * 2;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 31, lh = lane >> 5;
+    const int wr = wave >> 1, wq = wave & 1;
+    const int split = blockIdx.x % p.nsplit;
+    const int qt = blockIdx.x / p.nsplit;
+    const int obj = blockIdx.y;
+    const int q0 = qt * QT;
+    const int B = p.bank_len[obj];
+    const float* K = p.bank_k + (size_t)obj * p.stride_k;
+    const float* V = p.bank_v + (size_t)obj * p.stride_v;
+
+    {   // query image
+        const int c = tid & 31;
+        for (int r = tid >> 5; r < QT; r += 8) {
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (q0 + r < p.HW) v = *reinterpret_cast<const f32x4*>(p.q + (size_t)(q0 + r) * p.ldq + c * 4);
+            bf16x4 h, l;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { h[e] = (__bf16)v[e]; l[e] = (__bf16)(v[e] - (float)h[e]); }
+            const int off = swzq(r, c >> 1) + (c & 1) * 8;
+            *reinterpret_cast<bf16x4*>(sQh + off) = h;
+            if constexpr (X3) *reinterpret_cast<bf16x4*>(sQl + off) = l;
+        }
+    }
+
+    int c_lo, c_hi;
+    chunk_range(B, p.nsplit, split, c_lo, c_hi);
+
+    f32x16 o[2][4];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[a][b][r] = 0.f;
+
+    const float* vcol = V + wave * 128 + li * 4;     // + row*512; lane li owns channels 4li..4li+3 (one per tile tc)
+
+    if (c_lo < c_hi) chunk_load_async(sK, K + (size_t)c_lo * CH * DK, min(CH, B - c_lo * CH), wave, lane);
+    __syncthreads();
+
+    const int qcol = wq * 32 + li;
+    const bool qok = (q0 + qcol) < p.HW;
+    float qm = 0.f, ql_ = 1.f;
+    if (qok) {
+        qm = p.ml[((size_t)obj * p.HW + q0 + qcol) * 2];
+        ql_ = p.ml[((size_t)obj * p.HW + q0 + qcol) * 2 + 1];
+    }
+
+    for (int c = c_lo; c < c_hi; ++c) {
+        const int b0 = c * CH;
+        const bool more = c + 1 < c_hi;
+
+        // value rows of step 0 (16 bank rows; this lane half: rows 8*lh .. +7) -- they land behind the score GEMM
+        f32x4 raw[8];
+        auto load_raw = [&](int st) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int rr = min(b0 + 16 * st + 8 * lh + j, B - 1);      // rows past the end: P is exactly 0 there
+                raw[j] = *reinterpret_cast<const f32x4*>(vcol + (size_t)rr * DV);
+            }
+        };
+        load_raw(0);
+
+        // scores: A = key rows 32wr.., B = query columns 32wq..
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+        {
+            const int ra = wr * 32 + li, rq = wq * 32 + li;
+            f32x4 a[2][2];
+            a[0][0] = *reinterpret_cast<const f32x4*>(sK + swz(ra, 2 * lh));
+            a[0][1] = *reinterpret_cast<const f32x4*>(sK + swz(ra, 2 * lh + 1));
+#pragma unroll
+            for (int g = 0; g < 8; ++g) {
+                const int cur = g & 1;
+                if (g + 1 < 8) {
+                    a[cur ^ 1][0] = *reinterpret_cast<const f32x4*>(sK + swz(ra, 4 * (g + 1) + 2 * lh));
+                    a[cur ^ 1][1] = *reinterpret_cast<const f32x4*>(sK + swz(ra, 4 * (g + 1) + 2 * lh + 1));
+                }
+                const bf16x8 bh = *reinterpret_cast<const bf16x8*>(sQh + swzq(rq, 2 * g + lh));
+                bf16x8 bl = bh;
+                if constexpr (X3) bl = *reinterpret_cast<const bf16x8*>(sQl + swzq(rq, 2 * g + lh));
+                bf16x8 ah, al;
+                if constexpr (X3) split8(a[cur][0], a[cur][1], ah, al);
+                else { ah = cvt8(a[cur][0], a[cur][1]); al = ah; }
+                mfma_lp<X3>(acc, ah, al, bh, bl);
+            }
+        }
+
+        // p = exp(s - m) / l; hit counts; P^T -> LDS as bf16 (hi, lo)
+        const int rloc = wr * 32 + 4 * lh;
+        int mycnt = 0;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int rr = rloc + (r & 3) + 8 * (r >> 2);
+            float pv = 0.f;
+            if (qok && b0 + rr < B) pv = expf(acc[r] * p.scale - qm) / ql_;
+            acc[r] = pv;
+            const unsigned long long hit = __ballot(pv > p.thres);
+            const int rlo = (r & 3) + 8 * (r >> 2);
+            if (lh == 0) {
+                if (li == rlo) mycnt += __popcll(hit & 0xffffffffull);
+                if (li == rlo + 4) mycnt += __popcll(hit >> 32);
+            }
+        }
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {                // registers 4g..4g+3 = 4 consecutive bank rows of query qcol
+            const int brow = rloc + 8 * g;
+            bf16x4 h, l;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { h[e] = (__bf16)acc[4 * g + e]; l[e] = (__bf16)(acc[4 * g + e] - (float)h[e]); }
+            const int off = swzp(qcol, brow >> 3) + ((brow >> 2) & 1) * 8;
+            *reinterpret_cast<bf16x4*>(sPh + off) = h;
+            if constexpr (X3) *reinterpret_cast<bf16x4*>(sPl + off) = l;
+        }
+        if (p.cnt && lh == 0 && mycnt > 0) {
+            const int row = b0 + wr * 32 + li;
+            if (row < B) atomicAdd(p.cnt + (size_t)obj * p.stride_cnt + row, mycnt);
+        }
+        __syncthreads();                             // P^T visible; every wave is done reading sK
+        if (more) chunk_load_async(sK, K + (size_t)(b0 + CH) * DK, min(CH, B - b0 - CH), wave, lane);
+
+        // O^T[q][ch] += sum_b P^T[q][b] V[b][ch]: A = P^T (rows q), B = value rows (cols = channel 4li + tc)
+#pragma unroll
+        for (int st = 0; st < CH / 16; ++st) {
+            __builtin_amdgcn_sched_barrier(0);       // one step at a time: hoisting the next step's operands spills
+            bf16x8 ph[2], pl[2];
+#pragma unroll
+            for (int tq = 0; tq < 2; ++tq) {
+                ph[tq] = *reinterpret_cast<const bf16x8*>(sPh + swzp(tq * 32 + li, 2 * st + lh));
+                if constexpr (X3) pl[tq] = *reinterpret_cast<const bf16x8*>(sPl + swzp(tq * 32 + li, 2 * st + lh));
+                else pl[tq] = ph[tq];
+            }
+            // two channel tiles at a time (register budget: 128 accumulators + 32 raw + 16 converted + 16 P)
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+                __builtin_amdgcn_sched_barrier(0);
+                bf16x8 vh[2], vl[2];
+#pragma unroll
+                for (int t2 = 0; t2 < 2; ++t2)
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const float x = raw[j][2 * half + t2];
+                        const __bf16 hx = (__bf16)x;
+                        vh[t2][j] = hx;
+                        if constexpr (X3) vl[t2][j] = (__bf16)(x - (float)hx); else vl[t2][j] = hx;
+                    }
+                if (half == 1 && st + 1 < CH / 16) load_raw(st + 1);
+#pragma unroll
+                for (int t2 = 0; t2 < 2; ++t2)
+#pragma unroll
+                    for (int tq = 0; tq < 2; ++tq)
+                        mfma_lp<X3>(o[tq][2 * half + t2], ph[tq], pl[tq], vh[t2], vl[t2]);
+            }
+        }
+        __syncthreads();
+    }
+
+    float* dst = p.o_part + ((size_t)obj * p.nsplit + split) * p.HW * DV;
+#pragma unroll
+    for (int tq = 0; tq < 2; ++tq)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int q = q0 + tq * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+            if (q < p.HW) {
+                const f32x4 v = {o[tq][0][r], o[tq][1][r], o[tq][2][r], o[tq][3][r]};
+                *reinterpret_cast<f32x4*>(dst + (size_t)q * DV + wave * 128 + li * 4) = v;
+            }
+        }
+}
+
 // out[obj][q][0:512] = sum_split o_part ; out[obj][q][512:1024] = query value; then the hit-count bump
 __global__ void memread_finish_kernel(const vfn_memread_desc p) {
     const int obj = blockIdx.y;
@@ -458,11 +709,25 @@ extern "C" int vfn_bank_scan(const vfn_bankscan_desc* d, void* stream) {
     if (!d || !d->q || !d->bank_k || !d->bank_len || !d->part) return VFN_ERR_ARG;
     if (d->nsplit < 1 || d->HW < 1 || d->obj_n < 1 || d->ldq % 4) return VFN_ERR_ARG;
     if (d->mode == 1 && (!d->rowscale || d->stride_rs % 4)) return VFN_ERR_ARG;
+    if (d->precision < 0 || d->precision > 2) return VFN_ERR_ARG;
     static bool once = false;
-    if (!once) { allow_lds(bank_scan_kernel<0>, SCAN_LDS); allow_lds(bank_scan_kernel<1>, SCAN_LDS); once = true; }
+    if (!once) {
+        allow_lds(bank_scan_kernel<0, 0>, SCAN_LDS); allow_lds(bank_scan_kernel<1, 0>, SCAN_LDS);
+        allow_lds(bank_scan_kernel<0, 1>, SCAN_LDS); allow_lds(bank_scan_kernel<1, 1>, SCAN_LDS);
+        allow_lds(bank_scan_kernel<0, 2>, SCAN_LDS); allow_lds(bank_scan_kernel<1, 2>, SCAN_LDS);
+        once = true;
+    }
     const dim3 grid(cdiv(d->HW, QT) * d->nsplit, d->obj_n);
-    if (d->mode == 0) hipLaunchKernelGGL(bank_scan_kernel<0>, grid, dim3(256), SCAN_LDS, (hipStream_t)stream, *d);
-    else hipLaunchKernelGGL(bank_scan_kernel<1>, grid, dim3(256), SCAN_LDS, (hipStream_t)stream, *d);
+    hipStream_t s = (hipStream_t)stream;
+    switch (d->mode * 3 + d->precision) {
+        case 0: hipLaunchKernelGGL((bank_scan_kernel<0, 0>), grid, dim3(256), SCAN_LDS, s, *d); break;
+        case 1: hipLaunchKernelGGL((bank_scan_kernel<0, 1>), grid, dim3(256), SCAN_LDS, s, *d); break;
+        case 2: hipLaunchKernelGGL((bank_scan_kernel<0, 2>), grid, dim3(256), SCAN_LDS, s, *d); break;
+        case 3: hipLaunchKernelGGL((bank_scan_kernel<1, 0>), grid, dim3(256), SCAN_LDS, s, *d); break;
+        case 4: hipLaunchKernelGGL((bank_scan_kernel<1, 1>), grid, dim3(256), SCAN_LDS, s, *d); break;
+        case 5: hipLaunchKernelGGL((bank_scan_kernel<1, 2>), grid, dim3(256), SCAN_LDS, s, *d); break;
+        default: return VFN_ERR_ARG;
+    }
     return vfn_check_launch();
 }
 
@@ -485,10 +750,18 @@ extern "C" int vfn_bank_scan_finish(const float* part, int nsplit, int HW, int o
 extern "C" int vfn_memread_apply(const vfn_memread_desc* d, void* stream) {
     if (!d || !d->q || !d->bank_k || !d->bank_v || !d->bank_len || !d->ml || !d->o_part) return VFN_ERR_ARG;
     if (d->nsplit < 1 || d->ldq % 4) return VFN_ERR_ARG;
+    if (d->precision < 0 || d->precision > 2) return VFN_ERR_ARG;
     static bool once = false;
-    if (!once) { allow_lds(memread_apply_kernel, APPLY_LDS); once = true; }
+    if (!once) {
+        allow_lds(memread_apply_kernel, APPLY_LDS);
+        allow_lds(memread_apply_lp_kernel<false>, APPLY_LDS);
+        allow_lds(memread_apply_lp_kernel<true>, APPLY_LDS);
+        once = true;
+    }
     const dim3 grid(cdiv(d->HW, QT) * d->nsplit, d->obj_n);
-    hipLaunchKernelGGL(memread_apply_kernel, grid, dim3(256), APPLY_LDS, (hipStream_t)stream, *d);
+    if (d->precision == 0) hipLaunchKernelGGL(memread_apply_kernel, grid, dim3(256), APPLY_LDS, (hipStream_t)stream, *d);
+    else if (d->precision == 1) hipLaunchKernelGGL(memread_apply_lp_kernel<false>, grid, dim3(256), APPLY_LDS, (hipStream_t)stream, *d);
+    else hipLaunchKernelGGL(memread_apply_lp_kernel<true>, grid, dim3(256), APPLY_LDS, (hipStream_t)stream, *d);
     return vfn_check_launch();
 }
 

@@ -503,6 +503,7 @@ class Engine:
         d.stride_q, d.stride_k, d.stride_rs = 0, cap * DK, 0
         d.scale = scale
         d.ldq, d.q_per_obj, d.HW, d.obj_n, d.nsplit, d.mode = DK + DV, 0, HW, K, nsplit, 0
+        d.precision = self.mode
         check(L.vfn_bank_scan(_lib.C.byref(d), s), 'vfn_bank_scan')
         check(L.vfn_bank_scan_finish(ptr(p.ml_part), nsplit, HW, K, 0, ptr(p.ml), None, None, None, s),
               'vfn_bank_scan_finish')
@@ -515,6 +516,7 @@ class Engine:
         m.stride_k, m.stride_v, m.stride_cnt, m.stride_info = cap * DK, cap * DV, cap, cap * 2
         m.scale, m.thres = scale, 1e-3
         m.ldq, m.ldqv, m.ld_out, m.HW, m.obj_n, m.nsplit = DK + DV, DK + DV, p.dec_in.shape[-1], HW, K, nsplit
+        m.precision = self.mode
         check(L.vfn_memread_apply(_lib.C.byref(m), s), 'vfn_memread_apply')
         check(L.vfn_memread_finish(_lib.C.byref(m), s), 'vfn_memread_finish')
 

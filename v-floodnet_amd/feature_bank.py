@@ -44,11 +44,16 @@ def pick_nsplit(hw, obj_n, b_upper):
 
 
 class FeatureBank:
-    def __init__(self, obj_n, memory_budget, device, update_rate=0.1, thres_close=0.95):
+    def __init__(self, obj_n, memory_budget, device, update_rate=0.1, thres_close=0.95, precision=None):
         self.obj_n = obj_n
         self.update_rate = update_rate
         self.thres_close = thres_close
         self.device = torch.device(device)
+        # arithmetic of the cosine match in update() ('fp32' | 'bf16x3' | 'bf16', as AFB_URR(precision=...))
+        import os
+        self.precision = precision or os.environ.get('VFN_PRECISION', 'fp32')
+        if self.precision not in ops.MODES:
+            raise ValueError(f'precision must be one of {sorted(ops.MODES)}, got {self.precision!r}')
 
         self.peak_n = np.zeros(obj_n)
         self.replace_n = np.zeros(obj_n)
@@ -272,6 +277,7 @@ class FeatureBank:
         d.stride_q, d.stride_k, d.stride_rs = hw * ld, cap * DK, cap
         d.scale = 1.0
         d.ldq, d.q_per_obj, d.HW, d.obj_n, d.nsplit, d.mode = ld, 1, hw, o, nsplit, 1
+        d.precision = ops.MODES[self.precision]
         check(L.vfn_bank_scan(_lib.C.byref(d), s), 'vfn_bank_scan')
         check(L.vfn_bank_scan_finish(ptr(self._part), nsplit, hw, o, 1, None, ptr(self._midx), ptr(self._mcorr),
                                      ptr(self._nkinv), s), 'vfn_bank_scan_finish')

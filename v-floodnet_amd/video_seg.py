@@ -70,7 +70,8 @@ class ClipRunner:
         self.obj_n = obj_n
         self.size = size
         self.mem_every = mem_every
-        self.fb = FeatureBank(obj_n, budget, self.device, update_rate=update_rate, thres_close=thres_close)
+        self.fb = FeatureBank(obj_n, budget, self.device, update_rate=update_rate, thres_close=thres_close,
+                              precision=getattr(model, 'precision', None))
         self.t = 0
         self._pinned = None
         self._stats_pinned = None
