@@ -28,8 +28,13 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 PEAK_F32_MATRIX_TFLOPS = 157.3        # MI355X_MICROARCH.md, v_mfma_f32_32x32x2_f32
-WAVES = [(2, 2), (2, 2), (2, 2), (2, 2), (1, 2), (2, 1), (4, 1), (4, 2), (2, 4), (4, 2), (2, 4)]   # per conv cfg
-H0, W0 = 480, 854
+PEAK_BF16_MATRIX_TFLOPS = 2500.0      # dense bf16 (v_mfma_f32_32x32x16_bf16: 32 cycles per 32x32x16 on 1024 SIMDs at 2.4 GHz)
+# useful-FLOP peak per precision mode: bf16x3 spends three bf16 MFMAs per product
+PEAKS = {'fp32': PEAK_F32_MATRIX_TFLOPS, 'bf16': PEAK_BF16_MATRIX_TFLOPS, 'bf16x3': PEAK_BF16_MATRIX_TFLOPS / 3}
+DTYPES = {'fp32': 'f32', 'bf16': 'bf16 operands, f32 accumulate/storage', 'bf16x3': 'bf16x3 (split-bf16 operands, 3 MFMAs per product), f32 accumulate/storage'}
+WAVES = [(2, 2), (2, 2), (2, 2), (2, 2), (1, 2), (2, 1), (4, 1), (4, 2), (2, 4), (4, 2), (2, 4),
+         (2, 4), (2, 4), (2, 2), (4, 2), (4, 1), (2, 2), (2, 4), (2, 4), (2, 4)]   # per conv cfg
+WORKLOADS = {'C2': (480, 854, 1), 'C3': (720, 1280, 5)}      # H0, W0, memorize every n-th frame
 
 
 def miou(a, b):
@@ -91,7 +96,14 @@ def main():
     ap.add_argument('--no-overlap', action='store_true',
                     help="do not run the next frame's query encoder on a side stream under memorize/update")
     ap.add_argument('--sample-every', type=int, default=16, help='time the conv launches on every n-th frame')
+    ap.add_argument('--precision', choices=sorted(PEAKS), default='fp32',
+                    help='fp32 = BASELINE config C2 (the headline, exact f32); bf16x3 / bf16 = the reduced-precision configs')
+    ap.add_argument('--workload', choices=sorted(WORKLOADS), default='C2',
+                    help='C2: 480x854 clip, every frame memorised; C3: 720x1280 clip (resized to 480p on the device as '
+                         'test_video_seg.py:88,107 does), bank grows with every 5th frame')
     args = ap.parse_args()
+    H0, W0, mem_every = WORKLOADS[args.workload]
+    peak = PEAKS[args.precision]
 
     import vfloodnet_amd
     from vfloodnet_amd import AFB_URR, synth, ops, dist as vdist
@@ -107,7 +119,7 @@ def main():
 
     K, Wm = args.steps, args.warmup
     sd = synth.make_state_dict(20200212)
-    model = AFB_URR(dev, update_bank=True).to(dev).eval()
+    model = AFB_URR(dev, update_bank=True, precision=args.precision).to(dev).eval()
     model.load_state_dict(sd, strict=True)
 
     # ---- inputs resident in HBM
@@ -120,23 +132,25 @@ def main():
     timer = ConvTimer()
     timed_launch = timer.install()
     eng = model.engine()
+    from vfloodnet_amd.video_seg import resized_hw
+    Hn, Wn = resized_hw(H0, W0, 480)                 # the network always sees the 480p frame
     if not args.no_autotune:
-        eng.autotune(H0, W0, 2)
-    plan = eng.plan(H0, W0, 2)
+        eng.autotune(Hn, Wn, 2)
+    plan = eng.plan(Hn, Wn, 2)
     for lst in (plan.seg_pre, plan.seg_post, plan.mem):
         for l in lst:
             if l.fn is timer.orig:
                 l.fn = timed_launch
 
     # ---- warm-up on a throw-away bank
-    warm = ClipRunner(model, 2, args.budget)
+    warm = ClipRunner(model, 2, args.budget, mem_every=mem_every)
     warm.start(frames[0:1], onehot)
     for t in range(1, Wm + 1):
         warm.step(frames[(t % (n_frames - 1)) + 1:(t % (n_frames - 1)) + 2])
     del warm
 
     # ---- timed region: exactly K steps
-    runner = ClipRunner(model, 2, args.budget, postprocess=True)     # largest-blob filter (:116) on the device too
+    runner = ClipRunner(model, 2, args.budget, mem_every=mem_every, postprocess=True)     # largest-blob filter (:116) on the device too
     runner.start(frames[0:1], onehot)
     labels = torch.empty(K + 1, H0, W0, dtype=torch.uint8, device=dev)
     labels[0] = m0.to(dev)
@@ -184,31 +198,32 @@ def main():
         tot_ms = sum(v[1] for v in per.values())
         fl, ms, n = per[dom]
         ach = fl / (ms * 1e-3) / 1e12
-        kname = f'conv_igemm_kernel<{tiles[dom][0]}, {tiles[dom][1]}, {WAVES[dom][0]}, {WAVES[dom][1]}>'
+        kname = f'conv_igemm_kernel<{tiles[dom][0]}, {tiles[dom][1]}, {WAVES[dom][0]}, {WAVES[dom][1]}, {ops.MODES[args.precision]}>'
         traffic = None                      # HBM bytes per launch of this kernel from the committed PMC passes
-        tpath = os.path.join(ROOT, 'profiles', 'r01_pmc_traffic.json')
+        tname = 'r01_pmc_traffic.json' if args.precision == 'fp32' else f'r01_pmc_traffic_{args.precision}.json'
+        tpath = os.path.join(ROOT, 'profiles', tname)
         if os.path.isfile(tpath):
             for k_, v_ in json.load(open(tpath)).get('kernels', {}).items():
-                if kname in k_:
+                if kname in k_ and args.workload == 'C2':
                     traffic = round(v_['hbm_bytes_per_launch'])
         roof = {'bound': 'mfma', 'kernel': kname,
-                'achieved': round(ach, 2), 'peak': PEAK_F32_MATRIX_TFLOPS, 'unit': 'TFLOP/s',
-                'frac': round(ach / PEAK_F32_MATRIX_TFLOPS, 4), 'traffic': traffic,
-                'traffic_source': 'profiles/r01_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, FETCH doubled per MI355X_MICROARCH.md)',
+                'achieved': round(ach, 2), 'peak': round(peak, 1), 'unit': 'TFLOP/s',
+                'frac': round(ach / peak, 4), 'traffic': traffic,
+                'traffic_source': f'profiles/{tname} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, FETCH doubled per MI355X_MICROARCH.md)',
                 'launches_timed': n, 'avg_launch_us': round(ms * 1e3 / n, 2),
                 'all_conv_achieved': round(tot_fl / (tot_ms * 1e-3) / 1e12, 2),
-                'all_conv_frac': round(tot_fl / (tot_ms * 1e-3) / 1e12 / PEAK_F32_MATRIX_TFLOPS, 4)}
+                'all_conv_frac': round(tot_fl / (tot_ms * 1e-3) / 1e12 / peak, 4)}
 
     # ---- whole-frame roofline: F_min(B) = 538.48 GFLOP + 3072*B*HW
     b_mean = bank_sum / (2.0 * K)
     fps = world * K / elapsed
     f_min = 538.48e9 + 3072.0 * b_mean * 1620
-    frame_frac = (fps / world) * f_min / (PEAK_F32_MATRIX_TFLOPS * 1e12)
+    frame_frac = (fps / world) * f_min / (peak * 1e12)
 
     # ---- CPU baseline + parity on the first frames of the same clip
     cpu = None
     parity = None
-    if not args.no_cpu_baseline and world == 1:
+    if not args.no_cpu_baseline and world == 1 and args.workload == 'C2':
         from oracle import afb_urr_ref as O
         nthr = min(16, os.cpu_count() or 1)     # fastest setting measured on the GPU box's 256-core host (8/16/32/64/128 tried)
         torch.set_num_threads(nthr)
@@ -226,7 +241,7 @@ def main():
                   'bank_sizes_equal': bank_sizes[:n_cpu] == ref['bank_sizes']}
 
     gpath = os.path.join(ROOT, 'tests', 'golden', 'c2_480x854_100.npz')
-    if world == 1 and K == 99 and os.path.isfile(gpath):
+    if world == 1 and K == 99 and args.workload == 'C2' and os.path.isfile(gpath):
         import numpy as np
         g = np.load(gpath)
         refl = torch.from_numpy(np.unpackbits(g['labels'], axis=-1)[..., :W0])
@@ -238,13 +253,15 @@ def main():
                        'full_clip_reference': 'tests/golden/c2_480x854_100.npz (reference model + FeatureBank on CPU, '
                                               'oracle/gen_c2_golden.py)'})
 
-    out = {'metric': 'segmented frames/sec at 480p', 'value': round(fps, 3), 'unit': 'frames/s', 'n_gpus': world,
+    out = {'metric': 'segmented frames/sec at 480p' if args.workload == 'C2' else f'segmented frames/sec at {H0}p', 'value': round(fps, 3), 'unit': 'frames/s', 'n_gpus': world,
            'steps': K, 'warmup': Wm, 'ms_per_step': round(1e3 * elapsed / K, 3), 'higher_is_better': True,
-           'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
-           'config': {'workload': f'C2: {K + 1}-frame 480x854 synthetic clip per GPU through the test_video_seg.py loop '
-                                  f'(segment+softmax+memorize+bank update+argmax+CCL), fp32, budget {args.budget}',
+           'scaling': 'weak', 'vs_baseline': None, 'dtype': DTYPES[args.precision], 'data': 'synthetic',
+           'config': {'workload': f'{args.workload}: {K + 1}-frame {H0}x{W0} synthetic clip per GPU through the test_video_seg.py loop '
+                                  f'(' + ('bicubic resize to 480p+' if (Hn, Wn) != (H0, W0) else '') +
+                                  f'segment+softmax+memorize' + (f' every {mem_every}th frame' if mem_every > 1 else '') +
+                                  f'+bank update+argmax+CCL), {args.precision}, budget {args.budget}',
                       'mean_bank_entries_per_object': round(b_mean, 1),
-                      'frame_mfma_frac_Fmin': round(frame_frac, 4)},
+                      'frame_mfma_frac_Fmin': round(frame_frac, 4) if mem_every == 1 else None},
            'roofline': roof, 'cpu_baseline': cpu, 'parity': parity}
     print(json.dumps(out))
     if world > 1:

@@ -138,3 +138,31 @@ def test_c2_full_clip_vs_reference(gpu, model):
         min(ious), sum(ious) / len(ious), drift, out['fb'].peak_n, out['fb'].replace_n, g['peak_n'], g['replace_n']))
     assert min(ious) >= 0.99, (min(ious), int(np.argmin(ious)) + 1)
     assert drift <= max(8, 0.001 * sizes.max())        # merge/append decisions sit on a float threshold
+
+
+def test_c2_clip_bf16x3_against_reference_labels(gpu):
+    import os
+    """The reduced-precision configuration this package recommends (precision='bf16x3': every matrix operand split
+    into two bf16, three bf16 MFMAs per product, f32 accumulation) on the full C2 clip against the labels of the
+    reference's own f32 CPU run.  Tolerance: mIoU >= 0.99 per frame (measured: min 0.9964, mean 0.9990; the exact-f32
+    path gives min 0.9983).  Plain 'bf16' is not asserted: with these random synthetic weights (margin-free logits)
+    it reaches mIoU ~0.79 -- see DESIGN.md."""
+    import numpy as np
+    from golden_util import GOLDEN
+    from vfloodnet_amd import AFB_URR, synth
+    from vfloodnet_amd.video_seg import run_clip
+    path = os.path.join(GOLDEN, 'c2_480x854_100.npz')
+    if not os.path.exists(path):
+        pytest.skip('c2 golden not generated')
+    g = np.load(path)
+    H, W = [int(x) for x in g['shape']]
+    ref = np.unpackbits(g['labels'], axis=-1)[..., :W]
+    T = ref.shape[0]
+    model = AFB_URR(gpu, update_bank=True, precision='bf16x3').to(gpu).eval()
+    model.load_state_dict(synth.make_state_dict(20200212))
+    frames, m0 = synth.clip(int(g['seed']), T, H, W)
+    out = run_clip(model, frames.to(gpu), m0)
+    lab = out['labels'].numpy()
+    ious = [miou(torch.from_numpy(lab[t]), torch.from_numpy(ref[t])) for t in range(1, T)]
+    print('C2 bf16x3 mIoU min %.5f mean %.5f' % (min(ious), sum(ious) / len(ious)))
+    assert min(ious) >= 0.99, (min(ious), int(np.argmin(ious)) + 1)
