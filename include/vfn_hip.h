@@ -247,6 +247,17 @@ int vfn_postprocess_pred_u8(const unsigned char* pred_host, int H, int W, unsign
 int vfn_postprocess_pred_device_u8(const unsigned char* pred, unsigned char* out, int* scratch, int H, int W,
                                    void* stream);
 
+/* ------------------------------------------------------------------ input / output side
+ * vfn_to_tensor_u8: torchvision ToTensor of a decoded frame (Video_DS.__getitem__, dataset/Water_DS.py:131-139):
+ *     uint8 [H][W][3] -> float32 [3][H][W], x / 255 (IEEE division: bit-identical to tensor.float().div(255)).
+ * vfn_overlay_u8: myutils.add_overlay + the uint8 conversion of save_overlay (myutils/data.py:56-84): RGB uint8
+ *     [H][W][3] from the float frame [3][H][W] in [0,1] and the label map; palette = 256 RGB triples
+ *     (myutils/data.py:14), alpha / cscale as add_overlay; scratch = one int.  Blend in f64, truncating casts, the
+ *     smallest label present is the background (`for i in ids[1:]`), 4-neighbour contours black. */
+int vfn_to_tensor_u8(const unsigned char* src, float* dst, int H, int W, void* stream);
+int vfn_overlay_u8(const float* frame, const unsigned char* mask, const unsigned char* palette, int* scratch,
+                   unsigned char* out, int H, int W, double alpha, double cscale, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

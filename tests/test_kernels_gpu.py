@@ -284,3 +284,39 @@ def test_device_ccl_matches_host_and_oracle(gpu):
         assert np.array_equal(postprocessing_pred(x), ref)
         out = ops.postprocess_pred_device(torch.from_numpy(x).to(gpu)).cpu().numpy()
         assert np.array_equal(out, ref), x.shape
+
+
+def test_to_tensor_device_bit_exact(gpu):
+    """vfn_to_tensor_u8 == torchvision ToTensor (uint8 HWC -> float CHW / 255), bit for bit."""
+    from vfloodnet_amd import ops
+    from vfloodnet_amd.dataset import to_tensor
+    g = torch.Generator().manual_seed(5)
+    img = torch.randint(0, 256, (37, 53, 3), generator=g, dtype=torch.uint8)
+    img[0, :, 0] = torch.arange(53, dtype=torch.uint8)        # includes 0 ... and 255 below
+    img[1, 0, :] = 255
+    got = ops.to_tensor_device(img.to(gpu)).cpu()
+    assert torch.equal(got, to_tensor(img.numpy()))
+
+
+@pytest.mark.parametrize('labels', ['two', 'three', 'no_background', 'single'])
+def test_overlay_device_matches_host(gpu, labels):
+    """vfn_overlay_u8 == add_overlay + the uint8 / BGR handling of save_overlay (myutils/data.py:56-84)."""
+    import numpy as np
+    from vfloodnet_amd import ops
+    from vfloodnet_amd.data import add_overlay, color_palette
+    g = torch.Generator().manual_seed(11)
+    H, W = 41, 67
+    frame = torch.rand(3, H, W, generator=g)
+    blob = torch.nn.functional.avg_pool2d(torch.rand(1, 1, H, W, generator=g), 5, 1, 2)[0, 0]
+    if labels == 'two':
+        mask = (blob > 0.5).to(torch.uint8)
+    elif labels == 'three':
+        mask = (blob > 0.45).to(torch.uint8) + (blob > 0.55).to(torch.uint8)
+    elif labels == 'no_background':
+        mask = 1 + (blob > 0.5).to(torch.uint8)
+    else:
+        mask = torch.ones(H, W, dtype=torch.uint8)
+    img = (frame.permute(1, 2, 0).numpy() * 255).astype(np.uint8)
+    ref = add_overlay(np.ascontiguousarray(img[..., ::-1]), mask.numpy(), color_palette)[..., ::-1]
+    got = ops.overlay_device(frame.to(gpu), mask.to(gpu), color_palette).cpu().numpy()
+    assert np.array_equal(got, ref)

@@ -61,6 +61,13 @@ def save_overlay(img, mask, overlay_path, colors=[255, 0, 0], alpha=0.4, cscale=
     Image.fromarray(np.ascontiguousarray(ov[..., ::-1])).save(overlay_path)      # cv2.imwrite(BGR) == save(RGB)
 
 
+def save_overlay_device(img, mask_dev, overlay_path, colors=color_palette, alpha=0.4, cscale=1):
+    """save_overlay with the blend / contour / uint8 conversion on the GPU (``vfn_overlay_u8``, bit-identical to
+    add_overlay): img float [3,H,W] and mask uint8 [H,W] on the device; only the RGB uint8 image crosses PCIe."""
+    ov = ops.overlay_device(img.contiguous(), mask_dev, colors, alpha, cscale)
+    Image.fromarray(ov.cpu().numpy()).save(overlay_path)
+
+
 def load_image_in_PIL(path, mode='RGB'):
     """data.py:87-90."""
     img = Image.open(path)

@@ -34,7 +34,12 @@ def to_onehot(mask, max_obj_n):
 
 
 class Video_DS(data.Dataset):
-    def __init__(self, img_list, first_frame, first_mask):
+    """dataset/Water_DS.py:105-139.  ``raw_u8=True`` (an extension used by ``video_seg.main``): ``__getitem__`` hands
+    out the decoded uint8 HWC frame and ``ToTensor`` runs on the GPU (``ops.to_tensor_device``, bit-identical),
+    so a frame crosses PCIe as 1 byte per sample."""
+
+    def __init__(self, img_list, first_frame, first_mask, raw_u8=False):
+        self.raw_u8 = raw_u8
         self.img_list = img_list[1:]
         self.video_len = len(self.img_list)
         first_mask = np.array(first_mask, np.uint8) > 0
@@ -48,6 +53,6 @@ class Video_DS(data.Dataset):
 
     def __getitem__(self, idx):
         img = load_image_in_PIL(self.img_list[idx], 'RGB')
-        frame = to_tensor(img)
+        frame = torch.from_numpy(np.array(img, np.uint8)) if self.raw_u8 else to_tensor(img)
         img_name = os.path.basename(self.img_list[idx])[:-4]
         return frame, img_name

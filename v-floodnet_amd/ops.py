@@ -265,6 +265,36 @@ def postprocess_pred_device(label, out=None, scratch=None):
     return out
 
 
+def to_tensor_device(img_u8, out=None):
+    """torchvision ToTensor on the device: uint8 [H,W,3] (device) -> float32 [3,H,W] = x / 255."""
+    H, W, c = img_u8.shape
+    assert c == 3 and img_u8.dtype == torch.uint8 and img_u8.is_contiguous()
+    if out is None:
+        out = torch.empty(3, H, W, device=img_u8.device, dtype=torch.float32)
+    check(_lib.lib().vfn_to_tensor_u8(ptr(img_u8), ptr(out), H, W, stream()), 'vfn_to_tensor_u8')
+    return out
+
+
+_palette_cache = {}
+
+
+def overlay_device(frame, label, palette, alpha=0.4, cscale=1, out=None):
+    """add_overlay + save_overlay's uint8 conversion on the device (myutils/data.py:56-84).
+    frame f32 [3,H,W] in [0,1], label uint8 [H,W] (both on the GPU); returns RGB uint8 [H,W,3] on the GPU."""
+    _, H, W = frame.shape
+    key = (tuple(palette), frame.device)
+    if key not in _palette_cache:
+        pal = (list(palette) + [0] * 768)[:768]
+        _palette_cache[key] = (torch.tensor(pal, dtype=torch.uint8, device=frame.device),
+                               torch.empty(1, dtype=torch.int32, device=frame.device))
+    pal, scratch = _palette_cache[key]
+    if out is None:
+        out = torch.empty(H, W, 3, dtype=torch.uint8, device=frame.device)
+    check(_lib.lib().vfn_overlay_u8(ptr(frame), ptr(label), ptr(pal), ptr(scratch), ptr(out), H, W,
+                                    float(alpha), float(cscale), stream()), 'vfn_overlay_u8')
+    return out
+
+
 # --------------------------------------------------------------------------- bank
 def row_norms(x, stride_obj, ld, dim, len_dev, rows, obj_n, nrm, inv, stride_n):
     check(_lib.lib().vfn_row_norms(ptr(x), int(stride_obj), ld, dim, ptr(len_dev), rows, obj_n, ptr(nrm), ptr(inv),

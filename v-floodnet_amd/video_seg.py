@@ -19,7 +19,7 @@ import numpy as np
 import torch
 
 from . import ops
-from .data import color_palette, load_image_in_PIL, save_overlay, save_seg_mask
+from .data import color_palette, load_image_in_PIL, save_overlay, save_overlay_device, save_seg_mask
 from .dataset import Video_DS
 from .feature_bank import FeatureBank
 from .model import AFB_URR
@@ -138,6 +138,10 @@ class ClipRunner:
         self.fb.absorb_stats(self._stats_pinned)
         return self._pinned if want_label else None
 
+    def label_device(self):
+        """The label map of the last step as it left the GPU (post-processed when ``postprocess``), still on the device."""
+        return self._post_dev if self.postprocess else self._label_dev
+
     def bank_sizes(self):
         return list(self.fb._len_host)
 
@@ -200,7 +204,7 @@ def main(args, device):
         test_waterseg(image_model_path, img_list[0], args.test_name, out_dir, device)
 
     first_mask = load_image_in_PIL(mask_path, 'P')
-    seq_dataset = Video_DS(img_list, first_frame, first_mask)
+    seq_dataset = Video_DS(img_list, first_frame, first_mask, raw_u8=True)       # uint8 over PCIe, ToTensor on the GPU
     seq_loader = torch.utils.data.DataLoader(seq_dataset, batch_size=1, shuffle=False, num_workers=1)
 
     seg_dir = os.path.join(out_dir, args.test_name, 'mask')
@@ -226,13 +230,13 @@ def main(args, device):
     with torch.no_grad():
         runner.start(ori_first_frame, ori_first_mask)
         for idx, (frame, frame_name) in enumerate(seq_loader):
-            ori_frame = frame.to(device)
+            ori_frame = ops.to_tensor_device(frame[0].to(device)).unsqueeze(0)      # Video_DS ToTensor (:131-139)
             pred = runner.step(ori_frame).numpy().copy()          # postprocessing_pred (:116) already ran on the GPU
             seg_path = os.path.join(seg_dir, f'{frame_name[0]}.png')
             save_seg_mask(pred, seg_path, color_palette)
             if args.viz:
                 overlay_path = os.path.join(overlay_dir, f'{frame_name[0]}.png')
-                save_overlay(ori_frame[0], pred, overlay_path, color_palette)
+                save_overlay_device(ori_frame[0], runner.label_device(), overlay_path, color_palette)
 
     runner.fb.print_peak_mem()
     return runner
