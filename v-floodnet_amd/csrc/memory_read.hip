@@ -135,6 +135,10 @@ __device__ __forceinline__ void mfma_lp(f32x16& acc, const bf16x8& ah, const bf1
     acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc, 0, 0, 0);
 }
 
+// exp for the softmax inner loops: v_exp_f32 on x*log2(e) (1 ulp hardware exp2; the f32 product adds at most
+// |x| * 6e-8 relative error, i.e. < 1e-6 where exp(x) still matters) -- the full-range expf is 10x the instructions
+__device__ __forceinline__ float fast_exp(float x) { return __expf(x); }
+
 __device__ __forceinline__ void chunk_range(int B, int nsplit, int split, int& c_lo, int& c_hi) {
     const int nchunks = (B + CH - 1) / CH;
     const int per = (nchunks + nsplit - 1) / nsplit;
@@ -204,17 +208,25 @@ void bank_scan_kernel(const vfn_bankscan_desc p) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = 0.f;
         if constexpr (PREC == 0) {
+            // two independent accumulation chains (even / odd k-steps): a single chain of 64 dependent MFMAs
+            // leaves issue bubbles between them
             const int ra = wr * 32 + li;
+            f32x16 acc2;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc2[r] = 0.f;
             f32x4 a[2];
             a[0] = *reinterpret_cast<const f32x4*>(sK + swz(ra, lh));
 #pragma unroll
             for (int kk = 0; kk < 16; ++kk) {
                 const int cur = kk & 1;
                 if (kk + 1 < 16) a[cur ^ 1] = *reinterpret_cast<const f32x4*>(sK + swz(ra, 2 * (kk + 1) + lh));
-#pragma unroll
-                for (int t = 0; t < 4; ++t)
-                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[cur][t], qf[kk][t], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[cur][0], qf[kk][0], acc, 0, 0, 0);
+                acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[cur][1], qf[kk][1], acc2, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[cur][2], qf[kk][2], acc, 0, 0, 0);
+                acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[cur][3], qf[kk][3], acc2, 0, 0, 0);
             }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] += acc2[r];
         } else {
             // key fragments: two 16-byte reads (f32 chunks 4g+2h, 4g+2h+1 = k 16g+8h .. +7), converted in registers
             const int ra = wr * 32 + li;
@@ -236,24 +248,36 @@ void bank_scan_kernel(const vfn_bankscan_desc p) {
         }
         const int rb = b0 + wr * 32 + 4 * lh;
         if (MODE == 0) {
-            float mx = -INFINITY;
+            if (b0 + CH <= B) {                          // whole chunk inside the bank (all but the last): no row checks
+                float mx = acc[0];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = rb + (r & 3) + 8 * (r >> 2);
-                const float s_ = acc[r] * p.scale;
-                acc[r] = s_;
-                if (row < B) mx = fmaxf(mx, s_);
-            }
-            const float mn = fmaxf(run_m, mx);
-            if (mn > -INFINITY) {
+                for (int r = 1; r < 16; ++r) mx = fmaxf(mx, acc[r]);
+                const float mn = fmaxf(run_m, mx * p.scale);     // scale > 0: max commutes with it
                 float sum = 0.f;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) sum += fast_exp(acc[r] * p.scale - mn);
+                run_l = run_l * expf(run_m - mn) + sum;       // exp(-inf)=0 on the first chunk
+                run_m = mn;
+            } else {
+                float mx = -INFINITY;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int row = rb + (r & 3) + 8 * (r >> 2);
-                    if (row < B) sum += expf(acc[r] - mn);
+                    const float s_ = acc[r] * p.scale;
+                    acc[r] = s_;
+                    if (row < B) mx = fmaxf(mx, s_);
                 }
-                run_l = run_l * expf(run_m - mn) + sum;       // exp(-inf)=0 on the first chunk
-                run_m = mn;
+                const float mn = fmaxf(run_m, mx);
+                if (mn > -INFINITY) {
+                    float sum = 0.f;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int row = rb + (r & 3) + 8 * (r >> 2);
+                        if (row < B) sum += fast_exp(acc[r] - mn);
+                    }
+                    run_l = run_l * expf(run_m - mn) + sum;
+                    run_m = mn;
+                }
             }
         } else {
             const float* rs = p.rowscale + (size_t)obj * p.stride_rs;
@@ -387,6 +411,7 @@ void memread_apply_kernel(const vfn_memread_desc p) {
         qm = p.ml[((size_t)obj * p.HW + q0 + qcol) * 2];
         ql = p.ml[((size_t)obj * p.HW + q0 + qcol) * 2 + 1];
     }
+    const float qinv = 1.f / ql;
 
     for (int c = c_lo; c < c_hi; ++c) {
         const int b0 = c * CH;
@@ -402,7 +427,7 @@ void memread_apply_kernel(const vfn_memread_desc p) {
         for (int r = 0; r < 16; ++r) {
             const int rr = rloc + (r & 3) + 8 * (r >> 2);
             float pv = 0.f;
-            if (qok && b0 + rr < B) pv = expf(acc[r] * p.scale - qm) / ql;
+            if (qok && b0 + rr < B) pv = fast_exp(acc[r] * p.scale - qm) * qinv;
             acc[r] = pv;
             const unsigned long long hit = __ballot(pv > p.thres);
             // lanes 0-31 hold row (r&3)+8*(r>>2), lanes 32-63 that + 4; lane li of the lower half owns row li
@@ -546,6 +571,7 @@ void memread_apply_lp_kernel(const vfn_memread_desc p) {
         qm = p.ml[((size_t)obj * p.HW + q0 + qcol) * 2];
         ql_ = p.ml[((size_t)obj * p.HW + q0 + qcol) * 2 + 1];
     }
+    const float qinv = 1.f / ql_;
 
     for (int c = c_lo; c < c_hi; ++c) {
         const int b0 = c * CH;
@@ -595,7 +621,7 @@ void memread_apply_lp_kernel(const vfn_memread_desc p) {
         for (int r = 0; r < 16; ++r) {
             const int rr = rloc + (r & 3) + 8 * (r >> 2);
             float pv = 0.f;
-            if (qok && b0 + rr < B) pv = expf(acc[r] * p.scale - qm) / ql_;
+            if (qok && b0 + rr < B) pv = fast_exp(acc[r] * p.scale - qm) * qinv;
             acc[r] = pv;
             const unsigned long long hit = __ballot(pv > p.thres);
             const int rlo = (r & 3) + 8 * (r >> 2);
