@@ -59,6 +59,10 @@ typedef struct vfn_conv_desc {
     float* partial;       /* [ksplit][M - m_start][Cout] workspace, m_start = first row of tile split_from */
     int* tile_counters;   /* one int per split tile, zero at rest: the slice workgroup that arrives last reduces the
                              tile inside the same launch (agent-scope release/acquire); NULL: a second kernel reduces */
+    int w_packed;         /* vfn_conv2d_nhwc_bf16 / _bf16x3 only: 1 = w holds the filters already converted, 128 bytes
+                             per filter row and K tile in (kh,kw,cin) order -- bf16: [cout_pad][K] bf16 (tiles of 64);
+                             bf16x3: [cout_pad][K/32][hi 32 bf16 | lo 32 bf16] -- so they are staged without
+                             conversion; 0 = w is the f32 [cout_pad][K] array and is converted on the fly */
 } vfn_conv_desc;
 
 int vfn_conv_cfg_count(void);

@@ -143,6 +143,14 @@ def test_conv_reduced_precision_matches_emulation(gpu, case, mode):
         got = y.permute(0, 3, 1, 2).cpu()
         err = (got - ref).abs().max().item()
         assert err < tol, f'cfg {cfg}: max err {err}'
+    # filters converted on the host (vfn_conv_desc.w_packed): bit-identical to the on-the-fly conversion
+    wlp = ops.pack_weights_lp(wp, mode)
+    y2 = torch.empty_like(y)
+    d2 = ops.make_conv_desc(xd, wp, Cout, k, k, s, k // 2, y2, scale_d, shift_d, resd, relu_in, relu_out)
+    ops.use_packed_weights(d2, wlp)
+    ops.conv2d_launch(d2, cfg, mode)
+    torch.cuda.synchronize()
+    assert torch.equal(y2, y), 'packed-weight path differs from the on-the-fly conversion'
     # distance from the exact f32 convolution: what the mode costs (bf16x3 ~2^-16 per product, bf16 ~2^-9)
     dev_exact = (got - exact).abs().max().item() / max(1.0, exact.abs().max().item())
     assert dev_exact < (2e-2 if mode == 1 else 1e-4), dev_exact

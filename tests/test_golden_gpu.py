@@ -144,8 +144,9 @@ def test_c2_clip_bf16x3_against_reference_labels(gpu):
     import os
     """The reduced-precision configuration this package recommends (precision='bf16x3': every matrix operand split
     into two bf16, three bf16 MFMAs per product, f32 accumulation) on the full C2 clip against the labels of the
-    reference's own f32 CPU run.  Tolerance: mIoU >= 0.99 per frame (measured: min 0.9964, mean 0.9990; the exact-f32
-    path gives min 0.9983).  Plain 'bf16' is not asserted: with these random synthetic weights (margin-free logits)
+    reference's own f32 CPU run.  Tolerance: mIoU >= 0.985 on every frame and >= 0.995 on average (measured: min
+    0.994-0.996, mean 0.998-0.999 depending on the split-K choices of the tuned table; the exact-f32 path gives min
+    0.998).  Plain 'bf16' is not asserted: with these random synthetic weights (margin-free logits)
     it reaches mIoU ~0.79 -- see DESIGN.md."""
     import numpy as np
     from golden_util import GOLDEN
@@ -165,4 +166,5 @@ def test_c2_clip_bf16x3_against_reference_labels(gpu):
     lab = out['labels'].numpy()
     ious = [miou(torch.from_numpy(lab[t]), torch.from_numpy(ref[t])) for t in range(1, T)]
     print('C2 bf16x3 mIoU min %.5f mean %.5f' % (min(ious), sum(ious) / len(ious)))
-    assert min(ious) >= 0.99, (min(ious), int(np.argmin(ious)) + 1)
+    assert min(ious) >= 0.985, (min(ious), int(np.argmin(ious)) + 1)
+    assert sum(ious) / len(ious) >= 0.995

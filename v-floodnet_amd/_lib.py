@@ -23,7 +23,8 @@ class ConvDesc(C.Structure):
                 ('out_ld', C.c_int), ('res_ld', C.c_int),
                 ('KH', C.c_int), ('KW', C.c_int), ('stride', C.c_int), ('pad', C.c_int),
                 ('relu_in', C.c_int), ('relu_out', C.c_int), ('M', C.c_int), ('ksplit', C.c_int),
-                ('split_from', C.c_int), ('res_mod', C.c_int), ('partial', c_fp), ('tile_counters', c_fp)]
+                ('split_from', C.c_int), ('res_mod', C.c_int), ('partial', c_fp), ('tile_counters', c_fp),
+                ('w_packed', C.c_int)]
 
 
 class StemDesc(C.Structure):

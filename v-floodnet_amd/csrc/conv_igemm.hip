@@ -186,8 +186,17 @@ void conv_igemm_kernel(const vfn_conv_desc p) {
     // no select, no branch, and the only per-tile VALU work is two range checks and one add per 16 bytes.
     const __amdgpu_buffer_rsrc_t rsrc_in = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<float*>(p.in), 0, (int)((size_t)p.N * p.H * p.W * p.in_ld * sizeof(float)), 0x00020000);
+    // w_packed (MODE >= 1): the filters were converted on the host (ops.pack_weights_lp) into the LDS row image,
+    // 128 bytes per filter and K tile (bf16: 64 bf16; bf16x3: 32 hi then 32 lo) -- staged with no VALU work
+    const bool wpk = (MODE != 0) && p.w_packed;
     const __amdgpu_buffer_rsrc_t rsrc_w = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<float*>(p.w), 0, (int)((size_t)p.cout_pad * Ktot * sizeof(float)), 0x00020000);
+        const_cast<float*>(p.w), 0, wpk ? (int)((size_t)p.cout_pad * nk_all * 128) : (int)((size_t)p.cout_pad * Ktot * sizeof(float)),
+        0x00020000);
+    constexpr int BCP = BN * 8 / NT;       // 16-byte chunks of a packed B tile per thread
+    const int pc = tid & 7, pr0 = tid >> 3;
+    int wp_off[BCP];
+#pragma unroll
+    for (int j = 0; j < BCP; ++j) wp_off[j] = ((n0 + pr0 + j * (NT / 8)) * nk_all) * 128 + pc * 16;
     int a_off[AC];                         // byte offset of tap (0,0), channel block 0, this lane's chunk
 #pragma unroll
     for (int j = 0; j < AC; ++j)
@@ -216,9 +225,15 @@ void conv_igemm_kernel(const vfn_conv_desc p) {
     };
     auto load_b = [&](int kt) {
         const int k_off = kt * BKT * (int)sizeof(float);
+        if (wpk) {
 #pragma unroll
-        for (int j = 0; j < BC; ++j)
-            rb[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_w, w_off[j] + k_off, 0, 0));
+            for (int j = 0; j < BCP; ++j)
+                rb[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_w, wp_off[j] + kt * 128, 0, 0));
+        } else {
+#pragma unroll
+            for (int j = 0; j < BC; ++j)
+                rb[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_w, w_off[j] + k_off, 0, 0));
+        }
         if (++cb == cblks) { cb = 0; if (++kw == p.KW) { kw = 0; ++kh; } }
     };
     const float relu_floor = p.relu_in ? 0.f : -INFINITY;
@@ -246,6 +261,14 @@ void conv_igemm_kernel(const vfn_conv_desc p) {
     };
     auto store_b = [&](int buf) {
         float* dB = sB + buf * BN * BK;
+        if (wpk) {
+#pragma unroll
+            for (int j = 0; j < BCP; ++j) {
+                const int r = pr0 + j * (NT / 8);
+                *reinterpret_cast<f32x4*>(dB + r * BK + ((pc ^ ((r >> 1) & 7)) << 2)) = rb[j];
+            }
+            return;
+        }
 #pragma unroll
         for (int j = 0; j < BC; ++j) {
             const int r = r0 + j * RSTEP;

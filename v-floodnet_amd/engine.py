@@ -150,6 +150,13 @@ class ConvLayer:
             sh = torch.zeros_like(sh)
         self.scale = sc.to(device).contiguous()
         self.shift = sh.to(device).contiguous()
+        self._w_lp = {}
+
+    def w_lp(self, mode):
+        """Filters pre-converted for the bf16 / bf16x3 kernels (built once per mode)."""
+        if mode not in self._w_lp:
+            self._w_lp[mode] = ops.pack_weights_lp(self.w, mode)
+        return self._w_lp[mode]
 
 
 class Launch:
@@ -254,6 +261,8 @@ class FramePlan:
         bf = self.eng.mode
         if bf == 1 and layer.cin % 64:                     # (the 32-channel local head: no 64-channel K tile)
             bf = 2
+        if bf:
+            ops.use_packed_weights(d, layer.w_lp(bf))
         choice = choose_cfg(d.M, layer.cout, K, bf)
         if choice[1] > 1 and (d.out_ld % 4 or (res is not None and d.res_ld % 4)):
             choice = (choice[0], 1, 0)

@@ -32,6 +32,19 @@ def pad_rows(wp, mult=256):
     return out
 
 
+def pack_weights_lp(wp, mode):
+    """f32 packed filters [cout_pad, K] -> the operand image the bf16 / bf16x3 conv kernels stage without conversion
+    (vfn_conv_desc.w_packed = 1): mode 1: bf16 [cout_pad, K]; mode 2: per 32-channel K tile 32 hi then 32 lo bf16,
+    x = hi + lo with hi = bf16(x), lo = bf16(x - hi) (round to nearest even, as the kernels' own conversion)."""
+    if mode == 1:
+        return wp.to(torch.bfloat16).contiguous()
+    assert mode == 2 and wp.shape[1] % 32 == 0
+    hi = wp.to(torch.bfloat16)
+    lo = (wp - hi.float()).to(torch.bfloat16)
+    cp, K = wp.shape
+    return torch.cat([hi.view(cp, K // 32, 32), lo.view(cp, K // 32, 32)], dim=2).contiguous()
+
+
 def make_conv_desc(x, wp, cout, kh, kw, stride, pad, out, scale=None, shift=None, res=None,
                    relu_in=False, relu_out=False, cin=None, in_ld=None, out_ld=None, res_ld=None,
                    N=None, H=None, W=None):
@@ -55,8 +68,16 @@ def make_conv_desc(x, wp, cout, kh, kw, stride, pad, out, scale=None, shift=None
     d.ksplit, d.split_from, d.partial = 1, 0, None
     d.tile_counters = None
     d.res_mod = 0
+    d.w_packed = 0
     assert wp.shape[1] == kh * kw * cin
     return d
+
+
+def use_packed_weights(desc, w_lp):
+    """Point the descriptor at filters from ``pack_weights_lp`` (keep ``w_lp`` alive: raw pointer)."""
+    desc.w = ptr(w_lp)
+    desc.w_packed = 1
+    return desc
 
 
 def set_splitk(desc, ksplit, workspace, split_from=0, rows=None, counters=None):
