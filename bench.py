@@ -118,6 +118,8 @@ def main():
     torch.cuda.set_device(dev)
 
     K, Wm = args.steps, args.warmup
+    if world > 1:       # N ranks share the host: keep the CPU-side weight synthesis of each from waking every core
+        torch.set_num_threads(max(1, min(16, (os.cpu_count() or 8) // (2 * world))))
     sd = synth.make_state_dict(20200212)
     model = AFB_URR(dev, update_bank=True, precision=args.precision).to(dev).eval()
     model.load_state_dict(sd, strict=True)
