@@ -18,16 +18,20 @@ budget = 2 * int(1.25 * 2 * T * 1620) + 4         # class_budget = 0.8 * budget/
 runner = ClipRunner(model, 2, budget)
 runner.start(f0.unsqueeze(0), onehot)
 curve = []
-torch.cuda.synchronize(); t_prev = time.perf_counter(); n_prev = 0
+every = 25 if T <= 500 else 100
+torch.cuda.synchronize(); t_prev = time.perf_counter(); n_prev = 0; t_start = t_prev
 for t in range(1, T + 1):
     fr = torch.roll(f0, shifts=(2 * t, 5 * t), dims=(1, 2)).unsqueeze(0)
     runner.step(fr, want_label=False)
-    if t % 25 == 0:
+    if t % every == 0:
         torch.cuda.synchronize(); now = time.perf_counter()
         curve.append({'frame': t, 'bank_entries_per_object': max(runner.bank_sizes()), 'ms_per_frame': round(1e3 * (now - t_prev) / (t - n_prev), 3),
                       'hbm_allocated_gb': round(torch.cuda.memory_allocated() / 1e9, 2)})
         print(curve[-1], flush=True)
         t_prev, n_prev = now, t
+total = time.perf_counter() - t_start
+print('whole stream: %d frames in %.1f s = %.2f frames/s' % (T, total, T / total))
 os.makedirs('gpurun_out', exist_ok=True)
 json.dump({'config': f'C5 shape: {T} frames 1920x1080 -> 853x480 (bicubic on device), {os.environ.get("VFN_PRECISION", "fp32")}, no eviction (budget {budget})',
-           'curve': curve}, open('gpurun_out/r01_c5_long_stream_%s.json' % os.environ.get('VFN_PRECISION', 'fp32'), 'w'), indent=1)
+           'frames': T, 'seconds': round(total, 2), 'frames_per_s': round(T / total, 3), 'curve': curve},
+          open('gpurun_out/r01_c5_long_stream_%s%s.json' % (os.environ.get('VFN_PRECISION', 'fp32'), '' if T == 400 else '_%d' % T), 'w'), indent=1)
