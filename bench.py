@@ -91,7 +91,7 @@ def main():
     ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--budget', type=int, default=250000)
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--cpu-frames', type=int, default=4)
+    ap.add_argument('--cpu-frames', type=int, default=10, help='frames of the CPU baseline sample (after a 2-frame warm-up)')
     ap.add_argument('--no-autotune', action='store_true')
     ap.add_argument('--no-overlap', action='store_true',
                     help="do not run the next frame's query encoder on a side stream under memorize/update")
@@ -221,6 +221,8 @@ def main():
     fps = world * K / elapsed
     f_min = 538.48e9 + 3072.0 * b_mean * 1620
     frame_frac = (fps / world) * f_min / (peak * 1e12)
+    f_ref = 666.56e9 + 3072.0 * b_mean * 1620          # op-for-op reference FLOPs (per-object duplicate convs counted)
+    frame_frac_ref = (fps / world) * f_ref / (peak * 1e12)
 
     # ---- CPU baseline + parity on the first frames of the same clip
     cpu = None
@@ -263,7 +265,8 @@ def main():
                                   f'segment+softmax+memorize' + (f' every {mem_every}th frame' if mem_every > 1 else '') +
                                   f'+bank update+argmax+CCL), {args.precision}, budget {args.budget}',
                       'mean_bank_entries_per_object': round(b_mean, 1),
-                      'frame_mfma_frac_Fmin': round(frame_frac, 4) if mem_every == 1 else None},
+                      'frame_mfma_frac_Fmin': round(frame_frac, 4) if mem_every == 1 else None,
+                      'frame_mfma_frac_Fref_reference_equivalent': round(frame_frac_ref, 4) if mem_every == 1 else None},
            'roofline': roof, 'cpu_baseline': cpu, 'parity': parity}
     print(json.dumps(out))
     if world > 1:
