@@ -229,3 +229,81 @@ def test_three_objects_vs_oracle(gpu, sd, model):
     margin = pm_ref[0].topk(2, dim=0).values
     margin = margin[0] - margin[1]
     assert torch.equal(pm.cpu()[0].argmax(0)[margin > 1e-3], pm_ref[0].argmax(0)[margin > 1e-3])
+
+
+def _step_vs_oracle(gpu, sd, model, frames, oh, obj_n, budget=250000, tol_prob=1e-3):
+    """memorize(frame 0) -> init_bank -> segment(frame 1) -> memorize -> update, HIP vs oracle."""
+    from vfloodnet_amd import FeatureBank, ops
+    from oracle import afb_urr_ref as O
+    k_ref, v_ref = O.memorize(sd, frames[0:1], oh)
+    fb_ref = O.FeatureBankRef(obj_n, budget)
+    fb_ref.init_bank(k_ref, v_ref)
+    score_ref, _ = O.segment(sd, frames[1:2], fb_ref)
+    pm_ref = torch.softmax(score_ref, dim=1)
+    k2r, v2r = O.memorize(sd, frames[1:2], pm_ref)
+    fb_ref.update(k2r, v2r, 1)
+
+    k, v = model.memorize(frames[0:1].to(gpu), oh.to(gpu))
+    fb = FeatureBank(obj_n, budget, gpu)
+    fb.init_bank(k, v)
+    score, _ = model.segment(frames[1:2].to(gpu), fb)
+    assert score.shape == score_ref.shape
+    pm = ops.softmax_objects(score)
+    assert (pm.cpu() - pm_ref).abs().max() < tol_prob
+    k2, v2 = model.memorize(frames[1:2].to(gpu), pm)
+    fb.update(k2, v2, 1)
+    for i in range(obj_n):
+        assert abs(fb.keys[i].shape[1] - fb_ref.keys[i].shape[1]) <= max(2, fb_ref.keys[i].shape[1] // 500)
+    return pm.cpu(), pm_ref, fb, fb_ref
+
+
+def test_single_object_all_background_mask(gpu, sd, model):
+    """First mask with no water at all: Video_DS gives obj_n = max+1 = 1 (Water_DS.py:97-98).  The reference cannot
+    segment that (calc_uncertainty takes a top-2 over one channel -> RuntimeError); same error type here, and
+    memorize / init_bank -- which the reference does complete -- still match."""
+    from vfloodnet_amd import synth, FeatureBank
+    from oracle import afb_urr_ref as O
+    H, W = 64, 96
+    frames, _ = synth.clip(5, 2, H, W)
+    oh = torch.ones(1, 1, H, W)
+    torch.set_num_threads(8)
+    k_ref, v_ref = O.memorize(sd, frames[0:1], oh)
+    fb_ref = O.FeatureBankRef(1, 5000)
+    fb_ref.init_bank(k_ref, v_ref)
+    with pytest.raises(RuntimeError):
+        O.segment(sd, frames[1:2], fb_ref)
+    k, v = model.memorize(frames[0:1].to(gpu), oh.to(gpu))
+    assert len(k) == 1 and (k[0].cpu() - k_ref[0]).abs().max() < 1e-4 * max(1, k_ref[0].abs().max().item())
+    fb = FeatureBank(1, 5000, gpu)
+    assert fb.class_budget == fb_ref.class_budget == 5000          # budget // 1, no 0.8 factor (FeatureBank.py:20-22)
+    fb.init_bank(k, v)
+    with pytest.raises(RuntimeError):
+        model.segment(frames[1:2].to(gpu), fb)
+
+
+def test_tiny_ragged_frame(gpu, sd, model):
+    """33 x 47 -> padded 48 x 48, 3 x 3 = 9 positions at 1/16: every tile of every kernel is partial."""
+    from vfloodnet_amd import synth
+    H, W = 33, 47
+    frames, m0 = synth.clip(6, 2, H, W)
+    oh = synth.onehot(m0).unsqueeze(0)
+    torch.set_num_threads(8)
+    pm, pm_ref, fb, fb_ref = _step_vs_oracle(gpu, sd, model, frames, oh, 2)
+    assert fb.keys[0].shape[0] == 128 and fb_ref.keys[0].shape[1] >= 9
+    margin = (pm_ref[0, 1] - pm_ref[0, 0]).abs()
+    assert torch.equal(pm[0].argmax(0)[margin > 1e-3], pm_ref[0].argmax(0)[margin > 1e-3])
+
+
+@pytest.mark.parametrize('H,W', [(720, 1280), (1080, 1920)])
+def test_native_resolution_step(gpu, sd, model, H, W):
+    """One step at native resolution -- the largest single-frame shapes SURVEY.md section 8 lists: 720p
+    (HW = 45 x 80 = 3600) and 1080p (padded 1088 x 1920, HW = 68 x 120 = 8160) -- against the oracle."""
+    from vfloodnet_amd import synth
+    frames, m0 = synth.clip(7, 2, H, W)
+    oh = synth.onehot(m0).unsqueeze(0)
+    torch.set_num_threads(16)
+    pm, pm_ref, fb, fb_ref = _step_vs_oracle(gpu, sd, model, frames, oh, 2, tol_prob=2e-3)
+    assert fb_ref.keys[0].shape[1] >= (H // 16) * (W // 16)
+    margin = (pm_ref[0, 1] - pm_ref[0, 0]).abs()
+    agree = (pm[0].argmax(0) == pm_ref[0].argmax(0))[margin > 1e-3].float().mean().item()
+    assert agree == 1.0, agree

@@ -80,6 +80,10 @@ class AFB_URR(nn.Module):
         """AFB_URR.py:274-318 (eval branch).  Returns (logits f32[1,obj_n,h,w], None)."""
         if self.training:
             raise RuntimeError('the HIP path implements eval-mode inference only (call model.eval())')
+        if fb_global.obj_n < 2:
+            # the reference fails here as well: calc_uncertainty takes the top-2 over the object axis
+            # (myutils/data.py:40-46, `score.topk(k=2, dim=1)` -> "selected index k out of range")
+            raise RuntimeError('segment needs at least two objects (background + 1): selected index k out of range')
         return self.engine().segment(frame, fb_global, self.update_bank), None
 
     def forward(self, x):  # AFB_URR.py:320-321
