@@ -101,8 +101,12 @@ def main():
     ap.add_argument('--workload', choices=sorted(WORKLOADS), default='C2',
                     help='C2: 480x854 clip, every frame memorised; C3: 720x1280 clip (resized to 480p on the device as '
                          'test_video_seg.py:88,107 does), bank grows with every 5th frame')
+    ap.add_argument('--native', action='store_true',
+                    help='run the network at the input resolution instead of the reference semantics (resize to a 480-pixel '
+                         'short edge, test_video_seg.py:46,107); only meaningful with --workload C3')
     args = ap.parse_args()
     H0, W0, mem_every = WORKLOADS[args.workload]
+    net_size = H0 if args.native else 480
     peak = PEAKS[args.precision]
 
     import vfloodnet_amd
@@ -135,7 +139,7 @@ def main():
     timed_launch = timer.install()
     eng = model.engine()
     from vfloodnet_amd.video_seg import resized_hw
-    Hn, Wn = resized_hw(H0, W0, 480)                 # the network always sees the 480p frame
+    Hn, Wn = resized_hw(H0, W0, net_size)            # reference semantics: the network always sees the 480p frame
     if not args.no_autotune:
         eng.autotune(Hn, Wn, 2)
     plan = eng.plan(Hn, Wn, 2)
@@ -145,14 +149,14 @@ def main():
                 l.fn = timed_launch
 
     # ---- warm-up on a throw-away bank
-    warm = ClipRunner(model, 2, args.budget, mem_every=mem_every)
+    warm = ClipRunner(model, 2, args.budget, size=net_size, mem_every=mem_every)
     warm.start(frames[0:1], onehot)
     for t in range(1, Wm + 1):
         warm.step(frames[(t % (n_frames - 1)) + 1:(t % (n_frames - 1)) + 2])
     del warm
 
     # ---- timed region: exactly K steps
-    runner = ClipRunner(model, 2, args.budget, mem_every=mem_every, postprocess=True)     # largest-blob filter (:116) on the device too
+    runner = ClipRunner(model, 2, args.budget, size=net_size, mem_every=mem_every, postprocess=True)     # largest-blob filter (:116) on the device too
     runner.start(frames[0:1], onehot)
     labels = torch.empty(K + 1, H0, W0, dtype=torch.uint8, device=dev)
     labels[0] = m0.to(dev)
@@ -219,6 +223,7 @@ def main():
     # ---- whole-frame roofline: F_min(B) = 538.48 GFLOP + 3072*B*HW
     b_mean = bank_sum / (2.0 * K)
     fps = world * K / elapsed
+    HWn = ((Hn + 15) // 16) * ((Wn + 15) // 16)
     f_min = 538.48e9 + 3072.0 * b_mean * 1620
     frame_frac = (fps / world) * f_min / (peak * 1e12)
     f_ref = 666.56e9 + 3072.0 * b_mean * 1620          # op-for-op reference FLOPs (per-object duplicate convs counted)
@@ -265,6 +270,7 @@ def main():
                                   f'segment+softmax+memorize' + (f' every {mem_every}th frame' if mem_every > 1 else '') +
                                   f'+bank update+argmax+CCL), {args.precision}, budget {args.budget}',
                       'mean_bank_entries_per_object': round(b_mean, 1),
+                      'network_resolution': f'{Hn}x{Wn} ' + ('(native)' if args.native and (Hn, Wn) == (H0, W0) else '(reference semantics: 480-pixel short edge)'),
                       'frame_mfma_frac_Fmin': round(frame_frac, 4) if mem_every == 1 else None,
                       'frame_mfma_frac_Fref_reference_equivalent': round(frame_frac_ref, 4) if mem_every == 1 else None},
            'roofline': roof, 'cpu_baseline': cpu, 'parity': parity}
