@@ -97,8 +97,6 @@ __global__ void row_norms_kernel(const float* __restrict__ x, long long stride_o
 __global__ __launch_bounds__(256)
 void bank_merge_kernel(const vfn_bank_desc p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    int* s_idx = reinterpret_cast<int*>(smem);                          // [HW]
-    unsigned char* s_mrg = reinterpret_cast<unsigned char*>(s_idx + p.HW);   // [HW]
     __shared__ int s_any;
     const int obj = blockIdx.y, hw = blockIdx.x, tid = threadIdx.x;
     const int* idx = p.match_idx + (size_t)obj * p.HW;
@@ -113,7 +111,13 @@ void bank_merge_kernel(const vfn_bank_desc p) {
     if (found) s_any = 1;
     __syncthreads();
     if (s_any) return;
-    for (int j = tid; j < p.HW; j += 256) { s_idx[j] = idx[j]; s_mrg[j] = corr[j] > p.thres_close; }
+    // bitmap of the sources merged into tgt (this block is their leader): set in parallel, walked in ascending order
+    unsigned* s_bits = reinterpret_cast<unsigned*>(smem);               // [(HW + 31) / 32]
+    const int nwords = (p.HW + 31) >> 5;
+    for (int w = tid; w < nwords; w += 256) s_bits[w] = 0u;
+    __syncthreads();
+    for (int j = hw + tid; j < p.HW; j += 256)
+        if (idx[j] == tgt && corr[j] > p.thres_close) atomicOr(&s_bits[j >> 5], 1u << (j & 31));
     __syncthreads();
 
     const float* nk = p.new_k + (size_t)obj * p.stride_new;       // [HW][ld_new]: key at +0, value at +voff
@@ -121,8 +125,11 @@ void bank_merge_kernel(const vfn_bank_desc p) {
     const float* nvn = p.new_vnorm + (size_t)obj * p.HW;
     float ak = 0.f, av0 = 0.f, av1 = 0.f;
     int cnt = 0;
-    for (int j = hw; j < p.HW; ++j) {                              // ascending order == scatter_add order
-        if (s_mrg[j] && s_idx[j] == tgt) {
+    for (int w = hw >> 5; w < nwords; ++w) {                       // ascending order == scatter_add order
+        unsigned bits = s_bits[w];
+        while (bits) {
+            const int j = (w << 5) + __ffs(bits) - 1;
+            bits &= bits - 1;
             const float* row = nk + (size_t)j * p.ld_new;
             const float dk = fmaxf(nkn[j], 1e-12f), dv = fmaxf(nvn[j], 1e-12f);
             if (tid < DK) ak += row[tid] / dk;

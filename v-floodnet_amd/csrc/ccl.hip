@@ -53,9 +53,12 @@ __global__ void ccl_merge_kernel(const unsigned char* __restrict__ pred, int* __
         const int y = i / W, x = i - y * W;
         if (x > 0 && pred[i - 1]) uf_union(parent, i, i - 1);
         if (y > 0) {
-            if (pred[i - W]) uf_union(parent, i, i - W);
-            if (x > 0 && pred[i - W - 1]) uf_union(parent, i, i - W - 1);
-            if (x < W - 1 && pred[i - W + 1]) uf_union(parent, i, i - W + 1);
+            if (pred[i - W]) {
+                uf_union(parent, i, i - W);          // N is water: NW / NE, if water, hang on N through its own W links
+            } else {
+                if (x > 0 && pred[i - W - 1]) uf_union(parent, i, i - W - 1);
+                if (x < W - 1 && pred[i - W + 1]) uf_union(parent, i, i - W + 1);
+            }
         }
     }
 }
