@@ -311,27 +311,32 @@ class FramePlan:
                                    2.0 * self.h2 * self.w2 * 64 * 147))
         r4 = self._trunk(self.seg_pre, e.enc_q, self.q, 1, 'encoder_q')
         self._conv(self.seg_pre, e.keyval, r4, self.kv_q, 1, self.h16, self.w16, name='keyval')
-        self._ws_cur, self._cnt_cur = self.ws, self.cnt
-        # ---- decoder
-        L = self.seg_post
+        # ---- decoder work that depends on the frame only (not on the bank): the skip-feature branches of the two
+        # Refine stages (AFB_URR.py:122-127: ResFS(convFS(f)) -- one image, shared by the objects), the query-value
+        # half of convFM and the r1 half of local_convFM.  They ride with the query encoder, i.e. on the side stream
+        # underneath memorize/update of the previous frame when the next frame is known (Engine.prefetch_query).
+        P = self.seg_pre
         D = e.dec
         d16, s8, d8, s4, d4 = self.d16, self.s8, self.d8, self.s4, self.d4
         # convFM(cat([mem_i, q_out])) = convFM[:, :512](mem_i) + convFM[:, 512:](q_out): the second term is the
         # same for every object (AFB_URR.py:159,176) -> computed once (with the bias) and added as a shared residual
         kvq_val = self.kv_q[:, :, DK:]                          # [1, HW, 512] view, pixel stride 640
-        self._conv(L, D['convFM_q'], kvq_val, self.fm_q, 1, self.h16, self.w16, name='decoder.convFM.q',
+        self._conv(P, D['convFM_q'], kvq_val, self.fm_q, 1, self.h16, self.w16, name='decoder.convFM.q',
                    in_ld=DK + DV)
+        self._conv(P, D['RF3']['convFS'], self.q['res3']['out'], s8[0], 1, self.h8, self.w8, name='decoder.RF3.convFS')
+        self._resblock(P, D['RF3']['ResFS'], s8[0], s8[1], s8[2], 1, self.h8, self.w8, 'decoder.RF3.ResFS')
+        self._conv(P, D['RF2']['convFS'], self.q['res2']['out'], s4[0], 1, self.h4, self.w4, name='decoder.RF2.convFS')
+        self._resblock(P, D['RF2']['ResFS'], s4[0], s4[1], s4[2], 1, self.h4, self.w4, 'decoder.RF2.ResFS')
+        # local_convFM(cat([r1, r1_local])): the r1 half is shared by the objects (AFB_URR.py:231-232)
+        self._conv(P, D['local_convFM_r1'], self.q['r1'], self.lq, 1, self.h2, self.w2, name='decoder.local_convFM.r1')
+        self._ws_cur, self._cnt_cur = self.ws, self.cnt
+        # ---- decoder, bank-dependent part
+        L = self.seg_post
         self._conv(L, D['convFM_m'], self.dec_in, d16[0], K, self.h16, self.w16, res=self.fm_q, res_mod=self.HW,
                    name='decoder.convFM.mem')
         self._resblock(L, D['ResMM'], d16[0], d16[1], d16[2], K, self.h16, self.w16, 'decoder.ResMM')
-        # RF3 (feature branch shared by the objects: N=1)
-        self._conv(L, D['RF3']['convFS'], self.q['res3']['out'], s8[0], 1, self.h8, self.w8, name='decoder.RF3.convFS')
-        self._resblock(L, D['RF3']['ResFS'], s8[0], s8[1], s8[2], 1, self.h8, self.w8, 'decoder.RF3.ResFS')
         L.append(Launch(ops.upsample2x_add, (s8[2], d16[2], d8[0], True), 'decoder.RF3.up_add'))
         self._resblock(L, D['RF3']['ResMM'], d8[0], d8[1], d8[2], K, self.h8, self.w8, 'decoder.RF3.ResMM')
-        # RF2
-        self._conv(L, D['RF2']['convFS'], self.q['res2']['out'], s4[0], 1, self.h4, self.w4, name='decoder.RF2.convFS')
-        self._resblock(L, D['RF2']['ResFS'], s4[0], s4[1], s4[2], 1, self.h4, self.w4, 'decoder.RF2.ResFS')
         L.append(Launch(ops.upsample2x_add, (s4[2], d8[2], d4[0], True), 'decoder.RF2.up_add'))
         self._resblock(L, D['RF2']['ResMM'], d4[0], d4[1], d4[2], K, self.h4, self.w4, 'decoder.RF2.ResMM')
         self._conv(L, D['pred2'], d4[2], self.pp, K, self.h4, self.w4, relu_in=True, name='decoder.pred2')
@@ -339,8 +344,6 @@ class FramePlan:
         L.append(Launch(ops.local_stats, (self.q['r1'], self.rough, self.hs, self.hr, self.hm, self.lm, self.conf),
                         'decoder.local_stats'))
         l2 = self.l2
-        # local_convFM(cat([r1, r1_local])) likewise: the r1 half is shared by the objects (AFB_URR.py:231-232)
-        self._conv(L, D['local_convFM_r1'], self.q['r1'], self.lq, 1, self.h2, self.w2, name='decoder.local_convFM.r1')
         self._conv(L, D['local_convFM_loc'], self.lm, l2[0], K, self.h2, self.w2, res=self.lq,
                    res_mod=self.h2 * self.w2, name='decoder.local_convFM.local')
         self._resblock(L, D['local_ResMM'], l2[0], l2[1], l2[2], K, self.h2, self.w2, 'decoder.local_ResMM')
@@ -481,10 +484,12 @@ class Engine:
         return p.score
 
     def prefetch_query(self, frame, obj_n):
-        """Run the query encoder + KeyValue of ``frame`` (the *next* frame of the clip) on a side stream.
-        It depends only on that frame, so it may overlap ``memorize`` / ``FeatureBank.update`` of the
-        current frame; the next ``segment(frame, ...)`` call picks the result up.  Call it after the
-        current frame's ``segment`` (the decoder reads the query encoder's skip features)."""
+        """Run the frame-only part of ``segment`` for ``frame`` (the *next* frame of the clip: query encoder, KeyValue
+        and the decoder's skip-feature branches) on a side stream.  It depends only on that frame, so it may overlap
+        ``memorize`` / ``FeatureBank.update`` of the current frame; the next ``segment(frame, ...)`` call picks the
+        result up.  Call it after the current frame's ``segment`` (whose decoder reads the same buffers).
+        (Starting it earlier still -- second buffer set, underneath the current frame's memory read and decoder --
+        was measured slower, 104 vs 110 frames/s: the two streams then fight over the CUs on the critical path.)"""
         self._check_frame(frame)
         p = self.plan(frame.shape[2], frame.shape[3], obj_n)
         if self._side is None:
