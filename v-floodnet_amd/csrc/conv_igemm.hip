@@ -92,6 +92,71 @@ __device__ __forceinline__ void splitk_finish(const vfn_conv_desc& p, int* flag,
     }
 }
 
+// Wide epilogue shared by the register-staged and the LDS-DMA kernel: the accumulators (lane = filter column,
+// registers = pixel rows) are transposed through the now idle staging LDS, so that every lane then owns 4 consecutive
+// channels of one pixel: 16-byte residual loads and 16-byte stores (a quarter of the store instructions of the dword
+// form -- the thin-K 1x1 layers are bound by exactly those).  One round per row of 32x32 accumulator tiles of the wave.
+// Returns false when the shapes do not allow 16-byte accesses (the caller then runs the dword epilogue).
+// Precondition: every wave has passed the barrier behind the last K tile (the staging buffers are dead).
+template <int BM, int BN, int WM, int WN, int LDS_FLOATS = 2 * (BM + BN) * BK>
+__device__ __forceinline__ bool wide_epilogue(const vfn_conv_desc& p, char* smem, f32x16 (&acc)[BM / WM / 32][BN / WN / 32],
+                                              bool split_tile, int kz, int m0, int n0, int n_tiles) {
+    constexpr int NT = WM * WN * 64;
+    constexpr int TM = BM / WM / 32;
+    constexpr int TN = BN / WN / 32;
+    constexpr int ROWS = WM * 32;                                   // tile rows handled per round
+    constexpr int PITCH = (ROWS * (BN + 4) <= LDS_FLOATS) ? BN + 4 : BN;
+    static_assert(ROWS * PITCH <= LDS_FLOATS, "C tile does not fit the staging LDS");
+    const bool wide = (p.Cout % 4 == 0) && (p.out_ld % 4 == 0) && (!p.res || p.res_ld % 4 == 0) && !(split_tile && p.tile_counters);
+    if (!wide) return false;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int li = lane & 31, lh = lane >> 5;
+    float* sC = reinterpret_cast<float*>(smem);
+    constexpr int C4 = BN / 4;
+    constexpr int RPP = NT / C4;                                    // rows per pass of the read-back
+    const int c4 = tid % C4, rr0 = tid / C4;
+    const int col = n0 + c4 * 4;
+    const bool col_ok = col < p.Cout;
+    f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
+    float* part = nullptr;
+    if (split_tile) {
+        const int m_start = (p.split_from / n_tiles) * BM;
+        part = p.partial + ((long long)kz * (p.M - m_start) - m_start) * (long long)p.Cout;
+    } else if (col_ok) {
+        if (p.scale) sc = *reinterpret_cast<const f32x4*>(p.scale + col);
+        if (p.shift) sh = *reinterpret_cast<const f32x4*>(p.shift + col);
+    }
+#pragma unroll
+    for (int h = 0; h < TM; ++h) {
+        if (h > 0) __syncthreads();                                 // the previous round has been read back
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                sC[(wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh) * PITCH + (wn * TN + j) * 32 + li] = acc[h][j][r];
+        __syncthreads();
+        for (int rr = rr0; rr < ROWS; rr += RPP) {
+            const int row = m0 + (rr >> 5) * (TM * 32) + h * 32 + (rr & 31);
+            if (row >= p.M || !col_ok) continue;
+            f32x4 v = *reinterpret_cast<const f32x4*>(sC + rr * PITCH + c4 * 4);
+            if (split_tile) {
+                *reinterpret_cast<f32x4*>(part + (size_t)row * p.Cout + col) = v;
+                continue;
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = v[e] * sc[e] + sh[e];
+            if (p.res) v += *reinterpret_cast<const f32x4*>(p.res + (size_t)(p.res_mod > 0 ? row % p.res_mod : row) * p.res_ld + col);
+            if (p.relu_out) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+            }
+            *reinterpret_cast<f32x4*>(p.out + (size_t)row * p.out_ld + col) = v;
+        }
+    }
+    return true;
+}
+
 template <int BM, int BN, int WM, int WN, int MODE = 0>
 __global__ __launch_bounds__(WM * WN * 64)
 void conv_igemm_kernel(const vfn_conv_desc p) {
@@ -385,6 +450,8 @@ void conv_igemm_kernel(const vfn_conv_desc p) {
         __syncthreads();
     }
 
+    if (wide_epilogue<BM, BN, WM, WN>(p, smem, acc, split_tile, kz, m0, n0, n_tiles)) return;
+
     // split-K: raw partial sums to the workspace slab of this split; vfn_conv_splitk_reduce finishes
     if (split_tile) {
         const int m_start = (p.split_from / n_tiles) * BM;          // first row covered by split tiles
@@ -600,6 +667,8 @@ void conv_igemm_dma_kernel(const vfn_conv_desc p) {
         compute_tile(buf);
         __syncthreads();                               // next tile landed; this buffer may be refilled
     }
+
+    if (wide_epilogue<BM, BN, WM, WN>(p, smem, acc, split_tile, kz, m0, n0, n_tiles)) return;
 
     if (split_tile) {
         const int m_start = (p.split_from / n_tiles) * BM;
