@@ -93,19 +93,32 @@ void stem_kernel(const vfn_stem_desc p) {
         }
     }
 
-    // epilogue: BN + ReLU, NHWC store
+    // epilogue: BN + ReLU, NHWC store.  The 128 x 64 tile is transposed through LDS (the filter image is dead) so
+    // that a lane owns 4 consecutive channels of one pixel: 16-byte stores instead of 16 dword stores per lane.
+    __syncthreads();
+    constexpr int CP = 68;                                  // padded pitch (floats)
+    float* sC = reinterpret_cast<float*>(smem);             // [128 pixels][CP]
 #pragma unroll
-    for (int tn = 0; tn < 2; ++tn) {
-        const int col = tn * 32 + li;
-        const float sc = p.scale[col], sh = p.shift[col];
+    for (int tn = 0; tn < 2; ++tn)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const int pix = (r & 3) + 8 * (r >> 2) + 4 * lh;       // 0..31 within the wave tile
-            const int oy = oy0 + 2 * wave + (pix >> 4), ox = ox0 + (pix & 15);
+            const int pix = wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;      // 0..127 within the block tile
+            sC[pix * CP + tn * 32 + li] = tn == 0 ? acc0[r] : acc1[r];
+        }
+    __syncthreads();
+    {
+        const int c4 = tid & 15;
+        const f32x4 sc = *reinterpret_cast<const f32x4*>(p.scale + c4 * 4);
+        const f32x4 sh = *reinterpret_cast<const f32x4*>(p.shift + c4 * 4);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int pix = (tid >> 4) + 16 * k;            // wave-tile pixel: rows 2*(pix>>5) + ((pix&31)>>4), col pix&15
+            const int oy = oy0 + 2 * (pix >> 5) + ((pix & 31) >> 4), ox = ox0 + (pix & 15);
             if (oy < p.Ho && ox < p.Wo) {
-                const float a = tn == 0 ? acc0[r] : acc1[r];
-                const float v = fmaxf(a * sc + sh, 0.f);
-                p.out[(((size_t)n * p.Ho + oy) * p.Wo + ox) * 64 + col] = v;
+                f32x4 v = *reinterpret_cast<const f32x4*>(sC + pix * CP + c4 * 4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e] * sc[e] + sh[e], 0.f);
+                *reinterpret_cast<f32x4*>(p.out + (((size_t)n * p.Ho + oy) * p.Wo + ox) * 64 + c4 * 4) = v;
             }
         }
     }
