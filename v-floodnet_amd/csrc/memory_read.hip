@@ -202,8 +202,10 @@ void bank_scan_kernel(const vfn_bankscan_desc p) {
     for (int c = c_lo; c < c_hi; ++c) {
         const int b0 = c * CH;
         const float* sK = sKb + ((c - c_lo) & 1) * CH * DK;
+#ifndef VFN_ABLATE_KLOAD
         if (c + 1 < c_hi)
             chunk_load_async(sKb + ((c + 1 - c_lo) & 1) * CH * DK, K + (size_t)(b0 + CH) * DK, min(CH, B - b0 - CH), wave, lane);
+#endif
         f32x16 acc;
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = 0.f;

@@ -535,8 +535,10 @@ class Engine:
         check(L.vfn_memread_finish(_lib.C.byref(m), s), 'vfn_memread_finish')
 
     # ------------------------------------------------------------------ tuning
-    def autotune(self, H0, W0, obj_n, iters=3):
-        """Time every tile config for every distinct conv shape of this frame size; keep the fastest."""
+    def autotune(self, H0, W0, obj_n, iters=3, only_missing=False):
+        """Time every tile config for every distinct conv shape of this frame size; keep the fastest.
+        ``only_missing``: leave shapes that the measured table already covers alone (a frame size the shipped
+        tables were not tuned for costs a few seconds once, e.g. at the start of ``video_seg.main``)."""
         p = self.plan(H0, W0, obj_n)
         seen = {}
         for lst in (p.seg_pre, p.seg_post, p.mem):
@@ -544,6 +546,8 @@ class Engine:
                 if l.fn is ops.conv2d_launch:
                     d = l.args[0]
                     key = (d.M, d.Cout, d.KH * d.KW * d.Cin, int(l.args[2]))
+                    if only_missing and key[:3] in _TABLES[key[3]]:
+                        continue
                     seen.setdefault(key, []).append(l)
         tiles = ops.conv_cfg_tiles()
 

@@ -63,9 +63,10 @@ class ClipRunner:
     """test_video_seg.py:83-121 on device tensors."""
 
     def __init__(self, model, obj_n=2, budget=250000, update_rate=0.1, thres_close=0.95, size=480, mem_every=1,
-                 postprocess=False):
+                 postprocess=False, autotune=False):
         self.model = model
         self.postprocess = postprocess       # run postprocessing_pred (:116) on the device before the D2H
+        self.autotune = autotune             # measure tile / split-K choices for conv shapes the shipped tables lack
         self.device = model.device
         self.obj_n = obj_n
         self.size = size
@@ -92,6 +93,8 @@ class ClipRunner:
         self.ori_size = (H0, W0)
         f = self._net_frame(first_frame)
         h, w = f.shape[-2:]
+        if self.autotune:
+            self.model.engine().autotune(h, w, self.obj_n, only_missing=True)
         m = first_mask_onehot.to(torch.float32).contiguous()
         if (h, w) != (H0, W0):
             m = ops.resize_nearest(m, h, w)                      # TF.resize(mask, 480, NEAREST) (:89)
@@ -215,7 +218,7 @@ def main(args, device):
 
     obj_n = seq_dataset.obj_n
     runner = ClipRunner(model, obj_n, args.budget, update_rate=args.update_rate, thres_close=args.merge_thres,
-                        size=downsample_size, mem_every=getattr(args, 'mem_every', 1), postprocess=True)
+                        size=downsample_size, mem_every=getattr(args, 'mem_every', 1), postprocess=True, autotune=True)
 
     ori_first_frame = seq_dataset.first_frame.unsqueeze(0).to(device)
     ori_first_mask = seq_dataset.first_mask.unsqueeze(0).to(device)
