@@ -406,18 +406,11 @@ void conv_igemm_kernel(const vfn_conv_desc p) {
                     }
             }
         } else {
-        // the staging of tile kt+1 is spread over the four k-groups of tile kt (loads first, LDS writes in
-        // the second half) so that no long MFMA-free stretch sits at either end of the iteration
-#pragma unroll
-        for (int kk = 0; kk < 4; ++kk) {
-            if (more) {
-                if (kk == 0) load_a();
-                if (kk == 1) load_b(kt_begin + kt + 1);
-                if (kk == 2) store_a(buf ^ 1);
-                if (kk == 3) store_b(buf ^ 1);
-            }
+        // the staging of tile kt+1 is spread over the four k-groups of tile kt (both global loads up front, the LDS
+        // writes in the second half), and the fragments of k-group kk+1 are read before the MFMAs of kk are issued,
+        // so that neither an LDS round trip nor a late global load sits in front of the matrix pipe
+        auto read_frags = [&](int kk, f32x4 (&a)[TM], f32x4 (&b)[TN]) {
             const int lc = 2 * kk + lh;
-            f32x4 a[TM], b[TN];
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
                 const int r = i * 32 + li;      // (wm*TM*32) is a multiple of 32: swizzle bits unchanged
@@ -428,6 +421,19 @@ void conv_igemm_kernel(const vfn_conv_desc p) {
                 const int r = j * 32 + li;
                 b[j] = *reinterpret_cast<const f32x4*>(cB + r * BK + ((lc ^ ((r >> 1) & 7)) << 2));
             }
+        };
+        f32x4 fa[2][TM], fb[2][TN];
+        read_frags(0, fa[0], fb[0]);
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            if (more) {
+                if (kk == 0) { load_a(); load_b(kt_begin + kt + 1); }
+                if (kk == 2) store_a(buf ^ 1);
+                if (kk == 3) store_b(buf ^ 1);
+            }
+            if (kk + 1 < 4) read_frags(kk + 1, fa[(kk + 1) & 1], fb[(kk + 1) & 1]);
+            f32x4 (&a)[TM] = fa[kk & 1];
+            f32x4 (&b)[TN] = fb[kk & 1];
             if constexpr (BF) {
                 // the 16 bytes are 8 bf16 = k 16*kk + 8*h .. +7: one 32x32x16 step per tile pair
 #pragma unroll
