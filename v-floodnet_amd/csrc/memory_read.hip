@@ -148,24 +148,25 @@ __device__ __forceinline__ void chunk_range(int B, int nsplit, int split, int& c
 
 // ------------------------------------------------------------------ pass 1: softmax statistics
 // MODE 0: (max, sum exp) of scale*s per query.  MODE 1: arg-max of s*rowscale[b] per query.
+// One workgroup = 128 query columns x one slice of the bank; wave w owns queries 32w..32w+31 against ALL 64 rows of
+// every chunk (two 32x32 accumulator tiles), so a key fragment read from LDS feeds eight MFMAs, a key chunk is
+// streamed once per 128 queries, and a query's statistics never leave its lane pair (no cross-wave reduction).
 // Query fragments live in registers (64 VGPRs), key chunks are double-buffered in LDS by LDS-DMA:
 // 64 KB of LDS -> two workgroups per CU, one barrier per chunk, the next chunk lands behind the MFMAs.
+constexpr int QTS = 128;    // query columns per scan workgroup
+
 template <int MODE, int PREC = 0>
 __global__ __launch_bounds__(256, 2)
 void bank_scan_kernel(const vfn_bankscan_desc p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* sKb = reinterpret_cast<float*>(smem);     // [2][64][128]
-    float* sRed = sKb;                               // [2][64][2], reused after the last chunk
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 31, lh = lane >> 5;
-    const int wr = wave >> 1, wq = wave & 1;
-    const int sstride = p.nsplit;                    // nsplit % 8 == 0 -> one bank slice per XCD
-    const int split = blockIdx.x % sstride;
-    const int qt = blockIdx.x / sstride;
-    if (split >= p.nsplit) return;
+    const int split = blockIdx.x % p.nsplit;
+    const int qt = blockIdx.x / p.nsplit;
     const int obj = blockIdx.y;
-    const int q0 = qt * QT;
+    const int q0 = qt * QTS + wave * 32;             // first query of this wave
     const int B = p.bank_len[obj];
     const float* K = p.bank_k + (size_t)obj * p.stride_k;
     const float* Q = p.q + (size_t)(p.q_per_obj ? obj : 0) * p.stride_q;
@@ -178,7 +179,7 @@ void bank_scan_kernel(const vfn_bankscan_desc p) {
     f32x4 qf[PREC == 0 ? 16 : 1];
     bf16x8 qh[PREC == 0 ? 1 : 8], ql[PREC == 2 ? 8 : 1];
     {
-        const int q = min(q0 + wq * 32 + li, p.HW - 1);          // columns past HW are never written out
+        const int q = min(q0 + li, p.HW - 1);                    // columns past HW are never written out
         if constexpr (PREC == 0) {
             const float* qrow = Q + (size_t)q * p.ldq + 4 * lh;
 #pragma unroll
@@ -206,77 +207,79 @@ void bank_scan_kernel(const vfn_bankscan_desc p) {
         if (c + 1 < c_hi)
             chunk_load_async(sKb + ((c + 1 - c_lo) & 1) * CH * DK, K + (size_t)(b0 + CH) * DK, min(CH, B - b0 - CH), wave, lane);
 #endif
-        f32x16 acc;
+        f32x16 acc[2];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
         if constexpr (PREC == 0) {
-            // two independent accumulation chains (even / odd k-steps): a single chain of 64 dependent MFMAs
-            // leaves issue bubbles between them
-            const int ra = wr * 32 + li;
-            f32x16 acc2;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc2[r] = 0.f;
-            f32x4 a[2];
-            a[0] = *reinterpret_cast<const f32x4*>(sK + swz(ra, lh));
+            f32x4 a[2][2];
+            a[0][0] = *reinterpret_cast<const f32x4*>(sK + swz(li, lh));
+            a[0][1] = *reinterpret_cast<const f32x4*>(sK + swz(32 + li, lh));
 #pragma unroll
             for (int kk = 0; kk < 16; ++kk) {
                 const int cur = kk & 1;
-                if (kk + 1 < 16) a[cur ^ 1] = *reinterpret_cast<const f32x4*>(sK + swz(ra, 2 * (kk + 1) + lh));
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[cur][0], qf[kk][0], acc, 0, 0, 0);
-                acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[cur][1], qf[kk][1], acc2, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[cur][2], qf[kk][2], acc, 0, 0, 0);
-                acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[cur][3], qf[kk][3], acc2, 0, 0, 0);
-            }
+                if (kk + 1 < 16) {
+                    a[cur ^ 1][0] = *reinterpret_cast<const f32x4*>(sK + swz(li, 2 * (kk + 1) + lh));
+                    a[cur ^ 1][1] = *reinterpret_cast<const f32x4*>(sK + swz(32 + li, 2 * (kk + 1) + lh));
+                }
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[r] += acc2[r];
+                for (int t = 0; t < 4; ++t) {
+                    acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[cur][0][t], qf[kk][t], acc[0], 0, 0, 0);
+                    acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[cur][1][t], qf[kk][t], acc[1], 0, 0, 0);
+                }
+            }
         } else {
-            // key fragments: two 16-byte reads (f32 chunks 4g+2h, 4g+2h+1 = k 16g+8h .. +7), converted in registers
-            const int ra = wr * 32 + li;
-            f32x4 a[2][2];
-            a[0][0] = *reinterpret_cast<const f32x4*>(sK + swz(ra, 2 * lh));
-            a[0][1] = *reinterpret_cast<const f32x4*>(sK + swz(ra, 2 * lh + 1));
+            // key fragments: two 16-byte reads (f32 chunks 4g+2h, 4g+2h+1 = k 16g+8h .. +7) per row tile, converted in registers
 #pragma unroll
             for (int g = 0; g < 8; ++g) {
-                const int cur = g & 1;
-                if (g + 1 < 8) {
-                    a[cur ^ 1][0] = *reinterpret_cast<const f32x4*>(sK + swz(ra, 4 * (g + 1) + 2 * lh));
-                    a[cur ^ 1][1] = *reinterpret_cast<const f32x4*>(sK + swz(ra, 4 * (g + 1) + 2 * lh + 1));
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    const f32x4 x0 = *reinterpret_cast<const f32x4*>(sK + swz(32 * i + li, 4 * g + 2 * lh));
+                    const f32x4 x1 = *reinterpret_cast<const f32x4*>(sK + swz(32 * i + li, 4 * g + 2 * lh + 1));
+                    bf16x8 ah, al;
+                    if constexpr (PREC == 2) split8(x0, x1, ah, al);
+                    else { ah = cvt8(x0, x1); al = ah; }
+                    mfma_lp<PREC == 2>(acc[i], ah, al, qh[g], ql[PREC == 2 ? g : 0]);
                 }
-                bf16x8 ah, al;
-                if constexpr (PREC == 2) split8(a[cur][0], a[cur][1], ah, al);
-                else { ah = cvt8(a[cur][0], a[cur][1]); al = ah; }
-                mfma_lp<PREC == 2>(acc, ah, al, qh[g], ql[PREC == 2 ? g : 0]);
             }
         }
-        const int rb = b0 + wr * 32 + 4 * lh;
         if (MODE == 0) {
             if (b0 + CH <= B) {                          // whole chunk inside the bank (all but the last): no row checks
-                float mx = acc[0];
+                float mx = acc[0][0];
 #pragma unroll
-                for (int r = 1; r < 16; ++r) mx = fmaxf(mx, acc[r]);
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) mx = fmaxf(mx, acc[i][r]);
                 const float mn = fmaxf(run_m, mx * p.scale);     // scale > 0: max commutes with it
                 float sum = 0.f;
 #pragma unroll
-                for (int r = 0; r < 16; ++r) sum += fast_exp(acc[r] * p.scale - mn);
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) sum += fast_exp(acc[i][r] * p.scale - mn);
                 run_l = run_l * expf(run_m - mn) + sum;       // exp(-inf)=0 on the first chunk
                 run_m = mn;
             } else {
                 float mx = -INFINITY;
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int row = rb + (r & 3) + 8 * (r >> 2);
-                    const float s_ = acc[r] * p.scale;
-                    acc[r] = s_;
-                    if (row < B) mx = fmaxf(mx, s_);
-                }
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int row = b0 + 32 * i + 4 * lh + (r & 3) + 8 * (r >> 2);
+                        const float s_ = acc[i][r] * p.scale;
+                        acc[i][r] = s_;
+                        if (row < B) mx = fmaxf(mx, s_);
+                    }
                 const float mn = fmaxf(run_m, mx);
                 if (mn > -INFINITY) {
                     float sum = 0.f;
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int row = rb + (r & 3) + 8 * (r >> 2);
-                        if (row < B) sum += fast_exp(acc[r] - mn);
-                    }
+                    for (int i = 0; i < 2; ++i)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            const int row = b0 + 32 * i + 4 * lh + (r & 3) + 8 * (r >> 2);
+                            if (row < B) sum += fast_exp(acc[i][r] - mn);
+                        }
                     run_l = run_l * expf(run_m - mn) + sum;
                     run_m = mn;
                 }
@@ -284,24 +287,26 @@ void bank_scan_kernel(const vfn_bankscan_desc p) {
         } else {
             const float* rs = p.rowscale + (size_t)obj * p.stride_rs;
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {                // registers 4g..4g+3 = rows rb+8g .. +3: one 16-byte load
-                const int row0 = rb + 8 * g;
-                f32x4 sc = {0.f, 0.f, 0.f, 0.f};
-                if (row0 < B) sc = *reinterpret_cast<const f32x4*>(rs + row0);     // (slab rows past B are finite scratch)
+            for (int i = 0; i < 2; ++i)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const int row = row0 + j;
-                    if (row < B) {
-                        const float s_ = acc[4 * g + j] * sc[j];
-                        if (s_ > run_m) { run_m = s_; run_i = row; }   // ascending rows: first max wins
+                for (int g = 0; g < 4; ++g) {            // registers 4g..4g+3 = rows +8g .. +3: one 16-byte load
+                    const int row0 = b0 + 32 * i + 4 * lh + 8 * g;
+                    f32x4 sc = {0.f, 0.f, 0.f, 0.f};
+                    if (row0 < B) sc = *reinterpret_cast<const f32x4*>(rs + row0);     // (slab rows past B are finite scratch)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int row = row0 + j;
+                        if (row < B) {
+                            const float s_ = acc[i][4 * g + j] * sc[j];
+                            if (s_ > run_m) { run_m = s_; run_i = row; }   // (ties: smaller row wins, below)
+                        }
                     }
                 }
-            }
         }
         __syncthreads();                               // next chunk landed; this buffer is free again
     }
 
-    // combine the two lane halves, then the two row-halves (waves wr = 0, 1) of each query half
+    // combine the two lane halves of a query; lanes 0..31 write the slice result
     {
         const float om = __shfl_xor(run_m, 32, 64);
         if (MODE == 0) {
@@ -315,28 +320,11 @@ void bank_scan_kernel(const vfn_bankscan_desc p) {
             if (om > run_m || (om == run_m && oi < run_i)) { run_m = om; run_i = oi; }
         }
     }
-    if (lh == 0) {
-        sRed[(wr * QT + wq * 32 + li) * 2 + 0] = run_m;
-        sRed[(wr * QT + wq * 32 + li) * 2 + 1] = (MODE == 0) ? run_l : __int_as_float(run_i);
-    }
-    __syncthreads();
-    if (tid < QT) {
-        float m = sRed[tid * 2], x = sRed[tid * 2 + 1];
-        const float om = sRed[(QT + tid) * 2], ox = sRed[(QT + tid) * 2 + 1];
-        if (MODE == 0) {
-            const float mn = fmaxf(m, om);
-            if (mn > -INFINITY) x = x * expf(m - mn) + ox * expf(om - mn);
-            else x = 0.f;
-            m = mn;
-        } else {
-            const int i0 = __float_as_int(x), i1 = __float_as_int(ox);
-            if (om > m || (om == m && i1 < i0)) { m = om; x = ox; }
-        }
-        const int q = q0 + tid;
-        if (q < p.HW) {
-            float* dst = p.part + (((size_t)obj * p.nsplit + split) * p.HW + q) * 2;
-            dst[0] = m; dst[1] = x;
-        }
+    const int q = q0 + li;
+    if (lh == 0 && q < p.HW) {
+        float* dst = p.part + (((size_t)obj * p.nsplit + split) * p.HW + q) * 2;
+        dst[0] = run_m;
+        dst[1] = (MODE == 0) ? run_l : __int_as_float(run_i);
     }
 }
 
@@ -745,7 +733,7 @@ extern "C" int vfn_bank_scan(const vfn_bankscan_desc* d, void* stream) {
         allow_lds(bank_scan_kernel<0, 2>, SCAN_LDS); allow_lds(bank_scan_kernel<1, 2>, SCAN_LDS);
         once = true;
     }
-    const dim3 grid(cdiv(d->HW, QT) * d->nsplit, d->obj_n);
+    const dim3 grid(cdiv(d->HW, QTS) * d->nsplit, d->obj_n);
     hipStream_t s = (hipStream_t)stream;
     switch (d->mode * 3 + d->precision) {
         case 0: hipLaunchKernelGGL((bank_scan_kernel<0, 0>), grid, dim3(256), SCAN_LDS, s, *d); break;

@@ -23,19 +23,21 @@ from . import _lib, ops
 from ._lib import ptr, stream, check, BankDesc, BankScanDesc
 
 DK, DV = 128, 512
-MAX_SPLIT = 16
-QT, CH = 64, 64
+MAX_SPLIT = 16            # memory-read apply: 64 query columns per workgroup
+MAX_SPLIT_SCAN = 32       # bank scans (softmax statistics, cosine arg-max): 128 query columns per workgroup
+QT, QT_SCAN, CH = 64, 128, 64
 
 
-def pick_nsplit(hw, obj_n, b_upper):
+def pick_nsplit(hw, obj_n, b_upper, qt=QT, max_split=MAX_SPLIT):
     """Bank slices per query tile: fill the 256 CUs x 2 resident workgroups in whole rounds."""
     nchunks = max(1, (b_upper + CH - 1) // CH)
-    qtiles = (hw + QT - 1) // QT
+    qtiles = (hw + qt - 1) // qt
     import os
-    if os.environ.get('VFN_NSPLIT'):
-        return min(int(os.environ['VFN_NSPLIT']), nchunks)
+    env = 'VFN_NSPLIT' if qt == QT else 'VFN_NSPLIT_SCAN'
+    if os.environ.get(env):
+        return min(int(os.environ[env]), nchunks, max_split)
     best, best_eff = 1, -1.0
-    for s in range(1, max(1, min(nchunks // 3, MAX_SPLIT)) + 1):      # >= 3 chunks per slice
+    for s in range(1, max(1, min(nchunks // 3, max_split)) + 1):      # >= 3 chunks per slice
         blocks = qtiles * obj_n * s
         eff = blocks / (((blocks + 255) // 256) * 256)
         if eff >= best_eff:
@@ -101,7 +103,7 @@ class FeatureBank:
         self._midx = torch.empty(o, hw, dtype=torch.int32, device=dev)
         self._mcorr = torch.empty(o, hw, device=dev)
         self._app_pos = torch.empty(o, hw, dtype=torch.int32, device=dev)
-        self._part = torch.empty(o, MAX_SPLIT, hw, 2, device=dev)
+        self._part = torch.empty(o, MAX_SPLIT_SCAN, hw, 2, device=dev)
         self._stats_pinned = torch.zeros(o, 4, dtype=torch.int32).pin_memory()
         self._scratch = None
 
@@ -271,7 +273,7 @@ class FeatureBank:
 
         # cosine arg-max over the bank per new feature
         b_up = self.len_upper()
-        nsplit = pick_nsplit(hw, o, b_up)
+        nsplit = pick_nsplit(hw, o, b_up, QT_SCAN, MAX_SPLIT_SCAN)
         d = BankScanDesc()
         d.q, d.bank_k, d.bank_len, d.rowscale, d.part = ptr(new), ptr(self._kbuf), ptr(self._len_dev), ptr(self._kinv), ptr(self._part)
         d.stride_q, d.stride_k, d.stride_rs = hw * ld, cap * DK, cap
