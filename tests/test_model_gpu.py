@@ -134,6 +134,25 @@ def test_clip_vs_oracle(gpu, sd, model):
     assert min(ious) >= 0.99, ious
 
 
+def test_clip_with_eviction_every_frame(gpu, sd, model):
+    """Free-running loop with a budget so small that FeatureBank.remove() (LFU eviction, FeatureBank.py:117-143)
+    fires on every update: bank sizes, peak / replace counters and labels against the oracle."""
+    from vfloodnet_amd import synth
+    from vfloodnet_amd.video_seg import run_clip
+    from oracle import afb_urr_ref as O
+    frames, m0 = synth.clip(8, 12, 160, 256)
+    torch.set_num_threads(8)
+    budget = 1200                                           # class_budget = 0.8 * 600 = 480 < 3 frames of 160 entries
+    ref = O.run_clip(sd, frames, m0, size=160, budget=budget)
+    out = run_clip(model, frames.to(gpu), m0, size=160, budget=budget)
+    assert max(max(b) for b in ref['bank_sizes']) <= 480 and ref['fb'].replace_n.sum() > 0
+    assert out['bank_sizes'] == ref['bank_sizes']
+    assert np.array_equal(out['fb'].peak_n, ref['fb'].peak_n)
+    assert np.abs(out['fb'].replace_n - ref['fb'].replace_n).max() <= 2
+    ious = [miou(out['labels'][t], ref['labels'][t]) for t in range(1, 12)]
+    assert min(ious) >= 0.99, ious
+
+
 def test_cpu_device_fails_loudly(sd):
     from vfloodnet_amd import AFB_URR, FeatureBank
     m = AFB_URR('cpu', update_bank=True, _allow_cpu_container=True).eval()
@@ -146,7 +165,7 @@ def test_cpu_device_fails_loudly(sd):
 def test_c3_shape_720p_mem_every_5(gpu, sd, model):
     """BASELINE config C3's shape at reference semantics: a 1280x720 clip is resized (bicubic, HIP kernel) to
     853x480, padded to 864x480, the bank is updated every 5th frame (harness option; the reference memorises every
-    frame) -- fp32 here; the bf16 variant of C3 is not built yet."""
+    frame) -- fp32 here; bench.py --workload C3 --precision bf16x3|bf16 runs the reduced-precision variants."""
     from vfloodnet_amd import synth
     from vfloodnet_amd.video_seg import run_clip
     from oracle import afb_urr_ref as O
