@@ -353,6 +353,35 @@ __global__ void bank_scan_finish_kernel(const float* __restrict__ part, int nspl
     else { idx[i] = __float_as_int(x); corr[i] = m * colscale[i]; }
 }
 
+// p = exp(scale*s - m) * (1/l) for the 16 scores of a lane (branch-free: an out-of-range query carries m = +big and
+// 1/l = 0, rows past the bank end are masked only in the last chunk), and the hit counts of the wave's 32 bank rows:
+// 16 ballots give 32 row masks (lanes 0-31: row (r&3)+8*(r>>2), lanes 32-63: that + 4); their popcounts are dropped
+// into lane = row of `cnt` with v_writelane -- no divergent branch anywhere.
+__device__ __forceinline__ int softmax_hits(f32x16& acc, float scale, float qm, float qinv, float thres, int nvalid, int rloc) {
+    int cnt = 0;
+    const float sm = -qm;
+    if (nvalid >= CH) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = fast_exp(fmaf(acc[r], scale, sm)) * qinv;
+    } else {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int rr = rloc + (r & 3) + 8 * (r >> 2);
+            const float pv = fast_exp(fmaf(acc[r], scale, sm)) * qinv;
+            acc[r] = rr < nvalid ? pv : 0.f;
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const unsigned long long hit = __ballot(acc[r] > thres);
+        const int rlo = (r & 3) + 8 * (r >> 2);
+        const int c_lo = __popcll(hit & 0xffffffffull), c_hi = __popcll(hit >> 32);      // wave-uniform
+        asm volatile("v_writelane_b32 %0, %1, %2" : "+v"(cnt) : "s"(c_lo), "n"(rlo));
+        asm volatile("v_writelane_b32 %0, %1, %2" : "+v"(cnt) : "s"(c_hi), "n"(rlo + 4));
+    }
+    return cnt;                                       // lane i (0..31) holds the hits of chunk-local row 32*wr + i
+}
+
 // ------------------------------------------------------------------ pass 2: P^T V and hit counts
 __global__ __launch_bounds__(256, 2)
 void memread_apply_kernel(const vfn_memread_desc p) {
@@ -396,12 +425,11 @@ void memread_apply_kernel(const vfn_memread_desc p) {
 
     const int qcol = wq * 32 + li;                   // this lane's query column in the score tile
     const bool qok = (q0 + qcol) < p.HW;
-    float qm = 0.f, ql = 1.f;                        // softmax statistics of this lane's query (pass 1)
-    if (qok) {
+    float qm = 1e30f, qinv = 0.f;                    // softmax statistics of this lane's query (pass 1);
+    if (qok) {                                       // a column past HW gets p = exp(-big) * 0 = 0
         qm = p.ml[((size_t)obj * p.HW + q0 + qcol) * 2];
-        ql = p.ml[((size_t)obj * p.HW + q0 + qcol) * 2 + 1];
+        qinv = 1.f / p.ml[((size_t)obj * p.HW + q0 + qcol) * 2 + 1];
     }
-    const float qinv = 1.f / ql;
 
     for (int c = c_lo; c < c_hi; ++c) {
         const int b0 = c * CH;
@@ -412,21 +440,7 @@ void memread_apply_kernel(const vfn_memread_desc p) {
 
         // p = exp(s - m) / l; hit counts; P^T -> LDS
         const int rloc = wr * 32 + 4 * lh;           // chunk-local row of register 0
-        int mycnt = 0;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int rr = rloc + (r & 3) + 8 * (r >> 2);
-            float pv = 0.f;
-            if (qok && b0 + rr < B) pv = fast_exp(acc[r] * p.scale - qm) * qinv;
-            acc[r] = pv;
-            const unsigned long long hit = __ballot(pv > p.thres);
-            // lanes 0-31 hold row (r&3)+8*(r>>2), lanes 32-63 that + 4; lane li of the lower half owns row li
-            const int rlo = (r & 3) + 8 * (r >> 2);
-            if (lh == 0) {
-                if (li == rlo) mycnt += __popcll(hit & 0xffffffffull);
-                if (li == rlo + 4) mycnt += __popcll(hit >> 32);
-            }
-        }
+        const int mycnt = softmax_hits(acc, p.scale, qm, qinv, p.thres, B - b0, rloc);
 #pragma unroll
         for (int g = 0; g < 4; ++g) {                // registers 4g..4g+3 = 4 consecutive bank rows
             const int brow = rloc + 8 * g;           // chunk-local row, multiple of 4
@@ -556,12 +570,11 @@ void memread_apply_lp_kernel(const vfn_memread_desc p) {
 
     const int qcol = wq * 32 + li;
     const bool qok = (q0 + qcol) < p.HW;
-    float qm = 0.f, ql_ = 1.f;
+    float qm = 1e30f, qinv = 0.f;
     if (qok) {
         qm = p.ml[((size_t)obj * p.HW + q0 + qcol) * 2];
-        ql_ = p.ml[((size_t)obj * p.HW + q0 + qcol) * 2 + 1];
+        qinv = 1.f / p.ml[((size_t)obj * p.HW + q0 + qcol) * 2 + 1];
     }
-    const float qinv = 1.f / ql_;
 
     for (int c = c_lo; c < c_hi; ++c) {
         const int b0 = c * CH;
@@ -606,20 +619,7 @@ void memread_apply_lp_kernel(const vfn_memread_desc p) {
 
         // p = exp(s - m) / l; hit counts; P^T -> LDS as bf16 (hi, lo)
         const int rloc = wr * 32 + 4 * lh;
-        int mycnt = 0;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int rr = rloc + (r & 3) + 8 * (r >> 2);
-            float pv = 0.f;
-            if (qok && b0 + rr < B) pv = fast_exp(acc[r] * p.scale - qm) * qinv;
-            acc[r] = pv;
-            const unsigned long long hit = __ballot(pv > p.thres);
-            const int rlo = (r & 3) + 8 * (r >> 2);
-            if (lh == 0) {
-                if (li == rlo) mycnt += __popcll(hit & 0xffffffffull);
-                if (li == rlo + 4) mycnt += __popcll(hit >> 32);
-            }
-        }
+        const int mycnt = softmax_hits(acc, p.scale, qm, qinv, p.thres, B - b0, rloc);
 #pragma unroll
         for (int g = 0; g < 4; ++g) {                // registers 4g..4g+3 = 4 consecutive bank rows of query qcol
             const int brow = rloc + 8 * g;
