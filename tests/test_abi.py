@@ -28,7 +28,7 @@ def test_library_exports_every_declared_symbol():
     L = _lib.lib()
     for s in declared_symbols():
         assert hasattr(L, s), s
-    assert L.vfn_abi_version() == 1
+    assert L.vfn_abi_version() == 2
     assert L.vfn_conv_cfg_count() == 20
 
 

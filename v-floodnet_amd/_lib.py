@@ -67,16 +67,24 @@ class BankDesc(C.Structure):
                 ('obj_n', C.c_int), ('cap', C.c_int), ('rm_class', C.c_int), ('rm_request', C.c_int)]
 
 
+ABI_VERSION = 2          # include/vfn_hip.h descriptor layouts; csrc/abi.hip
+
+
 def lib():
-    """Load the shared library once; raise loudly if it is absent."""
+    """Load the shared library once; raise loudly if it is absent or stale."""
     global _lib
     if _lib is None:
         if not os.path.isfile(LIB_PATH):
             raise RuntimeError(
                 f'{LIB_PATH} not found: build the HIP kernels first '
                 '(python -c "import __graft_entry__ as g; g.build()" or make -C v-floodnet_amd/csrc)')
-        _lib = C.CDLL(LIB_PATH)
-        _declare(_lib)
+        L = C.CDLL(LIB_PATH)
+        L.vfn_abi_version.restype = C.c_int
+        if L.vfn_abi_version() != ABI_VERSION:
+            raise RuntimeError(f'{LIB_PATH} has ABI version {L.vfn_abi_version()}, this package expects {ABI_VERSION} '
+                               '(descriptor layouts differ): rebuild it (make -C v-floodnet_amd/csrc)')
+        _declare(L)
+        _lib = L
     return _lib
 
 
