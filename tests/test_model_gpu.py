@@ -326,3 +326,21 @@ def test_native_resolution_step(gpu, sd, model, H, W):
     margin = (pm_ref[0, 1] - pm_ref[0, 0]).abs()
     agree = (pm[0].argmax(0) == pm_ref[0].argmax(0))[margin > 1e-3].float().mean().item()
     assert agree == 1.0, agree
+
+
+def test_run_to_run_determinism(gpu, sd, model):
+    """Two runs of the same clip give bit-identical labels and bank contents: split-K slabs are reduced in slice
+    order, merges are summed in ascending source order, hit counts are integer atomics, the CCL root is the smallest
+    pixel index (torch_scatter's CUDA scatter_mean, by contrast, sums with float atomics)."""
+    from vfloodnet_amd import synth
+    from vfloodnet_amd.video_seg import run_clip
+    frames, m0 = synth.clip(9, 10, 240, 426)
+    fr = frames.to(gpu)
+    a = run_clip(model, fr, m0, size=240, budget=6000, postprocess=True)
+    b = run_clip(model, fr, m0, size=240, budget=6000, postprocess=True, overlap=False)
+    assert torch.equal(a['labels'], b['labels'])
+    assert a['bank_sizes'] == b['bank_sizes']
+    for i in range(2):
+        assert torch.equal(a['fb'].keys[i], b['fb'].keys[i])
+        assert torch.equal(a['fb'].values[i], b['fb'].values[i])
+        assert torch.equal(a['fb'].info[i], b['fb'].info[i])
