@@ -34,7 +34,7 @@ PEAKS = {'fp32': PEAK_F32_MATRIX_TFLOPS, 'bf16': PEAK_BF16_MATRIX_TFLOPS, 'bf16x
 DTYPES = {'fp32': 'f32', 'bf16': 'bf16 operands, f32 accumulate/storage', 'bf16x3': 'bf16x3 (split-bf16 operands, 3 MFMAs per product), f32 accumulate/storage'}
 WAVES = [(2, 2), (2, 2), (2, 2), (2, 2), (1, 2), (2, 1), (4, 1), (4, 2), (2, 4), (4, 2), (2, 4),
          (2, 4), (2, 4), (2, 2), (4, 2), (4, 1), (2, 2), (2, 4), (2, 4), (2, 4)]   # per conv cfg
-WORKLOADS = {'C2': (480, 854, 1), 'C3': (720, 1280, 5)}      # H0, W0, memorize every n-th frame
+WORKLOADS = {'C2': (480, 854, 1), 'C3': (720, 1280, 5), 'C5': (1080, 1920, 1)}      # H0, W0, memorize every n-th frame
 
 
 def miou(a, b):
@@ -100,12 +100,15 @@ def main():
                     help='fp32 = BASELINE config C2 (the headline, exact f32); bf16x3 / bf16 = the reduced-precision configs')
     ap.add_argument('--workload', choices=sorted(WORKLOADS), default='C2',
                     help='C2: 480x854 clip, every frame memorised; C3: 720x1280 clip (resized to 480p on the device as '
-                         'test_video_seg.py:88,107 does), bank grows with every 5th frame')
+                         'test_video_seg.py:88,107 does), bank grows with every 5th frame; C5: 1920x1080 stream, every frame '
+                         'memorised, bank budget sized so that nothing is evicted (use --steps 2000 for the full config)')
     ap.add_argument('--native', action='store_true',
                     help='run the network at the input resolution instead of the reference semantics (resize to a 480-pixel '
                          'short edge, test_video_seg.py:46,107); only meaningful with --workload C3')
     args = ap.parse_args()
     H0, W0, mem_every = WORKLOADS[args.workload]
+    if args.workload == 'C5':                      # class_budget = 0.8 * budget / 2 >= steps * HW: the bank only grows
+        args.budget = max(args.budget, 2 * int(1.25 * 2 * (args.steps + args.warmup + 2) * 1620) + 4)
     net_size = H0 if args.native else 480
     peak = PEAKS[args.precision]
 
@@ -130,9 +133,13 @@ def main():
 
     # ---- inputs resident in HBM
     seed = rank + 1
-    n_frames = min(K + 1, 400)
-    frames, m0 = synth.clip(seed, n_frames, H0, W0)
-    frames = frames.to(dev)
+    if args.workload == 'C5':
+        n_frames = K + 1                           # a stream never repeats: all frames resident (2001 x 1080p = 50 GB of HBM)
+        frames, m0 = synth.clip_on_device(seed, n_frames, H0, W0, dev)
+    else:
+        n_frames = min(K + 1, 400)                 # (longer runs cycle through the frames)
+        frames, m0 = synth.clip(seed, n_frames, H0, W0)
+        frames = frames.to(dev)
     onehot = synth.onehot(m0).unsqueeze(0).to(dev)
 
     timer = ConvTimer()

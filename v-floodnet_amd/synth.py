@@ -62,6 +62,17 @@ def clip(seed, T, H, W_):
     return frames.contiguous(), m0
 
 
+def clip_on_device(seed, T, H, W_, device):
+    """``clip`` built in device memory (frame 0 is synthesised on the host, the rolls run on the GPU): a long
+    high-resolution stream -- 2000 x 1080p = 50 GB -- never exists in host memory."""
+    f0, m0 = frame0(seed, H, W_)
+    f0 = f0.to(device)
+    frames = torch.empty(T, 3, H, W_, device=device)
+    for t in range(T):
+        frames[t] = torch.roll(f0, shifts=(2 * t, 5 * t), dims=(1, 2))
+    return frames, m0
+
+
 def onehot(mask_u8, obj_n=2):
     """``ToOnehot`` semantics (transforms.py:383-421): channel 0 = 1 - sum(objects)."""
     m = torch.zeros(obj_n, *mask_u8.shape, dtype=torch.uint8)
