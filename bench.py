@@ -11,6 +11,7 @@ RCCL all-gather inside the timed bracket (BASELINE.json config C4).
 Prints ONE JSON line (rank 0) with the driver's contract fields plus
   roofline      the dominant kernel (f32-MFMA implicit-GEMM conv): algorithmic FLOP / HIP-event time
                 measured on sampled frames of the timed region, against the 157.3 TFLOP/s f32 matrix peak
+  memory_read   the fused memory read of the sampled frames: algorithmic FLOP (scores counted once) / HIP-event time
   cpu_baseline  the CPU oracle (oracle/afb_urr_ref.py, torch CPU, all host cores) on the first
                 frames of the same clip -- a reported baseline, not the target
   parity        mIoU / max |dprob| of the HIP labels against that oracle run on the same frames.
@@ -144,6 +145,20 @@ def main():
 
     timer = ConvTimer()
     timed_launch = timer.install()
+    # the memory read (bank scan + apply + finish) of the sampled frames, timed the same way
+    from vfloodnet_amd.engine import Engine
+    mem_records = []                               # (bank entries summed over objects, HW, ev0, ev1)
+    orig_memread = Engine._memory_read
+
+    def timed_memread(self_, p_, fb_, update_bank_):
+        if not timer.active:
+            return orig_memread(self_, p_, fb_, update_bank_)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        orig_memread(self_, p_, fb_, update_bank_)
+        e1.record()
+        mem_records.append((sum(fb_._len_host), p_.HW, e0, e1))
+    Engine._memory_read = timed_memread
     eng = model.engine()
     from vfloodnet_amd.video_seg import resized_hw
     Hn, Wn = resized_hw(H0, W0, net_size)            # reference semantics: the network always sees the 480p frame
@@ -230,6 +245,17 @@ def main():
                 'all_conv_achieved': round(tot_fl / (tot_ms * 1e-3) / 1e12, 2),
                 'all_conv_frac': round(tot_fl / (tot_ms * 1e-3) / 1e12 / peak, 4)}
 
+    memread = None
+    if mem_records:
+        ms = sum(e0.elapsed_time(e1) for _, _, e0, e1 in mem_records)
+        alg = sum(1280.0 * b * hw for b, hw, _, _ in mem_records)          # 2*(128+512) FLOP per (entry, query): scores once
+        done = sum(1536.0 * b * hw for b, hw, _, _ in mem_records)         # as executed: the scores are formed in both passes
+        memread = {'kernels': 'bank_scan_kernel<0> + memread_apply kernel + finish', 'frames_timed': len(mem_records),
+                   'ms_per_frame': round(ms / len(mem_records), 3),
+                   'achieved_algorithmic': round(alg / (ms * 1e-3) / 1e12, 2), 'achieved_executed': round(done / (ms * 1e-3) / 1e12, 2),
+                   'peak': round(peak, 1), 'unit': 'TFLOP/s', 'frac_algorithmic': round(alg / (ms * 1e-3) / 1e12 / peak, 4),
+                   'mean_bank_entries_per_object': round(sum(b for b, _, _, _ in mem_records) / (2.0 * len(mem_records)), 1)}
+
     # ---- whole-frame roofline: F_min(B) = 538.48 GFLOP + 3072*B*HW
     b_mean = bank_sum / (2.0 * K)
     fps = world * K / elapsed
@@ -283,7 +309,7 @@ def main():
                       'network_resolution': f'{Hn}x{Wn} ' + ('(native)' if args.native and (Hn, Wn) == (H0, W0) else '(reference semantics: 480-pixel short edge)'),
                       'frame_mfma_frac_Fmin': round(frame_frac, 4) if mem_every == 1 else None,
                       'frame_mfma_frac_Fref_reference_equivalent': round(frame_frac_ref, 4) if mem_every == 1 else None},
-           'roofline': roof, 'cpu_baseline': cpu, 'parity': parity}
+           'roofline': roof, 'memory_read': memread, 'cpu_baseline': cpu, 'parity': parity}
     print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()
