@@ -50,7 +50,7 @@ class MemReadDesc(C.Structure):
                 ('stride_info', C.c_longlong),
                 ('scale', C.c_float), ('thres', C.c_float),
                 ('ldq', C.c_int), ('ldqv', C.c_int), ('ld_out', C.c_int), ('HW', C.c_int), ('obj_n', C.c_int),
-                ('nsplit', C.c_int), ('precision', C.c_int)]
+                ('nsplit', C.c_int), ('precision', C.c_int), ('wide', C.c_int)]
 
 
 class BankDesc(C.Structure):

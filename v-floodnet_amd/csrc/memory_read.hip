@@ -109,6 +109,7 @@ __device__ __forceinline__ void score_tile(const float* sK, const float* sQ, int
 // ---- reduced-precision operands (BASELINE configs C3 / C5; precision 1 = bf16, 2 = bf16x3)
 // 8 consecutive k of one operand row -> one v_mfma_f32_32x32x16_bf16 fragment.  bf16x3: x = hi + lo (two bf16,
 // 16 significant bits); a product is hi*hi + hi*lo + lo*hi, the 2^-16 lo*lo term is dropped.
+typedef __attribute__((ext_vector_type(2))) float f32x2;
 typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 
@@ -686,6 +687,180 @@ void memread_apply_lp_kernel(const vfn_memread_desc p) {
         }
 }
 
+// ------------------------------------------------------------------ pass 2, bf16 / bf16x3, wide query tile
+// For the bandwidth-bound regime (reduced-precision MFMAs are 5-16x faster than the f32 ones, so streaming the bank
+// becomes the cost; at the C5 sizes every query tile re-reads a multi-GB bank): 128 query columns per workgroup,
+// 8 waves.  A key chunk and a value row are fetched once per 128 queries (half the traffic of the 64-query kernel);
+// wave w owns value channels 64w..64w+63 for all 128 queries, so no value row is loaded or converted twice.
+// LDS: query image bf16 hi/lo [128][128] (32 + 32 KB), key chunk f32 [64][128] (32 KB), P^T bf16 hi/lo [128 q][64 b]
+// (16 + 16 KB): 128 KB for bf16x3, one workgroup per CU (8 waves = two per SIMD, as the other kernels).
+constexpr int QTW = 128;
+
+__device__ __forceinline__ void chunk_load_async8(float* sK, const float* src, int valid, int wave, int lane) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {                    // 8 waves x 4 instructions x 2 rows = 64 rows
+        const int r = (wave * 4 + j) * 2 + (lane >> 5);
+        const int pc = lane & 31;
+        const int rr = min(r, valid - 1);
+        const float* g = src + (size_t)rr * DK + ((pc ^ (r & 15)) << 2);
+        __builtin_amdgcn_global_load_lds(g, sK + (wave * 4 + j) * 2 * DK, 16, 0, 0);
+    }
+}
+
+template <bool X3>
+__global__ __launch_bounds__(512, 1)
+void memread_apply_lpw_kernel(const vfn_memread_desc p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* sQh = smem;                                         // [128][128] bf16
+    char* sQl = sQh + QTW * DK * 2;                           // (bf16x3 only)
+    float* sK = reinterpret_cast<float*>(sQh + (X3 ? 2 : 1) * QTW * DK * 2);   // [64][128] f32
+    char* sPh = reinterpret_cast<char*>(sK + CH * DK);        // [128 q][64 b] bf16
+    char* sPl = sPh + QTW * CH * 2;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 31, lh = lane >> 5;
+    const int wr = wave >> 2, wq = wave & 3;                  // score tile: key rows 32wr.., query columns 32wq..
+    const int split = blockIdx.x % p.nsplit;
+    const int qt = blockIdx.x / p.nsplit;
+    const int obj = blockIdx.y;
+    const int q0 = qt * QTW;
+    const int B = p.bank_len[obj];
+    const float* K = p.bank_k + (size_t)obj * p.stride_k;
+    const float* V = p.bank_v + (size_t)obj * p.stride_v;
+
+    {   // query image
+        const int c = tid & 31;
+        for (int r = tid >> 5; r < QTW; r += 16) {
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (q0 + r < p.HW) v = *reinterpret_cast<const f32x4*>(p.q + (size_t)(q0 + r) * p.ldq + c * 4);
+            bf16x4 h, l;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { h[e] = (__bf16)v[e]; l[e] = (__bf16)(v[e] - (float)h[e]); }
+            const int off = swzq(r, c >> 1) + (c & 1) * 8;
+            *reinterpret_cast<bf16x4*>(sQh + off) = h;
+            if constexpr (X3) *reinterpret_cast<bf16x4*>(sQl + off) = l;
+        }
+    }
+
+    int c_lo, c_hi;
+    chunk_range(B, p.nsplit, split, c_lo, c_hi);
+
+    f32x16 o[4][2];                                           // O^T tiles: [query tile][channel tile]
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[a][b][r] = 0.f;
+
+    // value channels of this wave: 64*wave .. +63; lane li owns channels 2*li, 2*li+1 (one per 32-wide tile tc)
+    const float* vcol = V + wave * 64 + li * 2;               // + row*512
+
+    if (c_lo < c_hi) chunk_load_async8(sK, K + (size_t)c_lo * CH * DK, min(CH, B - c_lo * CH), wave, lane);
+    __syncthreads();
+
+    const int qcol = wq * 32 + li;
+    const bool qok = (q0 + qcol) < p.HW;
+    float qm = 1e30f, qinv = 0.f;
+    if (qok) {
+        qm = p.ml[((size_t)obj * p.HW + q0 + qcol) * 2];
+        qinv = 1.f / p.ml[((size_t)obj * p.HW + q0 + qcol) * 2 + 1];
+    }
+
+    for (int c = c_lo; c < c_hi; ++c) {
+        const int b0 = c * CH;
+        const bool more = c + 1 < c_hi;
+
+        // value rows of step 0 (16 bank rows; this lane half: rows 8*lh .. +7) -- they land behind the score GEMM
+        f32x2 raw[8];
+        auto load_raw = [&](int st) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int rr = min(b0 + 16 * st + 8 * lh + j, B - 1);      // rows past the end: P is exactly 0 there
+                raw[j] = *reinterpret_cast<const f32x2*>(vcol + (size_t)rr * DV);
+            }
+        };
+        load_raw(0);
+
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+        {
+            const int ra = wr * 32 + li, rq = wq * 32 + li;
+#pragma unroll
+            for (int g = 0; g < 8; ++g) {
+                const f32x4 x0 = *reinterpret_cast<const f32x4*>(sK + swz(ra, 4 * g + 2 * lh));
+                const f32x4 x1 = *reinterpret_cast<const f32x4*>(sK + swz(ra, 4 * g + 2 * lh + 1));
+                const bf16x8 bh = *reinterpret_cast<const bf16x8*>(sQh + swzq(rq, 2 * g + lh));
+                bf16x8 bl = bh;
+                if constexpr (X3) bl = *reinterpret_cast<const bf16x8*>(sQl + swzq(rq, 2 * g + lh));
+                bf16x8 ah, al;
+                if constexpr (X3) split8(x0, x1, ah, al);
+                else { ah = cvt8(x0, x1); al = ah; }
+                mfma_lp<X3>(acc, ah, al, bh, bl);
+            }
+        }
+
+        const int rloc = wr * 32 + 4 * lh;
+        const int mycnt = softmax_hits(acc, p.scale, qm, qinv, p.thres, B - b0, rloc);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {                // registers 4g..4g+3 = 4 consecutive bank rows of query qcol
+            const int brow = rloc + 8 * g;
+            bf16x4 h, l;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { h[e] = (__bf16)acc[4 * g + e]; l[e] = (__bf16)(acc[4 * g + e] - (float)h[e]); }
+            const int off = swzp(qcol, brow >> 3) + ((brow >> 2) & 1) * 8;
+            *reinterpret_cast<bf16x4*>(sPh + off) = h;
+            if constexpr (X3) *reinterpret_cast<bf16x4*>(sPl + off) = l;
+        }
+        // one wave per 32 x 32 score tile: the four query groups add their hits of the same bank rows
+        if (p.cnt && lh == 0 && mycnt > 0) {
+            const int row = b0 + wr * 32 + li;
+            if (row < B) atomicAdd(p.cnt + (size_t)obj * p.stride_cnt + row, mycnt);
+        }
+        __syncthreads();                             // P^T visible; every wave is done reading sK
+        if (more) chunk_load_async8(sK, K + (size_t)(b0 + CH) * DK, min(CH, B - b0 - CH), wave, lane);
+
+        // O^T[q][ch] += sum_b P^T[q][b] V[b][ch]: A = P^T (rows q, 4 tiles), B = value rows (cols = channel 2li + tc)
+#pragma unroll
+        for (int st = 0; st < CH / 16; ++st) {
+            bf16x8 vh[2], vl[2];
+#pragma unroll
+            for (int tc = 0; tc < 2; ++tc)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float x = raw[j][tc];
+                    const __bf16 hx = (__bf16)x;
+                    vh[tc][j] = hx;
+                    if constexpr (X3) vl[tc][j] = (__bf16)(x - (float)hx); else vl[tc][j] = hx;
+                }
+            if (st + 1 < CH / 16) load_raw(st + 1);
+#pragma unroll
+            for (int tq = 0; tq < 4; ++tq) {
+                const bf16x8 ph = *reinterpret_cast<const bf16x8*>(sPh + swzp(tq * 32 + li, 2 * st + lh));
+                bf16x8 pl = ph;
+                if constexpr (X3) pl = *reinterpret_cast<const bf16x8*>(sPl + swzp(tq * 32 + li, 2 * st + lh));
+#pragma unroll
+                for (int tc = 0; tc < 2; ++tc) mfma_lp<X3>(o[tq][tc], ph, pl, vh[tc], vl[tc]);
+            }
+        }
+        __syncthreads();
+    }
+
+    float* dst = p.o_part + ((size_t)obj * p.nsplit + split) * p.HW * DV;
+#pragma unroll
+    for (int tq = 0; tq < 4; ++tq)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int q = q0 + tq * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+            if (q < p.HW) {
+                const f32x2 v = {o[tq][0][r], o[tq][1][r]};
+                *reinterpret_cast<f32x2*>(dst + (size_t)q * DV + wave * 64 + li * 2) = v;
+            }
+        }
+}
+
+
 // out[obj][q][0:512] = sum_split o_part ; out[obj][q][512:1024] = query value; then the hit-count bump
 __global__ void memread_finish_kernel(const vfn_memread_desc p) {
     const int obj = blockIdx.y;
@@ -773,6 +948,16 @@ extern "C" int vfn_memread_apply(const vfn_memread_desc* d, void* stream) {
         allow_lds(memread_apply_lp_kernel<false>, APPLY_LDS);
         allow_lds(memread_apply_lp_kernel<true>, APPLY_LDS);
         once = true;
+    }
+    if (d->precision != 0 && d->wide) {
+        static bool once_w = false;
+        constexpr size_t LDS_W1 = (size_t)QTW * DK * 2 + (size_t)CH * DK * 4 + 2 * (size_t)QTW * CH * 2;         // 80 KB
+        constexpr size_t LDS_W2 = LDS_W1 + (size_t)QTW * DK * 2;                                                // 112 KB + 16
+        if (!once_w) { allow_lds(memread_apply_lpw_kernel<false>, LDS_W1); allow_lds(memread_apply_lpw_kernel<true>, LDS_W2); once_w = true; }
+        const dim3 gridw(cdiv(d->HW, QTW) * d->nsplit, d->obj_n);
+        if (d->precision == 1) hipLaunchKernelGGL(memread_apply_lpw_kernel<false>, gridw, dim3(512), LDS_W1, (hipStream_t)stream, *d);
+        else hipLaunchKernelGGL(memread_apply_lpw_kernel<true>, gridw, dim3(512), LDS_W2, (hipStream_t)stream, *d);
+        return vfn_check_launch();
     }
     const dim3 grid(cdiv(d->HW, QT) * d->nsplit, d->obj_n);
     if (d->precision == 0) hipLaunchKernelGGL(memread_apply_kernel, grid, dim3(256), APPLY_LDS, (hipStream_t)stream, *d);
