@@ -173,7 +173,7 @@ typedef struct vfn_memread_desc {
     float scale, thres;
     int ldq, ldqv, ld_out, HW, obj_n, nsplit;
     int precision;         /* as vfn_bankscan_desc.precision (scores, P and value operands); softmax in f32 */
-    int wide;              /* precision != 0 only: 1 = 128 query columns per workgroup (8 waves; keys and values are
+    int wide;              /* 1 = 128 query columns per workgroup (8 waves; keys and values are
                               streamed half as often -- the large-bank / bandwidth-bound regime); the slices of
                               o_part are then chosen for ceil(HW/128) query tiles */
 } vfn_memread_desc;

@@ -166,7 +166,7 @@ def test_memory_read(gpu, B, HW):
     fb._ibuf[:, :B, 1] = 0.5
     plan = types.SimpleNamespace(HW=HW, kv_q=kvq.to(gpu), ml=torch.empty(2, HW, 2, device=gpu),
                                  ml_part=torch.empty(2, 32, HW, 2, device=gpu),
-                                 o_part=torch.empty(2, 16, HW, 512, device=gpu),
+                                 o_part=torch.empty(2, 20, HW, 512, device=gpu),
                                  dec_in=torch.empty(2, HW, 512, device=gpu))
     Engine._memory_read(types.SimpleNamespace(mode=0), plan, fb, True)
     torch.cuda.synchronize()
@@ -219,7 +219,7 @@ def test_memory_read_reduced_precision(gpu, B, HW, mode):
     fb._set_lengths([B, B])
     plan = types.SimpleNamespace(HW=HW, kv_q=kvq.to(gpu), ml=torch.empty(2, HW, 2, device=gpu),
                                  ml_part=torch.empty(2, 32, HW, 2, device=gpu),
-                                 o_part=torch.empty(2, 16, HW, 512, device=gpu),
+                                 o_part=torch.empty(2, 20, HW, 512, device=gpu),
                                  dec_in=torch.empty(2, HW, 512, device=gpu))
     Engine._memory_read(types.SimpleNamespace(mode=mode), plan, fb, True)
     torch.cuda.synchronize()

@@ -861,6 +861,128 @@ void memread_apply_lpw_kernel(const vfn_memread_desc p) {
 }
 
 
+// ------------------------------------------------------------------ pass 2 (f32), wide query tile
+// 128 query columns per workgroup, 8 waves: the score tile is 64 x 128 (one 32x32 tile per wave), wave w then owns
+// value channels 64w..64w+63 for all 128 queries.  Same MFMA work per wave as memread_apply_kernel, but a key chunk
+// and a value row are fetched once per 128 queries and a chunk costs one barrier pair per 128 queries.
+// LDS: queries [128][128] 64 KB + key chunk 32 KB + P^T [128 q][64 b] 32 KB = 128 KB, one workgroup per CU.
+__global__ __launch_bounds__(512, 1)
+void memread_apply_wide_kernel(const vfn_memread_desc p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* sQ = reinterpret_cast<float*>(smem);      // [128][128]
+    float* sK = sQ + QTW * DK;                       // [64][128]
+    float* sP = sK + CH * DK;                        // [128 q][64 b]  (P^T)
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 31, lh = lane >> 5;
+    const int wr = wave >> 2, wq = wave & 3;
+    const int split = blockIdx.x % p.nsplit;
+    const int qt = blockIdx.x / p.nsplit;
+    const int obj = blockIdx.y;
+    const int q0 = qt * QTW;
+    const int B = p.bank_len[obj];
+    const float* K = p.bank_k + (size_t)obj * p.stride_k;
+    const float* V = p.bank_v + (size_t)obj * p.stride_v;
+
+    {   // query image (zero past HW)
+        const int c = tid & 31;
+        for (int r = tid >> 5; r < QTW; r += 16) {
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (q0 + r < p.HW) v = *reinterpret_cast<const f32x4*>(p.q + (size_t)(q0 + r) * p.ldq + c * 4);
+            *reinterpret_cast<f32x4*>(sQ + swz(r, c)) = v;
+        }
+    }
+
+    int c_lo, c_hi;
+    chunk_range(B, p.nsplit, split, c_lo, c_hi);
+
+    f32x16 o[4][2];                                  // O^T tiles: [query tile][channel tile]
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[a][b][r] = 0.f;
+
+    const float* vcol = V + wave * 64 + li * 2;      // + row*512; lane li owns channels 2*li, 2*li+1 (tile tc)
+
+    if (c_lo < c_hi) chunk_load_async8(sK, K + (size_t)c_lo * CH * DK, min(CH, B - c_lo * CH), wave, lane);
+    __syncthreads();
+
+    const int qcol = wq * 32 + li;
+    const bool qok = (q0 + qcol) < p.HW;
+    float qm = 1e30f, qinv = 0.f;
+    if (qok) {
+        qm = p.ml[((size_t)obj * p.HW + q0 + qcol) * 2];
+        qinv = 1.f / p.ml[((size_t)obj * p.HW + q0 + qcol) * 2 + 1];
+    }
+
+    for (int c = c_lo; c < c_hi; ++c) {
+        const int b0 = c * CH;
+        const bool more = c + 1 < c_hi;
+
+        f32x16 acc;
+        score_tile(sK, sQ, wr, wq, li, lh, acc);
+
+        const int rloc = wr * 32 + 4 * lh;
+        const int mycnt = softmax_hits(acc, p.scale, qm, qinv, p.thres, B - b0, rloc);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int brow = rloc + 8 * g;
+            const f32x4 v = {acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]};
+            *reinterpret_cast<f32x4*>(sP + swz64(qcol, brow >> 2)) = v;
+        }
+        if (p.cnt && lh == 0 && mycnt > 0) {
+            const int row = b0 + wr * 32 + li;
+            if (row < B) atomicAdd(p.cnt + (size_t)obj * p.stride_cnt + row, mycnt);
+        }
+        __syncthreads();                             // P^T visible; every wave is done reading sK
+        if (more) chunk_load_async8(sK, K + (size_t)(b0 + CH) * DK, min(CH, B - b0 - CH), wave, lane);
+
+        f32x2 vb[3][4];                              // ring: value rows two k-groups ahead of their MFMAs
+        auto load_v = [&](int kk, int slot) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const int rr = min(b0 + 8 * kk + 4 * lh + t, B - 1);      // past the end: P is exactly 0 there
+                vb[slot][t] = *reinterpret_cast<const f32x2*>(vcol + (size_t)rr * DV);
+            }
+        };
+        load_v(0, 0);
+        load_v(1, 1);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int kk = 0; kk < CH / 8; ++kk) {
+            const int cur = kk % 3;
+            if (kk + 2 < CH / 8) load_v(kk + 2, (kk + 2) % 3);
+            __builtin_amdgcn_sched_barrier(0);
+            const int lc = 2 * kk + lh;
+            f32x4 a[4];
+#pragma unroll
+            for (int tq = 0; tq < 4; ++tq) a[tq] = *reinterpret_cast<const f32x4*>(sP + swz64(tq * 32 + li, lc));
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int tq = 0; tq < 4; ++tq) {
+                    o[tq][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[tq][t], vb[cur][t][0], o[tq][0], 0, 0, 0);
+                    o[tq][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[tq][t], vb[cur][t][1], o[tq][1], 0, 0, 0);
+                }
+        }
+        __syncthreads();                             // next chunk's keys visible; sP free again
+    }
+
+    float* dst = p.o_part + ((size_t)obj * p.nsplit + split) * p.HW * DV;
+#pragma unroll
+    for (int tq = 0; tq < 4; ++tq)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int q = q0 + tq * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+            if (q < p.HW) {
+                const f32x2 v = {o[tq][0][r], o[tq][1][r]};
+                *reinterpret_cast<f32x2*>(dst + (size_t)q * DV + wave * 64 + li * 2) = v;
+            }
+        }
+}
+
 // out[obj][q][0:512] = sum_split o_part ; out[obj][q][512:1024] = query value; then the hit-count bump
 __global__ void memread_finish_kernel(const vfn_memread_desc p) {
     const int obj = blockIdx.y;
@@ -948,6 +1070,14 @@ extern "C" int vfn_memread_apply(const vfn_memread_desc* d, void* stream) {
         allow_lds(memread_apply_lp_kernel<false>, APPLY_LDS);
         allow_lds(memread_apply_lp_kernel<true>, APPLY_LDS);
         once = true;
+    }
+    if (d->precision == 0 && d->wide) {
+        static bool once_f = false;
+        constexpr size_t LDS_WF = (size_t)(QTW * DK + CH * DK + QTW * CH) * sizeof(float);       // 128 KB
+        if (!once_f) { allow_lds(memread_apply_wide_kernel, LDS_WF); once_f = true; }
+        const dim3 gridw(cdiv(d->HW, QTW) * d->nsplit, d->obj_n);
+        hipLaunchKernelGGL(memread_apply_wide_kernel, gridw, dim3(512), LDS_WF, (hipStream_t)stream, *d);
+        return vfn_check_launch();
     }
     if (d->precision != 0 && d->wide) {
         static bool once_w = false;

@@ -72,8 +72,7 @@ def pad_divide_by(h, w, d=16):
     return (lw, uw, lh, uh), new_h, new_w
 
 
-WIDE_APPLY_FROM = 0                 # bank entries / object from which the wide reduced-precision apply kernel is used
-                                    # (measured faster at every size: 1.3x at 56 k entries, 1.5-1.6x from 100 k on)
+WIDE_APPLY_FROM = 0                 # bank entries / object from which the 128-query-wide apply kernels are used
 WS_FLOATS = 16 * 1024 * 1024        # split-K workspace (64 MB), shared by all launches of a plan
 _INLAUNCH_SPLITK = __import__('os').environ.get('VFN_INLAUNCH_SPLITK') == '1'
 
@@ -535,10 +534,11 @@ class Engine:
         m.scale, m.thres = scale, 1e-3
         m.ldq, m.ldqv, m.ld_out, m.HW, m.obj_n, m.nsplit = DK + DV, DK + DV, p.dec_in.shape[-1], HW, K, nsplit
         m.precision = self.mode
-        # reduced precision: 128 query columns per workgroup -- keys / values are streamed half as often and a value
-        # row is converted once per 128 queries (VFN_WIDE_APPLY=0 selects the 64-query kernel)
+        # 128 query columns per workgroup (8 waves): keys / values are streamed half as often, one barrier pair per 128
+        # queries and -- in the reduced-precision modes -- a value row is converted once per 128 queries.  Measured
+        # faster at every bank size in every mode (f32: -8 % at 56 k entries); VFN_WIDE_APPLY=0 selects the 64-query kernels
         wide = os.environ.get('VFN_WIDE_APPLY')
-        m.wide = int(self.mode != 0 and (wide == '1' or (wide is None and fb.len_upper() >= WIDE_APPLY_FROM)))
+        m.wide = int(wide == '1' or (wide is None and fb.len_upper() >= WIDE_APPLY_FROM))
         if m.wide:
             m.nsplit = pick_nsplit(HW, K, fb.len_upper(), QT_SCAN, MAX_SPLIT)
         check(L.vfn_memread_apply(_lib.C.byref(m), s), 'vfn_memread_apply')

@@ -23,7 +23,7 @@ from . import _lib, ops
 from ._lib import ptr, stream, check, BankDesc, BankScanDesc
 
 DK, DV = 128, 512
-MAX_SPLIT = 16            # memory-read apply: 64 query columns per workgroup
+MAX_SPLIT = 20            # memory-read apply slices (o_part slabs)
 MAX_SPLIT_SCAN = 32       # bank scans (softmax statistics, cosine arg-max): 128 query columns per workgroup
 QT, QT_SCAN, CH = 64, 128, 64
 
