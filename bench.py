@@ -93,7 +93,10 @@ def main():
     ap.add_argument('--budget', type=int, default=250000)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-frames', type=int, default=10, help='frames of the CPU baseline sample (after a 2-frame warm-up)')
-    ap.add_argument('--no-autotune', action='store_true')
+    ap.add_argument('--autotune', action='store_true',
+                    help='re-measure the tile / split-K choice of every conv shape before the run instead of using the shipped '
+                         'tables (tuned_gfx950*.json, from scripts/tune.py); shapes the tables lack are always measured')
+    ap.add_argument('--no-autotune', action='store_true', help='(default behaviour; kept for old command lines)')
     ap.add_argument('--no-overlap', action='store_true',
                     help="do not run the next frame's query encoder on a side stream under memorize/update")
     ap.add_argument('--sample-every', type=int, default=16, help='time the conv launches on every n-th frame')
@@ -162,8 +165,7 @@ def main():
     eng = model.engine()
     from vfloodnet_amd.video_seg import resized_hw
     Hn, Wn = resized_hw(H0, W0, net_size)            # reference semantics: the network always sees the 480p frame
-    if not args.no_autotune:
-        eng.autotune(Hn, Wn, 2)
+    eng.autotune(Hn, Wn, 2, only_missing=not args.autotune)      # the shipped tables cover C2 / C3 / C5 at reference semantics
     plan = eng.plan(Hn, Wn, 2)
     for lst in (plan.seg_pre, plan.seg_post, plan.mem):
         for l in lst:
