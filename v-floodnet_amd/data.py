@@ -68,6 +68,38 @@ def save_overlay_device(img, mask_dev, overlay_path, colors=color_palette, alpha
     Image.fromarray(ov.cpu().numpy()).save(overlay_path)
 
 
+class AsyncWriter:
+    """PNG encoding off the loop thread: zlib-compressing a 480p overlay takes 15-25 ms on one core -- more than two
+    frames of GPU time -- so ``video_seg.main`` hands finished arrays to a small thread pool (Pillow releases the GIL
+    while it encodes).  Files are byte-identical to the synchronous path; ``close()`` waits and re-raises."""
+
+    def __init__(self, workers=4):
+        from concurrent.futures import ThreadPoolExecutor
+        self._pool = ThreadPoolExecutor(max_workers=workers)
+        self._pending = []
+
+    def submit(self, fn, *args):
+        self._pending.append(self._pool.submit(fn, *args))
+        if len(self._pending) > 64:                      # bound the queue (and surface errors early)
+            self._pending.pop(0).result()
+
+    def close(self):
+        for f in self._pending:
+            f.result()
+        self._pending = []
+        self._pool.shutdown(wait=True)
+
+
+def _save_rgb(arr, path):
+    Image.fromarray(arr).save(path)
+
+
+def save_overlay_device_async(writer, img, mask_dev, overlay_path, colors=color_palette, alpha=0.4, cscale=1):
+    """``save_overlay_device`` with the PNG encoding on ``writer``'s threads."""
+    ov = ops.overlay_device(img.contiguous(), mask_dev, colors, alpha, cscale).cpu().numpy()
+    writer.submit(_save_rgb, ov, overlay_path)
+
+
 def load_image_in_PIL(path, mode='RGB'):
     """data.py:87-90."""
     img = Image.open(path)

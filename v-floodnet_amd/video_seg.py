@@ -19,7 +19,8 @@ import numpy as np
 import torch
 
 from . import ops
-from .data import color_palette, load_image_in_PIL, save_overlay, save_overlay_device, save_seg_mask
+from .data import (AsyncWriter, color_palette, load_image_in_PIL, save_overlay, save_overlay_device,
+                   save_overlay_device_async, save_seg_mask)
 from .dataset import Video_DS
 from .feature_bank import FeatureBank
 from .model import AFB_URR
@@ -38,6 +39,8 @@ def get_args(argv=None):
                         help='Max number of features that feature bank can store. Default: 300000')
     parser.add_argument('--viz', action='store_true', default=True, help='Visualize data.')
     parser.add_argument('--no-viz', dest='viz', action='store_false', help='Skip the overlay PNGs.')
+    parser.add_argument('--load-workers', type=int, default=4, help='DataLoader worker processes (frame decoding).')
+    parser.add_argument('--png-workers', type=int, default=16, help='Threads that encode the mask / overlay PNGs.')
     parser.add_argument('--model-path', type=str, default='records/video_seg_checkpoint_20200212-001734.pth',
                         help='Path to the checkpoint (default: none)')
     parser.add_argument('--update-rate', type=float, default=0.1, help='Update Rate. Impact of merging new features.')
@@ -208,7 +211,10 @@ def main(args, device):
 
     first_mask = load_image_in_PIL(mask_path, 'P')
     seq_dataset = Video_DS(img_list, first_frame, first_mask, raw_u8=True)       # uint8 over PCIe, ToTensor on the GPU
-    seq_loader = torch.utils.data.DataLoader(seq_dataset, batch_size=1, shuffle=False, num_workers=1)
+    # (the reference uses one worker; decoding is ~2 ms per 480p JPEG but the per-item hand-over costs more than that)
+    n_load = int(getattr(args, 'load_workers', 4))
+    seq_loader = torch.utils.data.DataLoader(seq_dataset, batch_size=1, shuffle=False, num_workers=n_load,
+                                             prefetch_factor=4 if n_load > 0 else None)
 
     seg_dir = os.path.join(out_dir, args.test_name, 'mask')
     os.makedirs(seg_dir, exist_ok=True)
@@ -230,16 +236,26 @@ def main(args, device):
         overlay_path = os.path.join(overlay_dir, f'{first_name}.png')
         save_overlay(ori_first_frame[0], pred, overlay_path, color_palette)
 
+    # host-side pipelining around the GPU loop (results identical to the sequential reference loop):
+    #   * one frame of look-ahead, so the next frame's encoder work overlaps this frame's memorize (ClipRunner.step)
+    #   * PNG encoding on a thread pool (AsyncWriter) -- it would otherwise bound the loop at ~40 frames/s with --viz
+    writer = AsyncWriter(getattr(args, 'png_workers', 16))
     with torch.no_grad():
+        it = iter(seq_loader)                    # (workers start decoding while the first frame is memorised)
         runner.start(ori_first_frame, ori_first_mask)
-        for idx, (frame, frame_name) in enumerate(seq_loader):
-            ori_frame = ops.to_tensor_device(frame[0].to(device)).unsqueeze(0)      # Video_DS ToTensor (:131-139)
-            pred = runner.step(ori_frame).numpy().copy()          # postprocessing_pred (:116) already ran on the GPU
+        nxt = next(it, None)
+        nxt_dev = ops.to_tensor_device(nxt[0][0].to(device)).unsqueeze(0) if nxt is not None else None   # ToTensor (:131-139)
+        while nxt is not None:
+            (frame, frame_name), ori_frame = nxt, nxt_dev
+            nxt = next(it, None)
+            nxt_dev = ops.to_tensor_device(nxt[0][0].to(device)).unsqueeze(0) if nxt is not None else None
+            pred = runner.step(ori_frame, next_frame=nxt_dev).numpy().copy()   # postprocessing_pred (:116) ran on the GPU
             seg_path = os.path.join(seg_dir, f'{frame_name[0]}.png')
-            save_seg_mask(pred, seg_path, color_palette)
+            writer.submit(save_seg_mask, pred, seg_path, color_palette)
             if args.viz:
                 overlay_path = os.path.join(overlay_dir, f'{frame_name[0]}.png')
-                save_overlay_device(ori_frame[0], runner.label_device(), overlay_path, color_palette)
+                save_overlay_device_async(writer, ori_frame[0], runner.label_device(), overlay_path, color_palette)
+    writer.close()
 
     runner.fb.print_peak_mem()
     return runner
