@@ -184,6 +184,12 @@ def main():
     runner.start(frames[0:1], onehot)
     labels = torch.empty(K + 1, H0, W0, dtype=torch.uint8, device=dev)
     labels[0] = m0.to(dev)
+    if world > 1:
+        # the collective of the timed region once, untimed: RCCL sets up its channels / buffers at the first call of a
+        # given collective and size, which would otherwise be charged to the clip
+        labels[1:].zero_()
+        vdist.gather_masks(labels.unsqueeze(0), world, rank, world)
+        torch.cuda.synchronize()
     bank_sum = 0
     bank_sizes = []
     torch.cuda.synchronize()
