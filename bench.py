@@ -129,6 +129,7 @@ def main():
     torch.cuda.set_device(dev)
 
     K, Wm = args.steps, args.warmup
+    args.sample_every = max(1, min(args.sample_every, K))       # at least one frame is sampled for the roofline
     if world > 1:       # N ranks share the host: keep the CPU-side weight synthesis of each from waking every core
         torch.set_num_threads(max(1, min(16, (os.cpu_count() or 8) // (2 * world))))
     sd = synth.make_state_dict(20200212)
