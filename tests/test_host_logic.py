@@ -146,3 +146,18 @@ def test_overlay_matches_reference_formula():
     ref[mask == 1] = canvas[mask == 1]
     ref[binary_dilation(mask == 1) ^ (mask == 1), :] = 0
     assert np.array_equal(out, ref)
+
+
+def test_bench_and_entry_modules_import_on_cpu():
+    """bench.py / __graft_entry__.py only touch the GPU inside main() / smoke(): importing them here catches syntax
+    and contract regressions (the driver's JSON fields) without a device."""
+    import importlib
+    import os
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    bench = importlib.import_module('bench')
+    assert set(bench.WORKLOADS) == {'C2', 'C3', 'C5'} and bench.WORKLOADS['C2'] == (480, 854, 1)
+    assert bench.PEAKS['fp32'] == 157.3 and abs(bench.PEAKS['bf16x3'] * 3 - bench.PEAKS['bf16']) < 1e-9
+    entry = importlib.import_module('__graft_entry__')
+    assert callable(entry.build) and callable(entry.smoke)
