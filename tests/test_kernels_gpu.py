@@ -279,6 +279,21 @@ def test_device_ccl_matches_host_and_oracle(gpu):
         s_[r, :] = 1
         s_[r:r + 4, 63 if (r // 4) % 2 == 0 else 0] = 1
     cases.append(s_)
+    # run-based merging: diagonal-only connectivity, checkerboards, runs crossing / ending at the 64-pixel segment
+    # boundaries of a row, single-pixel runs touching only by a corner
+    d = np.zeros((70, 200), np.uint8)
+    for k in range(70):
+        d[k, k] = 1; d[k, 199 - k] = 1                     # two diagonals that cross (one component)
+    d[5:9, 100:140] = 1
+    cases.append(d)
+    cases.append((np.indices((33, 131)).sum(0) % 2).astype(np.uint8))           # checkerboard: all 8-connected
+    e = np.zeros((10, 300), np.uint8)
+    e[2, 60:70] = 1; e[3, 70:130] = 1; e[4, 127:129] = 1; e[5, 129] = 1; e[6, 63] = 1; e[7, 64:128] = 1; e[8, 128] = 1
+    cases.append(e)
+    f_ = np.zeros((40, 64 * 3 + 5), np.uint8); f_[::2, :] = 1; f_[1::4, 63] = 1; f_[3::4, 64] = 1   # comb joined at a seam
+    cases.append(f_)
+    for thr in (0.4, 0.5, 0.6):
+        cases.append((rng.rand(61, 257) > thr).astype(np.uint8))
     for x in cases:
         ref = O.postprocessing_pred(x.copy())
         assert np.array_equal(postprocessing_pred(x), ref)

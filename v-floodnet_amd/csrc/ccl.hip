@@ -5,8 +5,8 @@
 // Union-find with atomicMin on a parent array (root = smallest pixel index of the component, i.e. its first
 // pixel in raster order -- the order in which OpenCV / the reference's `for i in range(label_cnt)` loop meets
 // the components, so size ties resolve to the same component):
-//   1. init      parent[i] = i for water pixels, -1 for background
-//   2. merge     every water pixel unions itself with its W, NW, N, NE water neighbours
+//   1. init      parent[i] = start of i's horizontal run inside its 64-pixel row segment (one ballot), -1 for background
+//   2. merge     runs are united with the runs of the row above that touch them (8-connectivity), once per pair
 //   3. flatten   parent[i] = root(i); count[root] += 1
 //   4. pick      arg-max of count (ties: smallest root) ; number of components
 //   5. write     out = (root == best), with the reference's special cases:
@@ -39,36 +39,69 @@ __device__ __forceinline__ void uf_union(int* parent, int a, int b) {
     }
 }
 
-__global__ void ccl_init_kernel(const unsigned char* __restrict__ pred, int* __restrict__ parent, int* __restrict__ count, int n) {
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-        parent[i] = pred[i] ? i : -1;
+// One wave per 64-pixel segment of a row.  A pixel's first parent is the start of its horizontal run inside the
+// segment (found with one ballot), so a run is a depth-1 tree before any atomic is issued.
+__global__ void ccl_init_kernel(const unsigned char* __restrict__ pred, int* __restrict__ parent, int* __restrict__ count,
+                                int H, int W, int segs) {
+    const int lane = threadIdx.x & 63;
+    const int seg = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    if (seg >= H * segs) return;                                        // (whole waves leave together)
+    const int y = seg / segs, x0 = (seg - y * segs) * 64, x = x0 + lane;
+    const bool in = x < W;
+    const int i = y * W + x;
+    const bool water = in && pred[i];
+    const unsigned long long mask = __ballot(water);
+    const unsigned long long below = ~mask & ((1ull << lane) - 1ull);   // non-water lanes below this one
+    const int start = below ? 64 - __clzll(below) : 0;
+    if (in) {
+        parent[i] = water ? (y * W + x0 + start) : -1;
         count[i] = 0;
     }
 }
 
-__global__ void ccl_merge_kernel(const unsigned char* __restrict__ pred, int* __restrict__ parent, int H, int W) {
-    const int n = H * W;
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-        if (!pred[i]) continue;
-        const int y = i / W, x = i - y * W;
-        if (x > 0 && pred[i - 1]) uf_union(parent, i, i - 1);
-        if (y > 0) {
-            if (pred[i - W]) {
-                uf_union(parent, i, i - W);          // N is water: NW / NE, if water, hang on N through its own W links
-            } else {
-                if (x > 0 && pred[i - W - 1]) uf_union(parent, i, i - W - 1);
-                if (x < W - 1 && pred[i - W + 1]) uf_union(parent, i, i - W + 1);
-            }
-        }
+// Unions between runs only: a run R = [xs, xe] of row y is united with every run of row y-1 that overlaps
+// [xs-1, xe+1] (8-connectivity), exactly once per pair -- at the above-run's first pixel inside that window.
+// (A per-pixel formulation issues ~4 atomics per water pixel; this one a handful per run.)
+__global__ void ccl_merge_kernel(const unsigned char* __restrict__ pred, int* __restrict__ parent, int H, int W, int segs) {
+    const int lane = threadIdx.x & 63;
+    const int seg = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    if (seg >= H * segs) return;
+    const int y = seg / segs, x0 = (seg - y * segs) * 64, x = x0 + lane;
+    if (x >= W) return;
+    const int i = y * W + x;
+    if (!pred[i]) return;
+    const bool left = x > 0 && pred[i - 1];
+    const bool right = x < W - 1 && pred[i + 1];
+    if (lane == 0 && left) uf_union(parent, i, i - 1);                  // the run continues from the previous segment
+    if (y > 0) {
+        const bool up = pred[i - W];
+        const bool upl = x > 0 && pred[i - W - 1];
+        const bool upr = x < W - 1 && pred[i - W + 1];
+        if (up && !upl) uf_union(parent, i, i - W);                     // an above-run begins here, inside [xs, xe]
+        if (!left && upl) uf_union(parent, i, i - W - 1);               // x = xs: the above-run that covers xs-1
+        if (!right && upr && !up) uf_union(parent, i, i - W + 1);       // x = xe: an above-run that begins at xe+1
     }
 }
 
+// parent[i] = root(i); count[root] += 1, aggregated per wave (most waves sit inside one component: one atomic)
 __global__ void ccl_flatten_kernel(int* __restrict__ parent, int* __restrict__ count, int n) {
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-        if (parent[i] < 0) continue;
-        const int r = uf_find(parent, i);
-        parent[i] = r;                                   // safe: r is a root, roots never change after the merge pass
-        atomicAdd(&count[r], 1);
+    const int lane = threadIdx.x & 63;
+    const int nround = (n + (int)(gridDim.x * blockDim.x) - 1) / (int)(gridDim.x * blockDim.x);
+    for (int k = 0; k < nround; ++k) {
+        const int i = (k * gridDim.x + blockIdx.x) * blockDim.x + threadIdx.x;
+        int r = -1;
+        if (i < n && parent[i] >= 0) {
+            r = uf_find(parent, i);
+            parent[i] = r;                               // safe: r is a root, roots never change after the merge pass
+        }
+        unsigned long long todo = __ballot(r >= 0);
+        while (todo) {                                   // one atomic per distinct root in the wave
+            const int leader = __ffsll((long long)todo) - 1;
+            const int rl = __shfl(r, leader, 64);
+            const unsigned long long same = __ballot(r == rl);
+            if (lane == leader) atomicAdd(&count[rl], __popcll(same));
+            todo &= ~same;
+        }
     }
 }
 
@@ -90,9 +123,16 @@ __global__ void ccl_pick_kernel(const int* __restrict__ parent, const int* __res
         key = other > key ? other : key;
         ncomp += __shfl_xor(ncomp, o, 64);
     }
-    if ((threadIdx.x & 63) == 0) {
-        atomicMax(reinterpret_cast<unsigned long long*>(result + 4), key);
-        atomicAdd(&result[2], ncomp);
+    // one pair of atomics per workgroup (a 64-bit atomicMax on one hot address is slow when every wave issues it)
+    __shared__ unsigned long long s_key[16];
+    __shared__ int s_n[16];
+    const int wave = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+    if ((threadIdx.x & 63) == 0) { s_key[wave] = key; s_n[wave] = ncomp; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < nw; ++w) { key = s_key[w] > key ? s_key[w] : key; ncomp += s_n[w]; }
+        if (key) atomicMax(reinterpret_cast<unsigned long long*>(result + 4), key);
+        if (ncomp) atomicAdd(&result[2], ncomp);
     }
 }
 
@@ -123,10 +163,12 @@ extern "C" int vfn_postprocess_pred_device_u8(const unsigned char* pred, unsigne
     hipStream_t s = (hipStream_t)stream;
     const int blocks = cdiv(n, 256) < 2048 ? cdiv(n, 256) : 2048;
     hipMemsetAsync(result, 0, 8 * sizeof(int), s);
-    hipLaunchKernelGGL(ccl_init_kernel, dim3(blocks), dim3(256), 0, s, pred, parent, count, n);
-    hipLaunchKernelGGL(ccl_merge_kernel, dim3(blocks), dim3(256), 0, s, pred, parent, H, W);
+    const int segs = cdiv(W, 64);                                  // 64-pixel row segments, one wave each
+    const int rblocks = cdiv(H * segs, 4);                         // 4 waves per workgroup
+    hipLaunchKernelGGL(ccl_init_kernel, dim3(rblocks), dim3(256), 0, s, pred, parent, count, H, W, segs);
+    hipLaunchKernelGGL(ccl_merge_kernel, dim3(rblocks), dim3(256), 0, s, pred, parent, H, W, segs);
     hipLaunchKernelGGL(ccl_flatten_kernel, dim3(blocks), dim3(256), 0, s, parent, count, n);
-    hipLaunchKernelGGL(ccl_pick_kernel, dim3(blocks < 256 ? blocks : 256), dim3(256), 0, s, parent, count, result, n);
+    hipLaunchKernelGGL(ccl_pick_kernel, dim3(blocks < 128 ? blocks : 128), dim3(1024), 0, s, parent, count, result, n);
     hipLaunchKernelGGL(ccl_write_kernel, dim3(blocks), dim3(256), 0, s, pred, parent, result, out, n);
     return vfn_check_launch();
 }
