@@ -2,23 +2,37 @@
 
     python bench.py --gpus N --steps K --warmup W
 
-One *step* = one frame of ``test_video_seg.py:105-115``: bicubic resize (identity at 480p) ->
-``segment`` -> object softmax -> ``memorize`` -> ``FeatureBank.update`` -> resize+argmax -> largest-component filter -> label D2H, on a synthetic 480x854 clip (BASELINE.json config C2, fp32) that is resident in HBM when
-the timed region starts.  For N > 1 every rank runs its own clip (seed = rank + 1, weak
-scaling, no collective on the data path) and the per-clip label masks are exchanged with one
-RCCL all-gather inside the timed bracket (BASELINE.json config C4).
+One *step* = one frame of ``test_video_seg.py:105-116``: bicubic resize (identity at 480p) -> ``segment`` ->
+object softmax -> ``memorize`` -> ``FeatureBank.update`` -> resize+argmax -> largest-component filter -> label D2H,
+on a synthetic clip that is resident in HBM when the timed region starts.
+
+Workload (BASELINE.json config C2, fp32): the **100-frame 480x854 clip**, whatever ``--steps`` says.
+  * ``--steps 99`` (default): all 99 loop iterations of the clip are timed.
+  * ``--steps K < 99``: the clip still runs from its first frame; frames ``1 .. s-1`` are an untimed pre-roll
+    (they build the bank exactly as the reference loop would), the K frames ``s .. s+K-1`` are timed -- ``s`` is chosen
+    so that the mean bank size of the timed frames equals the full-clip mean (the memory read and the bank update
+    cost grows with the bank) -- and the clip is then finished untimed.  ``full_clip_fps`` reports all 99 iterations.
+``--warmup W`` steps on a throw-away bank precede everything (the contract's warm-up; repeated until the device has
+been busy for ``--min-warm-s`` so the timed region never starts on an idle-clocked GPU).
+
+``--gpus N``: every rank runs its own clip (seed = rank + 1, weak scaling, no collective on the data path) and the
+per-clip label masks are exchanged with one RCCL all-gather inside the timed bracket (config C4).  Under
+``torch.distributed.run`` the ranks come from the environment; without it (``WORLD_SIZE`` unset) this script starts
+the N ranks itself as child processes *before anything touches the GPU* and rank 0 prints the line.
 
 Prints ONE JSON line (rank 0) with the driver's contract fields plus
   roofline      the dominant kernel (f32-MFMA implicit-GEMM conv): algorithmic FLOP / HIP-event time
                 measured on sampled frames of the timed region, against the 157.3 TFLOP/s f32 matrix peak
   memory_read   the fused memory read of the sampled frames: algorithmic FLOP (scores counted once) / HIP-event time
-  cpu_baseline  the CPU oracle (oracle/afb_urr_ref.py, torch CPU, all host cores) on the first
-                frames of the same clip -- a reported baseline, not the target
-  parity        mIoU / max |dprob| of the HIP labels against that oracle run on the same frames.
+  cpu_baseline  the CPU oracle (oracle/afb_urr_ref.py, torch CPU) on the first frames of the same clip -- a
+                reported baseline, not the target
+  parity        mIoU of the HIP labels against that oracle run and against the committed reference-generated clip.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -33,9 +47,9 @@ PEAK_BF16_MATRIX_TFLOPS = 2500.0      # dense bf16 (v_mfma_f32_32x32x16_bf16: 32
 # useful-FLOP peak per precision mode: bf16x3 spends three bf16 MFMAs per product
 PEAKS = {'fp32': PEAK_F32_MATRIX_TFLOPS, 'bf16': PEAK_BF16_MATRIX_TFLOPS, 'bf16x3': PEAK_BF16_MATRIX_TFLOPS / 3}
 DTYPES = {'fp32': 'f32', 'bf16': 'bf16 operands, f32 accumulate/storage', 'bf16x3': 'bf16x3 (split-bf16 operands, 3 MFMAs per product), f32 accumulate/storage'}
-WAVES = [(2, 2), (2, 2), (2, 2), (2, 2), (1, 2), (2, 1), (4, 1), (4, 2), (2, 4), (4, 2), (2, 4),
-         (2, 4), (2, 4), (2, 2), (4, 2), (4, 1), (2, 2), (2, 4), (2, 4), (2, 4)]   # per conv cfg
 WORKLOADS = {'C2': (480, 854, 1), 'C3': (720, 1280, 5), 'C5': (1080, 1920, 1)}      # H0, W0, memorize every n-th frame
+CLIP_FRAMES = 100                     # BASELINE.json configs[1]: "100-frame 480p synthetic clip"
+PROFILE_ROUND = 'r02'
 
 
 def miou(a, b):
@@ -55,12 +69,10 @@ class ConvTimer:
         from vfloodnet_amd import ops
         self.ops = ops
         self.orig = ops.conv2d_launch
-        self.records = []        # (cfg, flops, ev0, ev1)
+        self.records = []        # (kernel key, flops, ev0, ev1)
         self.active = False
 
     def install(self):
-        ops = self.ops
-
         def timed(desc, cfg, mode=0):
             if not self.active:
                 return self.orig(desc, cfg, mode)
@@ -70,8 +82,7 @@ class ConvTimer:
             self.orig(desc, cfg, mode)
             e1.record()
             self.records.append((cfg, 2.0 * desc.M * desc.Cout * desc.KH * desc.KW * desc.Cin, e0, e1))
-        ops.conv2d_launch = timed
-        # launches were bound at plan-build time: rebind
+        self.ops.conv2d_launch = timed
         return timed
 
     def summary(self):
@@ -85,11 +96,14 @@ class ConvTimer:
         return per
 
 
-def main():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=99)
     ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--min-warm-s', type=float, default=1.0,
+                    help='keep repeating the warm-up steps until the device has been busy this long (clock ramp after the '
+                         'CPU-only weight synthesis); 0 = exactly --warmup steps')
     ap.add_argument('--budget', type=int, default=250000)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-frames', type=int, default=10, help='frames of the CPU baseline sample (after a 2-frame warm-up)')
@@ -103,22 +117,114 @@ def main():
     ap.add_argument('--precision', choices=sorted(PEAKS), default='fp32',
                     help='fp32 = BASELINE config C2 (the headline, exact f32); bf16x3 / bf16 = the reduced-precision configs')
     ap.add_argument('--workload', choices=sorted(WORKLOADS), default='C2',
-                    help='C2: 480x854 clip, every frame memorised; C3: 720x1280 clip (resized to 480p on the device as '
-                         'test_video_seg.py:88,107 does), bank grows with every 5th frame; C5: 1920x1080 stream, every frame '
-                         'memorised, bank budget sized so that nothing is evicted (use --steps 2000 for the full config)')
+                    help='C2: 100-frame 480x854 clip, every frame memorised; C3: 100-frame 720x1280 clip (resized to 480p on '
+                         'the device as test_video_seg.py:88,107 does), bank grows with every 5th frame; C5: 1920x1080 stream of '
+                         '--steps frames, every frame memorised, bank budget sized so that nothing is evicted (--steps 2000 for '
+                         'the full config)')
     ap.add_argument('--native', action='store_true',
                     help='run the network at the input resolution instead of the reference semantics (resize to a 480-pixel '
                          'short edge, test_video_seg.py:46,107); only meaningful with --workload C3')
-    args = ap.parse_args()
+    ap.add_argument('--launch-check', action='store_true',
+                    help='bring the N ranks up, run the mask all-gather on a dummy clip and print the line skeleton without '
+                         'touching the GPU (tests/test_bench_launch.py: the launch logic on a CPU-only machine)')
+    return ap.parse_args(argv)
+
+
+# ------------------------------------------------------------------------------------------------ launch
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def self_launch(args, argv):
+    """``python bench.py --gpus N`` without torchrun: start N ranks as *child processes* (this parent never touches
+    the GPU: no exec of an initialised process, see the harness notes), one per device, rank 0 prints the line.
+    The seam in the reference is the sequential loop of ``scripts/batch_test_video_seg.py:40-47``."""
+    n = args.gpus
+    port = _free_port()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ)
+        env.update(RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+        env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        env.setdefault('OMP_NUM_THREADS', str(max(1, min(16, (os.cpu_count() or 8) // (2 * n)))))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env))
+    rc = 0
+    try:
+        for p in procs:
+            p.wait()
+            rc = rc or p.returncode
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()                              # exact PIDs we started
+    return rc
+
+
+def launch_check(args):
+    """The distributed bring-up + the one collective of the run, on host tensors (``gloo``)."""
+    from vfloodnet_amd import dist as vdist
+    import torch.distributed as dist
+    rank, local_rank, world = vdist.init(backend='gloo' if not torch.cuda.is_available() else None)
+    lab = torch.full((1, 4, 6, 8), rank + 1, dtype=torch.uint8)
+    allm = vdist.gather_masks(lab, world, rank, world)
+    ok = all(int(allm[c].min()) == c + 1 and int(allm[c].max()) == c + 1 for c in range(world))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps({'launch_check': True, 'n_gpus': world, 'gather_ok': bool(ok), 'gpus_arg': args.gpus}))
+    return 0 if ok else 1
+
+
+# ------------------------------------------------------------------------------------------------ timed window
+def pick_window(K, n_iter, golden_sizes=None):
+    """First timed iteration ``s`` (1-based) of a K-frame window inside a clip of ``n_iter`` iterations whose mean bank
+    size is closest to the full-clip mean.  ``golden_sizes`` = per-iteration bank sizes of the reference's own run of the
+    same clip (tests/golden/c2_480x854_100.npz) when available; the bank grows almost linearly, so without it the
+    centred window is used."""
+    if K >= n_iter:
+        return 1
+    if golden_sizes is not None and len(golden_sizes) == n_iter:
+        tot = [float(sum(x)) for x in golden_sizes]
+        full = sum(tot) / n_iter
+        best, best_d = 1, None
+        for s in range(1, n_iter - K + 2):
+            d = abs(sum(tot[s - 1:s - 1 + K]) / K - full)
+            if best_d is None or d < best_d:
+                best, best_d = s, d
+        return best
+    return 1 + (n_iter - K) // 2
+
+
+def main(argv=None):
+    argv = list(sys.argv[1:] if argv is None else argv)
+    args = parse_args(argv)
+    env_world = os.environ.get('WORLD_SIZE')
+    if env_world is None and args.gpus > 1:
+        return self_launch(args, argv)
+    if env_world is not None and int(env_world) != args.gpus and '--gpus' in ' '.join(argv):
+        raise SystemExit(f'bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={env_world} ranks')
+    if args.launch_check:
+        import vfloodnet_amd  # noqa: F401
+        return launch_check(args)
+
     H0, W0, mem_every = WORKLOADS[args.workload]
-    if args.workload == 'C5':                      # class_budget = 0.8 * budget / 2 >= steps * HW: the bank only grows
+    stream_mode = args.workload == 'C5'
+    if stream_mode:                                # class_budget = 0.8 * budget / 2 >= steps * HW: the bank only grows
         args.budget = max(args.budget, 2 * int(1.25 * 2 * (args.steps + args.warmup + 2) * 1620) + 4)
     net_size = H0 if args.native else 480
     peak = PEAKS[args.precision]
 
-    import vfloodnet_amd
-    from vfloodnet_amd import AFB_URR, synth, ops, dist as vdist
-    from vfloodnet_amd.video_seg import ClipRunner
+    import vfloodnet_amd  # noqa: F401
+    from vfloodnet_amd import AFB_URR, ops, dist as vdist
+    from vfloodnet_amd.video_seg import ClipRunner, resized_hw
+    from vfloodnet_amd.engine import Engine
+    from tools import synth
     import torch.distributed as dist
 
     rank, local_rank, world = vdist.init()
@@ -138,19 +244,30 @@ def main():
 
     # ---- inputs resident in HBM
     seed = rank + 1
-    if args.workload == 'C5':
+    if stream_mode:
         n_frames = K + 1                           # a stream never repeats: all frames resident (2001 x 1080p = 50 GB of HBM)
         frames, m0 = synth.clip_on_device(seed, n_frames, H0, W0, dev)
     else:
-        n_frames = min(K + 1, 400)                 # (longer runs cycle through the frames)
+        n_frames = CLIP_FRAMES                     # the BASELINE clip, whatever --steps is (longer runs cycle through it)
         frames, m0 = synth.clip(seed, n_frames, H0, W0)
         frames = frames.to(dev)
+    n_iter = n_frames - 1
     onehot = synth.onehot(m0).unsqueeze(0).to(dev)
+
+    golden_sizes = None
+    gpath = os.path.join(ROOT, 'tests', 'golden', 'c2_480x854_100.npz')
+    golden = None
+    if args.workload == 'C2' and os.path.isfile(gpath):
+        import numpy as np
+        golden = np.load(gpath)
+        if seed == int(golden['seed']):
+            golden_sizes = golden['bank_sizes'].tolist()
+    s_first = 1 if stream_mode else pick_window(K, n_iter, golden_sizes)
+    last_iter = max(n_iter, s_first + K - 1)        # K > 99: the timed region cycles through the clip's frames
 
     timer = ConvTimer()
     timed_launch = timer.install()
     # the memory read (bank scan + apply + finish) of the sampled frames, timed the same way
-    from vfloodnet_amd.engine import Engine
     mem_records = []                               # (bank entries summed over objects, HW, ev0, ev1)
     orig_memread = Engine._memory_read
 
@@ -164,7 +281,6 @@ def main():
         mem_records.append((sum(fb_._len_host), p_.HW, e0, e1))
     Engine._memory_read = timed_memread
     eng = model.engine()
-    from vfloodnet_amd.video_seg import resized_hw
     Hn, Wn = resized_hw(H0, W0, net_size)            # reference semantics: the network always sees the 480p frame
     eng.autotune(Hn, Wn, 2, only_missing=not args.autotune)      # the shipped tables cover C2 / C3 / C5 at reference semantics
     plan = eng.plan(Hn, Wn, 2)
@@ -173,71 +289,96 @@ def main():
             if l.fn is timer.orig:
                 l.fn = timed_launch
 
-    # ---- warm-up on a throw-away bank
-    warm = ClipRunner(model, 2, args.budget, size=net_size, mem_every=mem_every)
+    def frame_of(t):                                 # loop iteration t >= 1 -> frame index (cycling past the clip's end)
+        return ((t - 1) % n_iter) + 1
+
+    # ---- warm-up on a throw-away bank: W steps, repeated until the device has been busy for --min-warm-s
+    warm = ClipRunner(model, 2, args.budget, size=net_size, mem_every=mem_every, postprocess=True)
     warm.start(frames[0:1], onehot)
-    for t in range(1, Wm + 1):
-        warm.step(frames[(t % (n_frames - 1)) + 1:(t % (n_frames - 1)) + 2])
+    w0 = time.perf_counter()
+    warm_steps = 0
+    while warm_steps < Wm or (Wm > 0 and time.perf_counter() - w0 < args.min_warm_s and warm_steps < 400):
+        warm_steps += 1
+        warm.step(frames[frame_of(warm_steps):frame_of(warm_steps) + 1], want_label=False)
     del warm
 
-    # ---- timed region: exactly K steps
-    runner = ClipRunner(model, 2, args.budget, size=net_size, mem_every=mem_every, postprocess=True)     # largest-blob filter (:116) on the device too
+    # ---- the clip: pre-roll (untimed) | exactly K timed steps | rest of the clip (untimed)
+    runner = ClipRunner(model, 2, args.budget, size=net_size, mem_every=mem_every, postprocess=True)   # largest-blob filter (:116) on the device too
     runner.start(frames[0:1], onehot)
-    labels = torch.empty(K + 1, H0, W0, dtype=torch.uint8, device=dev)
+    n_lab = last_iter + 1
+    labels = torch.empty(n_lab, H0, W0, dtype=torch.uint8, device=dev)        # what the loop emits (after :116)
+    labels_raw = torch.empty(n_lab, H0, W0, dtype=torch.uint8, device=dev)    # before post-processing (parity vs golden)
     labels[0] = m0.to(dev)
+    labels_raw[0] = labels[0]
     if world > 1:
         # the collective of the timed region once, untimed: RCCL sets up its channels / buffers at the first call of a
         # given collective and size, which would otherwise be charged to the clip
         labels[1:].zero_()
-        vdist.gather_masks(labels.unsqueeze(0), world, rank, world)
+        vdist.gather_masks(labels[s_first:s_first + K].unsqueeze(0), world, rank, world)
         torch.cuda.synchronize()
-    bank_sum = 0
     bank_sizes = []
-    torch.cuda.synchronize()
+    frame_ms = []
+
+    def run_iters(t_from, t_to, sampling):
+        for t in range(t_from, t_to + 1):
+            idx = frame_of(t)
+            timer.active = sampling and ((t - s_first + 1) % args.sample_every == 0)
+            # no prefetch into / out of a sampled frame: its kernels are timed alone on the device
+            sampled_next = sampling and ((t - s_first + 2) % args.sample_every == 0)
+            nxt = frame_of(t + 1) if (t < last_iter and not args.no_overlap and not timer.active and not sampled_next) else None
+            c0 = time.perf_counter()
+            runner.step(frames[idx:idx + 1], want_label=False,
+                        next_frame=frames[nxt:nxt + 1] if nxt is not None else None)
+            frame_ms.append((t, 1e3 * (time.perf_counter() - c0)))
+            timer.active = False
+            labels[t].copy_(runner.label_device(), non_blocking=True)
+            labels_raw[t].copy_(runner._label_dev, non_blocking=True)
+            bank_sizes.append(runner.bank_sizes())
+
+    def bracket():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        return time.perf_counter()
+
+    clip0 = bracket()
+    run_iters(1, s_first - 1, False)                                       # untimed pre-roll
+    t0 = bracket()
+    run_iters(s_first, s_first + K - 1, True)                              # ---- exactly K timed steps
     if world > 1:
-        dist.barrier()
-    t0 = time.perf_counter()
-    for t in range(1, K + 1):
-        idx = ((t - 1) % (n_frames - 1)) + 1
-        timer.active = (t % args.sample_every == 0)
-        # no prefetch into / out of a sampled frame: its kernels are timed alone on the device
-        sampled_next = ((t + 1) % args.sample_every == 0)
-        nxt = ((t % (n_frames - 1)) + 1) if (t < K and not args.no_overlap and not timer.active and not sampled_next) else None
-        runner.step(frames[idx:idx + 1], want_label=False,
-                    next_frame=frames[nxt:nxt + 1] if nxt is not None else None)
-        timer.active = False
-        labels[t].copy_(runner._label_dev, non_blocking=True)
-        bank_sum += sum(runner.bank_sizes())
-        bank_sizes.append(runner.bank_sizes())
+        vdist.gather_masks(labels[s_first:s_first + K].unsqueeze(0), world, rank, world)   # one RCCL all-gather
+    t1 = bracket()
+    run_iters(s_first + K, last_iter, False)                               # rest of the clip, untimed
     if world > 1:
-        all_labels = vdist.gather_masks(labels.unsqueeze(0), world, rank, world)   # one RCCL all-gather
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    t1 = time.perf_counter()
-    elapsed = torch.tensor([t1 - t0], dtype=torch.float64, device=dev if (world == 1 or dist.get_backend() == 'nccl') else 'cpu')
-    if world > 1:
-        dist.all_reduce(elapsed, op=dist.ReduceOp.MAX)
-    elapsed = float(elapsed.item())
+        vdist.gather_masks(labels[1:].unsqueeze(0), world, rank, world)
+    clip1 = bracket()
+
+    def max_over_ranks(x):
+        v = torch.tensor([x], dtype=torch.float64, device=dev if (world == 1 or dist.get_backend() == 'nccl') else 'cpu')
+        if world > 1:
+            dist.all_reduce(v, op=dist.ReduceOp.MAX)
+        return float(v.item())
+    elapsed = max_over_ranks(t1 - t0)
+    clip_elapsed = max_over_ranks(clip1 - clip0)
 
     if rank != 0:
         if world > 1:
             dist.destroy_process_group()
-        return
+        return 0
 
     # ---- roofline of the dominant kernel
     per = timer.summary()
     roof = None
     if per:
-        tiles = ops.conv_cfg_tiles()
+        names = ops.conv_cfg_names(ops.MODES[args.precision])
         dom = max(per, key=lambda c: per[c][1])
         tot_fl = sum(v[0] for v in per.values())
         tot_ms = sum(v[1] for v in per.values())
         fl, ms, n = per[dom]
         ach = fl / (ms * 1e-3) / 1e12
-        kname = f'conv_igemm_kernel<{tiles[dom][0]}, {tiles[dom][1]}, {WAVES[dom][0]}, {WAVES[dom][1]}, {ops.MODES[args.precision]}>'
+        kname = names[dom]
         traffic = None                      # HBM bytes per launch of this kernel from the committed PMC passes
-        tname = 'r01_pmc_traffic.json' if args.precision == 'fp32' else f'r01_pmc_traffic_{args.precision}.json'
+        tname = f'{PROFILE_ROUND}_pmc_traffic.json' if args.precision == 'fp32' else f'{PROFILE_ROUND}_pmc_traffic_{args.precision}.json'
         tpath = os.path.join(ROOT, 'profiles', tname)
         if os.path.isfile(tpath):
             for k_, v_ in json.load(open(tpath)).get('kernels', {}).items():
@@ -246,11 +387,12 @@ def main():
         roof = {'bound': 'mfma', 'kernel': kname,
                 'achieved': round(ach, 2), 'peak': round(peak, 1), 'unit': 'TFLOP/s',
                 'frac': round(ach / peak, 4), 'traffic': traffic,
-                'traffic_source': f'profiles/{tname} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, FETCH doubled per MI355X_MICROARCH.md)',
+                'traffic_source': f'profiles/{tname} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes of this command, '
+                                  f'FETCH doubled per MI355X_MICROARCH.md; not re-measured in this run)',
                 'launches_timed': n, 'avg_launch_us': round(ms * 1e3 / n, 2),
                 'timing': 'HIP events around every launch of frames that take no part in the side-stream overlap (kernel alone '
-                          'on the device); rocprofv3 counterpart: profiles/r01_kernel_stats_no_overlap.csv (--no-overlap run); '
-                          'profiles/r01_kernel_stats.csv is the default command, where overlapped launches run longer',
+                          f'on the device); rocprofv3 counterpart: profiles/{PROFILE_ROUND}_kernel_stats_no_overlap.csv (--no-overlap run); '
+                          f'profiles/{PROFILE_ROUND}_kernel_stats.csv is the default command, where overlapped launches run longer',
                 'all_conv_achieved': round(tot_fl / (tot_ms * 1e-3) / 1e12, 2),
                 'all_conv_frac': round(tot_fl / (tot_ms * 1e-3) / 1e12 / peak, 4)}
 
@@ -266,63 +408,85 @@ def main():
                    'mean_bank_entries_per_object': round(sum(b for b, _, _, _ in mem_records) / (2.0 * len(mem_records)), 1)}
 
     # ---- whole-frame roofline: F_min(B) = 538.48 GFLOP + 3072*B*HW
-    b_mean = bank_sum / (2.0 * K)
+    timed_sizes = bank_sizes[s_first - 1:s_first - 1 + K]
+    b_mean = sum(sum(x) for x in timed_sizes) / (2.0 * K)
+    b_mean_clip = sum(sum(x) for x in bank_sizes[:n_iter]) / (2.0 * n_iter)
     fps = world * K / elapsed
-    HWn = ((Hn + 15) // 16) * ((Wn + 15) // 16)
+    full_clip_fps = world * last_iter / clip_elapsed
     f_min = 538.48e9 + 3072.0 * b_mean * 1620
     frame_frac = (fps / world) * f_min / (peak * 1e12)
     f_ref = 666.56e9 + 3072.0 * b_mean * 1620          # op-for-op reference FLOPs (per-object duplicate convs counted)
     frame_frac_ref = (fps / world) * f_ref / (peak * 1e12)
+    f_min_clip = 538.48e9 + 3072.0 * b_mean_clip * 1620
+    tms = sorted(ms_ for t_, ms_ in frame_ms if s_first <= t_ < s_first + K)
+    frame_stats = {'p50': round(tms[len(tms) // 2], 3), 'p90': round(tms[min(len(tms) - 1, int(0.9 * len(tms)))], 3),
+                   'max': round(tms[-1], 3), 'min': round(tms[0], 3),
+                   'note': 'host wall per step incl. its one synchronisation; sampled frames (events around every launch, no overlap) are the slow tail'}
 
     # ---- CPU baseline + parity on the first frames of the same clip
     cpu = None
     parity = None
-    if not args.no_cpu_baseline and world == 1 and args.workload == 'C2':
+    if not args.no_cpu_baseline and world == 1:
         from oracle import afb_urr_ref as O
         nthr = min(16, os.cpu_count() or 1)     # fastest setting measured on the GPU box's 256-core host (8/16/32/64/128 tried)
         torch.set_num_threads(nthr)
-        n_cpu = min(args.cpu_frames, K)
+        n_cpu = min(args.cpu_frames, last_iter)
         fr_cpu = frames[:n_cpu + 1].cpu()
-        O.run_clip(sd, fr_cpu[:2], m0, budget=args.budget)                 # warm the CPU kernels
+        kw = dict(budget=args.budget, size=net_size, mem_every=mem_every)
+        O.run_clip(sd, fr_cpu[:2], m0, **kw)                               # warm the CPU kernels
         c0 = time.perf_counter()
-        ref = O.run_clip(sd, fr_cpu, m0, budget=args.budget, return_scores=True)
+        ref = O.run_clip(sd, fr_cpu, m0, **kw)
         c1 = time.perf_counter()
         cpu = {'value': round(n_cpu / (c1 - c0), 4), 'unit': 'frames/s', 'cores': nthr, 'kind': 'port',
-               'sample': f'first {n_cpu} frames of the same 480x854 clip (incl. first-frame memorize), torch CPU oracle'}
-        lab = labels[:n_cpu + 1].cpu()
-        parity = {'frames': n_cpu,
-                  'miou_vs_oracle': round(min(miou(lab[t], ref['labels'][t]) for t in range(1, n_cpu + 1)), 5),
-                  'bank_sizes_equal': bank_sizes[:n_cpu] == ref['bank_sizes']}
+               'sample': f'first {n_cpu} frames of the same {H0}x{W0} clip (incl. first-frame memorize), torch CPU oracle '
+                         f'(oracle/afb_urr_ref.py, pinned against the reference: tests/test_oracle_golden.py)'}
+        lab = labels_raw[:n_cpu + 1].cpu()
+        ious = [miou(lab[t], ref['labels'][t]) for t in range(1, n_cpu + 1)]
+        parity = {'frames': n_cpu, 'miou_vs_oracle': round(min(ious), 5), 'miou_vs_oracle_mean': round(sum(ious) / len(ious), 5),
+                  'bank_sizes_equal': bank_sizes[:n_cpu] == ref['bank_sizes'],
+                  'oracle_dtype': 'f32 (the reduced-precision modes are compared with the f32 oracle labels)'}
 
-    gpath = os.path.join(ROOT, 'tests', 'golden', 'c2_480x854_100.npz')
-    if world == 1 and K == 99 and args.workload == 'C2' and os.path.isfile(gpath):
+    if world == 1 and golden is not None and golden_sizes is not None and last_iter >= n_iter:
         import numpy as np
-        g = np.load(gpath)
-        refl = torch.from_numpy(np.unpackbits(g['labels'], axis=-1)[..., :W0])
-        lab = labels.cpu()
-        ious = [miou(lab[t], refl[t]) for t in range(1, K + 1)]
+        refl = torch.from_numpy(np.unpackbits(golden['labels'], axis=-1)[..., :W0])
+        lab = labels_raw[:n_frames].cpu()
+        ious = [miou(lab[t], refl[t]) for t in range(1, n_frames)]
         parity = dict(parity or {})
-        parity.update({'full_clip_frames': K, 'full_clip_miou_min': round(min(ious), 5),
+        gs = golden['bank_sizes']
+        parity.update({'full_clip_frames': n_iter, 'full_clip_miou_min': round(min(ious), 5),
                        'full_clip_miou_mean': round(sum(ious) / len(ious), 5),
+                       'full_clip_bank_max_abs_diff': int(max(abs(int(a) - int(b)) for x, y in zip(bank_sizes[:n_iter], gs) for a, b in zip(x, y))),
                        'full_clip_reference': 'tests/golden/c2_480x854_100.npz (reference model + FeatureBank on CPU, '
                                               'oracle/gen_c2_golden.py)'})
 
+    timed_desc = (f'all {n_iter} loop iterations timed' if (s_first == 1 and K == n_iter) else
+                  f'{K} iterations timed' + (f' (frames {s_first}-{s_first + K - 1}; frames 1-{s_first - 1} are an untimed pre-roll that '
+                                             f'builds the bank, the clip is finished untimed)' if not stream_mode and K < n_iter else ''))
     out = {'metric': 'segmented frames/sec at 480p' if args.workload == 'C2' else f'segmented frames/sec at {H0}p', 'value': round(fps, 3), 'unit': 'frames/s', 'n_gpus': world,
            'steps': K, 'warmup': Wm, 'ms_per_step': round(1e3 * elapsed / K, 3), 'higher_is_better': True,
            'scaling': 'weak', 'vs_baseline': None, 'dtype': DTYPES[args.precision], 'data': 'synthetic',
-           'config': {'workload': f'{args.workload}: {K + 1}-frame {H0}x{W0} synthetic clip per GPU through the test_video_seg.py loop '
+           'config': {'workload': f'{args.workload}: {n_frames}-frame {H0}x{W0} synthetic clip per GPU through the test_video_seg.py loop '
                                   f'(' + ('bicubic resize to 480p+' if (Hn, Wn) != (H0, W0) else '') +
                                   f'segment+softmax+memorize' + (f' every {mem_every}th frame' if mem_every > 1 else '') +
-                                  f'+bank update+argmax+CCL), {args.precision}, budget {args.budget}',
+                                  f'+bank update+argmax+CCL), {args.precision}, budget {args.budget}; {timed_desc}',
+                      'timed_frames': [s_first, s_first + K - 1], 'preroll_frames': s_first - 1, 'warm_steps_run': warm_steps,
                       'mean_bank_entries_per_object': round(b_mean, 1),
+                      'full_clip_mean_bank_entries_per_object': round(b_mean_clip, 1),
                       'network_resolution': f'{Hn}x{Wn} ' + ('(native)' if args.native and (Hn, Wn) == (H0, W0) else '(reference semantics: 480-pixel short edge)'),
                       'frame_mfma_frac_Fmin': round(frame_frac, 4) if mem_every == 1 else None,
                       'frame_mfma_frac_Fref_reference_equivalent': round(frame_frac_ref, 4) if mem_every == 1 else None},
+           'full_clip_fps': round(full_clip_fps, 3),
+           'full_clip_frame_mfma_frac_Fmin': round((full_clip_fps / world) * f_min_clip / (peak * 1e12), 4) if mem_every == 1 else None,
+           'frame_ms': frame_stats,
            'roofline': roof, 'memory_read': memread, 'cpu_baseline': cpu, 'parity': parity}
     print(json.dumps(out))
+    if os.environ.get('VFN_BENCH_DUMP'):            # per-step host times of the whole run (diagnostics)
+        with open(os.environ['VFN_BENCH_DUMP'], 'w') as f:
+            json.dump({'frame_ms': frame_ms, 'bank_sizes': bank_sizes, 'timed': [s_first, s_first + K - 1]}, f)
     if world > 1:
         dist.destroy_process_group()
+    return 0
 
 
 if __name__ == '__main__':
-    main()
+    sys.exit(main() or 0)

@@ -24,8 +24,13 @@
 extern "C" {
 #endif
 
-/* ------------------------------------------------------------------ version */
+/* ------------------------------------------------------------------ version
+ * vfn_abi_version() == VFN_ABI_VERSION of the header the binding was written against, and
+ * vfn_sizeof_desc(which) == sizeof of the binding's own struct: checked when the library is loaded. */
+#define VFN_ABI_VERSION 3
+enum { VFN_DESC_CONV = 0, VFN_DESC_STEM = 1, VFN_DESC_BANKSCAN = 2, VFN_DESC_MEMREAD = 3, VFN_DESC_BANK = 4 };
 int vfn_abi_version(void);
+int vfn_sizeof_desc(int which);
 
 /* ------------------------------------------------------------------ conv (implicit GEMM, f32 MFMA)
  * Replaces nn.Conv2d (+ eval BatchNorm2d, + ReLU, + residual add) at
@@ -67,6 +72,9 @@ typedef struct vfn_conv_desc {
 
 int vfn_conv_cfg_count(void);
 int vfn_conv_cfg_tile(int cfg, int* bm, int* bn);
+/* tile configuration cfg: workgroup tile bm x bn, wm x wn waves, dma = 0 register-staged / 2 LDS-DMA ring;
+ * the kernel it launches is conv_igemm_kernel<bm, bn, wm, wn, MODE> (conv_igemm_dma_kernel<bm, bn, wm, wn, dma>) */
+int vfn_conv_cfg_info(int cfg, int* bm, int* bn, int* wm, int* wn, int* dma);
 int vfn_conv2d_nhwc_f32(const vfn_conv_desc* d, int cfg, void* stream);
 /* Same convolution with both operands rounded to bf16 (nearest-even) as they are staged into LDS and multiplied
  * on v_mfma_f32_32x32x16_bf16 with f32 accumulation; tensors stay f32 in HBM.  Cin must be a multiple of 64;

@@ -16,7 +16,7 @@ sys.path.insert(0, ROOT)
 
 def main(T=100, seed=1):
     import vfloodnet_amd  # noqa: F401
-    from vfloodnet_amd import synth
+    from tools import synth
     from oracle import refstubs
     from torch.nn import functional as F
     ref = refstubs.import_reference()

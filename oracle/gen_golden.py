@@ -38,7 +38,7 @@ def sample_idx(n, k, seed):
 
 def main():
     import vfloodnet_amd  # noqa: F401
-    from vfloodnet_amd import synth
+    from tools import synth
     from oracle import refstubs
     ref = refstubs.import_reference()
     os.makedirs(OUT, exist_ok=True)

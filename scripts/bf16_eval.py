@@ -4,7 +4,8 @@ import sys, os, time
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, root); sys.path.insert(0, os.path.join(root, 'tests'))
 import numpy as np, torch, vfloodnet_amd
-from vfloodnet_amd import AFB_URR, synth
+from vfloodnet_amd import AFB_URR
+from tools import synth
 from vfloodnet_amd.video_seg import run_clip
 
 gpu = torch.device('cuda', 0)

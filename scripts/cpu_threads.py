@@ -1,7 +1,7 @@
 import sys, os, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch, vfloodnet_amd
-from vfloodnet_amd import synth
+from tools import synth
 from oracle import afb_urr_ref as O
 sd = synth.make_state_dict(20200212)
 frames, m0 = synth.clip(1, 2, 480, 854)

@@ -4,7 +4,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from torch.nn import functional as F
 import vfloodnet_amd
-from vfloodnet_amd import synth, AFB_URR, FeatureBank, ops
+from vfloodnet_amd import AFB_URR, FeatureBank, ops
+from tools import synth
 from vfloodnet_amd.video_seg import ClipRunner
 from oracle import afb_urr_ref as O
 

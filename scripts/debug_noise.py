@@ -4,7 +4,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from torch.nn import functional as F
 import vfloodnet_amd
-from vfloodnet_amd import synth
+from tools import synth
 from oracle import afb_urr_ref as O
 
 H, W = 96, 160

@@ -4,7 +4,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from torch.nn import functional as F
 import vfloodnet_amd
-from vfloodnet_amd import synth, AFB_URR, FeatureBank
+from vfloodnet_amd import AFB_URR, FeatureBank
+from tools import synth
 from oracle import afb_urr_ref as O
 
 H, W = int(sys.argv[1]) if len(sys.argv) > 1 else 96, int(sys.argv[2]) if len(sys.argv) > 2 else 160

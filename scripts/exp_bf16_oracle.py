@@ -4,7 +4,7 @@ root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, root); sys.path.insert(0, os.path.join(root, 'oracle'))
 import torch, torch.nn.functional as F
 import vfloodnet_amd
-from vfloodnet_amd import synth
+from tools import synth
 import afb_urr_ref as ref
 
 H, W, T, size = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4])

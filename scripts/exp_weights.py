@@ -3,7 +3,7 @@ import sys, os, itertools
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import vfloodnet_amd
-from vfloodnet_amd import synth
+from tools import synth
 from oracle import afb_urr_ref as O
 
 def miou(x, y):

@@ -4,7 +4,8 @@ its budget and LFU eviction fires on every update (from frame ~102 on), HIP path
 import sys, os, time, json
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch, vfloodnet_amd
-from vfloodnet_amd import AFB_URR, synth
+from vfloodnet_amd import AFB_URR
+from tools import synth
 from vfloodnet_amd.video_seg import run_clip
 from oracle import afb_urr_ref as O
 

@@ -4,7 +4,8 @@ Frames are produced on the GPU by rolling frame 0 (a 2000-frame 1080p clip would
 import sys, os, json, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch, vfloodnet_amd
-from vfloodnet_amd import AFB_URR, synth
+from vfloodnet_amd import AFB_URR
+from tools import synth
 from vfloodnet_amd.video_seg import ClipRunner
 
 T = int(sys.argv[1]) if len(sys.argv) > 1 else 400

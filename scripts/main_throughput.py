@@ -4,7 +4,8 @@ import sys, os, time, argparse, tempfile
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch, vfloodnet_amd
 from PIL import Image
-from vfloodnet_amd import synth, video_seg
+from vfloodnet_amd import video_seg
+from tools import synth
 from vfloodnet_amd.data import save_seg_mask, color_palette
 
 T = int(sys.argv[1]) if len(sys.argv) > 1 else 80

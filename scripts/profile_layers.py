@@ -3,7 +3,8 @@ import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import vfloodnet_amd
-from vfloodnet_amd import AFB_URR, FeatureBank, synth, ops
+from vfloodnet_amd import AFB_URR, FeatureBank, ops
+from tools import synth
 
 dev = torch.device('cuda', 0)
 H0, W0 = 480, 854

@@ -4,7 +4,8 @@ import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 os.environ['VFN_IGNORE_TUNED'] = '1'
 import torch, vfloodnet_amd
-from vfloodnet_amd import AFB_URR, synth, engine, ops
+from vfloodnet_amd import AFB_URR, engine, ops
+from tools import synth
 prec = sys.argv[1] if len(sys.argv) > 1 else 'fp32'
 dev = torch.device('cuda', 0)
 model = AFB_URR(dev, update_bank=True, precision=prec).to(dev).eval()

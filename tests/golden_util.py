@@ -29,7 +29,7 @@ def state_dict():
     global _SD
     if _SD is None:
         import vfloodnet_amd  # noqa: F401
-        from vfloodnet_amd import synth
+        from tools import synth
         _SD = synth.make_state_dict(SEED)
         for k, ref in meta()['weights_checksum'].items():
             got = checksum(_SD[k])

@@ -28,8 +28,22 @@ def test_library_exports_every_declared_symbol():
     L = _lib.lib()
     for s in declared_symbols():
         assert hasattr(L, s), s
-    assert L.vfn_abi_version() == 2
+    hdr = open(os.path.join(ROOT, 'include', 'vfn_hip.h')).read()
+    assert L.vfn_abi_version() == _lib.ABI_VERSION == int(re.search(r'#define VFN_ABI_VERSION (\d+)', hdr).group(1))
     assert L.vfn_conv_cfg_count() == 20
+
+
+def test_descriptor_sizes_match_the_library():
+    """A binding whose ctypes struct drifted from include/vfn_hip.h is caught here (and at load time)."""
+    import ctypes as C
+    import vfloodnet_amd  # noqa: F401
+    from vfloodnet_amd import _lib
+    L = _lib.lib()
+    for which, cls in _lib.DESC_IDS.items():
+        assert L.vfn_sizeof_desc(which) == C.sizeof(cls), cls.__name__
+    assert L.vfn_sizeof_desc(99) == -1
+    names = __import__('vfloodnet_amd').ops.conv_cfg_names(0)
+    assert names[10] == 'conv_igemm_kernel<64, 128, 2, 4, 0>' and names[13] == 'conv_igemm_dma_kernel<64, 64, 2, 2, 2>'
 
 
 def test_missing_library_fails_loudly(monkeypatch):

@@ -69,7 +69,8 @@ def test_main_loop_pngs(gpu, tmp_path, monkeypatch):
     """vfloodnet_amd.video_seg.main on PNG frames == the PNGs the reference's main() wrote."""
     import argparse
     from PIL import Image
-    from vfloodnet_amd import video_seg, synth
+    from vfloodnet_amd import video_seg
+    from tools import synth
     from vfloodnet_amd.data import save_seg_mask, color_palette
     g = load('main_loop_120x200.npz')
     H, W = [int(x) for x in g['shape']]
@@ -96,7 +97,8 @@ def test_main_loop_pngs(gpu, tmp_path, monkeypatch):
 
 
 def test_full_size_samples(gpu, model):
-    from vfloodnet_amd import synth, FeatureBank
+    from vfloodnet_amd import FeatureBank
+    from tools import synth
     g = load('full_480x854.npz')
     frames, m0 = synth.clip(1, 2, 480, 854)
     oh = synth.onehot(m0).unsqueeze(0)
@@ -118,7 +120,7 @@ def test_c2_full_clip_vs_reference(gpu, model):
     model + FeatureBank on CPU (oracle/gen_c2_golden.py).  Target: mIoU >= 0.99 on every frame."""
     import os
     from golden_util import GOLDEN
-    from vfloodnet_amd import synth
+    from tools import synth
     from vfloodnet_amd.video_seg import run_clip
     path = os.path.join(GOLDEN, 'c2_480x854_100.npz')
     if not os.path.exists(path):
@@ -150,7 +152,8 @@ def test_c2_clip_bf16x3_against_reference_labels(gpu):
     it reaches mIoU ~0.79 -- see DESIGN.md."""
     import numpy as np
     from golden_util import GOLDEN
-    from vfloodnet_amd import AFB_URR, synth
+    from vfloodnet_amd import AFB_URR
+    from tools import synth
     from vfloodnet_amd.video_seg import run_clip
     path = os.path.join(GOLDEN, 'c2_480x854_100.npz')
     if not os.path.exists(path):

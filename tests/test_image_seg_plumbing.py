@@ -16,7 +16,8 @@ class StandIn:
 
 def test_c1_single_frame(tmp_path):
     import vfloodnet_amd  # noqa: F401
-    from vfloodnet_amd import image_seg, synth
+    from vfloodnet_amd import image_seg
+    from tools import synth
     frames, m0 = synth.clip(1, 1, 480, 854)
     src = tmp_path / 'frame.png'
     Image.fromarray((frames[0] * 255).round().to(torch.uint8).permute(1, 2, 0).numpy()).save(str(src))

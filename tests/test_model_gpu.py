@@ -15,7 +15,7 @@ SEED = 20200212
 
 @pytest.fixture(scope='module')
 def sd():
-    from vfloodnet_amd import synth
+    from tools import synth
     return synth.make_state_dict(SEED)
 
 
@@ -38,7 +38,8 @@ def miou(a, b):
 
 @pytest.mark.parametrize('H,W', [(96, 160), (90, 150)])
 def test_memorize_segment_vs_oracle(gpu, sd, model, H, W):
-    from vfloodnet_amd import synth, FeatureBank
+    from vfloodnet_amd import FeatureBank
+    from tools import synth
     from oracle import afb_urr_ref as O
     frames, m0 = synth.clip(1, 2, H, W)
     oh = synth.onehot(m0).unsqueeze(0)
@@ -122,7 +123,7 @@ def test_bank_update_vs_oracle(gpu, regime):
 
 def test_clip_vs_oracle(gpu, sd, model):
     """8-frame clip through the whole loop (resize up to short edge 128, memorize+update every frame)."""
-    from vfloodnet_amd import synth
+    from tools import synth
     from vfloodnet_amd.video_seg import run_clip
     from oracle import afb_urr_ref as O
     frames, m0 = synth.clip(3, 8, 64, 96)
@@ -137,7 +138,7 @@ def test_clip_vs_oracle(gpu, sd, model):
 def test_clip_with_eviction_every_frame(gpu, sd, model):
     """Free-running loop with a budget so small that FeatureBank.remove() (LFU eviction, FeatureBank.py:117-143)
     fires on every update: bank sizes, peak / replace counters and labels against the oracle."""
-    from vfloodnet_amd import synth
+    from tools import synth
     from vfloodnet_amd.video_seg import run_clip
     from oracle import afb_urr_ref as O
     frames, m0 = synth.clip(8, 12, 160, 256)
@@ -166,7 +167,7 @@ def test_c3_shape_720p_mem_every_5(gpu, sd, model):
     """BASELINE config C3's shape at reference semantics: a 1280x720 clip is resized (bicubic, HIP kernel) to
     853x480, padded to 864x480, the bank is updated every 5th frame (harness option; the reference memorises every
     frame) -- fp32 here; bench.py --workload C3 --precision bf16x3|bf16 runs the reduced-precision variants."""
-    from vfloodnet_amd import synth
+    from tools import synth
     from vfloodnet_amd.video_seg import run_clip
     from oracle import afb_urr_ref as O
     frames, m0 = synth.clip(5, 7, 720, 1280)
@@ -215,7 +216,8 @@ def test_bank_remove_and_append_api(gpu):
 def test_three_objects_vs_oracle(gpu, sd, model):
     """obj_n = 3 (background + two regions): the kernels are not specialised to the video path's obj_n = 2
     (class_budget is then budget // 3 without the 0.8 factor, FeatureBank.py:20-22)."""
-    from vfloodnet_amd import synth, FeatureBank, ops
+    from vfloodnet_amd import FeatureBank, ops
+    from tools import synth
     from oracle import afb_urr_ref as O
     H, W = 96, 160
     frames, m0 = synth.clip(4, 2, H, W)
@@ -280,7 +282,8 @@ def test_single_object_all_background_mask(gpu, sd, model):
     """First mask with no water at all: Video_DS gives obj_n = max+1 = 1 (Water_DS.py:97-98).  The reference cannot
     segment that (calc_uncertainty takes a top-2 over one channel -> RuntimeError); same error type here, and
     memorize / init_bank -- which the reference does complete -- still match."""
-    from vfloodnet_amd import synth, FeatureBank
+    from vfloodnet_amd import FeatureBank
+    from tools import synth
     from oracle import afb_urr_ref as O
     H, W = 64, 96
     frames, _ = synth.clip(5, 2, H, W)
@@ -302,7 +305,7 @@ def test_single_object_all_background_mask(gpu, sd, model):
 
 def test_tiny_ragged_frame(gpu, sd, model):
     """33 x 47 -> padded 48 x 48, 3 x 3 = 9 positions at 1/16: every tile of every kernel is partial."""
-    from vfloodnet_amd import synth
+    from tools import synth
     H, W = 33, 47
     frames, m0 = synth.clip(6, 2, H, W)
     oh = synth.onehot(m0).unsqueeze(0)
@@ -317,7 +320,7 @@ def test_tiny_ragged_frame(gpu, sd, model):
 def test_native_resolution_step(gpu, sd, model, H, W):
     """One step at native resolution -- the largest single-frame shapes SURVEY.md section 8 lists: 720p
     (HW = 45 x 80 = 3600) and 1080p (padded 1088 x 1920, HW = 68 x 120 = 8160) -- against the oracle."""
-    from vfloodnet_amd import synth
+    from tools import synth
     frames, m0 = synth.clip(7, 2, H, W)
     oh = synth.onehot(m0).unsqueeze(0)
     torch.set_num_threads(16)
@@ -332,7 +335,7 @@ def test_run_to_run_determinism(gpu, sd, model):
     """Two runs of the same clip give bit-identical labels and bank contents: split-K slabs are reduced in slice
     order, merges are summed in ascending source order, hit counts are integer atomics, the CCL root is the smallest
     pixel index (torch_scatter's CUDA scatter_mean, by contrast, sums with float atomics)."""
-    from vfloodnet_amd import synth
+    from tools import synth
     from vfloodnet_amd.video_seg import run_clip
     frames, m0 = synth.clip(9, 10, 240, 426)
     fr = frames.to(gpu)

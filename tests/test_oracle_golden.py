@@ -94,7 +94,7 @@ def test_main_loop_labels(sd):
 
 def test_full_size_samples(sd):
     """480x854 (the benchmark shape): sparse samples + checksums of the reference's outputs."""
-    from vfloodnet_amd import synth
+    from tools import synth
     g = load('full_480x854.npz')
     frames, m0 = synth.clip(1, 2, 480, 854)
     assert np.allclose(checksum(frames), g['frames_sum'], rtol=1e-6)

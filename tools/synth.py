@@ -25,7 +25,7 @@ import zlib
 import torch
 from torch.nn import functional as F
 
-from . import weights as W
+from vfloodnet_amd import weights as W
 
 CALIB_HW = (240, 426)          # padded to 240x432 by pad_divide_by, like 480x854 -> 480x864
 
@@ -201,7 +201,7 @@ def _calibrate(sd, seed, kn):
     f0, m0 = frame0(seed, H, W_)
     f1 = torch.roll(f0, shifts=(2, 5), dims=(1, 2))
     oh = onehot(m0).float()
-    from .engine import pad_divide_by
+    from vfloodnet_amd.engine import pad_divide_by
     pad, _, _ = pad_divide_by(H, W_)                 # myutils/data.py:132-149: zero pad *before* normalisation
     f0, f1, oh = F.pad(f0, pad), F.pad(f1, pad), F.pad(oh, pad)
     r4, r3, r2, r1 = _enc_q(sd, f1.unsqueeze(0), True)
@@ -246,7 +246,7 @@ def _calibrate(sd, seed, kn):
 
 def make_state_dict(seed=20200212, **knobs):
     """Deterministic calibrated state dict (CPU tensors, reference key names)."""
-    from .model import AFB_URR
+    from vfloodnet_amd.model import AFB_URR
     with torch.no_grad():
         tmpl = AFB_URR(torch.device('cpu'), update_bank=True, _allow_cpu_container=True).state_dict()
         sd = random_state_dict(tmpl, seed, knobs)

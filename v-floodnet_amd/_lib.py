@@ -67,7 +67,8 @@ class BankDesc(C.Structure):
                 ('obj_n', C.c_int), ('cap', C.c_int), ('rm_class', C.c_int), ('rm_request', C.c_int)]
 
 
-ABI_VERSION = 2          # include/vfn_hip.h descriptor layouts; csrc/abi.hip
+ABI_VERSION = 3          # include/vfn_hip.h VFN_ABI_VERSION; csrc/abi.hip
+DESC_IDS = {0: ConvDesc, 1: StemDesc, 2: BankScanDesc, 3: MemReadDesc, 4: BankDesc}     # vfn_sizeof_desc(which)
 
 
 def lib():
@@ -83,6 +84,11 @@ def lib():
         if L.vfn_abi_version() != ABI_VERSION:
             raise RuntimeError(f'{LIB_PATH} has ABI version {L.vfn_abi_version()}, this package expects {ABI_VERSION} '
                                '(descriptor layouts differ): rebuild it (make -C v-floodnet_amd/csrc)')
+        L.vfn_sizeof_desc.restype = C.c_int
+        for which, cls in DESC_IDS.items():
+            if L.vfn_sizeof_desc(which) != C.sizeof(cls):
+                raise RuntimeError(f'{LIB_PATH}: sizeof({cls.__name__}) is {L.vfn_sizeof_desc(which)} in the library, '
+                                   f'{C.sizeof(cls)} in this binding: rebuild it (make -C v-floodnet_amd/csrc)')
         _declare(L)
         _lib = L
     return _lib
@@ -93,6 +99,8 @@ def _declare(L):
     L.vfn_abi_version.restype = i
     L.vfn_conv_cfg_count.restype = i
     L.vfn_conv_cfg_tile.argtypes = [i, C.POINTER(i), C.POINTER(i)]
+    L.vfn_conv_cfg_info.argtypes = [i] + [C.POINTER(i)] * 5
+    L.vfn_sizeof_desc.argtypes = [i]
     L.vfn_conv2d_nhwc_f32.argtypes = [C.POINTER(ConvDesc), i, p]
     L.vfn_conv2d_nhwc_bf16.argtypes = [C.POINTER(ConvDesc), i, p]
     L.vfn_conv2d_nhwc_bf16x3.argtypes = [C.POINTER(ConvDesc), i, p]
@@ -134,7 +142,7 @@ SIGNATURES = {
 }
 # every symbol include/vfn_hip.h declares (checked by tests/test_abi.py)
 ALL_SYMBOLS = sorted(list(SIGNATURES) + [
-    'vfn_abi_version', 'vfn_conv_cfg_count', 'vfn_conv_cfg_tile', 'vfn_conv2d_nhwc_f32', 'vfn_conv2d_nhwc_bf16', 'vfn_conv2d_nhwc_bf16x3', 'vfn_conv3x3_cout2_f32',
+    'vfn_abi_version', 'vfn_sizeof_desc', 'vfn_conv_cfg_count', 'vfn_conv_cfg_tile', 'vfn_conv_cfg_info', 'vfn_conv2d_nhwc_f32', 'vfn_conv2d_nhwc_bf16', 'vfn_conv2d_nhwc_bf16x3', 'vfn_conv3x3_cout2_f32',
     'vfn_stem_conv7x7_f32',
     'vfn_bank_scan', 'vfn_memread_apply', 'vfn_memread_finish', 'vfn_bank_merge', 'vfn_bank_append', 'vfn_bank_remove'])
 

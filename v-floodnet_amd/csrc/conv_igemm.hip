@@ -838,18 +838,27 @@ int launch_cfg(const vfn_conv_desc& p, hipStream_t s) {
 
 extern "C" int vfn_conv_cfg_count(void) { return 20; }
 
-extern "C" int vfn_conv_cfg_tile(int cfg, int* bm, int* bn) {
+extern "C" int vfn_conv_cfg_info(int cfg, int* bm, int* bn, int* wm, int* wn, int* dma) {
     // 8..10: same tiles as 0 / 0 / 2 with twice the waves (smaller per-wave tiles, 4 waves per SIMD at 2 blocks/CU)
     // 11..16: LDS-DMA staging variants of 8 / 10 / 3 / 7 / 6 / 2
     // 17..19: 256-filter-wide tiles (input tile read once for all 256 filters): 128x256 and 64x256, 8 waves
-    static const int t[20][2] = {{128, 128}, {128, 64}, {64, 128}, {64, 64}, {32, 64}, {64, 32}, {128, 32}, {256, 128},
-                                 {128, 128}, {128, 128}, {64, 128},
-                                 {128, 128}, {64, 128}, {64, 64}, {256, 128}, {128, 32}, {64, 128},
-                                 {128, 256}, {128, 256}, {64, 256}};
+    // (must match the switch of vfn_conv2d_nhwc_f32 below)
+    static const int t[20][5] = {{128, 128, 2, 2, 0}, {128, 64, 2, 2, 0}, {64, 128, 2, 2, 0}, {64, 64, 2, 2, 0}, {32, 64, 1, 2, 0},
+                                 {64, 32, 2, 1, 0}, {128, 32, 4, 1, 0}, {256, 128, 4, 2, 0},
+                                 {128, 128, 2, 4, 0}, {128, 128, 4, 2, 0}, {64, 128, 2, 4, 0},
+                                 {128, 128, 2, 4, 2}, {64, 128, 2, 4, 2}, {64, 64, 2, 2, 2}, {256, 128, 4, 2, 2}, {128, 32, 4, 1, 2},
+                                 {64, 128, 2, 2, 2},
+                                 {128, 256, 2, 4, 0}, {128, 256, 2, 4, 2}, {64, 256, 2, 4, 0}};
     if (cfg < 0 || cfg >= 20) return VFN_ERR_ARG;
-    *bm = t[cfg][0]; *bn = t[cfg][1];
+    if (bm) *bm = t[cfg][0];
+    if (bn) *bn = t[cfg][1];
+    if (wm) *wm = t[cfg][2];
+    if (wn) *wn = t[cfg][3];
+    if (dma) *dma = t[cfg][4];
     return VFN_OK;
 }
+
+extern "C" int vfn_conv_cfg_tile(int cfg, int* bm, int* bn) { return vfn_conv_cfg_info(cfg, bm, bn, nullptr, nullptr, nullptr); }
 
 extern "C" int vfn_conv3x3_cout2_f32(const vfn_conv_desc* d, void* stream) {
     if (!d || !d->in || !d->w || !d->out) return VFN_ERR_ARG;

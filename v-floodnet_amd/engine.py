@@ -473,9 +473,11 @@ class Engine:
         if fb._hw != p.HW:
             raise RuntimeError('feature bank was built for a different frame size')
         pre = self._prefetched
-        if pre is not None and pre[0] is p and pre[1] == frame.data_ptr():
-            torch.cuda.current_stream().wait_event(pre[2])       # query encoder already ran on the side stream
-        else:
+        if pre is not None:
+            # whatever the side stream was given, it has finished with the plan's buffers before this stream touches
+            # them: a prefetch for a different frame (wrong hint, skipped frame, direct segment() call) is simply redone
+            torch.cuda.current_stream().wait_event(pre[2])
+        if not (pre is not None and pre[0] is p and pre[1] == frame.data_ptr() and pre[3] == frame._version):
             p.frame_q.copy_(frame[0])
             for l in p.seg_pre:
                 l()
@@ -505,7 +507,7 @@ class Engine:
                 l()
             done = torch.cuda.Event()
             done.record()
-        self._prefetched = (p, frame.data_ptr(), done)
+        self._prefetched = (p, frame.data_ptr(), done, frame._version)
 
     def _memory_read(self, p, fb, update_bank):
         """Matcher.forward (AFB_URR.py:136-178) on the bank slabs."""

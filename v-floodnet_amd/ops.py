@@ -21,6 +21,19 @@ def conv_cfg_tiles():
     return out
 
 
+def conv_cfg_names(mode=0):
+    """Kernel instantiation behind every tile configuration, as rocprofv3 prints it."""
+    L = _lib.lib()
+    out = []
+    for c in range(L.vfn_conv_cfg_count()):
+        v = [C.c_int() for _ in range(5)]
+        L.vfn_conv_cfg_info(c, *[C.byref(x) for x in v])
+        bm, bn, wm, wn, dma = [x.value for x in v]
+        out.append(f'conv_igemm_dma_kernel<{bm}, {bn}, {wm}, {wn}, {dma}>' if dma else
+                   f'conv_igemm_kernel<{bm}, {bn}, {wm}, {wn}, {int(mode)}>')
+    return out
+
+
 def pad_rows(wp, mult=256):
     """Pad packed weights [Cout,K] with zero rows to a multiple of ``mult`` filters."""
     cout = wp.shape[0]

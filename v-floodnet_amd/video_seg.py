@@ -104,6 +104,8 @@ class ClipRunner:
         k, v = self.model.memorize(f, m)
         self.fb.init_bank(k, v)
         self.t = 0
+        self._next_net = None                                    # no look-ahead carried over from a previous clip
+        self._next_src = None
         self._label_dev = torch.empty(H0, W0, dtype=torch.uint8, device=self.device)
         self._post_dev = torch.empty(H0, W0, dtype=torch.uint8, device=self.device)
         self._ccl_scratch = torch.empty(2 * H0 * W0 + 8, dtype=torch.int32, device=self.device)
