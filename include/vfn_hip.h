@@ -205,6 +205,7 @@ int vfn_memread_finish(const vfn_memread_desc* d, void* stream);
  *                   out[:,t] = (out[:,t] + sum_{index[s]==t} src[:,s]) / max(count_t,1) for every
  *                   t that occurs in index (other columns: out/1 = unchanged)   FeatureBank.py:78,92
  */
+#define VFN_BANK_MAX_HW 32768   /* new features per object and frame (1/16-resolution pixels) the bank kernels accept */
 typedef struct vfn_bank_desc {
     float* bank_k;             /* [obj][cap][128] */
     float* bank_v;             /* [obj][cap][512] */
@@ -224,7 +225,8 @@ typedef struct vfn_bank_desc {
     int* app_pos;              /* [obj][HW] scratch */
     int* keep_dst;             /* [obj][stride_n] scratch */
     int* plan;                 /* [obj][4] scratch */
-    int* stats;                /* [obj][4] persistent: len, peak_n, replace_n, last n_append */
+    int* stats;                /* [obj][4] persistent: len, peak_n, replace_n, last n_append (or, sticky, -1 / -2: the
+                                  LFU score of remove() held a NaN / was all-infinite -- the reference raises there) */
     long long stride_k, stride_v, stride_info, stride_n, stride_new;
     double class_budget;       /* FeatureBank.py:20-22: float 0.8*(budget//obj_n) when obj_n == 2 */
     float thres_close, update_rate, new_hit_init;

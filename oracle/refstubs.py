@@ -161,6 +161,42 @@ class _ToTensor:
         return t
 
 
+class _Compose:
+    def __init__(self, transforms):
+        self.transforms = transforms
+
+    def __call__(self, x):
+        for t in self.transforms:
+            x = t(x)
+        return x
+
+
+class _Resize:
+    """torchvision 0.9.2 ``transforms.Resize(size)``, default interpolation BILINEAR: a PIL image goes through
+    ``img.resize((w, h), PIL.Image.BILINEAR)`` (``functional_pil.resize``), a tensor through ``_tv_resize``
+    (``F.interpolate(bilinear, align_corners=False)``, no antialias).  Used by test_image_seg.py:57-61,109."""
+
+    def __init__(self, size, interpolation=_InterpolationMode.BILINEAR):
+        self.size, self.interpolation = size, interpolation
+
+    def __call__(self, img):
+        if _is_pil_image(img):
+            from PIL import Image
+            assert not isinstance(self.size, int) and len(self.size) == 2 and self.interpolation == _InterpolationMode.BILINEAR
+            return img.resize((self.size[1], self.size[0]), Image.BILINEAR)
+        return _tv_resize(img, self.size, self.interpolation)
+
+
+class _Normalize:
+    """``transforms.Normalize(mean, std)``: ``(x - mean[:, None, None]) / std[:, None, None]`` (tensor.sub_().div_())."""
+
+    def __init__(self, mean, std):
+        self.mean, self.std = torch.as_tensor(mean, dtype=torch.float32), torch.as_tensor(std, dtype=torch.float32)
+
+    def __call__(self, t):
+        return t.clone().sub_(self.mean.view(-1, 1, 1)).div_(self.std.view(-1, 1, 1))
+
+
 # --------------------------------------------------------------------------
 # torch_scatter.scatter_mean
 # --------------------------------------------------------------------------
@@ -227,6 +263,9 @@ def install():
     transforms.functional = functional
     transforms.InterpolationMode = _InterpolationMode
     transforms.ToTensor = _ToTensor
+    transforms.Compose = _Compose
+    transforms.Resize = _Resize
+    transforms.Normalize = _Normalize
     tv.models = models
     tv.transforms = transforms
     sys.modules['torchvision'] = tv
@@ -256,6 +295,7 @@ def import_reference():
         from video_module.model import AFB_URR, FeatureBank
         from video_module.dataset import Video_DS
         import test_video_seg
+        import test_image_seg
     ns = types.SimpleNamespace(myutils=myutils, AFB_URR=AFB_URR, FeatureBank=FeatureBank,
-                               Video_DS=Video_DS, test_video_seg=test_video_seg)
+                               Video_DS=Video_DS, test_video_seg=test_video_seg, test_image_seg=test_image_seg)
     return ns

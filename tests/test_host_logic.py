@@ -132,20 +132,18 @@ def test_postprocess_cases():
         assert np.array_equal(postprocessing_pred(c), O.postprocessing_pred(c))
 
 
-def test_overlay_matches_reference_formula():
+def test_overlay_matches_reference_outputs():
+    """data.add_overlay == the REFERENCE's myutils.add_overlay (outputs generated by oracle/gen_image_seg_golden.py):
+    two / three labels, no background label, a single label, a gap in the label ids."""
+    import os
     from vfloodnet_amd.data import add_overlay, color_palette
-    from scipy.ndimage import binary_dilation
-    rng = np.random.RandomState(1)
-    img = rng.randint(0, 255, (12, 14, 3)).astype(np.uint8)
-    mask = np.zeros((12, 14), np.uint8)
-    mask[3:8, 4:10] = 1
-    out = add_overlay(img, mask, color_palette)
-    colors = np.reshape(color_palette, (-1, 3))
-    canvas = img * 0.4 + np.ones(img.shape) * 0.6 * np.array(colors[1])[::-1]
-    ref = img.copy()
-    ref[mask == 1] = canvas[mask == 1]
-    ref[binary_dilation(mask == 1) ^ (mask == 1), :] = 0
-    assert np.array_equal(out, ref)
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'overlay_cases.npz'))
+    img = (np.transpose(g['frame'], (1, 2, 0)) * 255).astype(np.uint8)
+    bgr = np.ascontiguousarray(img[..., ::-1])
+    cases = [k[5:] for k in g.files if k.startswith('mask_')]
+    assert len(cases) == 5
+    for n in cases:
+        assert np.array_equal(add_overlay(bgr, g['mask_' + n], color_palette), g['bgr_out_' + n]), n
 
 
 def test_bench_and_entry_modules_import_on_cpu():

@@ -1,45 +1,59 @@
-"""BASELINE config C1: one 480x854 frame through the test_image_seg.py plumbing on CPU with a stand-in
-``.predict`` (the LinkNet weights / package are not available; only the contract around it is in scope)."""
+"""BASELINE config C1: one 480x854 frame through the test_image_seg.py plumbing on CPU (no GPU) with a stand-in
+``.predict`` (the LinkNet weights / package are not available; only the contract around it is in scope).
+
+Pinned against THE REFERENCE: tests/golden/image_seg_c1.npz holds what the reference's own ``test_waterseg`` /
+``predict_one`` / ``predict_pil`` / ``norm_imagenet`` (test_image_seg.py:44-151) wrote for the same frames with the same
+stand-in (oracle/gen_image_seg_golden.py)."""
+import os
+import zlib
+
 import numpy as np
+import pytest
 import torch
 from PIL import Image
 
-
-class StandIn:
-    """predict(x[1,3,416,416]) -> prob[1,1,416,416]: brightness threshold of the de-normalised image."""
-
-    def predict(self, x):
-        assert tuple(x.shape) == (1, 3, 416, 416) and x.dtype == torch.float32
-        g = (x * torch.tensor([0.229, 0.224, 0.225]).view(1, 3, 1, 1) + torch.tensor([0.485, 0.456, 0.406]).view(1, 3, 1, 1))
-        return (g.mean(1, keepdim=True) > 0.5).float() * 0.9
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'image_seg_c1.npz')
 
 
-def test_c1_single_frame(tmp_path):
+def _run(tmp_path, name, seed, H, W):
     import vfloodnet_amd  # noqa: F401
     from vfloodnet_amd import image_seg
     from tools import synth
-    frames, m0 = synth.clip(1, 1, 480, 854)
-    src = tmp_path / 'frame.png'
-    Image.fromarray((frames[0] * 255).round().to(torch.uint8).permute(1, 2, 0).numpy()).save(str(src))
-    image_seg.test_waterseg('unused.pth', str(src), 'clip', str(tmp_path / 'out'), torch.device('cpu'), model=StandIn())
-    mask = Image.open(str(tmp_path / 'out' / 'clip' / 'mask' / 'frame.png'))
-    assert mask.mode == 'P' and mask.size == (854, 480)
-    assert mask.getpalette()[:12] == [0, 0, 0, 0, 0, 128, 0, 128, 0, 128, 0, 0]
+    from tools.standin import StandIn
+    frames, _ = synth.clip(seed, 1, H, W)
+    src = tmp_path / f'{name}.png'
+    u8 = (frames[0] * 255).round().to(torch.uint8).permute(1, 2, 0).numpy()
+    Image.fromarray(u8).save(str(src))
+    image_seg.test_waterseg('unused.pth', str(src), name, str(tmp_path / 'out'), torch.device('cpu'), model=StandIn())
+    mask = Image.open(str(tmp_path / 'out' / name / 'mask' / f'{name}.png'))
+    ov = Image.open(str(tmp_path / 'out' / name / 'overlay' / f'{name}.png'))
+    return u8, mask, ov
+
+
+@pytest.mark.parametrize('name', ['c1', 'small'])
+def test_image_seg_matches_reference_files(tmp_path, name):
+    g = np.load(GOLD)
+    seed, H, W = [int(x) for x in g[f'{name}_seed_hw']]
+    u8, mask, ov = _run(tmp_path, name, seed, H, W)
+    assert mask.mode == 'P' and mask.size == (W, H)
+    assert mask.getpalette()[:768] == [int(x) for x in g[f'{name}_palette']]
     lab = np.array(mask)
-    assert set(np.unique(lab)) <= {0, 1} and 0 < lab.mean() < 1
-    # the output is one 8-connected blob (postprocessing_pred)
+    assert np.array_equal(lab, np.unpackbits(g[f'{name}_labels'], axis=-1)[:, :W])        # label map: exact
+    assert ov.mode == 'RGB' and ov.size == (W, H)
+    assert zlib.crc32(np.array(ov).tobytes()) == int(g[f'{name}_overlay_crc'])           # overlay: byte-exact
+    if name == 'small':
+        assert np.array_equal(u8, g['small_frame_u8'])
+        assert np.array_equal(np.array(ov), g['small_overlay'])
+    # the output is one 8-connected blob (postprocessing_pred), and the stand-in produced more than one before it
     from scipy import ndimage
     assert ndimage.label(lab, structure=np.ones((3, 3)))[1] == 1
-    ov = Image.open(str(tmp_path / 'out' / 'clip' / 'overlay' / 'frame.png'))
-    assert ov.size == (854, 480) and ov.mode == 'RGB'
+    assert 0.05 < lab.mean() < 0.95
 
 
-def test_norm_imagenet_matches_definition():
+def test_norm_imagenet_matches_reference():
     import vfloodnet_amd  # noqa: F401
     from vfloodnet_amd import image_seg
-    rng = np.random.RandomState(0)
-    img = Image.fromarray(rng.randint(0, 255, (60, 90, 3), dtype=np.uint8))
-    t = image_seg.norm_imagenet(img, (416, 416))
-    ref = torch.from_numpy(np.asarray(img.resize((416, 416), Image.BILINEAR)).transpose(2, 0, 1).copy()).float() / 255
-    ref = (ref - torch.tensor([0.485, 0.456, 0.406]).view(3, 1, 1)) / torch.tensor([0.229, 0.224, 0.225]).view(3, 1, 1)
-    assert t.shape == (3, 416, 416) and torch.equal(t, ref)
+    g = np.load(GOLD)
+    t = image_seg.norm_imagenet(Image.fromarray(g['small_frame_u8']), (416, 416))
+    assert t.shape == (3, 416, 416)
+    assert np.array_equal(t.numpy()[:, ::16, ::16], g['small_norm'])

@@ -313,25 +313,42 @@ def test_to_tensor_device_bit_exact(gpu):
     assert torch.equal(got, to_tensor(img.numpy()))
 
 
-@pytest.mark.parametrize('labels', ['two', 'three', 'no_background', 'single'])
-def test_overlay_device_matches_host(gpu, labels):
-    """vfn_overlay_u8 == add_overlay + the uint8 / BGR handling of save_overlay (myutils/data.py:56-84)."""
+@pytest.mark.parametrize('labels', ['two', 'three', 'no_background', 'single', 'gap'])
+def test_overlay_device_matches_reference(gpu, labels):
+    """vfn_overlay_u8 == the REFERENCE's add_overlay + the uint8 / BGR handling of save_overlay (myutils/data.py:56-84),
+    byte for byte, on outputs the reference itself produced (oracle/gen_image_seg_golden.py)."""
+    import os
     import numpy as np
     from vfloodnet_amd import ops
-    from vfloodnet_amd.data import add_overlay, color_palette
-    g = torch.Generator().manual_seed(11)
-    H, W = 41, 67
-    frame = torch.rand(3, H, W, generator=g)
-    blob = torch.nn.functional.avg_pool2d(torch.rand(1, 1, H, W, generator=g), 5, 1, 2)[0, 0]
-    if labels == 'two':
-        mask = (blob > 0.5).to(torch.uint8)
-    elif labels == 'three':
-        mask = (blob > 0.45).to(torch.uint8) + (blob > 0.55).to(torch.uint8)
-    elif labels == 'no_background':
-        mask = 1 + (blob > 0.5).to(torch.uint8)
-    else:
-        mask = torch.ones(H, W, dtype=torch.uint8)
-    img = (frame.permute(1, 2, 0).numpy() * 255).astype(np.uint8)
-    ref = add_overlay(np.ascontiguousarray(img[..., ::-1]), mask.numpy(), color_palette)[..., ::-1]
+    from vfloodnet_amd.data import color_palette
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'overlay_cases.npz'))
+    frame, mask = torch.from_numpy(g['frame']), torch.from_numpy(g['mask_' + labels])
     got = ops.overlay_device(frame.to(gpu), mask.to(gpu), color_palette).cpu().numpy()
-    assert np.array_equal(got, ref)
+    assert np.array_equal(got, g['bgr_out_' + labels][..., ::-1])
+
+
+def test_overlay_device_on_reference_loop_output(gpu):
+    """The overlay PNG the reference's main() wrote for frame 1 (tests/golden/main_loop_120x200.npz) from the
+    reference's own frame and label map: byte-equal."""
+    import os
+    import numpy as np
+    from vfloodnet_amd import ops
+    from vfloodnet_amd.data import color_palette
+    from vfloodnet_amd.dataset import to_tensor
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'main_loop_120x200.npz'))
+    W = int(g['shape'][1])
+    lab = np.unpackbits(g['labels'], axis=-1)[1, :, :W]
+    frame = to_tensor(np.ascontiguousarray(g['frames_u8'][1].transpose(1, 2, 0)))
+    got = ops.overlay_device(frame.to(gpu), torch.from_numpy(np.ascontiguousarray(lab)).to(gpu), color_palette).cpu().numpy()
+    assert np.array_equal(got, g['overlay1'])
+
+
+def test_scatter_mean_rejects_out_of_range_index(gpu):
+    from vfloodnet_amd import scatter_mean
+    src = torch.ones(4, 6, device=gpu)
+    out = torch.zeros(4, 5, device=gpu)
+    for bad in (5, -1):
+        idx = torch.tensor([0, 1, 2, bad, 3, 4], device=gpu).unsqueeze(0).expand(4, 6)
+        with pytest.raises(RuntimeError):
+            scatter_mean(src, idx, dim=1, out=out)
+    assert float(out.abs().sum()) == 0.0

@@ -347,3 +347,55 @@ def test_run_to_run_determinism(gpu, sd, model):
         assert torch.equal(a['fb'].keys[i], b['fb'].keys[i])
         assert torch.equal(a['fb'].values[i], b['fb'].values[i])
         assert torch.equal(a['fb'].info[i], b['fb'].info[i])
+
+
+def test_bank_update_large_native_hw(gpu):
+    """Native-resolution feature grids larger than the old 12,000-entry limit of the merge kernel (one limit now:
+    VFN_BANK_MAX_HW): a mixed merge / append update at HW = 13,000 against the oracle."""
+    from vfloodnet_amd import FeatureBank
+    from oracle import afb_urr_ref as O
+    g = torch.Generator().manual_seed(21)
+    hw = 13000
+    k0 = [torch.randn(128, hw, generator=g) for _ in range(2)]
+    v0 = [torch.randn(512, hw, generator=g) for _ in range(2)]
+    fb_ref = O.FeatureBankRef(2, 250000, 'cpu', thres_close=0.9)
+    fb = FeatureBank(2, 250000, gpu, thres_close=0.9)
+    fb_ref.init_bank([k.clone() for k in k0], [v.clone() for v in v0])
+    fb.init_bank([k.to(gpu) for k in k0], [v.to(gpu) for v in v0])
+    k1 = [(k0[i] * 1.5 + 0.2 * torch.randn(128, hw, generator=g)) for i in range(2)]
+    for i in range(2):
+        k1[i][:, ::3] = torch.randn(128, k1[i][:, ::3].shape[1], generator=g)       # a third of them: new entries
+    v1 = [torch.randn(512, hw, generator=g) for _ in range(2)]
+    torch.set_num_threads(8)
+    fb_ref.update([k.clone() for k in k1], [v.clone() for v in v1], 1)
+    fb.update([k.to(gpu) for k in k1], [v.to(gpu) for v in v1], 1)
+    for i in range(2):
+        assert fb.keys[i].shape == fb_ref.keys[i].shape and fb.keys[i].shape[1] > hw + 4000
+        assert (fb.keys[i].cpu() - fb_ref.keys[i]).abs().max() < 1e-4
+        assert (fb.values[i].cpu() - fb_ref.values[i]).abs().max() < 1e-4
+        assert torch.equal(fb.info[i].cpu(), fb_ref.info[i])
+
+
+def test_remove_with_undefined_lfu_raises_like_the_reference(gpu):
+    """FeatureBank.remove at the birth frame of entries without hits: LFU = 0 / 0 = NaN and the reference's
+    ``int(LFU.min())`` (FeatureBank.py:123) raises ValueError; all-infinite scores (hits / 0) raise OverflowError.
+    Neither removes anything."""
+    from vfloodnet_amd import FeatureBank
+    from oracle import afb_urr_ref as O
+    g = torch.Generator().manual_seed(5)
+    k0, v0 = _rand_feats(g, 2, 40)
+    for bump, exc in ((0.0, ValueError), (3.0, OverflowError)):
+        fb_ref = O.FeatureBankRef(2, 300, 'cpu')
+        fb = FeatureBank(2, 300, gpu)
+        fb_ref.init_bank([k.clone() for k in k0], [v.clone() for v in v0], frame_idx=5)
+        fb.init_bank([k.to(gpu) for k in k0], [v.to(gpu) for v in v0], frame_idx=5)
+        for i in range(2):
+            fb_ref.info[i][:, 1] += bump
+            fb.info[i][:, 1] += bump
+        with pytest.raises(exc):
+            fb_ref.remove(0, 10, 5)
+        with pytest.raises(exc):
+            fb.remove(0, 10, 5)
+        assert fb.keys[0].shape == (128, 40) and torch.equal(fb.keys[0].cpu(), k0[0])
+        # the bank stays usable: a later frame index gives finite scores
+        assert fb.remove(0, 10, 9) == fb_ref.remove(0, 10, 9)

@@ -187,11 +187,21 @@ void bank_plan_kernel(const vfn_bank_desc p) {
         const float* info = p.info + (size_t)obj * p.stride_info;
         int* dst = p.keep_dst + (size_t)obj * p.stride_n;
         float mn = INFINITY;
+        int has_nan = 0;
         for (int b = tid; b < B; b += 1024) {
             const float l = info[(size_t)b * 2 + 1] / ((float)p.frame_idx - info[(size_t)b * 2]);
+            has_nan |= (l != l);                    // 0 / 0: an entry born at frame_idx with no hits (fminf would drop it)
             mn = fminf(mn, l);
         }
         mn = block_reduce_min(mn, redf);
+        has_nan = block_reduce_sum_i(has_nan, redi);
+        // the reference evaluates int(LFU.min()) (FeatureBank.py:123): torch's min propagates NaN -> ValueError, and an
+        // all-infinite LFU -> OverflowError, before anything is removed or appended.  Same here: the object is left as
+        // it is and the host raises from the statistics block (stats[3] = -1 NaN / -2 infinite).
+        if (has_nan || (B > 0 && !(fabsf(mn) < INFINITY))) {
+            if (tid == 0) { plan[0] = 0; plan[1] = 0; plan[2] = B; plan[3] = 0; p.stats[obj * 4 + 3] = has_nan ? -1 : -2; }
+            return;
+        }
         int thr = (int)mn + 1;
         for (int it = 0; it < 100000; ++it) {
             int cnt = 0;
@@ -298,7 +308,7 @@ __global__ void bank_finalize_kernel(const vfn_bank_desc p) {
         st[0] = newlen;
         if (newlen > st[1]) st[1] = newlen;
         st[2] += plan[3];
-        if (p.rm_class < 0) st[3] = plan[0];
+        if (st[3] >= 0 && p.rm_class < 0) st[3] = plan[0];           // (< 0: error flag set by the plan kernel, sticky)
     }
 }
 
@@ -344,14 +354,14 @@ extern "C" int vfn_row_norms(const float* x, long long stride_obj, int ld, int d
 }
 
 static int bank_desc_ok(const vfn_bank_desc* d) {
-    return d && d->bank_k && d->bank_v && d->info && d->bank_len && d->HW > 0 && d->HW <= 2048 * 16 && d->obj_n > 0;
+    return d && d->bank_k && d->bank_v && d->info && d->bank_len && d->HW > 0 && d->HW <= VFN_BANK_MAX_HW && d->obj_n > 0;
 }
 
 extern "C" int vfn_bank_merge(const vfn_bank_desc* d, void* stream) {
-    if (!bank_desc_ok(d) || d->HW > 12000 || d->rm_class >= 0) return VFN_ERR_ARG;
+    if (!bank_desc_ok(d) || d->rm_class >= 0) return VFN_ERR_ARG;
     if (!d->match_idx || !d->match_corr || !d->new_k || !d->new_knorm || !d->new_vnorm || !d->bank_knorm || !d->bank_vnorm)
         return VFN_ERR_ARG;
-    hipLaunchKernelGGL(bank_merge_kernel, dim3(d->HW, d->obj_n), dim3(256), (size_t)d->HW * 5 + 16, (hipStream_t)stream, *d);
+    hipLaunchKernelGGL(bank_merge_kernel, dim3(d->HW, d->obj_n), dim3(256), (size_t)((d->HW + 31) / 32) * 4, (hipStream_t)stream, *d);
     return vfn_check_launch();
 }
 

@@ -27,30 +27,33 @@ def save_seg_mask(pred, seg_path, palette=color_palette):
     seg_img.save(seg_path)
 
 
-def _binary_dilation_cross(m):
-    """scipy.ndimage.binary_dilation default structure (4-connected cross), border value 0."""
-    out = m.copy()
-    out[1:, :] |= m[:-1, :]
-    out[:-1, :] |= m[1:, :]
-    out[:, 1:] |= m[:, :-1]
-    out[:, :-1] |= m[:, 1:]
-    return out
-
-
 def add_overlay(img, mask, colors=color_palette, alpha=0.4, cscale=1):
-    """data.py:56-75 (img is BGR uint8 [H,W,3])."""
-    ids = np.unique(mask)
-    img_overlay = img.copy()
-    ones_np = np.ones(img.shape) * (1 - alpha)
-    colors = np.reshape(colors, (-1, 3))
-    colors = np.atleast_2d(colors) * cscale
-    for i in ids[1:]:
-        canvas = img * alpha + ones_np * np.array(colors[i])[::-1]
-        binary_mask = mask == i
-        img_overlay[binary_mask] = canvas[binary_mask]
-        contour = _binary_dilation_cross(binary_mask) ^ binary_mask
-        img_overlay[contour, :] = 0
-    return img_overlay
+    """Host evaluation of the reference overlay (myutils/data.py:56-75; img BGR uint8 [H,W,3], mask uint8 [H,W]) --
+    used where no GPU is involved (BASELINE config C1, ``image_seg.predict_one``); the video loop uses
+    ``vfn_overlay_u8``.  Stated as one rule per pixel instead of the reference's per-label painting loop:
+
+    * labels are painted in ascending order and the smallest label present is never painted (background);
+    * a pixel of a painted label L shows ``trunc(img*alpha + (1-alpha)*cscale*palette[L])`` (float64, BGR);
+    * the 1-pixel outline of label j (its 4-neighbour dilation minus itself) is drawn right after j is painted, so a
+      pixel ends up black iff one of its 4 neighbours carries a painted label greater than its own.
+    """
+    mask = np.asarray(mask)
+    present = np.unique(mask)
+    pal = np.zeros((256, 3), np.float64)
+    rows = np.asarray(colors, dtype=np.float64).reshape(-1, 3)[:256]
+    pal[:len(rows)] = rows[:, ::-1] * cscale                         # palette is RGB, the image BGR
+    painted = mask != present[0]
+    out = img.copy()
+    blend = img[painted] * alpha + (1 - alpha) * pal[mask[painted]]
+    out[painted] = blend                                             # float64 -> uint8: truncation
+    lab = np.where(painted, mask.astype(np.int32), -1)               # background never outlines anything
+    nb = np.full(mask.shape, -1, np.int32)
+    nb[1:, :] = np.maximum(nb[1:, :], lab[:-1, :])
+    nb[:-1, :] = np.maximum(nb[:-1, :], lab[1:, :])
+    nb[:, 1:] = np.maximum(nb[:, 1:], lab[:, :-1])
+    nb[:, :-1] = np.maximum(nb[:, :-1], lab[:, 1:])
+    out[nb > lab] = 0
+    return out
 
 
 def save_overlay(img, mask, overlay_path, colors=[255, 0, 0], alpha=0.4, cscale=1):

@@ -26,6 +26,7 @@ DK, DV = 128, 512
 MAX_SPLIT = 20            # memory-read apply slices (o_part slabs)
 MAX_SPLIT_SCAN = 32       # bank scans (softmax statistics, cosine arg-max): 128 query columns per workgroup
 QT, QT_SCAN, CH = 64, 128, 64
+MAX_HW = 32768           # include/vfn_hip.h VFN_BANK_MAX_HW
 
 
 def pick_nsplit(hw, obj_n, b_upper, qt=QT, max_split=MAX_SPLIT):
@@ -123,6 +124,15 @@ class FeatureBank:
     def absorb_stats(self, stats_host):
         """Take a host copy of the device ``stats`` block (len, peak, replace, n_append per object)."""
         st = stats_host.numpy()
+        for i in range(self.obj_n):
+            if st[i, 3] < 0:                         # flagged by bank_plan_kernel; the object was left untouched
+                code = int(st[i, 3])
+                self._stats[i, 3] = 0
+                self._dirty = True
+                if code == -1:                       # int(LFU.min()) with a NaN score (0 hits / 0 age), FeatureBank.py:123
+                    raise ValueError('cannot convert float NaN to integer (FeatureBank.remove: an entry born at '
+                                     f'frame_idx with no hits, object {i})')
+                raise OverflowError(f'cannot convert float infinity to integer (FeatureBank.remove, object {i})')
         self._len_host = [int(st[i, 0]) for i in range(self.obj_n)]
         self._len_upper = list(self._len_host)
         for i in range(self.obj_n):
@@ -259,6 +269,8 @@ class FeatureBank:
         hw = prev_key[0].shape[1]
         if hw != self._hw:
             raise RuntimeError(f'feature count changed ({hw} vs {self._hw}): one bank serves one frame size')
+        if hw > MAX_HW:
+            raise RuntimeError(f'{hw} features per frame exceed the bank kernels\' limit of {MAX_HW} (VFN_BANK_MAX_HW)')
         L = _lib.lib()
         o, cap = self.obj_n, self._cap
         new, ld = self._stage_new(prev_key, prev_value)

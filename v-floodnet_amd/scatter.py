@@ -35,5 +35,8 @@ def scatter_mean(src, index, dim=-1, out=None, dim_size=None):
     if src.shape[1] == 0:
         return out            # nothing selected (an all-append frame): out/1 is out
     index_row = index_row.to(torch.int64).contiguous()
+    lo, hi = int(index_row.min()), int(index_row.max())       # (torch_scatter raises on an out-of-range index too)
+    if lo < 0 or hi >= out.shape[1]:
+        raise RuntimeError(f'scatter_mean: index range [{lo}, {hi}] outside out.shape[1] = {out.shape[1]}')
     ops.scatter_mean_launch(src, index_row, out)
     return out
