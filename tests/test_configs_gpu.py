@@ -1,0 +1,110 @@
+"""BASELINE.json configs C3 and C5 *in the dtype they name* (bf16), at their shapes, against the f32 CPU oracle.
+
+The reference has no reduced-precision path; this package offers two: ``bf16x3`` (every matrix operand
+split into two bf16, 16 significant bits, three MFMAs per product) and plain ``bf16`` (8 bits).  Both are run here on
+the configs' workloads and the mIoU they actually reach against the oracle's fp32 labels is asserted: bf16x3 is held to
+the fidelity bar (>= 0.99 per frame, identical bank sizes); plain bf16 is asserted at the level it honestly reaches with
+the margin-free synthetic weights (it is NOT a parity-green configuration, and the numbers say so)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+SEED = 20200212
+
+
+def miou(a, b):
+    v = []
+    for c in (0, 1):
+        inter = ((a == c) & (b == c)).sum().item()
+        union = ((a == c) | (b == c)).sum().item()
+        v.append(1.0 if union == 0 else inter / union)
+    return sum(v) / 2
+
+
+@pytest.fixture(scope='module')
+def sd():
+    from tools import synth
+    return synth.make_state_dict(SEED)
+
+
+@pytest.fixture(scope='module')
+def c3_oracle(sd):
+    """C3 workload: 1280x720 clip, resized to 480p by the loop, bank updated every 5th frame; oracle in f32."""
+    from tools import synth
+    from oracle import afb_urr_ref as O
+    frames, m0 = synth.clip(5, 12, 720, 1280)
+    torch.set_num_threads(16)
+    ref = O.run_clip(sd, frames, m0, size=480, mem_every=5)
+    return frames, m0, ref
+
+
+@pytest.mark.parametrize('precision', ['bf16x3', 'bf16'])
+def test_c3_720p_every_5th_reduced_precision(gpu, sd, c3_oracle, precision):
+    from vfloodnet_amd import AFB_URR
+    from vfloodnet_amd.video_seg import run_clip
+    frames, m0, ref = c3_oracle
+    model = AFB_URR(gpu, update_bank=True, precision=precision).to(gpu).eval()
+    model.load_state_dict(sd, strict=True)
+    out = run_clip(model, frames.to(gpu), m0, size=480, mem_every=5)
+    T = frames.shape[0]
+    assert out['labels'].shape == (T, 720, 1280)
+    ious = [miou(out['labels'][t], ref['labels'][t]) for t in range(1, T)]
+    print(f'C3 {precision}: mIoU min {min(ious):.5f} mean {sum(ious) / len(ious):.5f}; bank {out["bank_sizes"][-1]} vs {ref["bank_sizes"][-1]}')
+    # the bank only changes on frames 5 and 10
+    assert out['bank_sizes'][3] == out['bank_sizes'][0] and out['bank_sizes'][4] != out['bank_sizes'][3]
+    if precision == 'bf16x3':
+        assert out['bank_sizes'] == ref['bank_sizes']
+        assert min(ious) >= 0.99, ious
+    else:
+        # plain bf16 operands: 2^-9 relative noise per product against logits without margin (synthetic weights):
+        # several per cent of the pixels flip.  Asserted at what it reaches, not at the parity bar.
+        # Measured: 0.94 on the first frame, 0.63-0.75 once its own masks have been memorised (frames 5, 10).
+        assert ious[0] >= 0.90 and min(ious) >= 0.55, ious
+        drift = max(abs(a - b) for x, y in zip(out['bank_sizes'], ref['bank_sizes']) for a, b in zip(x, y))
+        assert drift <= 0.05 * max(ref['bank_sizes'][-1])
+
+
+def test_c5_shape_1080p_long_stream_bf16x3(gpu, sd):
+    """C5's shape: a 1920x1080 stream at reference semantics (resize to 480p), every frame memorised, bf16x3.
+    150 frames with a budget whose per-object share (200,000 entries) is reached around frame 123, so the run covers
+    the growing bank, B >= 200 k and LFU eviction.  The first frames are compared with the f32 oracle; beyond them the
+    domain's invariants are checked (FeatureBank.py:102-103,117-143; myutils/data.py:17-37)."""
+    from tools import synth
+    from vfloodnet_amd import AFB_URR, ops
+    from vfloodnet_amd.video_seg import ClipRunner
+    from oracle import afb_urr_ref as O
+    T, H, W, n_ref = 150, 1080, 1920, 6
+    budget = 500000                                   # class_budget = 0.8 * 250000 = 200000.0
+    frames, m0 = synth.clip_on_device(7, T, H, W, gpu)
+    torch.set_num_threads(16)
+    ref = O.run_clip(sd, frames[:n_ref + 1].cpu(), m0, size=480, budget=budget)
+    model = AFB_URR(gpu, update_bank=True, precision='bf16x3').to(gpu).eval()
+    model.load_state_dict(sd, strict=True)
+    runner = ClipRunner(model, 2, budget, size=480, postprocess=True)
+    onehot = synth.onehot(m0).unsqueeze(0).to(gpu)
+    runner.start(frames[0:1], onehot)
+    sizes, ious = [], []
+    for t in range(1, T):
+        lab = runner.step(frames[t:t + 1], next_frame=frames[t + 1:t + 2] if t + 1 < T else None)
+        sizes.append(runner.bank_sizes())
+        if t <= n_ref:
+            ious.append(miou(runner._label_dev.cpu(), ref['labels'][t]))           # before post-processing, as the oracle's
+        if t in (n_ref, T // 2, T - 1):
+            post = torch.from_numpy(lab.numpy().copy())
+            assert set(post.unique().tolist()) <= {0, 1}
+            again = ops.postprocess_pred_device(post.to(gpu)).cpu()
+            assert torch.equal(again, post)                                      # largest-blob filter is idempotent
+    print(f'C5 bf16x3: mIoU(first {n_ref}) min {min(ious):.5f}; bank {sizes[0]} -> {sizes[-1]}, replace_n {runner.fb.replace_n}')
+    # merge / append decisions sit on a float threshold (cosine > 0.95): 2^-16 operand noise may move single entries
+    drift = max(abs(a - b) for x, y in zip(sizes[:n_ref], ref['bank_sizes']) for a, b in zip(x, y))
+    assert drift <= 3, (sizes[:n_ref], ref['bank_sizes'])
+    assert min(ious) >= 0.99, ious
+    cb = runner.fb.class_budget
+    assert cb == 200000.0
+    peak = max(max(s) for s in sizes)
+    assert peak >= 195000 and all(max(s) <= cb for s in sizes)                   # B + n_append <= class_budget after remove()
+    first_evict = next(i for i in range(1, len(sizes)) if sizes[i][0] < sizes[i - 1][0] or sizes[i][1] < sizes[i - 1][1])
+    assert all(sizes[i][c] >= sizes[i - 1][c] for i in range(1, first_evict) for c in (0, 1))   # monotone until the budget
+    assert first_evict > 100
+    assert runner.fb.replace_n.sum() > 0 and np.all(runner.fb.peak_n <= cb)

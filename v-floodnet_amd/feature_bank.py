@@ -124,21 +124,20 @@ class FeatureBank:
     def absorb_stats(self, stats_host):
         """Take a host copy of the device ``stats`` block (len, peak, replace, n_append per object)."""
         st = stats_host.numpy()
-        for i in range(self.obj_n):
-            if st[i, 3] < 0:                         # flagged by bank_plan_kernel; the object was left untouched
-                code = int(st[i, 3])
-                self._stats[i, 3] = 0
-                self._dirty = True
-                if code == -1:                       # int(LFU.min()) with a NaN score (0 hits / 0 age), FeatureBank.py:123
-                    raise ValueError('cannot convert float NaN to integer (FeatureBank.remove: an entry born at '
-                                     f'frame_idx with no hits, object {i})')
-                raise OverflowError(f'cannot convert float infinity to integer (FeatureBank.remove, object {i})')
         self._len_host = [int(st[i, 0]) for i in range(self.obj_n)]
         self._len_upper = list(self._len_host)
         for i in range(self.obj_n):
             self.peak_n[i] = max(self.peak_n[i], float(st[i, 1]))
             self.replace_n[i] = float(st[i, 2])
         self._dirty = False
+        for i in range(self.obj_n):
+            if st[i, 3] < 0:                         # flagged by bank_plan_kernel; that object was left untouched
+                code = int(st[i, 3])
+                self._stats[i, 3] = 0
+                if code == -1:                       # int(LFU.min()) with a NaN score (0 hits / 0 age), FeatureBank.py:123
+                    raise ValueError('cannot convert float NaN to integer (FeatureBank.remove: an entry born at '
+                                     f'frame_idx with no hits, object {i})')
+                raise OverflowError(f'cannot convert float infinity to integer (FeatureBank.remove, object {i})')
 
     def stats_device(self):
         return self._stats
