@@ -275,6 +275,19 @@ int vfn_to_tensor_u8(const unsigned char* src, float* dst, int H, int W, void* s
 int vfn_overlay_u8(const float* frame, const unsigned char* mask, const unsigned char* palette, int* scratch,
                    unsigned char* out, int H, int W, double alpha, double cscale, void* stream);
 
+/* ------------------------------------------------------------------ PNG encoding on the device
+ * vfn_png_deflate_u8: the compression inside save_seg_mask (PIL mode-P PNG, myutils/data.py:49-53) and save_overlay
+ *     (cv2.imwrite, myutils/data.py:78-84).  raw = uint8 [H][W][bpp] on the device, bpp = 1 (palette indices) or 3 (RGB).
+ *     PNG row filter (Up for bpp 1, Paeth for bpp 3) + distance-1 run matches + a Huffman code of the image's own
+ *     histogram; out receives ONE final dynamic deflate block (RFC 1951), stats = {deflate bytes, Adler-32 of the
+ *     filtered scanlines, deflate bits, 0}.  The host wraps it: 78 01 | deflate | adler32 (big endian) = the IDAT
+ *     payload; signature / IHDR / PLTE / IDAT / IEND framing with CRC-32 stays on the host (a few hundred ns per KB).
+ * vfn_png_sizes: bytes of `work` and `out` the caller must provide for an H x W x bpp image.
+ */
+int vfn_png_sizes(int H, int W, int bpp, long long* work_bytes, long long* out_bytes);
+int vfn_png_deflate_u8(const unsigned char* raw, int H, int W, int bpp, void* work, unsigned char* out, int* stats,
+                       void* stream);
+
 #ifdef __cplusplus
 }
 #endif

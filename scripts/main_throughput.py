@@ -8,7 +8,7 @@ from vfloodnet_amd import video_seg
 from tools import synth
 from vfloodnet_amd.data import save_seg_mask, color_palette
 
-T = int(sys.argv[1]) if len(sys.argv) > 1 else 80
+T = int(sys.argv[1]) if len(sys.argv) > 1 else 100
 viz = (sys.argv[2] != '0') if len(sys.argv) > 2 else True
 tmp = tempfile.mkdtemp()
 fdir = os.path.join(tmp, 'frames'); os.makedirs(fdir)
@@ -24,17 +24,18 @@ args = argparse.Namespace(gpu=0, budget=250000, viz=viz, model_path=ckpt, update
                           test_path=fdir, test_name='clip')
 dev = torch.device('cuda', 0)
 video_seg.main(argparse.Namespace(**{**vars(args), 'test_name': 'warm'}) if False else args, dev)   # warm-up (plans, tables, page cache)
-# time the steady state of the frame loop: from step 40 to the end (files flushed), so that model construction,
-# checkpoint loading and the DataLoader workers' start-up are excluded
+# time the frame loop from iteration SKIP+1 to the end (files flushed), so that model construction, checkpoint loading
+# and the DataLoader workers' start-up are excluded; with the defaults these are frames 5-99 of the C2 clip
 marks = {'n': 0}
-orig_step = video_seg.ClipRunner.step
+SKIP = int(sys.argv[3]) if len(sys.argv) > 3 else 4      # loop iterations before the clock starts (DataLoader start-up)
+orig_step = video_seg.ClipRunner.launch
 def step(self, *a, **k):
     marks['n'] += 1
-    if marks['n'] == 40:
+    if marks['n'] == SKIP + 1:
         torch.cuda.synchronize(); marks['t0'] = time.perf_counter()
     return orig_step(self, *a, **k)
-video_seg.ClipRunner.step = step
+video_seg.ClipRunner.launch = step
 video_seg.main(args, dev)
 dt = time.perf_counter() - marks['t0']
-T = T - 39
+T = T - SKIP
 print('main() frame loop: %d frames, viz=%s: %.1f frames/s end to end, files on disk (%.1f ms/frame)' % (T - 1, viz, (T - 1) / dt, 1e3 * dt / (T - 1)))

@@ -121,15 +121,17 @@ class FeatureBank:
             self.absorb_stats(self._stats_pinned)
         return self._len_host
 
-    def absorb_stats(self, stats_host):
-        """Take a host copy of the device ``stats`` block (len, peak, replace, n_append per object)."""
+    def absorb_stats(self, stats_host, in_flight=0):
+        """Take a host copy of the device ``stats`` block (len, peak, replace, n_append per object).
+        ``in_flight``: updates already enqueued behind the one these statistics describe (a pipelined loop):
+        the upper bound the grids are sized with keeps room for them."""
         st = stats_host.numpy()
         self._len_host = [int(st[i, 0]) for i in range(self.obj_n)]
-        self._len_upper = list(self._len_host)
+        self._len_upper = [min(n + in_flight * self._hw, self._cap) for n in self._len_host]
         for i in range(self.obj_n):
             self.peak_n[i] = max(self.peak_n[i], float(st[i, 1]))
             self.replace_n[i] = float(st[i, 2])
-        self._dirty = False
+        self._dirty = in_flight > 0
         for i in range(self.obj_n):
             if st[i, 3] < 0:                         # flagged by bank_plan_kernel; that object was left untouched
                 code = int(st[i, 3])

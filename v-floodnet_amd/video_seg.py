@@ -19,8 +19,8 @@ import numpy as np
 import torch
 
 from . import ops
-from .data import (AsyncWriter, color_palette, load_image_in_PIL, save_overlay, save_overlay_device,
-                   save_overlay_device_async, save_seg_mask)
+from .data import AsyncWriter, color_palette, load_image_in_PIL, save_overlay, save_seg_mask
+from .png_device import PngSink
 from .dataset import Video_DS
 from .feature_bank import FeatureBank
 from .model import AFB_URR
@@ -40,7 +40,7 @@ def get_args(argv=None):
     parser.add_argument('--viz', action='store_true', default=True, help='Visualize data.')
     parser.add_argument('--no-viz', dest='viz', action='store_false', help='Skip the overlay PNGs.')
     parser.add_argument('--load-workers', type=int, default=4, help='DataLoader worker processes (frame decoding).')
-    parser.add_argument('--png-workers', type=int, default=16, help='Threads that encode the mask / overlay PNGs.')
+    parser.add_argument('--png-workers', type=int, default=4, help='Threads that frame and write the PNG files (compressed on the GPU).')
     parser.add_argument('--model-path', type=str, default='records/video_seg_checkpoint_20200212-001734.pth',
                         help='Path to the checkpoint (default: none)')
     parser.add_argument('--update-rate', type=float, default=0.1, help='Update Rate. Impact of merging new features.')
@@ -106,20 +106,36 @@ class ClipRunner:
         self.t = 0
         self._next_net = None                                    # no look-ahead carried over from a previous clip
         self._next_src = None
-        self._label_dev = torch.empty(H0, W0, dtype=torch.uint8, device=self.device)
-        self._post_dev = torch.empty(H0, W0, dtype=torch.uint8, device=self.device)
+        # two sets of per-frame outputs: frame t+1 may be enqueued (launch) before the host has looked at frame t
+        # (collect), and a side stream may still be compressing frame t's label map while frame t+1 runs
+        self._bufs = [dict(label=torch.empty(H0, W0, dtype=torch.uint8, device=self.device),
+                           post=torch.empty(H0, W0, dtype=torch.uint8, device=self.device),
+                           pinned=torch.empty(H0, W0, dtype=torch.uint8).pin_memory(),
+                           stats=torch.zeros(self.obj_n, 4, dtype=torch.int32).pin_memory(),
+                           done=torch.cuda.Event()) for _ in range(2)]
+        self._cur = self._bufs[0]
+        self._label_dev, self._post_dev, self._pinned = self._cur['label'], self._cur['post'], self._cur['pinned']
         self._ccl_scratch = torch.empty(2 * H0 * W0 + 8, dtype=torch.int32, device=self.device)
-        self._pinned = torch.empty(H0, W0, dtype=torch.uint8).pin_memory()
-        self._stats_pinned = torch.zeros(self.obj_n, 4, dtype=torch.int32).pin_memory()
+        self._pending = []
 
-    def step(self, frame, want_label=True, next_frame=None):
-        """One iteration of the hot loop (:105-115).  frame f32[1,3,H0,W0] on the GPU.
-        Returns the uint8 label map [H0,W0] as a pinned host tensor (valid until the next step).
+    def launch(self, frame, next_frame=None, want_label=True):
+        """Enqueue one iteration of the hot loop (:105-116) for ``frame`` f32[1,3,H0,W0] (on the GPU) and return
+        without waiting.  ``collect()`` later waits for it and absorbs the bank bookkeeping.  At most two launches may
+        be outstanding (the kernels read the true bank lengths from device memory; the host only needs upper bounds
+        to size the grids, ``FeatureBank.len_upper``).
 
         ``next_frame`` (optional, already on the GPU): lets the query encoder of frame t+1 -- which depends
         on nothing but that frame -- run on a side stream underneath memorize/update of frame t.  Results
         are identical with or without it."""
+        if len(self._pending) >= 2:
+            raise RuntimeError('ClipRunner: two frames already in flight; collect() first')
         self.t += 1
+        buf = self._bufs[self.t & 1]
+        if buf.get('reader_done') is not None:                    # e.g. the PNG side stream still reading frame t-2
+            torch.cuda.current_stream().wait_event(buf['reader_done'])
+            buf['reader_done'] = None
+        self._cur = buf
+        self._label_dev, self._post_dev, self._pinned = buf['label'], buf['post'], buf['pinned']
         if self._next_net is not None and self._next_src == frame.data_ptr():
             f = self._next_net                                    # resized when it was prefetched
         else:
@@ -135,16 +151,32 @@ class ClipRunner:
             k, v = self.model.memorize(f, pred_mask)              # :111 (soft masks are memorised)
             self.fb.update(k, v, self.t)                          # :112
         H0, W0 = self.ori_size
-        ops.resize_argmax(pred_mask, H0, W0, out=self._label_dev)  # :114-115
-        src = self._label_dev
+        ops.resize_argmax(pred_mask, H0, W0, out=buf['label'])    # :114-115
+        src = buf['label']
         if self.postprocess:                                       # :116, largest 8-connected water blob
-            src = ops.postprocess_pred_device(self._label_dev, self._post_dev, self._ccl_scratch)
-        # single sync point of the frame: labels + bank bookkeeping
-        self._pinned.copy_(src, non_blocking=True)
-        self._stats_pinned.copy_(self.fb.stats_device(), non_blocking=True)
-        torch.cuda.current_stream().synchronize()
-        self.fb.absorb_stats(self._stats_pinned)
-        return self._pinned if want_label else None
+            src = ops.postprocess_pred_device(buf['label'], buf['post'], self._ccl_scratch)
+        # the frame's single host hand-over: labels + bank bookkeeping
+        if want_label:
+            buf['pinned'].copy_(src, non_blocking=True)
+        buf['stats'].copy_(self.fb.stats_device(), non_blocking=True)
+        buf['done'].record()
+        self._pending.append(buf)
+        return buf
+
+    def collect(self):
+        """Wait for the oldest outstanding ``launch`` and take over its bank bookkeeping; returns its uint8 label map
+        [H0,W0] as a pinned host tensor (valid until the launch after next)."""
+        buf = self._pending.pop(0)
+        buf['done'].synchronize()
+        self.fb.absorb_stats(buf['stats'], in_flight=len(self._pending))
+        return buf['pinned']
+
+    def step(self, frame, want_label=True, next_frame=None):
+        """``launch`` + ``collect``: one iteration of the hot loop, synchronised (one host synchronisation per frame,
+        the one the reference also has at ``.cpu()``, test_video_seg.py:115)."""
+        self.launch(frame, next_frame, want_label)
+        lab = self.collect()
+        return lab if want_label else None
 
     def label_device(self):
         """The label map of the last step as it left the GPU (post-processed when ``postprocess``), still on the device."""
@@ -239,24 +271,34 @@ def main(args, device):
         save_overlay(ori_first_frame[0], pred, overlay_path, color_palette)
 
     # host-side pipelining around the GPU loop (results identical to the sequential reference loop):
-    #   * one frame of look-ahead, so the next frame's encoder work overlaps this frame's memorize (ClipRunner.step)
-    #   * PNG encoding on a thread pool (AsyncWriter) -- it would otherwise bound the loop at ~40 frames/s with --viz
-    writer = AsyncWriter(getattr(args, 'png_workers', 16))
+    #   * one frame of look-ahead, so the next frame's encoder work overlaps this frame's memorize (ClipRunner.launch)
+    #   * frame t+1 is enqueued before the host waits for frame t (launch / collect): decoding hand-over, uploads and
+    #     the bank bookkeeping of one frame hide under the kernels of the next
+    #   * the PNGs are compressed on the GPU on a side stream (png_device.PngSink); writer threads only frame + write
+    writer = AsyncWriter(getattr(args, 'png_workers', 4))
+    sink = PngSink(device, writer)
     with torch.no_grad():
         it = iter(seq_loader)                    # (workers start decoding while the first frame is memorised)
         runner.start(ori_first_frame, ori_first_mask)
-        nxt = next(it, None)
-        nxt_dev = ops.to_tensor_device(nxt[0][0].to(device)).unsqueeze(0) if nxt is not None else None   # ToTensor (:131-139)
-        while nxt is not None:
-            (frame, frame_name), ori_frame = nxt, nxt_dev
+
+        def upload(item):                        # ToTensor (Water_DS.py:108) on the device
+            return ops.to_tensor_device(item[0][0].to(device, non_blocking=True)).unsqueeze(0) if item is not None else None
+
+        cur = next(it, None)
+        cur_dev = upload(cur)
+        while cur is not None:
             nxt = next(it, None)
-            nxt_dev = ops.to_tensor_device(nxt[0][0].to(device)).unsqueeze(0) if nxt is not None else None
-            pred = runner.step(ori_frame, next_frame=nxt_dev).numpy().copy()   # postprocessing_pred (:116) ran on the GPU
-            seg_path = os.path.join(seg_dir, f'{frame_name[0]}.png')
-            writer.submit(save_seg_mask, pred, seg_path, color_palette)
-            if args.viz:
-                overlay_path = os.path.join(overlay_dir, f'{frame_name[0]}.png')
-                save_overlay_device_async(writer, ori_frame[0], runner.label_device(), overlay_path, color_palette)
+            nxt_dev = upload(nxt)
+            buf = runner.launch(cur_dev, next_frame=nxt_dev, want_label=False)   # postprocessing_pred (:116) runs on the GPU
+            name = cur[1][0]
+            buf['reader_done'] = sink.save(runner.label_device(), os.path.join(seg_dir, f'{name}.png'), color_palette,
+                                           frame=cur_dev[0] if args.viz else None,
+                                           overlay_path=os.path.join(overlay_dir, f'{name}.png') if args.viz else None)
+            if len(runner._pending) == 2:
+                runner.collect()                 # frame t-1: its bank statistics
+            cur, cur_dev = nxt, nxt_dev
+        while runner._pending:
+            runner.collect()
     writer.close()
 
     runner.fb.print_peak_mem()
