@@ -137,6 +137,11 @@ int vfn_local_vpass_f32(const float* hs, const float* hr, const float* hm, float
 int vfn_final_logits_f32(const float* p_up, const float* unc, const float* conf, const float* q, float* score,
                          int obj_n, int h, int w, int pad_top, int pad_left, int H0, int W0, void* stream);
 
+/* vfn_segment_uncertainty_f32: the scalar AFB_URR.segment returns in training mode (AFB_URR.py:302-305, consumed by the
+ *     loss at train_video_seg.py:73-74): mean over the batch of ||calc_uncertainty(softmax_objects(prob))||_2 / sqrt(n).
+ *     logit: [bs][obj][n] as returned by segment (n = H*W); partial: scratch float[bs*64]; out: one float. */
+int vfn_segment_uncertainty_f32(const float* logit, int bs, int obj_n, int n, float* partial, float* out, void* stream);
+
 /* ------------------------------------------------------------------ feature-bank contractions (f32 MFMA)
  * Bank layout: entry-major, keys [obj][cap][128], values [obj][cap][512], info [obj][cap][2]
  * (birth frame, log-hit accumulator), live length bank_len[obj] in DEVICE memory (kernels never

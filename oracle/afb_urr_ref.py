@@ -177,10 +177,14 @@ def memorize(sd, frame, mask):
     return [k4[i] for i in range(K)], [v4[i] for i in range(K)]
 
 
-def segment(sd, frame, fb, update_bank=True):
-    """AFB_URR.py:274-318 (eval mode)."""
+def segment(sd, frame, fb, update_bank=True, training=False):
+    """AFB_URR.py:274-318.  ``frame`` f32[bs,3,h,w] (the loop uses bs = 1, training bs = clip_n - 1,
+    train_video_seg.py:69).  ``training``: the branch ``model.train()`` takes with BatchNorm frozen
+    (train_video_seg.py:103-106): no padding (:278) and the scalar uncertainty of :302-305."""
     obj_n = fb.obj_n
-    [frame], pad = pad_divide_by([frame], 16, (frame.shape[2], frame.shape[3]))
+    pad = (0, 0, 0, 0)
+    if not training:
+        [frame], pad = pad_divide_by([frame], 16, (frame.shape[2], frame.shape[3]))
     r4, r3, r2, r1 = encoder_q(sd, frame)
     bs, _, gh, gw = r4.shape
     k4, v4 = keyval(sd, r4)
@@ -191,13 +195,19 @@ def segment(sd, frame, fb, update_bank=True):
     r1e = r1.unsqueeze(1).expand(-1, obj_n, -1, -1, -1).reshape(bs * obj_n, *r1.shape[1:])
     score = decoder(sd, res, r3e, r2e, r1e, (bs, obj_n, r1.shape[2], r1.shape[3]))
     score = score.view(bs, obj_n, *frame.shape[-2:])
+    uncertainty = None
+    if training:
+        uncertainty = calc_uncertainty(F.softmax(score, dim=1))
+        uncertainty = uncertainty.view(bs, -1).norm(p=2, dim=1) / math.sqrt(frame.shape[-2] * frame.shape[-1])
+        uncertainty = uncertainty.mean()
     score = torch.clamp(score, 1e-7, 1 - 1e-7)
     score = torch.log(score / (1 - score))
-    if pad[2] + pad[3] > 0:
-        score = score[:, :, pad[2]:-pad[3], :]
-    if pad[0] + pad[1] > 0:
-        score = score[:, :, :, pad[0]:-pad[1]]
-    return score, None
+    if not training:
+        if pad[2] + pad[3] > 0:
+            score = score[:, :, pad[2]:-pad[3], :]
+        if pad[0] + pad[1] > 0:
+            score = score[:, :, :, pad[0]:-pad[1]]
+    return score, uncertainty
 
 
 # ----------------------------------------------------------------- feature bank

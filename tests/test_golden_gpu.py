@@ -171,3 +171,38 @@ def test_c2_clip_bf16x3_against_reference_labels(gpu):
     print('C2 bf16x3 mIoU min %.5f mean %.5f' % (min(ious), sum(ious) / len(ious)))
     assert min(ious) >= 0.985, (min(ious), int(np.argmin(ious)) + 1)
     assert sum(ious) / len(ious) >= 0.995
+
+
+@pytest.mark.parametrize('tag,H,W,training', [('eval_90x150', 90, 150, False), ('train_96x160', 96, 160, True)])
+def test_segment_batch_and_training_branch(gpu, tag, H, W, training):
+    """SURVEY.md 8(f) row 4, first step: ``segment`` with a batch of frames (train_video_seg.py:69 passes bs = clip_n - 1)
+    in eval mode and in the training branch (no padding AFB_URR.py:278, scalar uncertainty :302-305, BatchNorm frozen as
+    train_video_seg.py:103-106), forward only, against the reference's own outputs (oracle/gen_bs2_golden.py)."""
+    from vfloodnet_amd import AFB_URR, FeatureBank
+    from tools import synth
+    g = load('segment_bs2.npz')
+    model = AFB_URR(gpu, update_bank=not training).to(gpu)
+    model.load_state_dict(state_dict(), strict=True)
+    model.train() if training else model.eval()
+    frames, m0 = synth.clip(6, 3, H, W)
+    oh = synth.onehot(m0).unsqueeze(0)
+    k, v = model.memorize(frames[0:1].to(gpu), oh.to(gpu))
+    fb = FeatureBank(2, 250000, gpu)
+    fb.init_bank(k, v)
+    score, unc = model.segment(frames[1:3].to(gpu), fb)
+    assert tuple(score.shape) == (2, 2, H, W)
+    ok, dl, dp = close_logits(score.cpu(), t(g[f'{tag}_score']), 1e-3)
+    assert ok, (dl, dp)
+    for i in range(2):
+        assert (fb.info[i][:, 1].cpu() - t(g[f'{tag}_info1'][i])).abs().max() < 1e-3      # hit counts: sample 0 only
+    if training:
+        assert unc.dim() == 0 and abs(float(unc) - float(g[f'{tag}_uncertainty'])) < 1e-5
+        with pytest.raises(RuntimeError):                       # no padding in this branch (AFB_URR.py:278)
+            model.segment(frames[1:3, :, :90, :150].contiguous().to(gpu), fb)
+    else:
+        assert unc is None
+        # a batch is its samples one by one (hit counts apart)
+        fb2 = FeatureBank(2, 250000, gpu)
+        fb2.init_bank(k, v)
+        one = model.segment(frames[2:3].to(gpu), fb2)[0].clone()
+        assert torch.equal(one[0], score[1])

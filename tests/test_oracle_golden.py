@@ -109,3 +109,28 @@ def test_full_size_samples(sd):
     ok, dl, dp = close_logits(score.flatten()[t(g['score_idx'])], t(g['score_val']))
     assert ok, (dl, dp)
     assert abs(float((score[0, 1] > score[0, 0]).float().mean()) - float(g['label_water_frac'])) < 1e-3
+
+
+def test_segment_batch_and_training_branch_vs_reference():
+    """oracle.segment with bs = 2 (eval, padded 90x150) and in the training branch (no pad, scalar uncertainty,
+    frozen BatchNorm) against the reference's own AFB_URR.segment (oracle/gen_bs2_golden.py)."""
+    from tools import synth
+    from golden_util import load, state_dict, t
+    sd = state_dict()
+    g = load('segment_bs2.npz')
+    torch.set_num_threads(8)
+    for tag, H, W, training in (('eval_90x150', 90, 150, False), ('train_96x160', 96, 160, True)):
+        frames, m0 = synth.clip(6, 3, H, W)
+        oh = synth.onehot(m0).unsqueeze(0)
+        k, v = O.memorize(sd, frames[0:1], oh)
+        fb = O.FeatureBankRef(2, 250000)
+        fb.init_bank(k, v)
+        score, unc = O.segment(sd, frames[1:3], fb, update_bank=not training, training=training)
+        assert tuple(score.shape) == (2, 2, H, W)
+        assert (score - t(g[f'{tag}_score'])).abs().max() < 1e-4
+        for i in range(2):
+            assert (fb.info[i][:, 1] - t(g[f'{tag}_info1'][i])).abs().max() < 1e-5
+        if training:
+            assert abs(float(unc) - float(g[f'{tag}_uncertainty'])) < 1e-6
+        else:
+            assert unc is None

@@ -139,6 +139,7 @@ SIGNATURES = {
     'vfn_postprocess_pred_device_u8': [_p, _p, _p, _i, _i, _p],
     'vfn_to_tensor_u8': [_p, _p, _i, _i, _p],
     'vfn_overlay_u8': [_p, _p, _p, _p, _p, _i, _i, C.c_double, C.c_double, _p],
+    'vfn_segment_uncertainty_f32': [_p, _i, _i, _i, _p, _p, _p],
     'vfn_png_sizes': [_i, _i, _i, C.POINTER(_ll), C.POINTER(_ll)],
     'vfn_png_deflate_u8': [_p, _i, _i, _i, _p, _p, _p, _p],
 }

@@ -206,6 +206,48 @@ __global__ void final_logits_kernel(const float* __restrict__ p_up, const float*
     }
 }
 
+// Training-branch scalar of AFB_URR.segment (AFB_URR.py:302-305): per sample
+//   u = calc_uncertainty(softmax_over_objects(score))   (myutils/data.py:40-46: exp(1 - top1 / (top2 + 1e-8)))
+//   ||u||_2 / sqrt(H W), then the mean over the batch.
+// `logit` holds the logits segment() returns; the probabilities are recovered as sigmoid(logit) (they were clamped to
+// [1e-7, 1 - 1e-7] before the logit -- below the f32 resolution of the result).  Two deterministic stages: block partial
+// sums of u^2 in a fixed order, then one thread per sample adds the partials in order.
+constexpr int UNC_BLOCKS = 64;
+__global__ __launch_bounds__(256)
+void uncertainty_partial_kernel(const float* __restrict__ logit, int obj_n, int n, float* __restrict__ partial) {
+    __shared__ float red[4];
+    const int b = blockIdx.y;
+    const float* src = logit + (size_t)b * obj_n * n;
+    float acc = 0.f;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        float s[MAX_OBJ], mx = -INFINITY;
+        for (int k = 0; k < obj_n; ++k) { s[k] = 1.f / (1.f + expf(-src[(size_t)k * n + i])); mx = fmaxf(mx, s[k]); }
+        float den = 0.f;
+        for (int k = 0; k < obj_n; ++k) { s[k] = expf(s[k] - mx); den += s[k]; }
+        float t1 = -1.f, t2 = -1.f;
+        for (int k = 0; k < obj_n; ++k) {
+            const float pk = s[k] / den;
+            if (pk > t1) { t2 = t1; t1 = pk; } else if (pk > t2) t2 = pk;
+        }
+        const float u = expf(1.f - t1 / (t2 + 1e-8f));
+        acc += u * u;
+    }
+    acc = wave_sum(acc);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) partial[b * UNC_BLOCKS + blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+__global__ void uncertainty_finish_kernel(const float* __restrict__ partial, int bs, int n, float* __restrict__ out) {
+    if (blockIdx.x != 0 || threadIdx.x != 0) return;
+    float mean = 0.f;
+    for (int b = 0; b < bs; ++b) {
+        float ssq = 0.f;
+        for (int j = 0; j < UNC_BLOCKS; ++j) ssq += partial[b * UNC_BLOCKS + j];
+        mean += sqrtf(ssq) / sqrtf((float)n);
+    }
+    out[0] = mean / (float)bs;
+}
+
 inline int grid_for(size_t total, int block = 256, int cap = 8192) {
     size_t b = (total + block - 1) / block;
     return (int)(b < (size_t)cap ? (b ? b : 1) : cap);
@@ -252,5 +294,13 @@ extern "C" int vfn_final_logits_f32(const float* p_up, const float* unc, const f
     if (pad_top + H0 > 2 * h || pad_left + W0 > 2 * w) return VFN_ERR_ARG;
     hipLaunchKernelGGL(final_logits_kernel, dim3(grid_for((size_t)obj_n * H0 * W0)), dim3(256), 0, (hipStream_t)stream,
                        p_up, unc, conf, q, score, obj_n, h, w, pad_top, pad_left, H0, W0);
+    return vfn_check_launch();
+}
+
+extern "C" int vfn_segment_uncertainty_f32(const float* logit, int bs, int obj_n, int n, float* partial, float* out,
+                                           void* stream) {
+    if (!logit || !partial || !out || bs < 1 || obj_n < 2 || obj_n > MAX_OBJ || n < 1) return VFN_ERR_ARG;
+    hipLaunchKernelGGL(uncertainty_partial_kernel, dim3(UNC_BLOCKS, bs), dim3(256), 0, (hipStream_t)stream, logit, obj_n, n, partial);
+    hipLaunchKernelGGL(uncertainty_finish_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, partial, bs, n, out);
     return vfn_check_launch();
 }

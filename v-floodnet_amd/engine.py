@@ -444,10 +444,9 @@ class Engine:
         return p
 
     @staticmethod
-    def _check_frame(frame):
-        if frame.dim() != 4 or frame.shape[0] != 1 or frame.shape[1] != 3:
-            raise RuntimeError(f'expected one RGB frame [1,3,h,w], got {tuple(frame.shape)} '
-                               '(the inference path is batch 1, test_video_seg.py:74)')
+    def _check_frame(frame, batch_ok=False):
+        if frame.dim() != 4 or frame.shape[1] != 3 or frame.shape[0] < 1 or (frame.shape[0] != 1 and not batch_ok):
+            raise RuntimeError(f'expected RGB frames [{"bs" if batch_ok else "1"},3,h,w], got {tuple(frame.shape)}')
         _lib.require_gpu(frame, 'frame')
 
     # ------------------------------------------------------------------ API
@@ -464,10 +463,19 @@ class Engine:
         v_list = [kv[i, :, DK:].t() for i in range(K)]            # [512, HW]
         return k_list, v_list
 
-    def segment(self, frame, fb, update_bank):
-        self._check_frame(frame)
+    def segment(self, frame, fb, update_bank, training=False):
+        """AFB_URR.segment for frame f32[bs,3,h,w].  bs = 1 is the inference loop (test_video_seg.py:108); bs > 1 is how
+        the training script calls it (train_video_seg.py:69): the samples of a batch are independent given the bank, so
+        they run one after the other through the same launch list, and -- as in the reference, AFB_URR.py:165 -- only
+        sample 0 contributes hit counts to ``fb.info``.  ``training``: no padding (AFB_URR.py:278: the frame size must
+        then be a multiple of 16, anything else fails in the reference's decoder as well)."""
+        self._check_frame(frame, batch_ok=True)
+        bs = frame.shape[0]
         K = fb.obj_n
-        p = self.plan(frame.shape[2], frame.shape[3], K)
+        H, Wd = frame.shape[2], frame.shape[3]
+        if training and (H % 16 or Wd % 16):
+            raise RuntimeError(f'training-mode segment does not pad (AFB_URR.py:278): {H}x{Wd} is not a multiple of 16')
+        p = self.plan(H, Wd, K)
         if fb._kbuf is None:
             raise RuntimeError('feature bank is empty: call fb.init_bank() first')
         if fb._hw != p.HW:
@@ -477,15 +485,20 @@ class Engine:
             # whatever the side stream was given, it has finished with the plan's buffers before this stream touches
             # them: a prefetch for a different frame (wrong hint, skipped frame, direct segment() call) is simply redone
             torch.cuda.current_stream().wait_event(pre[2])
-        if not (pre is not None and pre[0] is p and pre[1] == frame.data_ptr() and pre[3] == frame._version):
-            p.frame_q.copy_(frame[0])
-            for l in p.seg_pre:
-                l()
         self._prefetched = None
-        self._memory_read(p, fb, update_bank)
-        for l in p.seg_post:
-            l()
-        return p.score
+        out = p.score if bs == 1 else torch.empty(bs, K, H, Wd, device=self.device, dtype=torch.float32)
+        for b in range(bs):
+            fr = frame[b:b + 1]
+            if not (b == 0 and pre is not None and pre[0] is p and pre[1] == fr.data_ptr() and pre[3] == frame._version):
+                p.frame_q.copy_(fr[0])
+                for l in p.seg_pre:
+                    l()
+            self._memory_read(p, fb, update_bank and b == 0)
+            for l in p.seg_post:
+                l()
+            if bs > 1:
+                out[b].copy_(p.score[0])
+        return out
 
     def prefetch_query(self, frame, obj_n):
         """Run the frame-only part of ``segment`` for ``frame`` (the *next* frame of the clip: query encoder, KeyValue

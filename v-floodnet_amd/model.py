@@ -7,7 +7,7 @@ Drop-in for ``video_module.model.AFB_URR`` (``AFB_URR.py:242-321``) as used by
     model = model.to(device); model.eval()
     model.load_state_dict(checkpoint['model'], strict=False)       # 562 reference keys
     k4_list, v4_list = model.memorize(frame, mask)                  # lists of [128,HW] / [512,HW]
-    score, _ = model.segment(frame, fb)                             # logits [1,obj_n,h,w]; bumps fb.info
+    score, _ = model.segment(frame, fb)                             # logits [bs,obj_n,h,w]; bumps fb.info
 
 The module owns parameters only (``weights.py``); ``memorize`` / ``segment`` run
 entirely in hand-written HIP kernels through ``engine.Engine``.  There is no
@@ -70,21 +70,27 @@ class AFB_URR(nn.Module):
     # -- reference API ------------------------------------------------------
     @torch.no_grad()
     def memorize(self, frame, mask):
-        """AFB_URR.py:255-272.  frame f32[1,3,h,w] in [0,1]; mask [1,K,h,w] (u8 or float)."""
-        if self.training:
-            raise RuntimeError('the HIP path implements eval-mode inference only (call model.eval())')
+        """AFB_URR.py:255-272.  frame f32[1,3,h,w] in [0,1]; mask [1,K,h,w] (u8 or float).  Identical in eval and in
+        training mode (the reference pads here in both, :259); BatchNorm always uses its running statistics -- in
+        training mode that is the frozen-BN setting of train_video_seg.py:103-106."""
         return self.engine().memorize(frame, mask)
 
     @torch.no_grad()
     def segment(self, frame, fb_global):
-        """AFB_URR.py:274-318 (eval branch).  Returns (logits f32[1,obj_n,h,w], None)."""
-        if self.training:
-            raise RuntimeError('the HIP path implements eval-mode inference only (call model.eval())')
+        """AFB_URR.py:274-318, forward only.  frame f32[bs,3,h,w]; returns (logits f32[bs,obj_n,h,w], uncertainty).
+        eval: pads to a multiple of 16, uncertainty is None (test_video_seg.py:108).  After ``model.train()``: the
+        training branch -- no padding (:278) and the scalar uncertainty of :302-305 as a 0-dim tensor
+        (train_video_seg.py:69,73-74) -- with BatchNorm frozen as train_video_seg.py:103-106 sets it.  There is no
+        backward pass: the HIP path is inference / forward evaluation only."""
         if fb_global.obj_n < 2:
             # the reference fails here as well: calc_uncertainty takes the top-2 over the object axis
             # (myutils/data.py:40-46, `score.topk(k=2, dim=1)` -> "selected index k out of range")
             raise RuntimeError('segment needs at least two objects (background + 1): selected index k out of range')
-        return self.engine().segment(frame, fb_global, self.update_bank), None
+        score = self.engine().segment(frame, fb_global, self.update_bank, training=self.training)
+        if self.training:
+            from . import ops
+            return score, ops.segment_uncertainty(score.contiguous())
+        return score, None
 
     def forward(self, x):  # AFB_URR.py:320-321
         pass

@@ -233,6 +233,17 @@ def final_logits(p_up, unc, conf, q, score, pad, H0, W0):
                                           pad[2], pad[0], H0, W0, stream()), 'vfn_final_logits_f32')
 
 
+def segment_uncertainty(score):
+    """score: logits [bs,obj,H,W] from segment -> 0-dim tensor (AFB_URR.py:302-305)."""
+    bs, obj_n, H, W = score.shape
+    assert score.is_contiguous()
+    partial = torch.empty(bs * 64, device=score.device, dtype=torch.float32)
+    out = torch.empty(1, device=score.device, dtype=torch.float32)
+    check(_lib.lib().vfn_segment_uncertainty_f32(ptr(score), bs, obj_n, H * W, ptr(partial), ptr(out), stream()),
+          'vfn_segment_uncertainty_f32')
+    return out[0]
+
+
 # --------------------------------------------------------------------------- loop operators
 def resize_bicubic(x, Ho, Wo, out=None):
     """x [C,Hi,Wi] (or [1,C,Hi,Wi]) float32 -> [.., Ho, Wo]."""
