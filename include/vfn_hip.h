@@ -280,6 +280,30 @@ int vfn_to_tensor_u8(const unsigned char* src, float* dst, int H, int W, void* s
 int vfn_overlay_u8(const float* frame, const unsigned char* mask, const unsigned char* palette, int* scratch,
                    unsigned char* out, int H, int W, double alpha, double cscale, void* stream);
 
+/* ------------------------------------------------------------------ JPEG frames onto the device
+ * Replaces PIL's decode + torchvision ToTensor in Video_DS.__getitem__ (video_module/dataset/Water_DS.py:105-109,
+ * myutils/data.py:87-90; frames arrive at test_video_seg.py:103-105).
+ * vfn_jpeg_entropy_decode   HOST function (no GPU call): marker parsing + Huffman decoding of a baseline / extended
+ *     sequential 8-bit JPEG (grey, or YCbCr with 4:4:4 / 4:2:2 / 4:2:0 / 4:4:0 sampling, one interleaved scan, restart
+ *     intervals) into quantised coefficient blocks.  info: int[24] (0 width, 1 height, 2 components, 3 hmax, 4 vmax,
+ *     5 MCU columns, 6 MCU rows, 7+4c.. per component: h, v, blocks per row, block rows; 22 restart interval; 23 total
+ *     shorts of coefficients); qt: unsigned short [3][64] natural order, per component; coef: per component
+ *     [block rows][blocks per row][64] natural order, components back to back.  Returns 0, -1 (not a JPEG / truncated),
+ *     -2 (unsupported: progressive, arithmetic, 12-bit, CMYK / Adobe RGB, non-interleaved colour scans), -3 (coef_cap
+ *     too small: info[23] says how much), -4 (corrupt entropy data).  Call with coef = NULL to size the buffer.
+ * vfn_jpeg_idct_u8          dequantise + libjpeg's accurate integer IDCT (jidctint.c) of one component's blocks
+ *     (device memory) -> uint8 plane [block_rows*8][pitch], pitch >= blocks_per_row*8, multiple of 8.
+ * vfn_jpeg_to_tensor_f32    libjpeg "fancy" chroma upsampling (hs, vs = luma / chroma sampling ratio, 1 or 2) +
+ *     YCbCr -> RGB (jdcolor.c fixed point) + ToTensor: out_f32 [3][H][W] = rgb / 255 and / or out_u8 [H][W][3].
+ */
+int vfn_jpeg_entropy_decode(const unsigned char* data, long long size, short* coef, long long coef_cap,
+                            unsigned short* qt, int* info);
+int vfn_jpeg_idct_u8(const short* coef, const unsigned short* qt, unsigned char* plane, int blocks_per_row,
+                     int block_rows, int pitch, void* stream);
+int vfn_jpeg_to_tensor_f32(const unsigned char* y, const unsigned char* cb, const unsigned char* cr, int pitch_y,
+                           int pitch_c, int W, int H, int hs, int vs, int ncomp, float* out_f32, unsigned char* out_u8,
+                           void* stream);
+
 /* ------------------------------------------------------------------ PNG encoding on the device
  * vfn_png_deflate_u8: the compression inside save_seg_mask (PIL mode-P PNG, myutils/data.py:49-53) and save_overlay
  *     (cv2.imwrite, myutils/data.py:78-84).  raw = uint8 [H][W][bpp] on the device, bpp = 1 (palette indices) or 3 (RGB).

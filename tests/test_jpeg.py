@@ -1,0 +1,147 @@
+"""JPEG input side: host entropy decoder (C++ in libvfn_hip.so) + device IDCT / upsampling / colour / ToTensor against
+PIL (libjpeg-turbo), which is what the reference's Video_DS hands to the model (Water_DS.py:105-109).
+
+CPU: the product's entropy decoder feeds the numpy restatement of libjpeg's integer pipeline (oracle/jpeg_ref.py), which
+must reproduce PIL's RGB output exactly -- that pins both.  GPU: the device kernels against PIL, bit for bit."""
+import io
+
+import numpy as np
+import pytest
+import torch
+from PIL import Image
+
+# name, H, W, mode, quality, subsampling (PIL: 0 = 4:4:4, 1 = 4:2:2, 2 = 4:2:0), extra save options
+CASES = [('c2_frame_420', 480, 854, 'RGB', 92, 2, {}), ('q50_420', 97, 131, 'RGB', 50, 2, {}),
+         ('q100_444', 64, 80, 'RGB', 100, 0, {}), ('q85_422', 75, 101, 'RGB', 85, 1, {}),
+         ('grey', 50, 70, 'L', 90, 0, {}), ('tiny_3x5_420', 3, 5, 'RGB', 90, 2, {}), ('w2_420', 9, 2, 'RGB', 90, 2, {}),
+         ('one_px', 1, 1, 'RGB', 90, 2, {}), ('odd_17x33_420', 17, 33, 'RGB', 75, 2, {}),
+         ('restart_420', 120, 200, 'RGB', 80, 2, {'restart_marker_blocks': 3}), ('optimised_huffman', 90, 110, 'RGB', 92, 2, {'optimize': True}),
+         ('q30_noise_444', 40, 40, 'RGB', 30, 0, {})]
+
+
+def _jpeg_bytes(name, H, W, mode, quality, subsampling, extra):
+    from tools import synth
+    frames, _ = synth.clip(abs(hash(name)) % 97 + 1, 1, max(H, 8), max(W, 8))
+    img = (frames[0, :, :H, :W].permute(1, 2, 0).numpy() * 255).astype(np.uint8)
+    if 'noise' in name:
+        img = np.random.RandomState(3).randint(0, 256, (H, W, 3)).astype(np.uint8)
+    im = Image.fromarray(img)
+    if mode == 'L':
+        im = im.convert('L')
+    buf = io.BytesIO()
+    kw = dict(format='JPEG', quality=quality, **extra)
+    if mode != 'L':
+        kw['subsampling'] = subsampling
+    im.save(buf, **kw)
+    return buf.getvalue()
+
+
+def _pil_rgb(data):
+    return np.array(Image.open(io.BytesIO(data)).convert('RGB'))          # myutils.load_image_in_PIL (data.py:87-90)
+
+
+@pytest.mark.parametrize('case', CASES, ids=[c[0] for c in CASES])
+def test_host_entropy_decoder_and_oracle_match_pil(case):
+    import vfloodnet_amd  # noqa: F401
+    from vfloodnet_amd import jpeg_device
+    from oracle import jpeg_ref
+    data = _jpeg_bytes(*case)
+    coef, qt, info = jpeg_device.entropy_decode(data)
+    ref = _pil_rgb(data)
+    assert (int(info[0]), int(info[1])) == (ref.shape[1], ref.shape[0])
+    got = jpeg_ref.decode(coef, qt, info)
+    assert np.array_equal(got, ref), (case[0], int(np.abs(got.astype(int) - ref.astype(int)).max()))
+
+
+def test_unsupported_and_corrupt_files_fail_loudly():
+    import vfloodnet_amd  # noqa: F401
+    from vfloodnet_amd import jpeg_device
+    im = Image.fromarray(np.random.RandomState(0).randint(0, 256, (40, 50, 3)).astype(np.uint8))
+    buf = io.BytesIO()
+    im.save(buf, format='JPEG', progressive=True)
+    with pytest.raises(RuntimeError, match='unsupported'):
+        jpeg_device.entropy_decode(buf.getvalue())
+    buf = io.BytesIO()
+    im.convert('CMYK').save(buf, format='JPEG')
+    with pytest.raises(RuntimeError):
+        jpeg_device.entropy_decode(buf.getvalue())
+    with pytest.raises(RuntimeError, match='not a JPEG'):
+        jpeg_device.entropy_decode(b'\x89PNG\r\n\x1a\n' + b'\x00' * 64)
+    buf = io.BytesIO()
+    im.save(buf, format='JPEG')
+    with pytest.raises(RuntimeError):
+        jpeg_device.entropy_decode(buf.getvalue()[:200])                  # truncated inside the tables / scan
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('case', CASES, ids=[c[0] for c in CASES])
+def test_device_decode_equals_pil_to_tensor(gpu, case):
+    from vfloodnet_amd import jpeg_device
+    from vfloodnet_amd.dataset import to_tensor
+    data = _jpeg_bytes(*case)
+    coef, qt, info = jpeg_device.entropy_decode(data)
+    out, u8 = jpeg_device.to_tensor(coef, qt, info, gpu, want_u8=True)
+    ref = _pil_rgb(data)
+    assert np.array_equal(u8.cpu().numpy(), ref)                          # RGB bytes: exact
+    assert torch.equal(out.cpu(), to_tensor(ref))                         # ToTensor: bit-identical floats
+
+
+def test_video_ds_device_decode_items(tmp_path):
+    """Video_DS(decode='device'): JPEG frames come as entropy-decoded coefficients, PNG frames (and JPEG variants outside
+    the baseline subset) as uint8 images decoded by PIL."""
+    import vfloodnet_amd  # noqa: F401
+    from vfloodnet_amd.dataset import Video_DS
+    from oracle import jpeg_ref
+    rng = np.random.RandomState(1)
+    paths = []
+    for i, (ext, kw) in enumerate([('.png', {}), ('.jpg', dict(quality=90)), ('.png', {}), ('.jpg', dict(quality=90, progressive=True))]):
+        img = Image.fromarray(rng.randint(0, 256, (24, 40, 3)).astype(np.uint8))
+        pth = str(tmp_path / f'{i:05d}{ext}')
+        img.save(pth, **kw)
+        paths.append(pth)
+    mask = Image.fromarray((rng.rand(24, 40) > 0.5).astype(np.uint8))
+    ds = Video_DS(paths, Image.open(paths[0]).convert('RGB'), mask, raw_u8=True, decode='device')
+    assert len(ds) == 3
+    item, name = Video_DS.collate([ds[0]])
+    assert name == '00001' and set(item) == {'jpeg'}
+    coef, qt, info = item['jpeg']
+    assert np.array_equal(jpeg_ref.decode(coef.numpy(), qt.numpy().astype(np.uint16), info.numpy()),
+                          np.array(Image.open(paths[1]).convert('RGB')))
+    item, _ = ds[1]
+    assert set(item) == {'u8'} and np.array_equal(item['u8'].numpy(), np.array(Image.open(paths[2]).convert('RGB')))
+    item, _ = ds[2]                                                          # progressive JPEG: PIL decodes it
+    assert set(item) == {'u8'} and np.array_equal(item['u8'].numpy(), np.array(Image.open(paths[3]).convert('RGB')))
+
+
+@pytest.mark.gpu
+def test_main_loop_on_jpeg_frames_device_decode_equals_pil_decode(gpu, tmp_path, monkeypatch):
+    """video_seg.main on JPEG frames: --decode device and --decode pil write identical label maps (the input tensors are
+    bit-identical, so everything downstream is)."""
+    import argparse
+    from vfloodnet_amd import video_seg
+    from vfloodnet_amd.data import save_seg_mask, color_palette
+    from tools import synth
+    from golden_util import state_dict
+    T, H, W = 5, 120, 200
+    frames, m0 = synth.clip(2, T, H, W)
+    fdir = tmp_path / 'frames'
+    fdir.mkdir()
+    for i in range(T):
+        Image.fromarray((frames[i].permute(1, 2, 0).numpy() * 255).astype(np.uint8)).save(str(fdir / f'{i:05d}.jpg'), quality=92)
+    ckpt = str(tmp_path / 'ckpt.pth')
+    torch.save({'epoch': 0, 'model': state_dict(), 'loss': 0.0, 'seed': 20200212}, ckpt)
+    monkeypatch.chdir(tmp_path)
+    outs = {}
+    for mode in ('device', 'pil'):
+        name = f'clip_{mode}'
+        (tmp_path / 'output' / 'segs' / name / 'mask').mkdir(parents=True)
+        save_seg_mask(m0.numpy(), str(tmp_path / 'output' / 'segs' / name / 'mask' / '00000.png'), color_palette)
+        args = argparse.Namespace(gpu=0, budget=250000, viz=True, model_path=ckpt, update_rate=0.1, merge_thres=0.95,
+                                  test_path=str(fdir), test_name=name, decode=mode)
+        video_seg.main(args, gpu)
+        outs[mode] = [np.array(Image.open(str(tmp_path / 'output' / 'segs' / name / 'mask' / f'{i:05d}.png'))) for i in range(T)]
+        ov = Image.open(str(tmp_path / 'output' / 'segs' / name / 'overlay' / f'{T - 1:05d}.png'))
+        assert ov.mode == 'RGB' and ov.size == (W, H)
+    for i in range(T):
+        assert np.array_equal(outs['device'][i], outs['pil'][i]), i
+    assert 0 < outs['device'][-1].mean() < 1

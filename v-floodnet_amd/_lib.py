@@ -140,6 +140,9 @@ SIGNATURES = {
     'vfn_to_tensor_u8': [_p, _p, _i, _i, _p],
     'vfn_overlay_u8': [_p, _p, _p, _p, _p, _i, _i, C.c_double, C.c_double, _p],
     'vfn_segment_uncertainty_f32': [_p, _i, _i, _i, _p, _p, _p],
+    'vfn_jpeg_entropy_decode': [_p, _ll, _p, _ll, _p, _p],
+    'vfn_jpeg_idct_u8': [_p, _p, _p, _i, _i, _i, _p],
+    'vfn_jpeg_to_tensor_f32': [_p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p, _p, _p],
     'vfn_png_sizes': [_i, _i, _i, C.POINTER(_ll), C.POINTER(_ll)],
     'vfn_png_deflate_u8': [_p, _i, _i, _i, _p, _p, _p, _p],
 }

@@ -34,12 +34,22 @@ def to_onehot(mask, max_obj_n):
 
 
 class Video_DS(data.Dataset):
-    """dataset/Water_DS.py:105-139.  ``raw_u8=True`` (an extension used by ``video_seg.main``): ``__getitem__`` hands
-    out the decoded uint8 HWC frame and ``ToTensor`` runs on the GPU (``ops.to_tensor_device``, bit-identical),
-    so a frame crosses PCIe as 1 byte per sample."""
+    """dataset/Water_DS.py:105-139.  Extensions used by ``video_seg.main`` (the defaults are the reference's contract):
 
-    def __init__(self, img_list, first_frame, first_mask, raw_u8=False):
+    ``raw_u8=True``: ``__getitem__`` hands out the decoded uint8 HWC frame and ``ToTensor`` runs on the GPU
+    (``ops.to_tensor_device``, bit-identical), so a frame crosses PCIe as 1 byte per sample.
+
+    ``decode='device'``: baseline JPEG files are only entropy-decoded here (``jpeg_device.entropy_decode``, host C++,
+    safe in worker processes); the item is a dict ``{'jpeg': (coef, qt, info)}`` and inverse DCT, chroma upsampling,
+    colour conversion and ``ToTensor`` run on the GPU (``jpeg_device.to_tensor``) -- the same tensor, bit for bit.
+    PNG frames and JPEG variants outside the baseline subset (progressive, CMYK ...) are decoded by PIL as before and
+    come as ``{'u8': HWC uint8}``; use ``collate_fn=Video_DS.collate`` (batch size 1)."""
+
+    def __init__(self, img_list, first_frame, first_mask, raw_u8=False, decode='pil'):
+        if decode not in ('pil', 'device'):
+            raise ValueError("decode must be 'pil' or 'device'")
         self.raw_u8 = raw_u8
+        self.decode = decode
         self.img_list = img_list[1:]
         self.video_len = len(self.img_list)
         first_mask = np.array(first_mask, np.uint8) > 0
@@ -51,8 +61,26 @@ class Video_DS(data.Dataset):
     def __len__(self):
         return self.video_len
 
+    @staticmethod
+    def collate(batch):
+        assert len(batch) == 1, 'the inference loop runs with batch size 1 (test_video_seg.py:74)'
+        return batch[0]
+
     def __getitem__(self, idx):
-        img = load_image_in_PIL(self.img_list[idx], 'RGB')
+        path = self.img_list[idx]
+        img_name = os.path.basename(path)[:-4]
+        if self.decode == 'device':
+            if path.lower().endswith(('.jpg', '.jpeg')):
+                from . import jpeg_device
+                with open(path, 'rb') as f:
+                    data_ = f.read()
+                try:
+                    coef, qt, info = jpeg_device.entropy_decode(data_)
+                    return {'jpeg': (torch.from_numpy(coef), torch.from_numpy(qt.astype(np.int16)), torch.from_numpy(info))}, img_name
+                except RuntimeError as e:
+                    if 'unsupported' not in str(e):
+                        raise
+            return {'u8': torch.from_numpy(np.array(load_image_in_PIL(path, 'RGB'), np.uint8))}, img_name
+        img = load_image_in_PIL(path, 'RGB')
         frame = torch.from_numpy(np.array(img, np.uint8)) if self.raw_u8 else to_tensor(img)
-        img_name = os.path.basename(self.img_list[idx])[:-4]
         return frame, img_name

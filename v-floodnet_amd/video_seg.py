@@ -21,6 +21,7 @@ import torch
 from . import ops
 from .data import AsyncWriter, color_palette, load_image_in_PIL, save_overlay, save_seg_mask
 from .png_device import PngSink
+from . import jpeg_device
 from .dataset import Video_DS
 from .feature_bank import FeatureBank
 from .model import AFB_URR
@@ -48,6 +49,9 @@ def get_args(argv=None):
                         help='Merging Rate. If similarity higher than this, then merge, else append.')
     parser.add_argument('--test-path', type=str, required=True, help='Video Path')
     parser.add_argument('--test-name', type=str, required=True, help='Video Name')
+    parser.add_argument('--decode', choices=['device', 'pil'], default='device',
+                        help='device: JPEG frames are entropy-decoded by the loader workers and reconstructed on the GPU; '
+                             'pil: every frame is decoded by PIL (the reference path).')
     parser.add_argument('--size', type=int, default=480, help='Short-edge size the network runs at (reference: 480).')
     parser.add_argument('--mem-every', type=int, default=1, help='Memorise every n-th frame (reference: 1).')
     return parser.parse_args(argv)
@@ -244,11 +248,13 @@ def main(args, device):
         test_waterseg(image_model_path, img_list[0], args.test_name, out_dir, device)
 
     first_mask = load_image_in_PIL(mask_path, 'P')
-    seq_dataset = Video_DS(img_list, first_frame, first_mask, raw_u8=True)       # uint8 over PCIe, ToTensor on the GPU
-    # (the reference uses one worker; decoding is ~2 ms per 480p JPEG but the per-item hand-over costs more than that)
+    # JPEG frames: the workers undo the entropy coding only, the rest of the decode runs on the GPU (jpeg_device);
+    # PNG frames: PIL inflates them, ToTensor runs on the GPU.  Either way a frame crosses PCIe at ~1 byte per sample.
+    seq_dataset = Video_DS(img_list, first_frame, first_mask, decode=getattr(args, 'decode', 'device'), raw_u8=True)
+    # (the reference uses one worker; the per-item hand-over costs more than the decode)
     n_load = int(getattr(args, 'load_workers', 4))
     seq_loader = torch.utils.data.DataLoader(seq_dataset, batch_size=1, shuffle=False, num_workers=n_load,
-                                             prefetch_factor=4 if n_load > 0 else None)
+                                             prefetch_factor=4 if n_load > 0 else None, collate_fn=Video_DS.collate)
 
     seg_dir = os.path.join(out_dir, args.test_name, 'mask')
     os.makedirs(seg_dir, exist_ok=True)
@@ -281,8 +287,37 @@ def main(args, device):
         it = iter(seq_loader)                    # (workers start decoding while the first frame is memorised)
         runner.start(ori_first_frame, ori_first_mask)
 
-        def upload(item):                        # ToTensor (Water_DS.py:108) on the device
-            return ops.to_tensor_device(item[0][0].to(device, non_blocking=True)).unsqueeze(0) if item is not None else None
+        # Uploads go through pinned staging buffers on their own stream: a pageable-memory ``.to(device)`` is ordered
+        # behind everything already enqueued on the compute stream and blocks the host until it has run -- that would
+        # undo the launch / collect pipelining.  Three slots: frames t, t+1 (look-ahead) and the one being filled.
+        copy_stream = torch.cuda.Stream(device=device)
+        staging = {}
+        slot = [0]
+
+        def to_device_async(t):
+            key = (tuple(t.shape), t.dtype, slot[0] % 3)
+            if key not in staging:
+                staging[key] = (torch.empty(t.shape, dtype=t.dtype).pin_memory(), torch.cuda.Event())
+            pinned, free = staging[key]
+            free.synchronize()                   # the copy that last used this slot has finished (long ago)
+            np.copyto(pinned.numpy(), t.numpy())     # plain memcpy (a torch CPU copy_ would wake the whole OpenMP pool)
+            with torch.cuda.stream(copy_stream):
+                d = pinned.to(device, non_blocking=True)
+                free.record()
+            torch.cuda.current_stream().wait_stream(copy_stream)
+            d.record_stream(torch.cuda.current_stream())
+            return d
+
+        def upload(item):                        # the rest of Video_DS.__getitem__ (Water_DS.py:105-109) on the device
+            if item is None:
+                return None
+            slot[0] += 1
+            payload = item[0]
+            if isinstance(payload, dict) and 'jpeg' in payload:
+                coef, qt, info = payload['jpeg']
+                return jpeg_device.to_tensor(to_device_async(coef), to_device_async(qt), info, device).unsqueeze(0)
+            u8 = payload['u8'] if isinstance(payload, dict) else payload
+            return ops.to_tensor_device(to_device_async(u8)).unsqueeze(0)
 
         cur = next(it, None)
         cur_dev = upload(cur)
@@ -290,7 +325,7 @@ def main(args, device):
             nxt = next(it, None)
             nxt_dev = upload(nxt)
             buf = runner.launch(cur_dev, next_frame=nxt_dev, want_label=False)   # postprocessing_pred (:116) runs on the GPU
-            name = cur[1][0]
+            name = cur[1]
             buf['reader_done'] = sink.save(runner.label_device(), os.path.join(seg_dir, f'{name}.png'), color_palette,
                                            frame=cur_dev[0] if args.viz else None,
                                            overlay_path=os.path.join(overlay_dir, f'{name}.png') if args.viz else None)
