@@ -319,21 +319,34 @@ def main(argv=None):
     bank_sizes = []
     frame_ms = []
 
+    last_collect = [0.0]
+
+    def collect_one():
+        runner.collect()
+        bank_sizes.append(runner.bank_sizes())
+        now = time.perf_counter()
+        frame_ms.append((len(bank_sizes), 1e3 * (now - last_collect[0])))
+        last_collect[0] = now
+
     def run_iters(t_from, t_to, sampling):
+        """Frames t_from..t_to, pipelined across frames as video_seg.main does: frame t+1 is enqueued before the host
+        waits for frame t (ClipRunner.launch / collect), so the device never idles on the host between frames.  The
+        caller's bracket() drains the pipeline, so every timed region still contains exactly its own frames."""
+        last_collect[0] = time.perf_counter()
         for t in range(t_from, t_to + 1):
             idx = frame_of(t)
             timer.active = sampling and ((t - s_first + 1) % args.sample_every == 0)
             # no prefetch into / out of a sampled frame: its kernels are timed alone on the device
             sampled_next = sampling and ((t - s_first + 2) % args.sample_every == 0)
             nxt = frame_of(t + 1) if (t < last_iter and not args.no_overlap and not timer.active and not sampled_next) else None
-            c0 = time.perf_counter()
-            runner.step(frames[idx:idx + 1], want_label=False,
-                        next_frame=frames[nxt:nxt + 1] if nxt is not None else None)
-            frame_ms.append((t, 1e3 * (time.perf_counter() - c0)))
+            runner.launch(frames[idx:idx + 1], next_frame=frames[nxt:nxt + 1] if nxt is not None else None, want_label=False)
             timer.active = False
             labels[t].copy_(runner.label_device(), non_blocking=True)
             labels_raw[t].copy_(runner._label_dev, non_blocking=True)
-            bank_sizes.append(runner.bank_sizes())
+            if len(runner._pending) == 2:
+                collect_one()
+        while runner._pending:
+            collect_one()
 
     def bracket():
         torch.cuda.synchronize()
@@ -421,7 +434,7 @@ def main(argv=None):
     tms = sorted(ms_ for t_, ms_ in frame_ms if s_first <= t_ < s_first + K)
     frame_stats = {'p50': round(tms[len(tms) // 2], 3), 'p90': round(tms[min(len(tms) - 1, int(0.9 * len(tms)))], 3),
                    'max': round(tms[-1], 3), 'min': round(tms[0], 3),
-                   'note': 'host wall per step incl. its one synchronisation; sampled frames (events around every launch, no overlap) are the slow tail'}
+                   'note': 'host wall between the completions of consecutive steps (the loop keeps one step in flight); sampled frames (events around every launch, no overlap) are the slow tail'}
 
     # ---- CPU baseline + parity on the first frames of the same clip
     cpu = None

@@ -10,7 +10,7 @@ prec = sys.argv[1] if len(sys.argv) > 1 else 'fp32'
 dev = torch.device('cuda', 0)
 model = AFB_URR(dev, update_bank=True, precision=prec).to(dev).eval()
 for (h, w) in [(480, 854), (480, 853), (480, 800)]:
-    model.engine().autotune(h, w, 2, iters=5)
+    model.engine().autotune(h, w, 2, iters=int(os.environ.get('VFN_TUNE_ITERS', 12)))
 os.makedirs('gpurun_out', exist_ok=True)
 for mode in sorted(set([ops.MODES[prec], 2 if prec == 'bf16' else ops.MODES[prec]])):
     name = os.path.basename(engine._TABLE_PATHS[mode])

@@ -579,13 +579,17 @@ class Engine:
         def timeit(d, c, bf):
             ops.conv2d_launch(d, c, bf)
             torch.cuda.synchronize()
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            for _ in range(iters):
-                ops.conv2d_launch(d, c, bf)
-            e1.record()
-            torch.cuda.synchronize()
-            return e0.elapsed_time(e1)
+            best_ms = None
+            for _ in range(3):                                   # fastest of three batches: robust against a transient
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(iters):
+                    ops.conv2d_launch(d, c, bf)
+                e1.record()
+                torch.cuda.synchronize()
+                ms = e0.elapsed_time(e1)
+                best_ms = ms if best_ms is None else min(best_ms, ms)
+            return best_ms
 
         for key, launches in seen.items():
             d = launches[0].args[0]
