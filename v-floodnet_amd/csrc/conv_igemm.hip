@@ -836,20 +836,24 @@ int launch_cfg(const vfn_conv_desc& p, hipStream_t s) {
 
 }  // namespace
 
-extern "C" int vfn_conv_cfg_count(void) { return 20; }
+extern "C" int vfn_conv_cfg_count(void) { return 26; }
 
 extern "C" int vfn_conv_cfg_info(int cfg, int* bm, int* bn, int* wm, int* wn, int* dma) {
     // 8..10: same tiles as 0 / 0 / 2 with twice the waves (smaller per-wave tiles, 4 waves per SIMD at 2 blocks/CU)
     // 11..16: LDS-DMA staging variants of 8 / 10 / 3 / 7 / 6 / 2
     // 17..19: 256-filter-wide tiles (input tile read once for all 256 filters): 128x256 and 64x256, 8 waves
     // (must match the switch of vfn_conv2d_nhwc_f32 below)
-    static const int t[20][5] = {{128, 128, 2, 2, 0}, {128, 64, 2, 2, 0}, {64, 128, 2, 2, 0}, {64, 64, 2, 2, 0}, {32, 64, 1, 2, 0},
+    // 20..25 (f32 only): 32-row tiles for the 1/16-resolution layers (M = 1620: 51 x 32 rows instead of 26 x 64),
+    // single-wave 32x32 tiles (most workgroups for the smallest layers), and 8-wave variants of 128x64 / 256x64
+    static const int t[26][5] = {{128, 128, 2, 2, 0}, {128, 64, 2, 2, 0}, {64, 128, 2, 2, 0}, {64, 64, 2, 2, 0}, {32, 64, 1, 2, 0},
                                  {64, 32, 2, 1, 0}, {128, 32, 4, 1, 0}, {256, 128, 4, 2, 0},
                                  {128, 128, 2, 4, 0}, {128, 128, 4, 2, 0}, {64, 128, 2, 4, 0},
                                  {128, 128, 2, 4, 2}, {64, 128, 2, 4, 2}, {64, 64, 2, 2, 2}, {256, 128, 4, 2, 2}, {128, 32, 4, 1, 2},
                                  {64, 128, 2, 2, 2},
-                                 {128, 256, 2, 4, 0}, {128, 256, 2, 4, 2}, {64, 256, 2, 4, 0}};
-    if (cfg < 0 || cfg >= 20) return VFN_ERR_ARG;
+                                 {128, 256, 2, 4, 0}, {128, 256, 2, 4, 2}, {64, 256, 2, 4, 0},
+                                 {32, 128, 1, 4, 0}, {32, 32, 1, 1, 0}, {128, 64, 4, 2, 0}, {256, 64, 4, 2, 0}, {32, 64, 1, 1, 0},
+                                 {64, 64, 1, 2, 0}};
+    if (cfg < 0 || cfg >= 26) return VFN_ERR_ARG;
     if (bm) *bm = t[cfg][0];
     if (bn) *bn = t[cfg][1];
     if (wm) *wm = t[cfg][2];
@@ -904,6 +908,12 @@ extern "C" int vfn_conv2d_nhwc_f32(const vfn_conv_desc* d, int cfg, void* stream
         case 17: return launch_cfg<128, 256, 2, 4>(*d, s);
         case 18: return launch_cfg<128, 256, 2, 4, 2>(*d, s);
         case 19: return launch_cfg<64, 256, 2, 4>(*d, s);
+        case 20: return launch_cfg<32, 128, 1, 4>(*d, s);
+        case 21: return launch_cfg<32, 32, 1, 1>(*d, s);
+        case 22: return launch_cfg<128, 64, 4, 2>(*d, s);
+        case 23: return launch_cfg<256, 64, 4, 2>(*d, s);
+        case 24: return launch_cfg<32, 64, 1, 1>(*d, s);
+        case 25: return launch_cfg<64, 64, 1, 2>(*d, s);
     }
     return VFN_ERR_ARG;
 }
