@@ -247,6 +247,11 @@ int vfn_bank_append(const vfn_bank_desc* d, void* stream);
 /* FeatureBank.remove(class_idx, request_n, frame_idx) on its own (update() fuses it into vfn_bank_append):
  * LFU threshold loop + order-preserving compaction of one object; stats[obj] = {len, peak, replace_n, -}. */
 int vfn_bank_remove(const vfn_bank_desc* d, void* stream);
+/* Norms carried across frames instead of recomputed over the whole bank (FeatureBank.py:63-65,87-88 recompute them every
+ * update): call after vfn_bank_merge + vfn_bank_append of one update with the same descriptor; refreshes ||key||,
+ * 1/max(||key||,1e-12) and ||value|| of the entries that update touched (merged and appended rows; every row when it
+ * evicted), with the summation of vfn_row_norms -- bit-identical to recomputing them all. */
+int vfn_bank_refresh_norms(const vfn_bank_desc* d, float* bank_knorm, float* bank_kinv, float* bank_vnorm, void* stream);
 int vfn_scatter_mean_f32(const float* src, long long src_s0, long long src_s1, const long long* index,
                          int S, float* out, long long out_s0, long long out_s1, int D, void* stream);
 

@@ -399,3 +399,38 @@ def test_remove_with_undefined_lfu_raises_like_the_reference(gpu):
         assert fb.keys[0].shape == (128, 40) and torch.equal(fb.keys[0].cpu(), k0[0])
         # the bank stays usable: a later frame index gives finite scores
         assert fb.remove(0, 10, 9) == fb_ref.remove(0, 10, 9)
+
+
+def test_carried_bank_norms_equal_full_recomputation(gpu):
+    """FeatureBank.update carries ||key||, 1/||key||, ||value|| across frames (vfn_bank_refresh_norms) instead of
+    recomputing them over the whole bank like the reference (FeatureBank.py:63-65,87-88): two banks fed the same
+    updates, one of them forced to recompute everything every frame, must stay bit-identical -- through merges, appends
+    and evictions."""
+    from vfloodnet_amd import FeatureBank
+    g = torch.Generator().manual_seed(31)
+    hw = 150
+    k0, v0 = _rand_feats(g, 2, hw)
+    banks = [FeatureBank(2, 1000, gpu, 0.1, 0.9) for _ in range(2)]          # class_budget 400: evicts from frame 2 on
+    for fb in banks:
+        fb.init_bank([k.to(gpu) for k in k0], [v.to(gpu) for v in v0])
+    for t in range(1, 8):
+        k1, v1 = _rand_feats(g, 2, hw)
+        for i in range(2):
+            src = torch.randint(0, hw // 3, (hw // 2,), generator=g)
+            k1[i][:, :hw // 2] = 0.9 * k0[i][:, src] + 0.03 * torch.randn(128, hw // 2, generator=g)
+        bump = [torch.rand(banks[0]._len_host[i], generator=g) * 3 for i in range(2)]
+        for fb in banks:
+            for i in range(2):
+                fb._ibuf[i, :fb._len_host[i], 1] += bump[i].to(gpu)               # (not through the views: they invalidate)
+        banks[1]._norms_valid = False                                           # full recomputation every frame
+        assert banks[0]._norms_valid == (t > 1)
+        for fb in banks:
+            fb.update([k.to(gpu) for k in k1], [v.to(gpu) for v in v1], t)
+            fb._sync_len()
+        assert banks[0]._len_host == banks[1]._len_host
+        n = banks[0]._len_host
+        for i in range(2):
+            for name in ('_kbuf', '_vbuf', '_ibuf', '_knorm', '_kinv', '_vnorm'):
+                a, b = getattr(banks[0], name)[i, :n[i]], getattr(banks[1], name)[i, :n[i]]
+                assert torch.equal(a, b), (t, i, name)
+    assert banks[0].replace_n.sum() > 0

@@ -112,6 +112,7 @@ def _declare(L):
     L.vfn_bank_merge.argtypes = [C.POINTER(BankDesc), p]
     L.vfn_bank_append.argtypes = [C.POINTER(BankDesc), p]
     L.vfn_bank_remove.argtypes = [C.POINTER(BankDesc), p]
+    L.vfn_bank_refresh_norms.argtypes = [C.POINTER(BankDesc), p, p, p, p]
     for name, args in SIGNATURES.items():
         fn = getattr(L, name)
         fn.argtypes = args
@@ -150,7 +151,7 @@ SIGNATURES = {
 ALL_SYMBOLS = sorted(list(SIGNATURES) + [
     'vfn_abi_version', 'vfn_sizeof_desc', 'vfn_conv_cfg_count', 'vfn_conv_cfg_tile', 'vfn_conv_cfg_info', 'vfn_conv2d_nhwc_f32', 'vfn_conv2d_nhwc_bf16', 'vfn_conv2d_nhwc_bf16x3', 'vfn_conv3x3_cout2_f32',
     'vfn_stem_conv7x7_f32',
-    'vfn_bank_scan', 'vfn_memread_apply', 'vfn_memread_finish', 'vfn_bank_merge', 'vfn_bank_append', 'vfn_bank_remove'])
+    'vfn_bank_scan', 'vfn_memread_apply', 'vfn_memread_finish', 'vfn_bank_merge', 'vfn_bank_append', 'vfn_bank_remove', 'vfn_bank_refresh_norms'])
 
 
 def check(status, what):

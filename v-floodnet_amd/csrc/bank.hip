@@ -317,6 +317,48 @@ __global__ void bank_commit_len_kernel(const vfn_bank_desc p) {
     if (obj < p.obj_n) p.bank_len_rw[obj] = p.stats[obj * 4];
 }
 
+// ---------------------------------------------------------------- norms carried across frames
+// After an update only the merged entries (new values) and the appended entries (new rows) have norms that differ from
+// last frame's; an eviction moves everything.  One wave per row, the same summation as row_norms_kernel, so the carried
+// norms equal a full recomputation bit for bit.  Reads plan / app_pos of the update that just ran.
+__global__ void bank_refresh_norms_kernel(const vfn_bank_desc p, float* __restrict__ knorm, float* __restrict__ kinv,
+                                          float* __restrict__ vnorm) {
+    const int obj = blockIdx.y;
+    const int* plan = p.plan + obj * 4;
+    const bool all = plan[1] != 0;                                // rows were compacted: recompute every norm
+    const int newlen = p.stats[obj * 4];
+    const int base = plan[2];
+    const int items = all ? newlen : p.HW;
+    const int* idx = p.match_idx + (size_t)obj * p.HW;
+    const float* corr = p.match_corr + (size_t)obj * p.HW;
+    const int* pos = p.app_pos + (size_t)obj * p.HW;
+    const float* K = p.bank_k + (size_t)obj * p.stride_k;
+    const float* V = p.bank_v + (size_t)obj * p.stride_v;
+    const int lane = threadIdx.x & 63, wpb = blockDim.x >> 6;
+    for (int it = blockIdx.x * wpb + (threadIdx.x >> 6); it < items; it += gridDim.x * wpb) {
+        int row = it;
+        if (!all) row = (corr[it] > p.thres_close) ? idx[it] : base + pos[it];
+        if (row < 0 || row >= newlen) continue;
+        float sk = 0.f, sv = 0.f;
+        for (int d = lane * 4; d < DK; d += 256) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(K + (size_t)row * DK + d);
+            sk += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+        }
+        for (int d = lane * 4; d < DV; d += 256) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(V + (size_t)row * DV + d);
+            sv += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+        }
+        sk = wave_sum(sk);
+        sv = wave_sum(sv);
+        if (lane == 0) {
+            const float nk = sqrtf(sk);
+            knorm[(size_t)obj * p.stride_n + row] = nk;
+            kinv[(size_t)obj * p.stride_n + row] = 1.f / fmaxf(nk, 1e-12f);
+            vnorm[(size_t)obj * p.stride_n + row] = sqrtf(sv);
+        }
+    }
+}
+
 // ---------------------------------------------------------------- scatter_mean operator
 // out[d][t] = (out[d][t] + sum_{s: index[s]==t} src[d][s]) / max(count_t, 1), dim = 1, index row-broadcast
 __global__ __launch_bounds__(256)
@@ -400,5 +442,14 @@ extern "C" int vfn_scatter_mean_f32(const float* src, long long src_s0, long lon
     if (S == 0) return VFN_OK;
     hipLaunchKernelGGL(scatter_mean_kernel, dim3(S), dim3(256), 0, (hipStream_t)stream,
                        src, src_s0, src_s1, index, S, out, out_s0, out_s1, D);
+    return vfn_check_launch();
+}
+
+extern "C" int vfn_bank_refresh_norms(const vfn_bank_desc* d, float* bank_knorm, float* bank_kinv, float* bank_vnorm,
+                                      void* stream) {
+    if (!bank_desc_ok(d) || !d->plan || !d->stats || !d->match_idx || !d->match_corr || !d->app_pos) return VFN_ERR_ARG;
+    if (!bank_knorm || !bank_kinv || !bank_vnorm) return VFN_ERR_ARG;
+    hipLaunchKernelGGL(bank_refresh_norms_kernel, dim3(1024, d->obj_n), dim3(256), 0, (hipStream_t)stream, *d,
+                       bank_knorm, bank_kinv, bank_vnorm);
     return vfn_check_launch();
 }

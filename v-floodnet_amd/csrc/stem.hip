@@ -33,11 +33,12 @@ void stem_kernel(const vfn_stem_desc p) {
     const int lane = tid & 63, wave = tid >> 6;
     const int li = lane & 31, lh = lane >> 5;
 
+    // One workgroup per output tile, for ALL images of the batch: the frame planes (and with them the first 3 x 7 x 8
+    // k-steps of the GEMM) are the same for every object (AFB_URR.py:261 expands the frame), so their products are
+    // accumulated once and every object continues from that accumulator with its own two mask planes -- the same
+    // k-order as one 5-plane GEMM per object, bit for bit, at 7/10 of the matrix work and one filter load per tile.
     const int tiles_x = (p.Wo + TW - 1) / TW;
-    const int tiles_y = (p.Ho + TH - 1) / TH;
-    int b = blockIdx.x;
-    const int n = b / (tiles_x * tiles_y);
-    b -= n * tiles_x * tiles_y;
+    const int b = blockIdx.x;
     const int ty = b / tiles_x, tx = b - ty * tiles_x;
     const int oy0 = ty * TH, ox0 = tx * TW;
 
@@ -45,27 +46,30 @@ void stem_kernel(const vfn_stem_desc p) {
     for (int i = tid * 4; i < KP * 64; i += 256 * 4)
         *reinterpret_cast<f32x4*>(sW + i) = *reinterpret_cast<const f32x4*>(p.w + i);
 
-    // input patch -> LDS, with pad + normalisation semantics
+    // input patch -> LDS, with pad + normalisation semantics: planes [c_lo, c_hi) of image n
     const int gy0 = oy0 * 2 - 3, gx0 = ox0 * 2 - 3;     // padded-frame coordinates
-    for (int i = tid; i < CIN * PH * PW; i += 256) {
-        const int c = i / (PH * PW);
-        const int r = i - c * PH * PW;
-        const int y = r / PW, x = r - y * PW;
-        const int gy = gy0 + y, gx = gx0 + x;
-        float v = 0.f;
-        if (x < PW - 1 && (unsigned)gy < (unsigned)p.Hp && (unsigned)gx < (unsigned)p.Wp) {
-            const int ry = gy - p.pad_top, rx = gx - p.pad_left;
-            const bool inside = (unsigned)ry < (unsigned)p.H0 && (unsigned)rx < (unsigned)p.W0;
-            if (c < 3) {
-                const float raw = inside ? p.frame[((size_t)c * p.H0 + ry) * p.W0 + rx] : 0.f;
-                v = (raw - p.mean[c]) / p.std[c];
-            } else {
-                const float m = inside ? p.mask[((size_t)n * p.H0 + ry) * p.W0 + rx] : 0.f;
-                v = (c == 3) ? m : fminf(fmaxf(1.f - m, 0.f), 1.f);
+    auto load_planes = [&](int c_lo, int c_hi, int n) {
+        for (int i = c_lo * PH * PW + tid; i < c_hi * PH * PW; i += 256) {
+            const int c = i / (PH * PW);
+            const int r = i - c * PH * PW;
+            const int y = r / PW, x = r - y * PW;
+            const int gy = gy0 + y, gx = gx0 + x;
+            float v = 0.f;
+            if (x < PW - 1 && (unsigned)gy < (unsigned)p.Hp && (unsigned)gx < (unsigned)p.Wp) {
+                const int ry = gy - p.pad_top, rx = gx - p.pad_left;
+                const bool inside = (unsigned)ry < (unsigned)p.H0 && (unsigned)rx < (unsigned)p.W0;
+                if (c < 3) {
+                    const float raw = inside ? p.frame[((size_t)c * p.H0 + ry) * p.W0 + rx] : 0.f;
+                    v = (raw - p.mean[c]) / p.std[c];
+                } else {
+                    const float m = inside ? p.mask[((size_t)n * p.H0 + ry) * p.W0 + rx] : 0.f;
+                    v = (c == 3) ? m : fminf(fmaxf(1.f - m, 0.f), 1.f);
+                }
             }
+            sP[i] = v;
         }
-        sP[i] = v;
-    }
+    };
+    load_planes(0, 3, 0);
     __syncthreads();
 
     // this wave: 32 pixels = tile rows 2*wave, 2*wave+1; lane's pixel for the A operand
@@ -73,12 +77,10 @@ void stem_kernel(const vfn_stem_desc p) {
     const float* pa = sP + (2 * py) * PW + 2 * px + lh;      // + (c*PH+kh)*PW + 2*q
     const float* pb = sW + lh * 64 + li;                     // + (2*s)*64 + 32*tn
 
-    f32x16 acc0, acc1;
+    f32x16 accF0, accF1;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
-
-#pragma unroll
-    for (int c = 0; c < CIN; ++c) {
+    for (int r = 0; r < 16; ++r) { accF0[r] = 0.f; accF1[r] = 0.f; }
+    auto mac_planes = [&](f32x16& a0, f32x16& a1, int c) {
 #pragma unroll
         for (int kh = 0; kh < 7; ++kh) {
 #pragma unroll
@@ -87,29 +89,40 @@ void stem_kernel(const vfn_stem_desc p) {
                 const float a = pa[(c * PH + kh) * PW + 2 * q];
                 const float b0 = pb[(2 * s) * 64];
                 const float b1 = pb[(2 * s) * 64 + 32];
-                acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b0, acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b1, acc1, 0, 0, 0);
+                a0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b0, a0, 0, 0, 0);
+                a1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b1, a1, 0, 0, 0);
             }
         }
-    }
+    };
+#pragma unroll
+    for (int c = 0; c < 3; ++c) mac_planes(accF0, accF1, c);
 
-    // epilogue: BN + ReLU, NHWC store.  The 128 x 64 tile is transposed through LDS (the filter image is dead) so
-    // that a lane owns 4 consecutive channels of one pixel: 16-byte stores instead of 16 dword stores per lane.
-    __syncthreads();
-    constexpr int CP = 68;                                  // padded pitch (floats)
-    float* sC = reinterpret_cast<float*>(smem);             // [128 pixels][CP]
-#pragma unroll
-    for (int tn = 0; tn < 2; ++tn)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int pix = wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;      // 0..127 within the block tile
-            sC[pix * CP + tn * 32 + li] = tn == 0 ? acc0[r] : acc1[r];
+    // epilogue buffer: the 128 x 64 tile is transposed through LDS so that a lane owns 4 consecutive channels of one
+    // pixel (16-byte stores).  It lives in the image of the frame planes' filters, which are dead from here on.
+    constexpr int CP = 68;                                  // padded pitch (floats): 128 * 68 <= 168 * 64
+    float* sC = sW;
+    const int c4 = tid & 15;
+    const f32x4 sc = *reinterpret_cast<const f32x4*>(p.scale + c4 * 4);
+    const f32x4 sh = *reinterpret_cast<const f32x4*>(p.shift + c4 * 4);
+    for (int n = 0; n < p.N; ++n) {
+        f32x16 acc0 = accF0, acc1 = accF1;
+        if constexpr (CIN == 5) {
+            __syncthreads();                                 // previous object's mask planes / epilogue buffer are free
+            load_planes(3, 5, n);
+            __syncthreads();
+            mac_planes(acc0, acc1, 3);
+            mac_planes(acc0, acc1, 4);
+        } else {
+            __syncthreads();
         }
-    __syncthreads();
-    {
-        const int c4 = tid & 15;
-        const f32x4 sc = *reinterpret_cast<const f32x4*>(p.scale + c4 * 4);
-        const f32x4 sh = *reinterpret_cast<const f32x4*>(p.shift + c4 * 4);
+#pragma unroll
+        for (int tn = 0; tn < 2; ++tn)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int pix = wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;      // 0..127 within the block tile
+                sC[pix * CP + tn * 32 + li] = tn == 0 ? acc0[r] : acc1[r];
+            }
+        __syncthreads();
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
             const int pix = (tid >> 4) + 16 * k;            // wave-tile pixel: rows 2*(pix>>5) + ((pix&31)>>4), col pix&15
@@ -161,7 +174,7 @@ int launch_stem(const vfn_stem_desc& d, hipStream_t s) {
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = true;
     }
-    const int tiles = cdiv(d.Wo, TW) * cdiv(d.Ho, TH) * d.N;
+    const int tiles = cdiv(d.Wo, TW) * cdiv(d.Ho, TH);          // (all images of the batch in one workgroup)
     hipLaunchKernelGGL((stem_kernel<CIN>), dim3(tiles), dim3(256), lds, s, d);
     return vfn_check_launch();
 }
@@ -171,6 +184,7 @@ int launch_stem(const vfn_stem_desc& d, hipStream_t s) {
 extern "C" int vfn_stem_conv7x7_f32(const vfn_stem_desc* d, void* stream) {
     if (!d || !d->frame || !d->w || !d->out || !d->scale || !d->shift) return VFN_ERR_ARG;
     if (d->Hp % 2 || d->Wp % 2 || d->Ho != d->Hp / 2 || d->Wo != d->Wp / 2) return VFN_ERR_ARG;
+    if (d->N < 1) return VFN_ERR_ARG;
     if (d->cin == 3) return launch_stem<3>(*d, (hipStream_t)stream);
     if (d->cin == 5) { if (!d->mask) return VFN_ERR_ARG; return launch_stem<5>(*d, (hipStream_t)stream); }
     return VFN_ERR_ARG;

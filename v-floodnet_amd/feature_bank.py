@@ -72,6 +72,7 @@ class FeatureBank:
         self._dirty = False
         self._kbuf = self._vbuf = self._ibuf = None
         self._scratch = None
+        self._norms_valid = False    # bank norms on the device describe the bank as it is (carried across updates)
 
     # ------------------------------------------------------------------ storage
     def _require_gpu(self):
@@ -107,6 +108,7 @@ class FeatureBank:
         self._part = torch.empty(o, MAX_SPLIT_SCAN, hw, 2, device=dev)
         self._stats_pinned = torch.zeros(o, 4, dtype=torch.int32).pin_memory()
         self._scratch = None
+        self._norms_valid = False
 
     def _ensure_scratch(self):
         if self._scratch is None:
@@ -153,6 +155,7 @@ class FeatureBank:
         if self._kbuf is None:
             return None
         n = self._sync_len()
+        self._norms_valid = False           # the views are writable: a caller may edit entries
         return [self._kbuf[i, :n[i]].t() for i in range(self.obj_n)]
 
     @keys.setter
@@ -167,6 +170,7 @@ class FeatureBank:
         if self._vbuf is None:
             return None
         n = self._sync_len()
+        self._norms_valid = False
         return [self._vbuf[i, :n[i]].t() for i in range(self.obj_n)]
 
     @values.setter
@@ -227,6 +231,7 @@ class FeatureBank:
         if need > self._cap:
             self._grow(need)
         self._write_columns(keys, values, lens, frame_idx, 20.0)
+        self._norms_valid = False
         self._set_lengths([lens[i] + int(keys[i].shape[1]) for i in range(self.obj_n)])
 
     def _grow(self, need):
@@ -277,9 +282,11 @@ class FeatureBank:
         new, ld = self._stage_new(prev_key, prev_value)
         s = stream()
 
-        # norms: bank keys / values (device length), new keys / values
-        ops.row_norms(self._kbuf, cap * DK, DK, DK, self._len_dev, 0, o, self._knorm, self._kinv, cap)
-        ops.row_norms(self._vbuf, cap * DV, DV, DV, self._len_dev, 0, o, self._vnorm, None, cap)
+        # norms: bank keys / values (device length) -- carried from the previous update when nothing else has touched the
+        # bank since (vfn_bank_refresh_norms below), recomputed in full otherwise -- and new keys / values
+        if not self._norms_valid:
+            ops.row_norms(self._kbuf, cap * DK, DK, DK, self._len_dev, 0, o, self._knorm, self._kinv, cap)
+            ops.row_norms(self._vbuf, cap * DV, DV, DV, self._len_dev, 0, o, self._vnorm, None, cap)
         ops.row_norms(new, hw * ld, ld, DK, None, hw, o, self._nknorm, self._nkinv, hw)
         check(L.vfn_row_norms(_lib.C.c_void_p(new.data_ptr() + DK * 4), hw * ld, ld, DV, None, hw, o,
                               ptr(self._nvnorm), None, hw, s), 'vfn_row_norms')
@@ -318,6 +325,9 @@ class FeatureBank:
         bd.rm_class, bd.rm_request = -1, 0
         check(L.vfn_bank_merge(_lib.C.byref(bd), s), 'vfn_bank_merge')
         check(L.vfn_bank_append(_lib.C.byref(bd), s), 'vfn_bank_append')
+        check(L.vfn_bank_refresh_norms(_lib.C.byref(bd), ptr(self._knorm), ptr(self._kinv), ptr(self._vnorm), s),
+              'vfn_bank_refresh_norms')
+        self._norms_valid = True
 
         self._dirty = True
         self._len_upper = [min(n + hw, cap) for n in self._len_upper]
@@ -343,6 +353,7 @@ class FeatureBank:
         bd.frame_idx, bd.ld_new, bd.voff, bd.HW, bd.obj_n, bd.cap = int(frame_idx), DK + DV, DK, hw, o, cap
         bd.rm_class, bd.rm_request = int(class_idx), int(request_n)
         check(L.vfn_bank_remove(_lib.C.byref(bd), stream()), 'vfn_bank_remove')
+        self._norms_valid = False
         self._dirty = True
         n = self._sync_len()
         return (self.class_budget - n[class_idx]) - request_n
