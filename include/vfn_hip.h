@@ -27,7 +27,7 @@ extern "C" {
 /* ------------------------------------------------------------------ version
  * vfn_abi_version() == VFN_ABI_VERSION of the header the binding was written against, and
  * vfn_sizeof_desc(which) == sizeof of the binding's own struct: checked when the library is loaded. */
-#define VFN_ABI_VERSION 3
+#define VFN_ABI_VERSION 4
 enum { VFN_DESC_CONV = 0, VFN_DESC_STEM = 1, VFN_DESC_BANKSCAN = 2, VFN_DESC_MEMREAD = 3, VFN_DESC_BANK = 4 };
 int vfn_abi_version(void);
 int vfn_sizeof_desc(int which);
@@ -168,6 +168,9 @@ typedef struct vfn_bankscan_desc {
     int ldq, q_per_obj, HW, obj_n, nsplit, mode;
     int precision;         /* arithmetic of the contraction: 0 exact f32, 1 bf16 operands, 2 bf16x3 (see
                               vfn_conv2d_nhwc_bf16 / _bf16x3); tensors are f32 in every case */
+    int* work_counter;     /* one int of device memory: the queue head of the persistent workgroups (zeroed by the
+                              launcher on the stream); nsplit is the number of bank slices per (query tile, object) --
+                              work items -- and may be far larger than the number of resident workgroups */
 } vfn_bankscan_desc;
 
 typedef struct vfn_memread_desc {

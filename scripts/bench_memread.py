@@ -16,7 +16,7 @@ for B in [int(x) for x in (sys.argv[1:] or ['1620', '25000', '100000'])]:
     fb._kbuf.normal_(); fb._vbuf.normal_()
     fb._set_lengths([B, B])
     plan = types.SimpleNamespace(HW=HW, kv_q=torch.randn(1, HW, 640, device=dev), ml=torch.empty(2, HW, 2, device=dev),
-                                 ml_part=torch.empty(2, 32, HW, 2, device=dev), o_part=torch.empty(2, 20, HW, 512, device=dev),
+                                 ml_part=torch.empty(2, 256, HW, 2, device=dev), work=torch.zeros(4, dtype=torch.int32, device=dev), o_part=torch.empty(2, 20, HW, 512, device=dev),
                                  dec_in=torch.empty(2, HW, 512, device=dev))
     for _ in range(2):
         Engine._memory_read(eng, plan, fb, True)

@@ -67,14 +67,15 @@ def test_c3_720p_every_5th_reduced_precision(gpu, sd, c3_oracle, precision):
 
 def test_c5_shape_1080p_long_stream_bf16x3(gpu, sd):
     """C5's shape: a 1920x1080 stream at reference semantics (resize to 480p), every frame memorised, bf16x3.
-    150 frames with a budget whose per-object share (200,000 entries) is reached around frame 123, so the run covers
+    180 frames with a budget whose per-object share (200,000 entries) is reached around frame 157 (a good part of the new
+    features merge into existing entries instead of being appended), so the run covers
     the growing bank, B >= 200 k and LFU eviction.  The first frames are compared with the f32 oracle; beyond them the
     domain's invariants are checked (FeatureBank.py:102-103,117-143; myutils/data.py:17-37)."""
     from tools import synth
     from vfloodnet_amd import AFB_URR, ops
     from vfloodnet_amd.video_seg import ClipRunner
     from oracle import afb_urr_ref as O
-    T, H, W, n_ref = 150, 1080, 1920, 6
+    T, H, W, n_ref = 180, 1080, 1920, 6
     budget = 500000                                   # class_budget = 0.8 * 250000 = 200000.0
     frames, m0 = synth.clip_on_device(7, T, H, W, gpu)
     torch.set_num_threads(16)
@@ -106,5 +107,5 @@ def test_c5_shape_1080p_long_stream_bf16x3(gpu, sd):
     assert peak >= 195000 and all(max(s) <= cb for s in sizes)                   # B + n_append <= class_budget after remove()
     first_evict = next(i for i in range(1, len(sizes)) if sizes[i][0] < sizes[i - 1][0] or sizes[i][1] < sizes[i - 1][1])
     assert all(sizes[i][c] >= sizes[i - 1][c] for i in range(1, first_evict) for c in (0, 1))   # monotone until the budget
-    assert first_evict > 100
+    assert first_evict > 120
     assert runner.fb.replace_n.sum() > 0 and np.all(runner.fb.peak_n <= cb)

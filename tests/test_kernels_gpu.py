@@ -165,7 +165,7 @@ def test_memory_read(gpu, B, HW):
     fb._set_lengths([B, B])
     fb._ibuf[:, :B, 1] = 0.5
     plan = types.SimpleNamespace(HW=HW, kv_q=kvq.to(gpu), ml=torch.empty(2, HW, 2, device=gpu),
-                                 ml_part=torch.empty(2, 32, HW, 2, device=gpu),
+                                 ml_part=torch.empty(2, 256, HW, 2, device=gpu), work=torch.zeros(4, dtype=torch.int32, device=gpu),
                                  o_part=torch.empty(2, 20, HW, 512, device=gpu),
                                  dec_in=torch.empty(2, HW, 512, device=gpu))
     Engine._memory_read(types.SimpleNamespace(mode=0), plan, fb, True)
@@ -218,7 +218,7 @@ def test_memory_read_reduced_precision(gpu, B, HW, mode):
     fb._write_columns([k.to(gpu) for k in keys], [v.to(gpu) for v in vals], [0, 0], 0, 0.0)
     fb._set_lengths([B, B])
     plan = types.SimpleNamespace(HW=HW, kv_q=kvq.to(gpu), ml=torch.empty(2, HW, 2, device=gpu),
-                                 ml_part=torch.empty(2, 32, HW, 2, device=gpu),
+                                 ml_part=torch.empty(2, 256, HW, 2, device=gpu), work=torch.zeros(4, dtype=torch.int32, device=gpu),
                                  o_part=torch.empty(2, 20, HW, 512, device=gpu),
                                  dec_in=torch.empty(2, HW, 512, device=gpu))
     Engine._memory_read(types.SimpleNamespace(mode=mode), plan, fb, True)

@@ -42,7 +42,7 @@ def _memory_read(gpu, keys, vals, kvq, mode=0, update_bank=True):
     fb._write_columns([k.to(gpu) for k in keys], [v.to(gpu) for v in vals], [0, 0], 0, 0.0)
     fb._set_lengths([B, B])
     plan = types.SimpleNamespace(HW=HW, kv_q=kvq.to(gpu), ml=torch.empty(2, HW, 2, device=gpu),
-                                 ml_part=torch.empty(2, 32, HW, 2, device=gpu),
+                                 ml_part=torch.empty(2, 256, HW, 2, device=gpu), work=torch.zeros(4, dtype=torch.int32, device=gpu),
                                  o_part=torch.empty(2, 20, HW, 512, device=gpu),
                                  dec_in=torch.empty(2, HW, 512, device=gpu))
     Engine._memory_read(types.SimpleNamespace(mode=mode), plan, fb, update_bank)

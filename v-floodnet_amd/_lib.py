@@ -9,7 +9,7 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'libvfn_hip.so')
+LIB_PATH = os.environ.get('VFN_LIB_PATH') or os.path.join(_HERE, 'libvfn_hip.so')     # (override: ablation builds, scripts/)
 
 _lib = None
 
@@ -40,7 +40,7 @@ class BankScanDesc(C.Structure):
                 ('stride_q', C.c_longlong), ('stride_k', C.c_longlong), ('stride_rs', C.c_longlong),
                 ('scale', C.c_float),
                 ('ldq', C.c_int), ('q_per_obj', C.c_int), ('HW', C.c_int), ('obj_n', C.c_int),
-                ('nsplit', C.c_int), ('mode', C.c_int), ('precision', C.c_int)]
+                ('nsplit', C.c_int), ('mode', C.c_int), ('precision', C.c_int), ('work_counter', c_fp)]
 
 
 class MemReadDesc(C.Structure):
@@ -67,7 +67,7 @@ class BankDesc(C.Structure):
                 ('obj_n', C.c_int), ('cap', C.c_int), ('rm_class', C.c_int), ('rm_request', C.c_int)]
 
 
-ABI_VERSION = 3          # include/vfn_hip.h VFN_ABI_VERSION; csrc/abi.hip
+ABI_VERSION = 4          # include/vfn_hip.h VFN_ABI_VERSION; csrc/abi.hip
 DESC_IDS = {0: ConvDesc, 1: StemDesc, 2: BankScanDesc, 3: MemReadDesc, 4: BankDesc}     # vfn_sizeof_desc(which)
 
 

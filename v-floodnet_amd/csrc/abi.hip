@@ -2,6 +2,7 @@
 #include "../../include/vfn_hip.h"
 // 2: vfn_conv_desc.w_packed, vfn_bankscan_desc.precision, vfn_memread_desc.precision; bf16 / bf16x3 and I/O entry points
 // 3: vfn_memread_desc.wide (added at 2 without a bump), vfn_conv_cfg_info, vfn_sizeof_desc
+// 4: PNG / JPEG / segment-uncertainty / norm-refresh entry points (round 2)
 extern "C" int vfn_abi_version(void) { return VFN_ABI_VERSION; }
 
 // sizeof of every descriptor as THIS library was compiled: a binding whose struct layout drifted fails its

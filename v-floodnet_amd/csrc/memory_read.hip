@@ -156,17 +156,39 @@ __device__ __forceinline__ void chunk_range(int B, int nsplit, int split, int& c
 // 64 KB of LDS -> two workgroups per CU, one barrier per chunk, the next chunk lands behind the MFMAs.
 constexpr int QTS = 128;    // query columns per scan workgroup
 
+#ifdef VFN_CENSUS
+__device__ unsigned long long vfn_census_buf[4096 * 4];
+#endif
+
 template <int MODE, int PREC = 0>
 __global__ __launch_bounds__(256, 2)
 void bank_scan_kernel(const vfn_bankscan_desc p) {
+#ifdef VFN_CENSUS
+    const unsigned long long census_t0 = __builtin_amdgcn_s_memrealtime();
+#endif
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* sKb = reinterpret_cast<float*>(smem);     // [2][64][128]
+    __shared__ int s_item;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 31, lh = lane >> 5;
-    const int split = blockIdx.x % p.nsplit;
-    const int qt = blockIdx.x / p.nsplit;
-    const int obj = blockIdx.y;
+    // Persistent workgroups (two per CU) pull work items from a queue: item = (bank slice, query tile, object), slice
+    // slowest, so the workgroups that run at the same time walk the same part of the bank (L2).  A census of the former
+    // one-workgroup-per-(tile, slice) grid showed why it ran at 0.63 MFMA utilisation: two workgroups sharing a CU keep
+    // the matrix pipe 100 % busy, one alone only 71 %, and with 754 (or 494) equal workgroups on 512 slots the last
+    // third of the kernel ran half-empty.  With ~2000 small items every slot stays paired until the queue is dry.
+    // An item's result depends only on the item, so the output is bit-identical whichever workgroup computes it.
+    const int qtiles = (p.HW + QTS - 1) / QTS;
+    const int total = p.nsplit * qtiles * p.obj_n;
+  for (;;) {
+    if (tid == 0) s_item = atomicAdd(p.work_counter, 1);
+    __syncthreads();
+    const int item = s_item;
+    __syncthreads();                                   // (everyone has the item before thread 0 draws the next one)
+    if (item >= total) break;
+    const int obj = item % p.obj_n;
+    const int qt = (item / p.obj_n) % qtiles;
+    const int split = item / (p.obj_n * qtiles);
     const int q0 = qt * QTS + wave * 32;             // first query of this wave
     const int B = p.bank_len[obj];
     const float* K = p.bank_k + (size_t)obj * p.stride_k;
@@ -245,6 +267,9 @@ void bank_scan_kernel(const vfn_bankscan_desc p) {
                 }
             }
         }
+#ifdef VFN_ABLATE_SOFTMAX
+        if (true) { run_m = fmaxf(run_m, acc[0][0] + acc[1][5]); } else
+#endif
         if (MODE == 0) {
             if (b0 + CH <= B) {                          // whole chunk inside the bank (all but the last): no row checks
                 float mx = acc[0][0];
@@ -321,12 +346,25 @@ void bank_scan_kernel(const vfn_bankscan_desc p) {
             if (om > run_m || (om == run_m && oi < run_i)) { run_m = om; run_i = oi; }
         }
     }
+#ifdef VFN_CENSUS
+    if (threadIdx.x == 0) {
+        const int lin = blockIdx.y * gridDim.x + blockIdx.x;
+        if (lin < 4096) {
+            unsigned hw_id, xcc;
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw_id));
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+            vfn_census_buf[lin * 4] = census_t0; vfn_census_buf[lin * 4 + 1] = __builtin_amdgcn_s_memrealtime();
+            vfn_census_buf[lin * 4 + 2] = hw_id; vfn_census_buf[lin * 4 + 3] = xcc;
+        }
+    }
+#endif
     const int q = q0 + li;
     if (lh == 0 && q < p.HW) {
         float* dst = p.part + (((size_t)obj * p.nsplit + split) * p.HW + q) * 2;
         dst[0] = run_m;
         dst[1] = (MODE == 0) ? run_l : __int_as_float(run_i);
     }
+  }
 }
 
 // combine bank-split partials.  MODE 0 -> ml[obj][q] = (m, l); MODE 1 -> idx[obj][q], corr[obj][q]
@@ -360,6 +398,10 @@ __global__ void bank_scan_finish_kernel(const float* __restrict__ part, int nspl
 // into lane = row of `cnt` with v_writelane -- no divergent branch anywhere.
 __device__ __forceinline__ int softmax_hits(f32x16& acc, float scale, float qm, float qinv, float thres, int nvalid, int rloc) {
     int cnt = 0;
+#ifdef VFN_ABLATE_SOFTMAX
+    for (int r = 0; r < 16; ++r) acc[r] *= qinv;
+    return cnt;
+#endif
     const float sm = -qm;
     if (nvalid >= CH) {
 #pragma unroll
@@ -1030,8 +1072,11 @@ extern "C" int vfn_bank_scan(const vfn_bankscan_desc* d, void* stream) {
         allow_lds(bank_scan_kernel<0, 2>, SCAN_LDS); allow_lds(bank_scan_kernel<1, 2>, SCAN_LDS);
         once = true;
     }
-    const dim3 grid(cdiv(d->HW, QTS) * d->nsplit, d->obj_n);
+    if (!d->work_counter) return VFN_ERR_ARG;
+    const int items = cdiv(d->HW, QTS) * d->nsplit * d->obj_n;
+    const dim3 grid(items < 512 ? items : 512);        // two resident workgroups per CU (64 KB of LDS each)
     hipStream_t s = (hipStream_t)stream;
+    if (hipMemsetAsync(d->work_counter, 0, sizeof(int), s) != hipSuccess) return VFN_ERR_LAUNCH;
     switch (d->mode * 3 + d->precision) {
         case 0: hipLaunchKernelGGL((bank_scan_kernel<0, 0>), grid, dim3(256), SCAN_LDS, s, *d); break;
         case 1: hipLaunchKernelGGL((bank_scan_kernel<0, 1>), grid, dim3(256), SCAN_LDS, s, *d); break;
@@ -1104,3 +1149,9 @@ extern "C" int vfn_memread_finish(const vfn_memread_desc* d, void* stream) {
     hipLaunchKernelGGL(memread_finish_kernel, grid, dim3(256), 0, (hipStream_t)stream, *d);
     return vfn_check_launch();
 }
+
+#ifdef VFN_CENSUS
+extern "C" int vfn_debug_census(unsigned long long* host_out) {
+    return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(vfn_census_buf), sizeof(unsigned long long) * 4096 * 4) == hipSuccess ? 0 : 1;
+}
+#endif

@@ -23,7 +23,7 @@ import torch
 
 from . import _lib, ops, weights as W
 from ._lib import ptr, stream, check, MemReadDesc, BankScanDesc
-from .feature_bank import pick_nsplit, MAX_SPLIT, MAX_SPLIT_SCAN, QT_SCAN, DK, DV
+from .feature_bank import pick_nsplit, pick_scan_slices, MAX_SPLIT, MAX_SPLIT_SCAN, QT_SCAN, DK, DV
 
 # (BM, BN) -> relative efficiency of the tile shape in the implicit-GEMM kernel
 _CFG_EFF = {(128, 128): 1.00, (128, 64): 0.95, (64, 128): 0.95, (64, 64): 0.86, (32, 64): 0.74,
@@ -200,6 +200,7 @@ class FramePlan:
         # memory read
         self.ml = f(K, self.HW, 2)
         self.ml_part = f(K, MAX_SPLIT_SCAN, self.HW, 2)
+        self.work = torch.zeros(4, dtype=torch.int32, device=dev)       # queue head of the persistent scan kernel
         self.o_part = f(K, MAX_SPLIT, self.HW, DV)
         self.dec_in = f(K, self.h16, self.w16, DV)          # memory read-out only; the query-value half of
         self.fm_q = f(1, self.h16, self.w16, 256)            # cat([mem, q_out]) goes through its own conv (fm_q)
@@ -528,7 +529,7 @@ class Engine:
         s = stream()
         K, HW, cap = fb.obj_n, p.HW, fb._cap
         nsplit = pick_nsplit(HW, K, fb.len_upper())
-        nsplit_scan = pick_nsplit(HW, K, fb.len_upper(), QT_SCAN, MAX_SPLIT_SCAN)
+        nsplit_scan = pick_scan_slices(HW, K, fb.len_upper())
         scale = 1.0 / math.sqrt(DK)
         d = BankScanDesc()
         d.q, d.bank_k, d.bank_len, d.rowscale, d.part = ptr(p.kv_q), ptr(fb._kbuf), ptr(fb._len_dev), None, ptr(p.ml_part)
@@ -536,6 +537,7 @@ class Engine:
         d.scale = scale
         d.ldq, d.q_per_obj, d.HW, d.obj_n, d.nsplit, d.mode = DK + DV, 0, HW, K, nsplit_scan, 0
         d.precision = self.mode
+        d.work_counter = ptr(p.work)
         check(L.vfn_bank_scan(_lib.C.byref(d), s), 'vfn_bank_scan')
         check(L.vfn_bank_scan_finish(ptr(p.ml_part), nsplit_scan, HW, K, 0, ptr(p.ml), None, None, None, s),
               'vfn_bank_scan_finish')

@@ -24,9 +24,22 @@ from ._lib import ptr, stream, check, BankDesc, BankScanDesc
 
 DK, DV = 128, 512
 MAX_SPLIT = 20            # memory-read apply slices (o_part slabs)
-MAX_SPLIT_SCAN = 32       # bank scans (softmax statistics, cosine arg-max): 128 query columns per workgroup
+MAX_SPLIT_SCAN = 256      # bank slices (work items per query tile and object) of the persistent scan kernels
 QT, QT_SCAN, CH = 64, 128, 64
 MAX_HW = 32768           # include/vfn_hip.h VFN_BANK_MAX_HW
+
+
+def pick_scan_slices(hw, obj_n, b_upper, target_items=1536, min_chunks=8):
+    """Bank slices per (query tile, object) for the persistent scan kernels: about ``target_items`` work items in all
+    (three per resident workgroup slot, so the queue drains evenly), but at least ``min_chunks`` 64-entry chunks each
+    (a slice reloads its query fragments)."""
+    nchunks = max(1, (b_upper + CH - 1) // CH)
+    qtiles = (hw + QT_SCAN - 1) // QT_SCAN
+    import os
+    if os.environ.get('VFN_NSPLIT_SCAN'):
+        return max(1, min(int(os.environ['VFN_NSPLIT_SCAN']), nchunks, MAX_SPLIT_SCAN))
+    want = max(1, target_items // (qtiles * obj_n))
+    return max(1, min(want, nchunks // min_chunks if nchunks >= min_chunks else 1, MAX_SPLIT_SCAN))
 
 
 def pick_nsplit(hw, obj_n, b_upper, qt=QT, max_split=MAX_SPLIT):
@@ -106,6 +119,7 @@ class FeatureBank:
         self._mcorr = torch.empty(o, hw, device=dev)
         self._app_pos = torch.empty(o, hw, dtype=torch.int32, device=dev)
         self._part = torch.empty(o, MAX_SPLIT_SCAN, hw, 2, device=dev)
+        self._work = torch.zeros(4, dtype=torch.int32, device=dev)          # queue head of the persistent scan kernel
         self._stats_pinned = torch.zeros(o, 4, dtype=torch.int32).pin_memory()
         self._scratch = None
         self._norms_valid = False
@@ -293,13 +307,14 @@ class FeatureBank:
 
         # cosine arg-max over the bank per new feature
         b_up = self.len_upper()
-        nsplit = pick_nsplit(hw, o, b_up, QT_SCAN, MAX_SPLIT_SCAN)
+        nsplit = pick_scan_slices(hw, o, b_up)
         d = BankScanDesc()
         d.q, d.bank_k, d.bank_len, d.rowscale, d.part = ptr(new), ptr(self._kbuf), ptr(self._len_dev), ptr(self._kinv), ptr(self._part)
         d.stride_q, d.stride_k, d.stride_rs = hw * ld, cap * DK, cap
         d.scale = 1.0
         d.ldq, d.q_per_obj, d.HW, d.obj_n, d.nsplit, d.mode = ld, 1, hw, o, nsplit, 1
         d.precision = ops.MODES[self.precision]
+        d.work_counter = ptr(self._work)
         check(L.vfn_bank_scan(_lib.C.byref(d), s), 'vfn_bank_scan')
         check(L.vfn_bank_scan_finish(ptr(self._part), nsplit, hw, o, 1, None, ptr(self._midx), ptr(self._mcorr),
                                      ptr(self._nkinv), s), 'vfn_bank_scan_finish')
