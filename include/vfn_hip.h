@@ -134,6 +134,15 @@ int vfn_local_hpass_f32(const float* r1, const float* rough, float* hs, float* h
                         int h, int w, int C, void* stream);
 int vfn_local_vpass_f32(const float* hs, const float* hr, const float* hm, float* lm,
                         float* conf, int obj_n, int h, int w, int C, void* stream);
+/* vfn_local_stats_f32: vfn_local_hpass_f32 + vfn_local_vpass_f32 in one pass without scratch (AFB_URR.py:226-229): r1 once
+ *     in, lm = r1_local [obj][h][w][C] and conf [obj][h][w] out; C = 64, obj_n <= 4 (larger: the two-pass pair).
+ * vfn_pred2_gather_f32: second half of pred2 / local_pred2 (AFB_URR.py:195,202) evaluated as a tap GEMM: z [N][h][w][ldz]
+ *     holds, per pixel, the 18 products of the 9 filter taps x 2 filters with relu(x) (a 1x1 vfn_conv2d over the
+ *     repacked filters, which reads x once); out[n][y][x][o] = bias[o] + sum over the 3x3 neighbourhood (zero padding)
+ *     of z[..][tap*2+o].  Same result as vfn_conv3x3_cout2_f32 up to summation order. */
+int vfn_local_stats_f32(const float* r1, const float* rough, float* lm, float* conf, int obj_n, int h, int w, int C,
+                        void* stream);
+int vfn_pred2_gather_f32(const float* z, const float* bias, float* out, int N, int h, int w, int ldz, void* stream);
 int vfn_final_logits_f32(const float* p_up, const float* unc, const float* conf, const float* q, float* score,
                          int obj_n, int h, int w, int pad_top, int pad_left, int H0, int W0, void* stream);
 

@@ -35,7 +35,16 @@ def test_blocks(gpu, model, tag):
     for n, buf in dict(r1=p.q['r1'], r2=p.q['res2']['out'], r3=p.q['res3']['out'], r4=p.q['res4']['out']).items():
         x = buf.permute(0, 3, 1, 2).contiguous().cpu()
         assert (x.flatten()[t(g[n + '_idx'])] - t(g[n + '_val'])).abs().max() < 5e-4, n
-    assert (fb.info[0].cpu() - t(g['info0'])).abs().max() < 0.05
+    # info[:,1] = log(hit count + 1) (AFB_URR.py:161-174): the counts are integers, so an entry either agrees to the
+    # rounding of log() or one probability sat on the 1e-3 threshold and its count moved by one -- at most a couple of
+    # entries may do that, every other one must agree to 1e-3 (measured: identical)
+    got, ref = fb.info[0].cpu(), t(g['info0'])
+    d = (got - ref).abs().max(dim=1).values
+    flipped = d >= 1e-3
+    assert int(flipped.sum()) <= 2, int(flipped.sum())
+    dc = (torch.exp(got[flipped, 1]) - torch.exp(ref[flipped, 1])).abs()
+    assert bool((dc < 1.5).all()), dc
+    assert torch.equal(got[:, 0], ref[:, 0])
     pm = ops.softmax_objects(score)
     k2, v2 = model.memorize(frames[1:2], pm)
     assert (torch.stack([x.cpu() for x in k2]) - t(g['key1'])).abs().max() < 2e-3

@@ -352,3 +352,51 @@ def test_scatter_mean_rejects_out_of_range_index(gpu):
         with pytest.raises(RuntimeError):
             scatter_mean(src, idx, dim=1, out=out)
     assert float(out.abs().sum()) == 0.0
+
+
+@pytest.mark.parametrize('K,h,w', [(2, 240, 432), (3, 37, 53), (1, 9, 70), (4, 50, 16), (2, 24, 17)])
+def test_local_stats_fused_vs_torch_and_two_pass(gpu, K, h, w):
+    """vfn_local_stats_f32 (one pass, no scratch) against avg_pool / max_pool in torch (AFB_URR.py:226-229) and against
+    the two-pass kernels it replaces, at the full 1/2-resolution size and at ragged sizes (strip / row-chunk edges)."""
+    from vfloodnet_amd import ops
+    g = torch.Generator().manual_seed(K * 100 + h)
+    r1 = torch.rand(1, 64, h, w, generator=g)
+    rg = torch.softmax(torch.randn(1, K, h, w, generator=g) * 2, dim=1) if K > 1 else torch.rand(1, 1, h, w, generator=g)
+    rg = rg.view(K, 1, h, w)
+    ref_local = F.avg_pool2d(r1.expand(K, -1, -1, -1) * rg, 7, 1, 3) / (F.avg_pool2d(rg, 7, 1, 3) + 1e-8)
+    ref_conf = F.max_pool2d(rg, 7, 1, 3)[:, 0]
+    r1_d, rg_d = nhwc(r1).to(gpu), rg[:, 0].contiguous().to(gpu)
+    lm = torch.empty(K, h, w, 64, device=gpu)
+    cf = torch.empty(K, h, w, device=gpu)
+    ops.local_stats(r1_d, rg_d, None, None, None, lm, cf)
+    assert (nchw(lm.cpu()) - ref_local).abs().max() < 2e-5
+    assert torch.equal(cf.cpu(), ref_conf)
+    hs = torch.empty(K, h, w, 64, device=gpu); hr = torch.empty(K, h, w, device=gpu); hm = torch.empty(K, h, w, device=gpu)
+    lm2 = torch.empty_like(lm); cf2 = torch.empty_like(cf)
+    ops.local_stats_two_pass(r1_d, rg_d, hs, hr, hm, lm2, cf2)
+    assert torch.equal(cf, cf2)
+    assert (lm - lm2).abs().max() < 1e-6                     # same summation order: equal up to fma contraction
+
+
+@pytest.mark.parametrize('N,h,w,cin', [(2, 30, 54, 256), (2, 25, 33, 32), (1, 7, 9, 256)])
+def test_pred2_tap_gemm_matches_conv(gpu, N, h, w, cin):
+    """pred2 / local_pred2 as 1x1 tap GEMM + gather == 3x3 convolution with two filters on relu(x) (AFB_URR.py:213,234),
+    and == the direct two-filter kernel it replaces."""
+    from vfloodnet_amd import ops
+    from vfloodnet_amd.engine import Pred2Layer, choose_cfg, apply_choice
+    g = torch.Generator().manual_seed(cin + h)
+    conv = torch.nn.Conv2d(cin, 2, 3, padding=1)
+    with torch.no_grad():
+        conv.weight.copy_(torch.randn(2, cin, 3, 3, generator=g) / (3 * cin ** 0.5))
+        conv.bias.copy_(torch.randn(2, generator=g))
+    x = torch.randn(N, cin, h, w, generator=g)
+    ref = conv(F.relu(x)).detach()
+    layer = Pred2Layer(conv, gpu)
+    xd = nhwc(x).to(gpu)
+    z = torch.empty(N, h, w, Pred2Layer.TAPS, device=gpu)
+    d = ops.make_conv_desc(xd, layer.w, layer.cout, 1, 1, 1, 0, z, layer.scale, layer.shift, None, True, False)
+    cfg = apply_choice(d, choose_cfg(d.M, layer.cout, cin, 0), None)
+    ops.conv2d_launch(d, cfg, 0)
+    out = torch.empty(N, h, w, 2, device=gpu)
+    ops.pred2_gather(z, layer.bias, out)
+    assert (nchw(out.cpu()) - ref).abs().max() < 2e-5 * max(1.0, float(ref.abs().max()))

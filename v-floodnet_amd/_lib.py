@@ -128,6 +128,8 @@ SIGNATURES = {
     'vfn_rough_uncertainty_f32': [_p, _p, _p, _p, _i, _i, _i, _p],
     'vfn_local_hpass_f32': [_p, _p, _p, _p, _p, _i, _i, _i, _i, _p],
     'vfn_local_vpass_f32': [_p, _p, _p, _p, _p, _i, _i, _i, _i, _p],
+    'vfn_local_stats_f32': [_p, _p, _p, _p, _i, _i, _i, _i, _p],
+    'vfn_pred2_gather_f32': [_p, _p, _p, _i, _i, _i, _i, _p],
     'vfn_final_logits_f32': [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p],
     'vfn_bank_scan_finish': [_p, _i, _i, _i, _i, _p, _p, _p, _p, _p],
     'vfn_row_norms': [_p, _ll, _i, _i, _p, _i, _i, _p, _p, _ll, _p],

@@ -169,6 +169,156 @@ __global__ void local_vpass_kernel(const float* __restrict__ hs,
     }
 }
 
+// Fused window statistics (AFB_URR.py:226-229): r1_local = avg7x7(r1 * rough) / (avg7x7(rough) + 1e-8), r1_conf =
+// max7x7(rough), for every object -- one pass over r1, no horizontal-pass scratch in HBM.  A workgroup owns a strip of
+// 16 columns x YR rows (thread = column x channel quad) and walks down it: per image row the strip's 22-pixel segment of
+// r1 goes through LDS once (loaded a row ahead), every thread forms its 7-tap horizontal sums for each object, and a
+// 7-row register ring turns them into the 7x7 sums (added in the order rows y-3 .. y+3, columns x-3 .. x+3, like the
+// two-pass kernels above).  HBM traffic: r1 once (+ halo) in, r1_local once out.
+constexpr int LS_W = 16;                 // strip width (pixels)
+constexpr int LS_C4 = 16;                // channel quads (C = 64)
+constexpr int LS_SEG = LS_W + 6;         // pixels of one staged row segment
+
+template <int K>
+__global__ __launch_bounds__(256)
+void local_stats_fused_kernel(const float* __restrict__ r1, const float* __restrict__ rough, float* __restrict__ lm,
+                              float* __restrict__ conf, int h, int w, int yr) {
+    __shared__ __attribute__((aligned(16))) float s_r1[2][LS_SEG][LS_C4 * 4];
+    __shared__ float s_rg[2][K][LS_SEG + 2];
+    const int tid = threadIdx.x;
+    const int c4 = tid & 15, x = tid >> 4;                       // 16 x 16
+    const int strips = (w + LS_W - 1) / LS_W;
+    const int strip = blockIdx.x % strips, ychunk = blockIdx.x / strips;
+    const int x0 = strip * LS_W, y0 = ychunk * yr;
+    const int y1 = min(h, y0 + yr);                               // output rows [y0, y1)
+    const size_t plane = (size_t)h * w;
+    // staging role: 22 x 16 float4 of r1 + K x 22 floats of rough per row; thread t loads float4 t and t + 256
+    f32x4 st[2];
+    float sg[K];
+    auto load_row = [&](int yy) {
+        const bool row_ok = (unsigned)yy < (unsigned)h;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int e = tid + 256 * j;
+            st[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (e < LS_SEG * LS_C4) {
+                const int px = e / LS_C4, cc = e - px * LS_C4;
+                const int gx = x0 - 3 + px;
+                if (row_ok && (unsigned)gx < (unsigned)w) st[j] = *reinterpret_cast<const f32x4*>(r1 + ((size_t)yy * w + gx) * 64 + cc * 4);
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            sg[k] = -1.f;                                         // marks "outside the image" (rough is a probability >= 0)
+            if (tid < LS_SEG) {
+                const int gx = x0 - 3 + tid;
+                if (row_ok && (unsigned)gx < (unsigned)w) sg[k] = rough[(size_t)k * plane + (size_t)yy * w + gx];
+            }
+        }
+    };
+    auto store_row = [&](int buf) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int e = tid + 256 * j;
+            if (e < LS_SEG * LS_C4) *reinterpret_cast<f32x4*>(&s_r1[buf][e / LS_C4][(e % LS_C4) * 4]) = st[j];
+        }
+        if (tid < LS_SEG)
+#pragma unroll
+            for (int k = 0; k < K; ++k) s_rg[buf][k][tid] = sg[k];
+    };
+    f32x4 ring[K][7];
+    float rsum[K][7], rmax[K][7];
+#pragma unroll
+    for (int k = 0; k < K; ++k)
+#pragma unroll
+        for (int j = 0; j < 7; ++j) { ring[k][j] = f32x4{0.f, 0.f, 0.f, 0.f}; rsum[k][j] = 0.f; rmax[k][j] = -INFINITY; }
+
+    const int ya = y0 - 3, yb = y1 + 3;                           // input rows [ya, yb)
+    load_row(ya);
+    store_row(0);
+    __syncthreads();
+    for (int base = ya; base < yb; base += 7) {
+#pragma unroll
+        for (int j = 0; j < 7; ++j) {                            // statically indexed ring slot j
+            const int yy = base + j;
+            if (yy >= yb) break;
+            const int buf = (yy - ya) & 1;
+            if (yy + 1 < yb) load_row(yy + 1);                    // next row: global -> registers behind this row's math
+            // horizontal pass of row yy (zero / -inf where the row or the tap is outside the image)
+#pragma unroll
+            for (int k = 0; k < K; ++k) {
+                f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+                float sr = 0.f, mr = -INFINITY;
+#pragma unroll
+                for (int d = 0; d < 7; ++d) {
+                    const float g = s_rg[buf][k][x + d];
+                    if (g >= 0.f) {
+                        const f32x4 v = *reinterpret_cast<const f32x4*>(&s_r1[buf][x + d][c4 * 4]);
+                        acc += v * g;
+                        sr += g;
+                        mr = fmaxf(mr, g);
+                    }
+                }
+                ring[k][j] = acc; rsum[k][j] = sr; rmax[k][j] = mr;
+            }
+            // the window centred on row yo = yy - 3 is complete: rows yo-3 .. yo+3 sit in slots j+1 .. j+7 (mod 7)
+            const int yo = yy - 3;
+            if (yo >= y0 && yo < y1 && x0 + x < w) {
+#pragma unroll
+                for (int k = 0; k < K; ++k) {
+                    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+                    float sr = 0.f, mr = -INFINITY;
+#pragma unroll
+                    for (int d = 1; d <= 7; ++d) {
+                        const int sl = (j + d) % 7;
+                        acc += ring[k][sl]; sr += rsum[k][sl]; mr = fmaxf(mr, rmax[k][sl]);
+                    }
+                    const float den = sr / 49.f + 1e-8f;         // AvgPool2d(7,1,3), count_include_pad
+                    f32x4 loc;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) loc[e] = (acc[e] / 49.f) / den;
+                    const size_t pix = (size_t)yo * w + x0 + x;
+                    *reinterpret_cast<f32x4*>(lm + ((size_t)k * plane + pix) * 64 + c4 * 4) = loc;
+                    if (c4 == 0) conf[(size_t)k * plane + pix] = mr;
+                }
+            }
+            if (yy + 1 < yb) {
+                store_row(buf ^ 1);
+                __syncthreads();
+            }
+        }
+    }
+}
+
+// pred2 / local_pred2 (3x3, two filters; AFB_URR.py:195,202,213,234) as a tap GEMM + gather: z[p][tap*2+o] =
+// sum_c w[o][c][tap] * relu(x[p][c]) is a 1x1 convolution with 18 (padded to 20) filters that reads x exactly once on the
+// matrix cores; this kernel then adds the nine shifted taps: out[p][o] = bias[o] + sum_tap z[p + tap][tap*2+o].
+__global__ void pred2_gather_kernel(const float* __restrict__ z, const float* __restrict__ bias, float* __restrict__ out,
+                                    int N, int h, int w, int ldz) {
+    const size_t total = (size_t)N * h * w;
+    const float b0 = bias[0], b1 = bias[1];
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int x = i % w;
+        size_t t = i / w;
+        const int y = t % h;
+        const int n = t / h;
+        float a0 = 0.f, a1 = 0.f;
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy) {
+            const int yy = y + dy - 1;
+            if ((unsigned)yy >= (unsigned)h) continue;
+#pragma unroll
+            for (int dx = 0; dx < 3; ++dx) {
+                const int xx = x + dx - 1;
+                if ((unsigned)xx >= (unsigned)w) continue;
+                const float2 v = *reinterpret_cast<const float2*>(z + (((size_t)n * h + yy) * w + xx) * ldz + (dy * 3 + dx) * 2);
+                a0 += v.x; a1 += v.y;
+            }
+        }
+        *reinterpret_cast<float2*>(out + i * 2) = make_float2(a0 + b0, a1 + b1);
+    }
+}
+
 // score[obj][H0][W0] = logit(clamp(softmax(up2(p_up + unc*(conf*q)))[1]))
 __global__ void final_logits_kernel(const float* __restrict__ p_up, const float* __restrict__ unc,
                                     const float* __restrict__ conf, const float* __restrict__ q,
@@ -302,5 +452,28 @@ extern "C" int vfn_segment_uncertainty_f32(const float* logit, int bs, int obj_n
     if (!logit || !partial || !out || bs < 1 || obj_n < 2 || obj_n > MAX_OBJ || n < 1) return VFN_ERR_ARG;
     hipLaunchKernelGGL(uncertainty_partial_kernel, dim3(UNC_BLOCKS, bs), dim3(256), 0, (hipStream_t)stream, logit, obj_n, n, partial);
     hipLaunchKernelGGL(uncertainty_finish_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, partial, bs, n, out);
+    return vfn_check_launch();
+}
+
+extern "C" int vfn_local_stats_f32(const float* r1, const float* rough, float* lm, float* conf, int obj_n, int h, int w,
+                                   int C, void* stream) {
+    if (!r1 || !rough || !lm || !conf || C != 64 || obj_n < 1 || obj_n > 4 || h < 1 || w < 1) return VFN_ERR_ARG;
+    const int strips = (w + LS_W - 1) / LS_W;
+    int yr = 24;                                                   // rows per workgroup: >= 256 workgroups when the image allows
+    while (yr > 8 && strips * ((h + yr - 1) / yr) < 256) yr -= 4;
+    const dim3 grid(strips * ((h + yr - 1) / yr));
+    hipStream_t s = (hipStream_t)stream;
+    switch (obj_n) {
+        case 1: hipLaunchKernelGGL(local_stats_fused_kernel<1>, grid, dim3(256), 0, s, r1, rough, lm, conf, h, w, yr); break;
+        case 2: hipLaunchKernelGGL(local_stats_fused_kernel<2>, grid, dim3(256), 0, s, r1, rough, lm, conf, h, w, yr); break;
+        case 3: hipLaunchKernelGGL(local_stats_fused_kernel<3>, grid, dim3(256), 0, s, r1, rough, lm, conf, h, w, yr); break;
+        default: hipLaunchKernelGGL(local_stats_fused_kernel<4>, grid, dim3(256), 0, s, r1, rough, lm, conf, h, w, yr); break;
+    }
+    return vfn_check_launch();
+}
+
+extern "C" int vfn_pred2_gather_f32(const float* z, const float* bias, float* out, int N, int h, int w, int ldz, void* stream) {
+    if (!z || !bias || !out || ldz < 18 || ldz % 2) return VFN_ERR_ARG;
+    hipLaunchKernelGGL(pred2_gather_kernel, dim3(grid_for((size_t)N * h * w)), dim3(256), 0, (hipStream_t)stream, z, bias, out, N, h, w, ldz);
     return vfn_check_launch();
 }

@@ -161,6 +161,34 @@ class ConvLayer:
         return self._w_lp[mode]
 
 
+class Pred2Layer:
+    """A 3x3 convolution with two filters (pred2 / local_pred2, AFB_URR.py:195,202) as a tap GEMM: the 9 taps x 2 filters
+    become 18 (padded to 20) 1x1 filters, so the input is read once on the matrix cores; ``ops.pred2_gather`` then adds
+    the nine shifted taps and the bias."""
+    TAPS = 20
+
+    def __init__(self, conv, device):
+        w = conv.weight.detach().float()                       # [2, Cin, 3, 3]
+        assert w.shape[0] == 2 and w.shape[2:] == (3, 3)
+        self.cin = w.shape[1]
+        w18 = torch.zeros(self.TAPS, self.cin)
+        for dy in range(3):
+            for dx in range(3):
+                for o in range(2):
+                    w18[(dy * 3 + dx) * 2 + o] = w[o, :, dy, dx]
+        self.cout, self.k, self.stride, self.pad = self.TAPS, 1, 1, 0
+        self.w = ops.pad_rows(w18.contiguous()).to(device)
+        self.scale = torch.ones(self.TAPS, device=device)
+        self.shift = torch.zeros(self.TAPS, device=device)
+        self.bias = conv.bias.detach().float().to(device).contiguous()
+        self._w_lp = {}
+
+    def w_lp(self, mode):
+        if mode not in self._w_lp:
+            self._w_lp[mode] = ops.pack_weights_lp(self.w, mode)
+        return self._w_lp[mode]
+
+
 class Launch:
     """One pre-built kernel launch."""
     __slots__ = ('fn', 'args', 'name', 'flops')
@@ -211,12 +239,15 @@ class FramePlan:
         self.s4 = [f(1, self.h4, self.w4, 256) for _ in range(3)]
         self.d4 = [f(K, self.h4, self.w4, 256) for _ in range(3)]
         self.pp = f(K, self.h4, self.w4, 2)
+        self.z4 = f(K, self.h4, self.w4, Pred2Layer.TAPS)     # tap products of pred2 / local_pred2
+        self.z2 = f(K, self.h2, self.w2, Pred2Layer.TAPS)
         self.p_up = f(K, self.h2, self.w2, 2)
         self.rough = f(K, self.h2, self.w2)
         self.unc = f(self.h2, self.w2)
-        self.hs = f(K, self.h2, self.w2, 64)
-        self.hr = f(K, self.h2, self.w2)
-        self.hm = f(K, self.h2, self.w2)
+        fused_ok = K <= 4                                    # ops.local_stats: one fused pass, no scratch
+        self.hs = None if fused_ok else f(K, self.h2, self.w2, 64)
+        self.hr = None if fused_ok else f(K, self.h2, self.w2)
+        self.hm = None if fused_ok else f(K, self.h2, self.w2)
         self.lm = f(K, self.h2, self.w2, 64)                 # r1_local
         self.lq = f(1, self.h2, self.w2, 32)                 # local_convFM over the shared r1 half
         self.conf = f(K, self.h2, self.w2)
@@ -258,9 +289,6 @@ class FramePlan:
                                out_ld=out_ld, N=N, H=H, W=Wd)
         d.res_mod = int(res_mod)
         K = layer.k * layer.k * layer.cin
-        if layer.cout == 2 and layer.k == 3 and layer.cin in (32, 256) and res is None:
-            lst.append(Launch(ops.conv_cout2_launch, (d,), f'{name}[{d.M}x2x{K}]', 2.0 * d.M * 2 * K))
-            return out
         bf = self.eng.mode
         if bf == 1 and layer.cin % 64:                     # (the 32-channel local head: no 64-channel K tile)
             bf = 2
@@ -342,7 +370,8 @@ class FramePlan:
         self._resblock(L, D['RF3']['ResMM'], d8[0], d8[1], d8[2], K, self.h8, self.w8, 'decoder.RF3.ResMM')
         L.append(Launch(ops.upsample2x_add, (s4[2], d8[2], d4[0], True), 'decoder.RF2.up_add'))
         self._resblock(L, D['RF2']['ResMM'], d4[0], d4[1], d4[2], K, self.h4, self.w4, 'decoder.RF2.ResMM')
-        self._conv(L, D['pred2'], d4[2], self.pp, K, self.h4, self.w4, relu_in=True, name='decoder.pred2')
+        self._conv(L, D['pred2'], d4[2], self.z4, K, self.h4, self.w4, relu_in=True, name='decoder.pred2.taps')
+        L.append(Launch(ops.pred2_gather, (self.z4, D['pred2'].bias, self.pp), 'decoder.pred2.gather'))
         L.append(Launch(ops.rough_uncertainty, (self.pp, self.p_up, self.rough, self.unc), 'decoder.rough_unc'))
         L.append(Launch(ops.local_stats, (self.q['r1'], self.rough, self.hs, self.hr, self.hm, self.lm, self.conf),
                         'decoder.local_stats'))
@@ -350,7 +379,8 @@ class FramePlan:
         self._conv(L, D['local_convFM_loc'], self.lm, l2[0], K, self.h2, self.w2, res=self.lq,
                    res_mod=self.h2 * self.w2, name='decoder.local_convFM.local')
         self._resblock(L, D['local_ResMM'], l2[0], l2[1], l2[2], K, self.h2, self.w2, 'decoder.local_ResMM')
-        self._conv(L, D['local_pred2'], l2[2], self.qq, K, self.h2, self.w2, relu_in=True, name='decoder.local_pred2')
+        self._conv(L, D['local_pred2'], l2[2], self.z2, K, self.h2, self.w2, relu_in=True, name='decoder.local_pred2.taps')
+        L.append(Launch(ops.pred2_gather, (self.z2, D['local_pred2'].bias, self.qq), 'decoder.local_pred2.gather'))
         L.append(Launch(ops.final_logits, (self.p_up, self.unc, self.conf, self.qq, self.score, self.pad,
                                            self.H0, self.W0), 'decoder.final_logits'))
         # ---- memorize
@@ -429,9 +459,9 @@ class Engine:
                             convFM_q=ConvLayer(d.convFM, None, dev, (DV, 2 * DV)),
                             local_convFM_r1=ConvLayer(d.local_convFM, None, dev, (0, 64)),
                             local_convFM_loc=ConvLayer(d.local_convFM, None, dev, (64, 128), with_bias=False),
-                            ResMM=rb(d.ResMM), RF3=rf(d.RF3), RF2=rf(d.RF2), pred2=cl(d.pred2),
+                            ResMM=rb(d.ResMM), RF3=rf(d.RF3), RF2=rf(d.RF2), pred2=Pred2Layer(d.pred2, dev),
                             local_ResMM=rb(d.local_ResMM),
-                            local_pred2=cl(d.local_pred2))
+                            local_pred2=Pred2Layer(d.local_pred2, dev))
 
     # ------------------------------------------------------------------ plans
     def plan(self, H0, W0, obj_n):

@@ -218,13 +218,34 @@ def rough_uncertainty(p, p_up, rough, unc):
 
 
 def local_stats(r1, rough, hs, hr, hm, lm, conf):
+    """AFB_URR.py:226-229.  One fused pass (no scratch) for C = 64 and up to 4 objects; otherwise the two-pass pair, which
+    needs the scratch buffers hs [obj,h,w,C], hr / hm [obj,h,w]."""
     obj_n, h, w = rough.shape
     Cc = r1.shape[-1]
     L = _lib.lib()
+    if Cc == 64 and obj_n <= 4:
+        check(L.vfn_local_stats_f32(ptr(r1), ptr(rough), ptr(lm), ptr(conf), obj_n, h, w, Cc, stream()), 'vfn_local_stats_f32')
+        return
     check(L.vfn_local_hpass_f32(ptr(r1), ptr(rough), ptr(hs), ptr(hr), ptr(hm), obj_n, h, w, Cc, stream()),
           'vfn_local_hpass_f32')
     check(L.vfn_local_vpass_f32(ptr(hs), ptr(hr), ptr(hm), ptr(lm), ptr(conf), obj_n, h, w, Cc, stream()),
           'vfn_local_vpass_f32')
+
+
+def local_stats_two_pass(r1, rough, hs, hr, hm, lm, conf):
+    """The unfused pair (tests compare the fused kernel with it)."""
+    obj_n, h, w = rough.shape
+    Cc = r1.shape[-1]
+    L = _lib.lib()
+    check(L.vfn_local_hpass_f32(ptr(r1), ptr(rough), ptr(hs), ptr(hr), ptr(hm), obj_n, h, w, Cc, stream()), 'vfn_local_hpass_f32')
+    check(L.vfn_local_vpass_f32(ptr(hs), ptr(hr), ptr(hm), ptr(lm), ptr(conf), obj_n, h, w, Cc, stream()), 'vfn_local_vpass_f32')
+
+
+def pred2_gather(z, bias, out):
+    """z [N,h,w,ldz] (tap GEMM output) -> out [N,h,w,2] = bias + sum of the nine shifted taps."""
+    N, h, w, ldz = z.shape
+    check(_lib.lib().vfn_pred2_gather_f32(ptr(z), ptr(bias), ptr(out), N, h, w, ldz, stream()), 'vfn_pred2_gather_f32')
+    return out
 
 
 def final_logits(p_up, unc, conf, q, score, pad, H0, W0):
