@@ -459,8 +459,11 @@ extern "C" int vfn_local_stats_f32(const float* r1, const float* rough, float* l
                                    int C, void* stream) {
     if (!r1 || !rough || !lm || !conf || C != 64 || obj_n < 1 || obj_n > 4 || h < 1 || w < 1) return VFN_ERR_ARG;
     const int strips = (w + LS_W - 1) / LS_W;
-    int yr = 24;                                                   // rows per workgroup: >= 256 workgroups when the image allows
-    while (yr > 8 && strips * ((h + yr - 1) / yr) < 256) yr -= 4;
+    // rows per workgroup: the walk down a strip is a dependent chain (one barrier per row), so the kernel wants many
+    // short strips in flight -- >= 3 workgroups per CU when the image allows -- at the price of re-reading the 6 halo rows
+    // (from L2) per strip
+    int yr = 24;
+    while (yr > 8 && strips * ((h + yr - 1) / yr) < 768) yr -= 4;
     const dim3 grid(strips * ((h + yr - 1) / yr));
     hipStream_t s = (hipStream_t)stream;
     switch (obj_n) {
