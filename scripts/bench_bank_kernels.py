@@ -9,6 +9,7 @@ from vfloodnet_amd._lib import ptr, stream, check, MemReadDesc, BankScanDesc
 C = _lib.C
 dev = torch.device('cuda', 0)
 HW, K = 1620, 2
+PREC = int(os.environ.get('PREC', 0))
 L = _lib.lib()
 
 
@@ -23,7 +24,7 @@ def timeit(fn, reps=10):
 
 
 for B in [int(x) for x in (sys.argv[1:] or ['56000'])]:
-    fb = FeatureBank(K, 250000, dev)
+    fb = FeatureBank(K, max(250000, int(2.6 * B)), dev)
     fb._hw = HW
     fb._alloc(HW, B)
     fb._kbuf.normal_(); fb._vbuf.normal_()
@@ -41,7 +42,7 @@ for B in [int(x) for x in (sys.argv[1:] or ['56000'])]:
     d.stride_q, d.stride_k, d.stride_rs = 0, cap * DK, 0
     d.scale = scale
     d.work_counter = ptr(work)
-    d.ldq, d.q_per_obj, d.HW, d.obj_n, d.nsplit, d.mode, d.precision = DK + DV, 0, HW, K, nsplit_scan, 0, 0
+    d.ldq, d.q_per_obj, d.HW, d.obj_n, d.nsplit, d.mode, d.precision = DK + DV, 0, HW, K, nsplit_scan, 0, PREC
     t_scan0 = timeit(lambda: check(L.vfn_bank_scan(C.byref(d), stream()), 'scan'))
     check(L.vfn_bank_scan_finish(ptr(ml_part), nsplit_scan, HW, K, 0, ptr(ml), None, None, None, stream()), 'fin')
     m = MemReadDesc()
@@ -50,7 +51,7 @@ for B in [int(x) for x in (sys.argv[1:] or ['56000'])]:
     m.cnt, m.info, m.out = ptr(fb._cnt), ptr(fb._ibuf), ptr(dec_in)
     m.stride_k, m.stride_v, m.stride_cnt, m.stride_info = cap * DK, cap * DV, cap, cap * 2
     m.scale, m.thres = scale, 1e-3
-    m.ldq, m.ldqv, m.ld_out, m.HW, m.obj_n, m.nsplit, m.precision, m.wide = DK + DV, DK + DV, DV, HW, K, nsplit, 0, 1
+    m.ldq, m.ldqv, m.ld_out, m.HW, m.obj_n, m.nsplit, m.precision, m.wide = DK + DV, DK + DV, DV, HW, K, nsplit, PREC, 1
     t_apply = timeit(lambda: check(L.vfn_memread_apply(C.byref(m), stream()), 'apply'))
     t_fin = timeit(lambda: check(L.vfn_memread_finish(C.byref(m), stream()), 'finish'))
     d1 = BankScanDesc()
@@ -59,7 +60,7 @@ for B in [int(x) for x in (sys.argv[1:] or ['56000'])]:
     d1.stride_q, d1.stride_k, d1.stride_rs = HW * 640, cap * DK, cap
     d1.scale = 1.0
     d1.work_counter = ptr(work)
-    d1.ldq, d1.q_per_obj, d1.HW, d1.obj_n, d1.nsplit, d1.mode, d1.precision = 640, 1, HW, K, nsplit_scan, 1, 0
+    d1.ldq, d1.q_per_obj, d1.HW, d1.obj_n, d1.nsplit, d1.mode, d1.precision = 640, 1, HW, K, nsplit_scan, 1, PREC
     t_scan1 = timeit(lambda: check(L.vfn_bank_scan(C.byref(d1), stream()), 'scan1'))
     gf_scan = 2.0 * 128 * B * HW * K / 1e9
     gf_apply = 2.0 * 640 * B * HW * K / 1e9
