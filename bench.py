@@ -270,9 +270,27 @@ def main(argv=None):
     mem_records = []                               # (bank entries summed over objects, HW, ev0, ev1)
     orig_memread = Engine._memory_read
 
+    apply_records = []                             # the apply kernel of the same frames on its own: (entries, HW, ev0, ev1)
+    from vfloodnet_amd import _lib as vlib
+    L_ = vlib.lib()
+    orig_apply = L_.vfn_memread_apply
+    cur_mem = {}
+
+    def timed_apply(desc_ref, stream_):
+        if not timer.active:
+            return orig_apply(desc_ref, stream_)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        rc = orig_apply(desc_ref, stream_)
+        e1.record()
+        apply_records.append((cur_mem['entries'], cur_mem['HW'], e0, e1))
+        return rc
+    L_.vfn_memread_apply = timed_apply
+
     def timed_memread(self_, p_, fb_, update_bank_):
         if not timer.active:
             return orig_memread(self_, p_, fb_, update_bank_)
+        cur_mem.update(entries=sum(fb_._len_host), HW=p_.HW)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         orig_memread(self_, p_, fb_, update_bank_)
@@ -378,33 +396,50 @@ def main(argv=None):
             dist.destroy_process_group()
         return 0
 
-    # ---- roofline of the dominant kernel
+    # ---- roofline of the dominant kernel: the instrumented kernel with the most device time on the sampled frames
+    # (every implicit-GEMM instantiation and the memory-read apply kernel; the others are listed in roofline.kernels)
     per = timer.summary()
     roof = None
     if per:
         names = ops.conv_cfg_names(ops.MODES[args.precision])
-        dom = max(per, key=lambda c: per[c][1])
+        cands = []                          # (name, flops, ms, launches)
+        for c, (fl, ms, n) in per.items():
+            cands.append((names[c], fl, ms, n))
+        if apply_records:
+            a_ms = sum(e0.elapsed_time(e1) for _, _, e0, e1 in apply_records)
+            a_fl = sum(1280.0 * b * hw for b, hw, _, _ in apply_records)     # (2*128 + 2*512) FLOP per (entry, query): scores + P^T V
+            kn = {'fp32': 'memread_apply_wide_kernel', 'bf16': 'memread_apply_lpw_kernel<false>', 'bf16x3': 'memread_apply_lpw_kernel<true>'}[args.precision]
+            cands.append((kn, a_fl, a_ms, len(apply_records)))
         tot_fl = sum(v[0] for v in per.values())
         tot_ms = sum(v[1] for v in per.values())
-        fl, ms, n = per[dom]
+        all_ms = sum(c_[2] for c_ in cands)
+        kname, fl, ms, n = max(cands, key=lambda c_: c_[2])
         ach = fl / (ms * 1e-3) / 1e12
-        kname = names[dom]
-        traffic = None                      # HBM bytes per launch of this kernel from the committed PMC passes
         tname = f'{PROFILE_ROUND}_pmc_traffic.json' if args.precision == 'fp32' else f'{PROFILE_ROUND}_pmc_traffic_{args.precision}.json'
         tpath = os.path.join(ROOT, 'profiles', tname)
-        if os.path.isfile(tpath):
-            for k_, v_ in json.load(open(tpath)).get('kernels', {}).items():
-                if kname in k_ and args.workload == 'C2':
-                    traffic = round(v_['hbm_bytes_per_launch'])
+        pmc = json.load(open(tpath)).get('kernels', {}) if os.path.isfile(tpath) else {}
+
+        def traffic_of(name_):              # HBM bytes per launch of this kernel from the committed PMC passes
+            for k_, v_ in pmc.items():
+                if name_ in k_ and args.workload == 'C2' and 'hbm_bytes_per_launch' in v_:
+                    return round(v_['hbm_bytes_per_launch'])
+            return None
         roof = {'bound': 'mfma', 'kernel': kname,
                 'achieved': round(ach, 2), 'peak': round(peak, 1), 'unit': 'TFLOP/s',
-                'frac': round(ach / peak, 4), 'traffic': traffic,
+                'frac': round(ach / peak, 4), 'traffic': traffic_of(kname),
                 'traffic_source': f'profiles/{tname} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes of this command, '
                                   f'FETCH doubled per MI355X_MICROARCH.md; not re-measured in this run)',
                 'launches_timed': n, 'avg_launch_us': round(ms * 1e3 / n, 2),
+                'share_of_instrumented_time': round(ms / all_ms, 4),
+                'algorithmic_flop': '2*M*Cout*K per conv launch; 1280 * bank entries * HW per memory-read apply launch (scores once + P^T V)',
                 'timing': 'HIP events around every launch of frames that take no part in the side-stream overlap (kernel alone '
                           f'on the device); rocprofv3 counterpart: profiles/{PROFILE_ROUND}_kernel_stats_no_overlap.csv (--no-overlap run); '
                           f'profiles/{PROFILE_ROUND}_kernel_stats.csv is the default command, where overlapped launches run longer',
+                'kernels': [{'kernel': c_[0], 'achieved': round(c_[1] / (c_[2] * 1e-3) / 1e12, 2),
+                             'frac': round(c_[1] / (c_[2] * 1e-3) / 1e12 / peak, 4), 'avg_launch_us': round(c_[2] * 1e3 / c_[3], 2),
+                             'launches_timed': c_[3], 'share_of_instrumented_time': round(c_[2] / all_ms, 4),
+                             'traffic': traffic_of(c_[0])}
+                            for c_ in sorted(cands, key=lambda c_: -c_[2])],
                 'all_conv_achieved': round(tot_fl / (tot_ms * 1e-3) / 1e12, 2),
                 'all_conv_frac': round(tot_fl / (tot_ms * 1e-3) / 1e12 / peak, 4)}
 
