@@ -20,6 +20,12 @@ namespace {
 constexpr int TH = 8, TW = 16;            // output tile (pixels) per workgroup
 constexpr int PH = TH * 2 + 5;            // 21 input rows
 constexpr int PW = 38;                    // 37 input cols + 1 zero column for the padded 8th tap
+// LDS image of the input patch: even and odd columns in separate half-rows, [plane][row][parity][PP].  The stride-2
+// convolution makes a lane read column 2*px + 2*q + parity: in a plain row-major image the 32 lanes of a ds_read_b32 group
+// touch only every second bank (22 % of the LDS cycles were conflicts); de-interleaved they read px + q -- consecutive
+// banks -- and the two 16-lane halves (output rows py, py+1 = image rows +2) sit 4*PP = 80 words = 16 banks apart.
+constexpr int PP = 20;                    // columns per parity (19 used)
+constexpr int PROW = 2 * PP;              // words per image row
 
 template <int CIN>
 __global__ __launch_bounds__(256)
@@ -27,7 +33,7 @@ void stem_kernel(const vfn_stem_desc p) {
     constexpr int KP = CIN * 7 * 8;       // padded K
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* sW = reinterpret_cast<float*>(smem);        // [KP][64]
-    float* sP = sW + KP * 64;                          // [CIN][PH][PW]
+    float* sP = sW + KP * 64;                          // [CIN][PH][2][PP]
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
@@ -66,7 +72,7 @@ void stem_kernel(const vfn_stem_desc p) {
                     v = (c == 3) ? m : fminf(fmaxf(1.f - m, 0.f), 1.f);
                 }
             }
-            sP[i] = v;
+            sP[(c * PH + y) * PROW + (x & 1) * PP + (x >> 1)] = v;
         }
     };
     load_planes(0, 3, 0);
@@ -74,7 +80,7 @@ void stem_kernel(const vfn_stem_desc p) {
 
     // this wave: 32 pixels = tile rows 2*wave, 2*wave+1; lane's pixel for the A operand
     const int py = 2 * wave + (li >> 4), px = li & 15;
-    const float* pa = sP + (2 * py) * PW + 2 * px + lh;      // + (c*PH+kh)*PW + 2*q
+    const float* pa = sP + (2 * py) * PROW + lh * PP + px;   // + (c*PH+kh)*PROW + q   (column 2*px + 2*q + lh)
     const float* pb = sW + lh * 64 + li;                     // + (2*s)*64 + 32*tn
 
     f32x16 accF0, accF1;
@@ -86,7 +92,7 @@ void stem_kernel(const vfn_stem_desc p) {
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const int s = (c * 7 + kh) * 4 + q;          // k-step: k = 2s + lh
-                const float a = pa[(c * PH + kh) * PW + 2 * q];
+                const float a = pa[(c * PH + kh) * PROW + q];
                 const float b0 = pb[(2 * s) * 64];
                 const float b1 = pb[(2 * s) * 64 + 32];
                 a0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b0, a0, 0, 0, 0);
@@ -167,7 +173,7 @@ __global__ void maxpool3x3s2_kernel(const float* __restrict__ in, float* __restr
 template <int CIN>
 int launch_stem(const vfn_stem_desc& d, hipStream_t s) {
     constexpr int KP = CIN * 7 * 8;
-    const size_t lds = (size_t)(KP * 64 + CIN * PH * PW) * sizeof(float);
+    const size_t lds = (size_t)(KP * 64 + CIN * PH * PROW) * sizeof(float);
     static bool attr_set = false;
     if (!attr_set && lds > 64 * 1024) {
         hipFuncSetAttribute(reinterpret_cast<const void*>(&stem_kernel<CIN>),
