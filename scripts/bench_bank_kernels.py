@@ -35,7 +35,7 @@ for B in [int(x) for x in (sys.argv[1:] or ['56000'])]:
     o_part = torch.empty(K, MAX_SPLIT, HW, DV, device=dev); dec_in = torch.empty(K, HW, DV, device=dev)
     nsplit_scan = pick_scan_slices(HW, K, B)
     work = torch.zeros(4, dtype=torch.int32, device=dev)
-    nsplit = pick_nsplit(HW, K, B, QT_SCAN, MAX_SPLIT)
+    nsplit = int(os.environ.get('NSPLIT', 0)) or pick_nsplit(HW, K, B, QT_SCAN, MAX_SPLIT)
     scale = 1.0 / math.sqrt(DK)
     d = BankScanDesc()
     d.q, d.bank_k, d.bank_len, d.rowscale, d.part = ptr(kv_q), ptr(fb._kbuf), ptr(fb._len_dev), None, ptr(ml_part)
@@ -51,7 +51,7 @@ for B in [int(x) for x in (sys.argv[1:] or ['56000'])]:
     m.cnt, m.info, m.out = ptr(fb._cnt), ptr(fb._ibuf), ptr(dec_in)
     m.stride_k, m.stride_v, m.stride_cnt, m.stride_info = cap * DK, cap * DV, cap, cap * 2
     m.scale, m.thres = scale, 1e-3
-    m.ldq, m.ldqv, m.ld_out, m.HW, m.obj_n, m.nsplit, m.precision, m.wide = DK + DV, DK + DV, DV, HW, K, nsplit, PREC, 1
+    m.ldq, m.ldqv, m.ld_out, m.HW, m.obj_n, m.nsplit, m.precision, m.wide = DK + DV, DK + DV, DV, HW, K, nsplit, PREC, int(os.environ.get('WIDE', 1))
     t_apply = timeit(lambda: check(L.vfn_memread_apply(C.byref(m), stream()), 'apply'))
     t_fin = timeit(lambda: check(L.vfn_memread_finish(C.byref(m), stream()), 'finish'))
     d1 = BankScanDesc()

@@ -127,6 +127,34 @@ __device__ __forceinline__ void split8(const f32x4& a, const f32x4& b, bf16x8& h
         l[e] = (__bf16)(a[e] - (float)x); l[4 + e] = (__bf16)(b[e] - (float)y);
     }
 }
+// A key chunk that has landed in LDS as f32 ([64 rows][128], 16-byte chunks XOR-swizzled by row & 15) is converted ONCE,
+// in place, into the operand image the reduced-precision MFMAs read: per row 128 bf16 "hi" in the first 256 bytes and (bf16x3)
+// 128 bf16 "lo" in the second, 16-byte chunks (8 consecutive k) again swizzled by row & 15.  Before, every wave split the
+// fragments it read in registers -- the same key row was converted by every wave that used it (4x in the scan and in the
+// 128-query apply kernel) and the conversion VALU equalled the MFMA time of the score GEMM.  NT threads, two barriers.
+__device__ __forceinline__ int swzk(int row, int half, int chunk) { return row * 512 + half * 256 + ((chunk ^ (row & 15)) << 4); }   // bytes
+
+template <int NT, bool X3>
+__device__ __forceinline__ void convert_chunk_inplace(float* sK, int tid) {
+    constexpr int TPR = NT / CH;                   // threads per row (4 or 8)
+    constexpr int F4 = 32 / TPR;                   // float4 per thread (8 or 4)
+    const int r = tid / TPR, part = tid % TPR;
+    f32x4 v[F4];
+#pragma unroll
+    for (int j = 0; j < F4; ++j) v[j] = *reinterpret_cast<const f32x4*>(sK + swz(r, part * F4 + j));
+    __syncthreads();                               // every f32 value is in registers before the image is overwritten
+    char* base = reinterpret_cast<char*>(sK);
+#pragma unroll
+    for (int j = 0; j < F4; j += 2) {
+        bf16x8 h, l;
+        split8(v[j], v[j + 1], h, l);
+        const int chunk = (part * F4 + j) >> 1;    // 8 consecutive k = one 16-byte bf16 chunk
+        *reinterpret_cast<bf16x8*>(base + swzk(r, 0, chunk)) = h;
+        if constexpr (X3) *reinterpret_cast<bf16x8*>(base + swzk(r, 1, chunk)) = l;
+    }
+    __syncthreads();
+}
+
 template <bool X3>
 __device__ __forceinline__ void mfma_lp(f32x16& acc, const bf16x8& ah, const bf16x8& al, const bf16x8& bh, const bf16x8& bl) {
     if constexpr (X3) {
@@ -252,18 +280,31 @@ void bank_scan_kernel(const vfn_bankscan_desc p) {
                     acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[cur][1][t], qf[kk][t], acc[1], 0, 0, 0);
                 }
             }
+        } else if constexpr (PREC == 2) {
+            // bf16x3: the chunk is split into its hi | lo image ONCE (the four waves read the same 64 rows; splitting in
+            // registers per wave cost as many VALU cycles as the score MFMAs).  k = 16g + 8h .. +7 is chunk 2g + h of a half.
+            convert_chunk_inplace<256, true>(const_cast<float*>(sK), tid);
+            const char* kb = reinterpret_cast<const char*>(sK);
+#pragma unroll
+            for (int g = 0; g < 8; ++g) {
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    const bf16x8 ah = *reinterpret_cast<const bf16x8*>(kb + swzk(32 * i + li, 0, 2 * g + lh));
+                    const bf16x8 al = *reinterpret_cast<const bf16x8*>(kb + swzk(32 * i + li, 1, 2 * g + lh));
+                    mfma_lp<true>(acc[i], ah, al, qh[g], ql[g]);
+                }
+            }
         } else {
-            // key fragments: two 16-byte reads (f32 chunks 4g+2h, 4g+2h+1 = k 16g+8h .. +7) per row tile, converted in registers
+            // bf16: two 16-byte reads (f32 chunks 4g+2h, 4g+2h+1 = k 16g+8h .. +7) per row tile, rounded in registers
+            // (one cvt per pair; an in-LDS conversion pass measured slower here: 2 barriers for little VALU)
 #pragma unroll
             for (int g = 0; g < 8; ++g) {
 #pragma unroll
                 for (int i = 0; i < 2; ++i) {
                     const f32x4 x0 = *reinterpret_cast<const f32x4*>(sK + swz(32 * i + li, 4 * g + 2 * lh));
                     const f32x4 x1 = *reinterpret_cast<const f32x4*>(sK + swz(32 * i + li, 4 * g + 2 * lh + 1));
-                    bf16x8 ah, al;
-                    if constexpr (PREC == 2) split8(x0, x1, ah, al);
-                    else { ah = cvt8(x0, x1); al = ah; }
-                    mfma_lp<PREC == 2>(acc[i], ah, al, qh[g], ql[PREC == 2 ? g : 0]);
+                    const bf16x8 ah = cvt8(x0, x1);
+                    mfma_lp<false>(acc[i], ah, ah, qh[g], ql[0]);
                 }
             }
         }
@@ -762,9 +803,20 @@ void memread_apply_lpw_kernel(const vfn_memread_desc p) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 31, lh = lane >> 5;
     const int wr = wave >> 2, wq = wave & 3;                  // score tile: key rows 32wr.., query columns 32wq..
-    const int split = blockIdx.x % p.nsplit;
-    const int qt = blockIdx.x / p.nsplit;
-    const int obj = blockIdx.y;
+    int split, qt, obj;
+    if (p.wide == 2) {
+        // XCD-affine groups: the query tiles of one (object, bank slice) sit on ONE XCD (blocks b, b+8, .. share one) and
+        // start together, so the slice is fetched from HBM once per group and the other tiles hit that XCD's L2.  With
+        // the plain mapping every tile streams its slice on its own: 8.4x the bank's bytes per launch at 1.2M entries
+        // (profiles/r02_pmc_fetch_c5.txt), 3 TB/s of misses that two waves per SIMD cannot cover.
+        const int qn = (p.HW + QTW - 1) / QTW;
+        const int j = blockIdx.x >> 3;
+        const int gid = (j / qn) * 8 + (blockIdx.x & 7);
+        if (gid >= p.nsplit * p.obj_n) return;
+        qt = j % qn; obj = gid % p.obj_n; split = gid / p.obj_n;
+    } else {
+        split = blockIdx.x % p.nsplit; qt = blockIdx.x / p.nsplit; obj = blockIdx.y;
+    }
     const int q0 = qt * QTW;
     const int B = p.bank_len[obj];
     const float* K = p.bank_k + (size_t)obj * p.stride_k;
@@ -797,6 +849,7 @@ void memread_apply_lpw_kernel(const vfn_memread_desc p) {
 
     // value channels of this wave: 64*wave .. +63; lane li owns channels 2*li, 2*li+1 (one per 32-wide tile tc)
     const float* vcol = V + wave * 64 + li * 2;               // + row*512
+    const unsigned vlane_off = (unsigned)((8 * lh) * DV + wave * 64 + li * 2) * 4u;   // bytes, per lane
 
     if (c_lo < c_hi) chunk_load_async8(sK, K + (size_t)c_lo * CH * DK, min(CH, B - c_lo * CH), wave, lane);
     __syncthreads();
@@ -815,11 +868,23 @@ void memread_apply_lpw_kernel(const vfn_memread_desc p) {
 
         // value rows of step 0 (16 bank rows; this lane half: rows 8*lh .. +7) -- they land behind the score GEMM
         f32x2 raw[8];
+        const bool full = b0 + CH <= B;              // uniform; all but the last chunk of the bank
+        // buffer descriptor over this chunk's 64 value rows: scalar base + scalar row offset + one per-lane byte offset
+        const __amdgpu_buffer_rsrc_t vrsrc = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<float*>(V + (size_t)b0 * DV), 0, CH * DV * 4, 0x00020000);
         auto load_raw = [&](int st) {
+            if (full) {
+                // buffer loads: no per-load address arithmetic on the vector ALU (the clamped 64-bit form below costs
+                // ~7 VALU instructions per load, a fifth of the loop's VALU work)
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const int rr = min(b0 + 16 * st + 8 * lh + j, B - 1);      // rows past the end: P is exactly 0 there
-                raw[j] = *reinterpret_cast<const f32x2*>(vcol + (size_t)rr * DV);
+                for (int j = 0; j < 8; ++j)
+                    raw[j] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(vrsrc, vlane_off, (16 * st + j) * DV * 4, 0));
+            } else {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int rr = min(b0 + 16 * st + 8 * lh + j, B - 1);  // rows past the end: P is exactly 0 there
+                    raw[j] = *reinterpret_cast<const f32x2*>(vcol + (size_t)rr * DV);
+                }
             }
         };
         load_raw(0);
@@ -947,6 +1012,7 @@ void memread_apply_wide_kernel(const vfn_memread_desc p) {
             for (int r = 0; r < 16; ++r) o[a][b][r] = 0.f;
 
     const float* vcol = V + wave * 64 + li * 2;      // + row*512; lane li owns channels 2*li, 2*li+1 (tile tc)
+    const unsigned vlane_off = (unsigned)((4 * lh) * DV + wave * 64 + li * 2) * 4u;   // bytes, per lane
 
     if (c_lo < c_hi) chunk_load_async8(sK, K + (size_t)c_lo * CH * DK, min(CH, B - c_lo * CH), wave, lane);
     __syncthreads();
@@ -982,11 +1048,23 @@ void memread_apply_wide_kernel(const vfn_memread_desc p) {
         if (more) chunk_load_async8(sK, K + (size_t)(b0 + CH) * DK, min(CH, B - b0 - CH), wave, lane);
 
         f32x2 vb[3][4];                              // ring: value rows two k-groups ahead of their MFMAs
+        // whole chunks read their value rows through a buffer descriptor (scalar base and row offset, one per-lane byte
+        // offset): the 64-bit clamped addresses of the tail form cost ~7 vector-ALU instructions per load, and VALU
+        // issue comes straight out of the MFMA pipe's time on this SIMD
+        const bool full = b0 + CH <= B;
+        const __amdgpu_buffer_rsrc_t vrsrc = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<float*>(V + (size_t)b0 * DV), 0, CH * DV * 4, 0x00020000);
         auto load_v = [&](int kk, int slot) {
+            if (full) {
 #pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                const int rr = min(b0 + 8 * kk + 4 * lh + t, B - 1);      // past the end: P is exactly 0 there
-                vb[slot][t] = *reinterpret_cast<const f32x2*>(vcol + (size_t)rr * DV);
+                for (int t = 0; t < 4; ++t)
+                    vb[slot][t] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(vrsrc, vlane_off, (8 * kk + t) * DV * 4, 0));
+            } else {
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const int rr = min(b0 + 8 * kk + 4 * lh + t, B - 1);  // past the end: P is exactly 0 there
+                    vb[slot][t] = *reinterpret_cast<const f32x2*>(vcol + (size_t)rr * DV);
+                }
             }
         };
         load_v(0, 0);
@@ -1129,7 +1207,8 @@ extern "C" int vfn_memread_apply(const vfn_memread_desc* d, void* stream) {
         constexpr size_t LDS_W1 = (size_t)QTW * DK * 2 + (size_t)CH * DK * 4 + 2 * (size_t)QTW * CH * 2;         // 80 KB
         constexpr size_t LDS_W2 = LDS_W1 + (size_t)QTW * DK * 2;                                                // 112 KB + 16
         if (!once_w) { allow_lds(memread_apply_lpw_kernel<false>, LDS_W1); allow_lds(memread_apply_lpw_kernel<true>, LDS_W2); once_w = true; }
-        const dim3 gridw(cdiv(d->HW, QTW) * d->nsplit, d->obj_n);
+        dim3 gridw(cdiv(d->HW, QTW) * d->nsplit, d->obj_n);
+        if (d->wide == 2) gridw = dim3(8 * cdiv(d->nsplit * d->obj_n, 8) * cdiv(d->HW, QTW));
         if (d->precision == 1) hipLaunchKernelGGL(memread_apply_lpw_kernel<false>, gridw, dim3(512), LDS_W1, (hipStream_t)stream, *d);
         else hipLaunchKernelGGL(memread_apply_lpw_kernel<true>, gridw, dim3(512), LDS_W2, (hipStream_t)stream, *d);
         return vfn_check_launch();
