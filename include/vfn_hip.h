@@ -27,7 +27,7 @@ extern "C" {
 /* ------------------------------------------------------------------ version
  * vfn_abi_version() == VFN_ABI_VERSION of the header the binding was written against, and
  * vfn_sizeof_desc(which) == sizeof of the binding's own struct: checked when the library is loaded. */
-#define VFN_ABI_VERSION 4
+#define VFN_ABI_VERSION 5
 enum { VFN_DESC_CONV = 0, VFN_DESC_STEM = 1, VFN_DESC_BANKSCAN = 2, VFN_DESC_MEMREAD = 3, VFN_DESC_BANK = 4 };
 int vfn_abi_version(void);
 int vfn_sizeof_desc(int which);
@@ -180,6 +180,9 @@ typedef struct vfn_bankscan_desc {
     int* work_counter;     /* one int of device memory: the queue head of the persistent workgroups (zeroed by the
                               launcher on the stream); nsplit is the number of bank slices per (query tile, object) --
                               work items -- and may be far larger than the number of resident workgroups */
+    const void* bank_k_lp; /* precision 1 / 2 only, optional: the keys' split-bf16 image kept by vfn_bank_refresh_lp
+                              ([obj][cap][128 hi | 128 lo] bf16, object stride = stride_k * 4 bytes).  With it the
+                              kernel reads MFMA operands directly; NULL: keys are split on the fly (same results) */
 } vfn_bankscan_desc;
 
 typedef struct vfn_memread_desc {
@@ -201,6 +204,9 @@ typedef struct vfn_memread_desc {
     int wide;              /* 1 = 128 query columns per workgroup (8 waves; keys and values are
                               streamed half as often -- the large-bank / bandwidth-bound regime); the slices of
                               o_part are then chosen for ceil(HW/128) query tiles */
+    const void* bank_k_lp; /* precision 1 / 2 with wide: the split-bf16 images of keys and values kept by         */
+    const void* bank_v_lp; /* vfn_bank_refresh_lp (both or neither; same results as the on-the-fly split, without
+                              the conversion work in the kernel): values [obj][cap][128 groups][4 hi | 4 lo] bf16 */
 } vfn_memread_desc;
 
 int vfn_bank_scan(const vfn_bankscan_desc* d, void* stream);
@@ -251,6 +257,13 @@ typedef struct vfn_bank_desc {
     int rm_class;              /* -1 for update(); >= 0: vfn_bank_remove evicts from this object only */
     int rm_request;            /* remove(class_idx, request_n, frame_idx): room to make (FeatureBank.py:117-143) */
 } vfn_bank_desc;
+
+/* Split-bf16 image of the bank for the reduced-precision contractions (precision 1 / 2): per entry the keys as
+ * [128 hi | 128 lo] bf16 and the values as 128 groups of [4 hi | 4 lo] bf16 (hi = RNE bf16 of x, lo = RNE bf16 of
+ * x - hi): the same bytes per entry as the f32 rows, object strides stride_k / stride_v * 4 bytes.
+ * all_rows = 0: after vfn_bank_merge + vfn_bank_append of the same descriptor, re-split only the entries that update
+ * changed (merged or appended; every entry when it compacted the bank).  all_rows = 1: every live entry. */
+int vfn_bank_refresh_lp(const vfn_bank_desc* d, void* bank_k_lp, void* bank_v_lp, int all_rows, void* stream);
 
 int vfn_row_norms(const float* x, long long stride_obj, int ld, int dim, const int* len_dev, int rows,
                   int obj_n, float* nrm, float* inv /* 1/max(nrm,1e-12) or NULL */, long long stride_n, void* stream);

@@ -30,18 +30,20 @@ for B in [int(x) for x in (sys.argv[1:] or ['56000'])]:
     fb._kbuf.normal_(); fb._vbuf.normal_()
     fb._set_lengths([B] * K)
     cap = fb._cap
+    klp, vlp = (fb.lp_image() if PREC and os.environ.get('LP', '1') != '0' else (None, None))
     kv_q = torch.randn(1, HW, 640, device=dev)
     ml = torch.empty(K, HW, 2, device=dev); ml_part = torch.empty(K, MAX_SPLIT_SCAN, HW, 2, device=dev)
     o_part = torch.empty(K, MAX_SPLIT, HW, DV, device=dev); dec_in = torch.empty(K, HW, DV, device=dev)
     nsplit_scan = pick_scan_slices(HW, K, B)
     work = torch.zeros(4, dtype=torch.int32, device=dev)
-    nsplit = int(os.environ.get('NSPLIT', 0)) or pick_nsplit(HW, K, B, QT_SCAN, MAX_SPLIT)
+    nsplit = min(int(os.environ.get('NSPLIT', 0)), MAX_SPLIT) or pick_nsplit(HW, K, B, QT_SCAN, MAX_SPLIT)   # o_part holds MAX_SPLIT slabs
     scale = 1.0 / math.sqrt(DK)
     d = BankScanDesc()
     d.q, d.bank_k, d.bank_len, d.rowscale, d.part = ptr(kv_q), ptr(fb._kbuf), ptr(fb._len_dev), None, ptr(ml_part)
     d.stride_q, d.stride_k, d.stride_rs = 0, cap * DK, 0
     d.scale = scale
     d.work_counter = ptr(work)
+    d.bank_k_lp = ptr(klp)
     d.ldq, d.q_per_obj, d.HW, d.obj_n, d.nsplit, d.mode, d.precision = DK + DV, 0, HW, K, nsplit_scan, 0, PREC
     t_scan0 = timeit(lambda: check(L.vfn_bank_scan(C.byref(d), stream()), 'scan'))
     check(L.vfn_bank_scan_finish(ptr(ml_part), nsplit_scan, HW, K, 0, ptr(ml), None, None, None, stream()), 'fin')
@@ -52,6 +54,7 @@ for B in [int(x) for x in (sys.argv[1:] or ['56000'])]:
     m.stride_k, m.stride_v, m.stride_cnt, m.stride_info = cap * DK, cap * DV, cap, cap * 2
     m.scale, m.thres = scale, 1e-3
     m.ldq, m.ldqv, m.ld_out, m.HW, m.obj_n, m.nsplit, m.precision, m.wide = DK + DV, DK + DV, DV, HW, K, nsplit, PREC, int(os.environ.get('WIDE', 1))
+    m.bank_k_lp, m.bank_v_lp = ptr(klp), ptr(vlp)
     t_apply = timeit(lambda: check(L.vfn_memread_apply(C.byref(m), stream()), 'apply'))
     t_fin = timeit(lambda: check(L.vfn_memread_finish(C.byref(m), stream()), 'finish'))
     d1 = BankScanDesc()
@@ -60,6 +63,7 @@ for B in [int(x) for x in (sys.argv[1:] or ['56000'])]:
     d1.stride_q, d1.stride_k, d1.stride_rs = HW * 640, cap * DK, cap
     d1.scale = 1.0
     d1.work_counter = ptr(work)
+    d1.bank_k_lp = ptr(klp)
     d1.ldq, d1.q_per_obj, d1.HW, d1.obj_n, d1.nsplit, d1.mode, d1.precision = 640, 1, HW, K, nsplit_scan, 1, PREC
     t_scan1 = timeit(lambda: check(L.vfn_bank_scan(C.byref(d1), stream()), 'scan1'))
     gf_scan = 2.0 * 128 * B * HW * K / 1e9

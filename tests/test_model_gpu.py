@@ -476,3 +476,92 @@ def test_undamped_weights_teacher_forced(gpu):
             assert (k2[i].cpu() - k2r[i]).abs().max() < 2e-4 * max(1.0, float(k2r[i].abs().max()))
             assert (v2[i].cpu() - v2r[i]).abs().max() < 2e-4 * max(1.0, float(v2r[i].abs().max()))
         fb_ref.update(k2r, v2r, t)
+
+
+@pytest.mark.parametrize('precision', ['bf16x3', 'bf16'])
+def test_carried_split_image_equals_full_rebuild(gpu, precision):
+    """The reduced-precision kernels read a split-bf16 image of the bank (vfn_bank_refresh_lp) that update() keeps up to
+    date entry by entry.  Through merges, appends and evictions it must equal (a) a full rebuild from the f32 bank and
+    (b) the definition hi = bf16(x), lo = bf16(x - hi) in the documented layout; and a bank that reads its operands
+    through the image must evolve bit-identically to one that splits them on the fly (VFN_LP_IMAGE=0)."""
+    import os
+    from vfloodnet_amd import FeatureBank
+    g = torch.Generator().manual_seed(37)
+    hw = 150
+    k0, v0 = _rand_feats(g, 2, hw)
+    banks = [FeatureBank(2, 1000, gpu, 0.1, 0.9, precision=precision) for _ in range(2)]   # evicts from frame 2 on
+    for fb in banks:
+        fb.init_bank([k.to(gpu) for k in k0], [v.to(gpu) for v in v0])
+    for t in range(1, 8):
+        k1, v1 = _rand_feats(g, 2, hw)
+        for i in range(2):
+            src = torch.randint(0, hw // 3, (hw // 2,), generator=g)
+            k1[i][:, :hw // 2] = 0.9 * k0[i][:, src] + 0.03 * torch.randn(128, hw // 2, generator=g)
+        for j, fb in enumerate(banks):
+            os.environ['VFN_LP_IMAGE'] = '1' if j == 0 else '0'
+            try:
+                fb.update([k.to(gpu) for k in k1], [v.to(gpu) for v in v1], t)
+            finally:
+                os.environ.pop('VFN_LP_IMAGE', None)
+            fb._sync_len()
+        assert banks[1]._klp is None and banks[0]._lp_valid
+        assert banks[0]._len_host == banks[1]._len_host
+        n = banks[0]._len_host
+        fb = banks[0]
+        cap = fb._cap
+        klp = fb._klp[:2 * cap * 256].view(2, cap, 256).clone()
+        vlp = fb._vlp[:2 * cap * 1024].view(2, cap, 128, 8).clone()
+        fb._lp_valid = False
+        fb.lp_image()                                                          # full rebuild
+        for i in range(2):
+            assert torch.equal(banks[0]._kbuf[i, :n[i]], banks[1]._kbuf[i, :n[i]]), (t, i)
+            assert torch.equal(banks[0]._vbuf[i, :n[i]], banks[1]._vbuf[i, :n[i]]), (t, i)
+            assert torch.equal(klp[i, :n[i]], fb._klp[:2 * cap * 256].view(2, cap, 256)[i, :n[i]]), (t, i)
+            assert torch.equal(vlp[i, :n[i]], fb._vlp[:2 * cap * 1024].view(2, cap, 128, 8)[i, :n[i]]), (t, i)
+            x = fb._kbuf[i, :n[i]]
+            hi = x.to(torch.bfloat16)
+            lo = (x - hi.float()).to(torch.bfloat16)
+            assert torch.equal(klp[i, :n[i], :128].view(torch.bfloat16), hi)
+            assert torch.equal(klp[i, :n[i], 128:].view(torch.bfloat16), lo)
+            x = fb._vbuf[i, :n[i]].view(-1, 128, 4)
+            hi = x.to(torch.bfloat16)
+            lo = (x - hi.float()).to(torch.bfloat16)
+            assert torch.equal(vlp[i, :n[i], :, :4].view(torch.bfloat16), hi)
+            assert torch.equal(vlp[i, :n[i], :, 4:].view(torch.bfloat16), lo)
+    assert banks[0].replace_n.sum() > 0
+
+
+@pytest.mark.parametrize('precision', ['bf16x3', 'bf16'])
+def test_memory_read_through_split_image_is_bit_identical(gpu, sd, precision):
+    """segment() in the reduced-precision modes: reading keys / values through the kept split image gives the same bits
+    as splitting them in the kernel (same hi / lo operands, same MFMA order per output element), hit counts included --
+    at a bank long enough for the wide kernels, with a ragged last chunk."""
+    import os
+    from vfloodnet_amd import AFB_URR, FeatureBank
+    from tools import synth
+    model = AFB_URR(gpu, update_bank=True, precision=precision).to(gpu).eval()
+    model.load_state_dict(sd, strict=True)
+    H, W = 96, 160
+    hw = (H // 16) * (W // 16)
+    frames, m0 = synth.clip(5, 2, H, W)
+    g = torch.Generator().manual_seed(41)
+    n_bank = 64 * 37 + 29
+    out = []
+    for flag in ('1', '0'):
+        os.environ['VFN_LP_IMAGE'] = flag
+        os.environ['VFN_WIDE_APPLY'] = '1'
+        try:
+            g.manual_seed(41)
+            fb = FeatureBank(2, 250000, gpu, precision=precision)
+            keys = [torch.randn(128, n_bank, generator=g) for _ in range(2)]
+            vals = [torch.randn(512, n_bank, generator=g) for _ in range(2)]
+            fb.init_bank([k[:, :hw].to(gpu) for k in keys], [v[:, :hw].to(gpu) for v in vals])
+            fb.append([k[:, hw:].to(gpu) for k in keys], [v[:, hw:].to(gpu) for v in vals])
+            score, _ = model.segment(frames[1:2].to(gpu), fb)
+            out.append((score.clone(), fb.info[0].clone(), fb.info[1].clone(), fb._klp is not None))
+        finally:
+            os.environ.pop('VFN_LP_IMAGE', None)
+            os.environ.pop('VFN_WIDE_APPLY', None)
+    assert out[0][3] and not out[1][3]
+    assert torch.equal(out[0][0], out[1][0])
+    assert torch.equal(out[0][1], out[1][1]) and torch.equal(out[0][2], out[1][2])

@@ -40,7 +40,7 @@ class BankScanDesc(C.Structure):
                 ('stride_q', C.c_longlong), ('stride_k', C.c_longlong), ('stride_rs', C.c_longlong),
                 ('scale', C.c_float),
                 ('ldq', C.c_int), ('q_per_obj', C.c_int), ('HW', C.c_int), ('obj_n', C.c_int),
-                ('nsplit', C.c_int), ('mode', C.c_int), ('precision', C.c_int), ('work_counter', c_fp)]
+                ('nsplit', C.c_int), ('mode', C.c_int), ('precision', C.c_int), ('work_counter', c_fp), ('bank_k_lp', c_fp)]
 
 
 class MemReadDesc(C.Structure):
@@ -50,7 +50,7 @@ class MemReadDesc(C.Structure):
                 ('stride_info', C.c_longlong),
                 ('scale', C.c_float), ('thres', C.c_float),
                 ('ldq', C.c_int), ('ldqv', C.c_int), ('ld_out', C.c_int), ('HW', C.c_int), ('obj_n', C.c_int),
-                ('nsplit', C.c_int), ('precision', C.c_int), ('wide', C.c_int)]
+                ('nsplit', C.c_int), ('precision', C.c_int), ('wide', C.c_int), ('bank_k_lp', c_fp), ('bank_v_lp', c_fp)]
 
 
 class BankDesc(C.Structure):
@@ -67,7 +67,7 @@ class BankDesc(C.Structure):
                 ('obj_n', C.c_int), ('cap', C.c_int), ('rm_class', C.c_int), ('rm_request', C.c_int)]
 
 
-ABI_VERSION = 4          # include/vfn_hip.h VFN_ABI_VERSION; csrc/abi.hip
+ABI_VERSION = 5          # include/vfn_hip.h VFN_ABI_VERSION; csrc/abi.hip
 DESC_IDS = {0: ConvDesc, 1: StemDesc, 2: BankScanDesc, 3: MemReadDesc, 4: BankDesc}     # vfn_sizeof_desc(which)
 
 
@@ -113,6 +113,7 @@ def _declare(L):
     L.vfn_bank_append.argtypes = [C.POINTER(BankDesc), p]
     L.vfn_bank_remove.argtypes = [C.POINTER(BankDesc), p]
     L.vfn_bank_refresh_norms.argtypes = [C.POINTER(BankDesc), p, p, p, p]
+    L.vfn_bank_refresh_lp.argtypes = [C.POINTER(BankDesc), p, p, i, p]
     for name, args in SIGNATURES.items():
         fn = getattr(L, name)
         fn.argtypes = args
@@ -153,7 +154,7 @@ SIGNATURES = {
 ALL_SYMBOLS = sorted(list(SIGNATURES) + [
     'vfn_abi_version', 'vfn_sizeof_desc', 'vfn_conv_cfg_count', 'vfn_conv_cfg_tile', 'vfn_conv_cfg_info', 'vfn_conv2d_nhwc_f32', 'vfn_conv2d_nhwc_bf16', 'vfn_conv2d_nhwc_bf16x3', 'vfn_conv3x3_cout2_f32',
     'vfn_stem_conv7x7_f32',
-    'vfn_bank_scan', 'vfn_memread_apply', 'vfn_memread_finish', 'vfn_bank_merge', 'vfn_bank_append', 'vfn_bank_remove', 'vfn_bank_refresh_norms'])
+    'vfn_bank_scan', 'vfn_memread_apply', 'vfn_memread_finish', 'vfn_bank_merge', 'vfn_bank_append', 'vfn_bank_remove', 'vfn_bank_refresh_norms', 'vfn_bank_refresh_lp'])
 
 
 def check(status, what):

@@ -359,6 +359,60 @@ __global__ void bank_refresh_norms_kernel(const vfn_bank_desc p, float* __restri
     }
 }
 
+// ---------------------------------------------------------------- split-bf16 image of the bank (precision 1 / 2)
+// The reduced-precision contractions read every bank entry ~HW/128 times per frame, and splitting an f32 operand into
+// bf16 hi + lo in the consuming kernel costs as many vector-ALU cycles as its MFMAs.  The split is kept beside the
+// bank instead and re-done only for the entries an update changed (same row walk as bank_refresh_norms_kernel).
+// keys:   [row][128 hi | 128 lo] bf16           -- a chunk lands in LDS as the MFMA operand image
+// values: [row][group g of 4 channels][4 hi | 4 lo] bf16 -- one 16-byte load per lane and bank row in P^T V
+typedef __bf16 bf16x4_t __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+__global__ void bank_refresh_lp_kernel(const vfn_bank_desc p, char* __restrict__ klp, char* __restrict__ vlp, int all_rows) {
+    const int obj = blockIdx.y;
+    bool all = all_rows != 0;
+    int newlen, base = 0;
+    if (all) newlen = p.bank_len[obj];
+    else {
+        const int* plan = p.plan + obj * 4;
+        all = plan[1] != 0;                                       // rows were compacted: every row moved
+        newlen = p.stats[obj * 4];
+        base = plan[2];
+    }
+    const int items = all ? newlen : p.HW;
+    const int* idx = p.match_idx + (size_t)obj * p.HW;
+    const float* corr = p.match_corr + (size_t)obj * p.HW;
+    const int* pos = p.app_pos + (size_t)obj * p.HW;
+    const float* K = p.bank_k + (size_t)obj * p.stride_k;
+    const float* V = p.bank_v + (size_t)obj * p.stride_v;
+    char* KL = klp + (size_t)obj * p.stride_k * 4;
+    char* VL = vlp + (size_t)obj * p.stride_v * 4;
+    const int lane = threadIdx.x & 63, wpb = blockDim.x >> 6;
+    for (int it = blockIdx.x * wpb + (threadIdx.x >> 6); it < items; it += gridDim.x * wpb) {
+        int row = it;
+        if (!all) row = (corr[it] > p.thres_close) ? idx[it] : base + pos[it];
+        if (row < 0 || row >= newlen) continue;
+        {   // keys: lane l splits k = 2l, 2l+1
+            const float2 v = *reinterpret_cast<const float2*>(K + (size_t)row * DK + 2 * lane);
+            bf16x2_t h, l;
+            h[0] = (__bf16)v.x; h[1] = (__bf16)v.y;
+            l[0] = (__bf16)(v.x - (float)h[0]); l[1] = (__bf16)(v.y - (float)h[1]);
+            char* dst = KL + (size_t)row * (DK * 4);
+            *reinterpret_cast<bf16x2_t*>(dst + 4 * lane) = h;
+            *reinterpret_cast<bf16x2_t*>(dst + DK * 2 + 4 * lane) = l;
+        }
+#pragma unroll
+        for (int g = lane; g < DV / 4; g += 64) {                 // values: channel groups g = lane, lane + 64
+            const f32x4 v = *reinterpret_cast<const f32x4*>(V + (size_t)row * DV + 4 * g);
+            bf16x4_t h, l;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { h[e] = (__bf16)v[e]; l[e] = (__bf16)(v[e] - (float)h[e]); }
+            char* dst = VL + (size_t)row * (DV * 4) + 16 * g;
+            *reinterpret_cast<bf16x4_t*>(dst) = h;
+            *reinterpret_cast<bf16x4_t*>(dst + 8) = l;
+        }
+    }
+}
+
 // ---------------------------------------------------------------- scatter_mean operator
 // out[d][t] = (out[d][t] + sum_{s: index[s]==t} src[d][s]) / max(count_t, 1), dim = 1, index row-broadcast
 __global__ __launch_bounds__(256)
@@ -451,5 +505,13 @@ extern "C" int vfn_bank_refresh_norms(const vfn_bank_desc* d, float* bank_knorm,
     if (!bank_knorm || !bank_kinv || !bank_vnorm) return VFN_ERR_ARG;
     hipLaunchKernelGGL(bank_refresh_norms_kernel, dim3(1024, d->obj_n), dim3(256), 0, (hipStream_t)stream, *d,
                        bank_knorm, bank_kinv, bank_vnorm);
+    return vfn_check_launch();
+}
+
+extern "C" int vfn_bank_refresh_lp(const vfn_bank_desc* d, void* bank_k_lp, void* bank_v_lp, int all_rows, void* stream) {
+    if (!bank_desc_ok(d) || !bank_k_lp || !bank_v_lp) return VFN_ERR_ARG;
+    if (!all_rows && (!d->plan || !d->stats || !d->match_idx || !d->match_corr || !d->app_pos)) return VFN_ERR_ARG;
+    hipLaunchKernelGGL(bank_refresh_lp_kernel, dim3(all_rows ? 4096 : 1024, d->obj_n), dim3(256), 0, (hipStream_t)stream, *d,
+                       (char*)bank_k_lp, (char*)bank_v_lp, all_rows);
     return vfn_check_launch();
 }

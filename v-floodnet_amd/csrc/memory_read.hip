@@ -219,7 +219,10 @@ void bank_scan_kernel(const vfn_bankscan_desc p) {
     const int split = item / (p.obj_n * qtiles);
     const int q0 = qt * QTS + wave * 32;             // first query of this wave
     const int B = p.bank_len[obj];
-    const float* K = p.bank_k + (size_t)obj * p.stride_k;
+    // reduced precision with a kept split-bf16 image of the keys (vfn_bank_refresh_lp): same bytes per row as f32, the
+    // chunk lands in LDS as the operand image itself (hi | lo halves, chunks swizzled like swzk)
+    const bool lp_image = PREC != 0 && p.bank_k_lp != nullptr;
+    const float* K = (lp_image ? reinterpret_cast<const float*>(p.bank_k_lp) : p.bank_k) + (size_t)obj * p.stride_k;
     const float* Q = p.q + (size_t)(p.q_per_obj ? obj : 0) * p.stride_q;
 
     int c_lo, c_hi;
@@ -280,18 +283,20 @@ void bank_scan_kernel(const vfn_bankscan_desc p) {
                     acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[cur][1][t], qf[kk][t], acc[1], 0, 0, 0);
                 }
             }
-        } else if constexpr (PREC == 2) {
-            // bf16x3: the chunk is split into its hi | lo image ONCE (the four waves read the same 64 rows; splitting in
-            // registers per wave cost as many VALU cycles as the score MFMAs).  k = 16g + 8h .. +7 is chunk 2g + h of a half.
-            convert_chunk_inplace<256, true>(const_cast<float*>(sK), tid);
+        } else if (PREC == 2 || lp_image) {
+            // the chunk as hi | lo operand image: kept beside the bank, or split here ONCE (the four waves read the same
+            // 64 rows; splitting in registers per wave cost as many VALU cycles as the score MFMAs).
+            // k = 16g + 8h .. +7 is chunk 2g + h of a half.
+            if (!lp_image) convert_chunk_inplace<256, true>(const_cast<float*>(sK), tid);
             const char* kb = reinterpret_cast<const char*>(sK);
 #pragma unroll
             for (int g = 0; g < 8; ++g) {
 #pragma unroll
                 for (int i = 0; i < 2; ++i) {
                     const bf16x8 ah = *reinterpret_cast<const bf16x8*>(kb + swzk(32 * i + li, 0, 2 * g + lh));
-                    const bf16x8 al = *reinterpret_cast<const bf16x8*>(kb + swzk(32 * i + li, 1, 2 * g + lh));
-                    mfma_lp<true>(acc[i], ah, al, qh[g], ql[g]);
+                    bf16x8 al = ah;
+                    if constexpr (PREC == 2) al = *reinterpret_cast<const bf16x8*>(kb + swzk(32 * i + li, 1, 2 * g + lh));
+                    mfma_lp<PREC == 2>(acc[i], ah, al, qh[g], ql[PREC == 2 ? g : 0]);
                 }
             }
         } else {
@@ -803,20 +808,9 @@ void memread_apply_lpw_kernel(const vfn_memread_desc p) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 31, lh = lane >> 5;
     const int wr = wave >> 2, wq = wave & 3;                  // score tile: key rows 32wr.., query columns 32wq..
-    int split, qt, obj;
-    if (p.wide == 2) {
-        // XCD-affine groups: the query tiles of one (object, bank slice) sit on ONE XCD (blocks b, b+8, .. share one) and
-        // start together, so the slice is fetched from HBM once per group and the other tiles hit that XCD's L2.  With
-        // the plain mapping every tile streams its slice on its own: 8.4x the bank's bytes per launch at 1.2M entries
-        // (profiles/r02_pmc_fetch_c5.txt), 3 TB/s of misses that two waves per SIMD cannot cover.
-        const int qn = (p.HW + QTW - 1) / QTW;
-        const int j = blockIdx.x >> 3;
-        const int gid = (j / qn) * 8 + (blockIdx.x & 7);
-        if (gid >= p.nsplit * p.obj_n) return;
-        qt = j % qn; obj = gid % p.obj_n; split = gid / p.obj_n;
-    } else {
-        split = blockIdx.x % p.nsplit; qt = blockIdx.x / p.nsplit; obj = blockIdx.y;
-    }
+    const int split = blockIdx.x % p.nsplit;
+    const int qt = blockIdx.x / p.nsplit;
+    const int obj = blockIdx.y;
     const int q0 = qt * QTW;
     const int B = p.bank_len[obj];
     const float* K = p.bank_k + (size_t)obj * p.stride_k;
@@ -967,6 +961,179 @@ void memread_apply_lpw_kernel(const vfn_memread_desc p) {
         }
 }
 
+
+// ------------------------------------------------------------------ pass 2, bf16 / bf16x3, wide tile, kept split image
+// As memread_apply_lpw_kernel, for a bank that carries its split-bf16 image (vfn_bank_refresh_lp): no operand is
+// converted in the loop except P.  The key chunk lands in LDS as the hi | lo operand image; value rows are read as
+// [group of 4 channels][4 hi | 4 lo] -- one 16-byte buffer load per lane and bank row -- and transposed into the
+// K-contiguous B operand with byte permutes (32 v_perm per 16 bank rows; the split cost ~110 VALU instructions).
+// P^T V mapping: wave = (query half qh, channel quarter cq): 2 query tiles x 4 channel tiles (channel = 128cq + 4li + tc),
+// so P^T fragments are read from LDS half as often as with 4 query tiles x 2 channel tiles.
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+
+template <bool X3>
+__global__ __launch_bounds__(512, 1)
+void memread_apply_shw_kernel(const vfn_memread_desc p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* sQh = smem;                                         // [128][128] bf16
+    char* sQl = sQh + QTW * DK * 2;                           // (bf16x3 only)
+    float* sK = reinterpret_cast<float*>(sQh + (X3 ? 2 : 1) * QTW * DK * 2);   // [64][hi 256 B | lo 256 B]
+    char* sPh = reinterpret_cast<char*>(sK + CH * DK);        // [128 q][64 b] bf16
+    char* sPl = sPh + QTW * CH * 2;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 31, lh = lane >> 5;
+    const int wr = wave >> 2, wq = wave & 3;                  // score tile: key rows 32wr.., query columns 32wq..
+    const int qhalf = wave >> 2, cq = wave & 3;               // P^T V: queries 64qhalf.., channels 128cq..
+    const int split = blockIdx.x % p.nsplit;
+    const int qt = blockIdx.x / p.nsplit;
+    const int obj = blockIdx.y;
+    const int q0 = qt * QTW;
+    const int B = p.bank_len[obj];
+    const float* K = reinterpret_cast<const float*>(p.bank_k_lp) + (size_t)obj * p.stride_k;     // image rows are 512 B too
+    const char* V = reinterpret_cast<const char*>(p.bank_v_lp) + (size_t)obj * p.stride_v * 4;   // rows of 2048 B
+
+    {   // query image
+        const int c = tid & 31;
+        for (int r = tid >> 5; r < QTW; r += 16) {
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (q0 + r < p.HW) v = *reinterpret_cast<const f32x4*>(p.q + (size_t)(q0 + r) * p.ldq + c * 4);
+            bf16x4 h, l;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { h[e] = (__bf16)v[e]; l[e] = (__bf16)(v[e] - (float)h[e]); }
+            const int off = swzq(r, c >> 1) + (c & 1) * 8;
+            *reinterpret_cast<bf16x4*>(sQh + off) = h;
+            if constexpr (X3) *reinterpret_cast<bf16x4*>(sQl + off) = l;
+        }
+    }
+
+    int c_lo, c_hi;
+    chunk_range(B, p.nsplit, split, c_lo, c_hi);
+
+    f32x16 o[2][4];                                           // O^T tiles: [query tile][channel tile]
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[a][b][r] = 0.f;
+
+    const unsigned vlane_off = (unsigned)(8 * lh) * (DV * 4) + (unsigned)(cq * 32 + li) * 16u;   // bytes, per lane
+
+    if (c_lo < c_hi) chunk_load_async8(sK, K + (size_t)c_lo * CH * DK, min(CH, B - c_lo * CH), wave, lane);
+    __syncthreads();
+
+    const int qcol = wq * 32 + li;
+    const bool qok = (q0 + qcol) < p.HW;
+    float qm = 1e30f, qinv = 0.f;
+    if (qok) {
+        qm = p.ml[((size_t)obj * p.HW + q0 + qcol) * 2];
+        qinv = 1.f / p.ml[((size_t)obj * p.HW + q0 + qcol) * 2 + 1];
+    }
+
+    for (int c = c_lo; c < c_hi; ++c) {
+        const int b0 = c * CH;
+        const bool more = c + 1 < c_hi;
+        // buffer descriptor over this chunk's live value rows; the row goes into the per-lane offset (a constant add,
+        // folded into the instruction offset where it fits), which the hardware range check covers: rows past the bank
+        // end read 0 -- their P is exactly 0 as well -- so the last chunk needs no clamp and no branch
+        const int live = min(CH, B - b0);
+        const __amdgpu_buffer_rsrc_t vrsrc = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<char*>(V + (size_t)b0 * (DV * 4)), 0, live * DV * 4, 0x00020000);
+
+        u32x4 raw[8];                                // 8 bank rows x [4 hi | 4 lo] of this lane's channel group
+        auto load_raw = [&](int st) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                if constexpr (X3) raw[j] = __builtin_amdgcn_raw_buffer_load_b128(vrsrc, vlane_off + (16 * st + j) * DV * 4, 0, 0);
+                else {
+                    const u32x2 h = __builtin_amdgcn_raw_buffer_load_b64(vrsrc, vlane_off + (16 * st + j) * DV * 4, 0, 0);
+                    raw[j][0] = h[0]; raw[j][1] = h[1];
+                }
+            }
+        };
+        load_raw(0);                                 // lands behind the score GEMM
+
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+        {
+            const int ra = wr * 32 + li, rq = wq * 32 + li;
+            const char* kb = reinterpret_cast<const char*>(sK);
+#pragma unroll
+            for (int g = 0; g < 8; ++g) {
+                const bf16x8 ah = *reinterpret_cast<const bf16x8*>(kb + swzk(ra, 0, 2 * g + lh));
+                bf16x8 al = ah;
+                if constexpr (X3) al = *reinterpret_cast<const bf16x8*>(kb + swzk(ra, 1, 2 * g + lh));
+                const bf16x8 bh = *reinterpret_cast<const bf16x8*>(sQh + swzq(rq, 2 * g + lh));
+                bf16x8 bl = bh;
+                if constexpr (X3) bl = *reinterpret_cast<const bf16x8*>(sQl + swzq(rq, 2 * g + lh));
+                mfma_lp<X3>(acc, ah, al, bh, bl);
+            }
+        }
+
+        const int rloc = wr * 32 + 4 * lh;
+        const int mycnt = softmax_hits(acc, p.scale, qm, qinv, p.thres, B - b0, rloc);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {                // registers 4g..4g+3 = 4 consecutive bank rows of query qcol
+            const int brow = rloc + 8 * g;
+            bf16x4 h, l;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { h[e] = (__bf16)acc[4 * g + e]; l[e] = (__bf16)(acc[4 * g + e] - (float)h[e]); }
+            const int off = swzp(qcol, brow >> 3) + ((brow >> 2) & 1) * 8;
+            *reinterpret_cast<bf16x4*>(sPh + off) = h;
+            if constexpr (X3) *reinterpret_cast<bf16x4*>(sPl + off) = l;
+        }
+        if (p.cnt && lh == 0 && mycnt > 0) {
+            const int row = b0 + wr * 32 + li;
+            if (row < B) atomicAdd(p.cnt + (size_t)obj * p.stride_cnt + row, mycnt);
+        }
+        __syncthreads();                             // P^T visible; every wave is done reading sK
+        if (more) chunk_load_async8(sK, K + (size_t)(b0 + CH) * DK, min(CH, B - b0 - CH), wave, lane);
+
+        // O^T[q][ch] += sum_b P^T[q][b] V[b][ch]: A = P^T (2 query tiles), B = value rows (4 channel tiles)
+#pragma unroll
+        for (int st = 0; st < CH / 16; ++st) {
+            bf16x8 vh[4], vl[4];
+#pragma unroll
+            for (int tc = 0; tc < 4; ++tc) {
+                const unsigned sel = (tc & 1) ? 0x07060302u : 0x05040100u;   // high / low halves of two dwords
+                u32x4 th, tl;
+#pragma unroll
+                for (int m = 0; m < 4; ++m) {        // dword m = rows 2m, 2m+1 of channel tc
+                    th[m] = __builtin_amdgcn_perm(raw[2 * m + 1][tc >> 1], raw[2 * m][tc >> 1], sel);
+                    if constexpr (X3) tl[m] = __builtin_amdgcn_perm(raw[2 * m + 1][2 + (tc >> 1)], raw[2 * m][2 + (tc >> 1)], sel);
+                }
+                vh[tc] = __builtin_bit_cast(bf16x8, th);
+                if constexpr (X3) vl[tc] = __builtin_bit_cast(bf16x8, tl); else vl[tc] = vh[tc];
+            }
+            if (st + 1 < CH / 16) load_raw(st + 1);
+#pragma unroll
+            for (int tq = 0; tq < 2; ++tq) {
+                const int prow = qhalf * 64 + tq * 32 + li;
+                const bf16x8 ph = *reinterpret_cast<const bf16x8*>(sPh + swzp(prow, 2 * st + lh));
+                bf16x8 pl = ph;
+                if constexpr (X3) pl = *reinterpret_cast<const bf16x8*>(sPl + swzp(prow, 2 * st + lh));
+#pragma unroll
+                for (int tc = 0; tc < 4; ++tc) mfma_lp<X3>(o[tq][tc], ph, pl, vh[tc], vl[tc]);
+            }
+        }
+        __syncthreads();
+    }
+
+    float* dst = p.o_part + ((size_t)obj * p.nsplit + split) * p.HW * DV;
+#pragma unroll
+    for (int tq = 0; tq < 2; ++tq)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int q = q0 + qhalf * 64 + tq * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+            if (q < p.HW) {
+                const f32x4 v = {o[tq][0][r], o[tq][1][r], o[tq][2][r], o[tq][3][r]};
+                *reinterpret_cast<f32x4*>(dst + (size_t)q * DV + cq * 128 + li * 4) = v;
+            }
+        }
+}
 
 // ------------------------------------------------------------------ pass 2 (f32), wide query tile
 // 128 query columns per workgroup, 8 waves: the score tile is 64 x 128 (one 32x32 tile per wave), wave w then owns
@@ -1207,8 +1374,16 @@ extern "C" int vfn_memread_apply(const vfn_memread_desc* d, void* stream) {
         constexpr size_t LDS_W1 = (size_t)QTW * DK * 2 + (size_t)CH * DK * 4 + 2 * (size_t)QTW * CH * 2;         // 80 KB
         constexpr size_t LDS_W2 = LDS_W1 + (size_t)QTW * DK * 2;                                                // 112 KB + 16
         if (!once_w) { allow_lds(memread_apply_lpw_kernel<false>, LDS_W1); allow_lds(memread_apply_lpw_kernel<true>, LDS_W2); once_w = true; }
-        dim3 gridw(cdiv(d->HW, QTW) * d->nsplit, d->obj_n);
-        if (d->wide == 2) gridw = dim3(8 * cdiv(d->nsplit * d->obj_n, 8) * cdiv(d->HW, QTW));
+        const dim3 gridw(cdiv(d->HW, QTW) * d->nsplit, d->obj_n);
+        // bf16x3 only: in plain bf16 the image's 8-byte hi halves sit 16 bytes apart and the kernel measured 11 % slower
+        // than the f32 rows rounded in registers (9.9 vs 8.9 ms at 1.2M entries)
+        if (d->bank_k_lp && d->bank_v_lp && d->precision == 2) {
+            static bool once_s = false;
+            if (!once_s) { allow_lds(memread_apply_shw_kernel<false>, LDS_W1); allow_lds(memread_apply_shw_kernel<true>, LDS_W2); once_s = true; }
+            if (d->precision == 1) hipLaunchKernelGGL(memread_apply_shw_kernel<false>, gridw, dim3(512), LDS_W1, (hipStream_t)stream, *d);
+            else hipLaunchKernelGGL(memread_apply_shw_kernel<true>, gridw, dim3(512), LDS_W2, (hipStream_t)stream, *d);
+            return vfn_check_launch();
+        }
         if (d->precision == 1) hipLaunchKernelGGL(memread_apply_lpw_kernel<false>, gridw, dim3(512), LDS_W1, (hipStream_t)stream, *d);
         else hipLaunchKernelGGL(memread_apply_lpw_kernel<true>, gridw, dim3(512), LDS_W2, (hipStream_t)stream, *d);
         return vfn_check_launch();

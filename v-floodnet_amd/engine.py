@@ -568,6 +568,8 @@ class Engine:
         d.ldq, d.q_per_obj, d.HW, d.obj_n, d.nsplit, d.mode = DK + DV, 0, HW, K, nsplit_scan, 0
         d.precision = self.mode
         d.work_counter = ptr(p.work)
+        klp, vlp = fb.lp_image() if self.mode else (None, None)      # the bank's kept split-bf16 image (reduced precision)
+        d.bank_k_lp = ptr(klp) if klp is not None else None
         check(L.vfn_bank_scan(_lib.C.byref(d), s), 'vfn_bank_scan')
         check(L.vfn_bank_scan_finish(ptr(p.ml_part), nsplit_scan, HW, K, 0, ptr(p.ml), None, None, None, s),
               'vfn_bank_scan_finish')
@@ -588,6 +590,8 @@ class Engine:
         m.wide = int(wide == '1' or (wide is None and fb.len_upper() >= WIDE_APPLY_FROM))
         if m.wide:
             m.nsplit = pick_nsplit(HW, K, fb.len_upper(), QT_SCAN, MAX_SPLIT)
+        if m.wide and klp is not None:
+            m.bank_k_lp, m.bank_v_lp = ptr(klp), ptr(vlp)
         check(L.vfn_memread_apply(_lib.C.byref(m), s), 'vfn_memread_apply')
         check(L.vfn_memread_finish(_lib.C.byref(m), s), 'vfn_memread_finish')
 

@@ -85,7 +85,8 @@ class FeatureBank:
         self._dirty = False
         self._kbuf = self._vbuf = self._ibuf = None
         self._scratch = None
-        self._norms_valid = False    # bank norms on the device describe the bank as it is (carried across updates)
+        self._norms_valid = self._lp_valid = False    # bank norms on the device describe the bank as it is (carried across updates)
+        self._klp = self._vlp = None  # split-bf16 image of keys / values for the reduced-precision kernels (lp_image)
 
     # ------------------------------------------------------------------ storage
     def _require_gpu(self):
@@ -122,12 +123,44 @@ class FeatureBank:
         self._work = torch.zeros(4, dtype=torch.int32, device=dev)          # queue head of the persistent scan kernel
         self._stats_pinned = torch.zeros(o, 4, dtype=torch.int32).pin_memory()
         self._scratch = None
-        self._norms_valid = False
+        self._klp = self._vlp = None
+        self._norms_valid = self._lp_valid = False
 
     def _ensure_scratch(self):
         if self._scratch is None:
             self._scratch = (torch.empty_like(self._kbuf), torch.empty_like(self._vbuf), torch.empty_like(self._ibuf))
         return self._scratch
+
+    def _bank_desc(self):
+        o, cap = self.obj_n, self._cap
+        bd = BankDesc()
+        bd.bank_k, bd.bank_v, bd.info = ptr(self._kbuf), ptr(self._vbuf), ptr(self._ibuf)
+        bd.bank_len, bd.bank_len_rw = ptr(self._len_dev), ptr(self._len_dev)
+        bd.stride_k, bd.stride_v, bd.stride_info, bd.stride_n = cap * DK, cap * DV, cap * 2, cap
+        bd.HW, bd.obj_n, bd.cap = self._hw, o, cap
+        return bd
+
+    def lp_image(self):
+        """Device pointers (keys, values) of the bank's split-bf16 image for the reduced-precision kernels
+        (``vfn_bank_refresh_lp``: per entry keys [128 hi | 128 lo], values 128 x [4 hi | 4 lo] bf16 -- the bytes of the f32
+        rows again), brought up to date first.  ``update`` re-splits only the entries it changed; anything else that
+        touches the bank (``keys`` / ``values`` views, ``append``, ``remove``) makes the next call rebuild it.
+        ``VFN_LP_IMAGE=0``: (None, None) -- the kernels then split their operands on the fly (same results, slower)."""
+        import os
+        if os.environ.get('VFN_LP_IMAGE', '1') == '0' or self._kbuf is None:
+            return None, None
+        if self._klp is None:
+            o, cap = self.obj_n, self._cap
+            # zero-initialised, one chunk of slack: every row a kernel can address holds finite values
+            self._klp = torch.zeros(o * cap * DK * 2 + CH * DK * 2, dtype=torch.int16, device=self.device)
+            self._vlp = torch.zeros(o * cap * DV * 2 + CH * DV * 2, dtype=torch.int16, device=self.device)
+            self._lp_valid = False
+        if not self._lp_valid:
+            bd = self._bank_desc()
+            check(_lib.lib().vfn_bank_refresh_lp(_lib.C.byref(bd), ptr(self._klp), ptr(self._vlp), 1, stream()),
+                  'vfn_bank_refresh_lp')
+            self._lp_valid = True
+        return self._klp, self._vlp
 
     # ------------------------------------------------------------------ lengths
     def _sync_len(self):
@@ -169,7 +202,7 @@ class FeatureBank:
         if self._kbuf is None:
             return None
         n = self._sync_len()
-        self._norms_valid = False           # the views are writable: a caller may edit entries
+        self._norms_valid = self._lp_valid = False           # the views are writable: a caller may edit entries
         return [self._kbuf[i, :n[i]].t() for i in range(self.obj_n)]
 
     @keys.setter
@@ -184,7 +217,7 @@ class FeatureBank:
         if self._vbuf is None:
             return None
         n = self._sync_len()
-        self._norms_valid = False
+        self._norms_valid = self._lp_valid = False
         return [self._vbuf[i, :n[i]].t() for i in range(self.obj_n)]
 
     @values.setter
@@ -245,7 +278,7 @@ class FeatureBank:
         if need > self._cap:
             self._grow(need)
         self._write_columns(keys, values, lens, frame_idx, 20.0)
-        self._norms_valid = False
+        self._norms_valid = self._lp_valid = False
         self._set_lengths([lens[i] + int(keys[i].shape[1]) for i in range(self.obj_n)])
 
     def _grow(self, need):
@@ -258,6 +291,8 @@ class FeatureBank:
             setattr(self, name, new)
         self._cap = cap
         self._scratch = None
+        self._klp = self._vlp = None
+        self._lp_valid = False
         del lens
 
     def _stage_new(self, prev_key, prev_value):
@@ -315,6 +350,9 @@ class FeatureBank:
         d.ldq, d.q_per_obj, d.HW, d.obj_n, d.nsplit, d.mode = ld, 1, hw, o, nsplit, 1
         d.precision = ops.MODES[self.precision]
         d.work_counter = ptr(self._work)
+        if d.precision:
+            klp, _ = self.lp_image()
+            d.bank_k_lp = ptr(klp) if klp is not None else None
         check(L.vfn_bank_scan(_lib.C.byref(d), s), 'vfn_bank_scan')
         check(L.vfn_bank_scan_finish(ptr(self._part), nsplit, hw, o, 1, None, ptr(self._midx), ptr(self._mcorr),
                                      ptr(self._nkinv), s), 'vfn_bank_scan_finish')
@@ -343,6 +381,8 @@ class FeatureBank:
         check(L.vfn_bank_refresh_norms(_lib.C.byref(bd), ptr(self._knorm), ptr(self._kinv), ptr(self._vnorm), s),
               'vfn_bank_refresh_norms')
         self._norms_valid = True
+        if self._klp is not None and self._lp_valid:     # re-split the merged / appended entries only
+            check(L.vfn_bank_refresh_lp(_lib.C.byref(bd), ptr(self._klp), ptr(self._vlp), 0, s), 'vfn_bank_refresh_lp')
 
         self._dirty = True
         self._len_upper = [min(n + hw, cap) for n in self._len_upper]
@@ -368,7 +408,7 @@ class FeatureBank:
         bd.frame_idx, bd.ld_new, bd.voff, bd.HW, bd.obj_n, bd.cap = int(frame_idx), DK + DV, DK, hw, o, cap
         bd.rm_class, bd.rm_request = int(class_idx), int(request_n)
         check(L.vfn_bank_remove(_lib.C.byref(bd), stream()), 'vfn_bank_remove')
-        self._norms_valid = False
+        self._norms_valid = self._lp_valid = False
         self._dirty = True
         n = self._sync_len()
         return (self.class_budget - n[class_idx]) - request_n
