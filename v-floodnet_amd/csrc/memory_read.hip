@@ -1135,6 +1135,13 @@ void memread_apply_shw_kernel(const vfn_memread_desc p) {
         }
 }
 
+#ifdef VFN_CENSUS
+#define PH_DECL unsigned long long ph_t = __builtin_amdgcn_s_memtime(), ph_acc[5] = {0, 0, 0, 0, 0}
+#define PH_MARK(k) do { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); ph_acc[k] += t_ - ph_t; ph_t = t_; } while (0)
+#else
+#define PH_DECL
+#define PH_MARK(k)
+#endif
 // ------------------------------------------------------------------ pass 2 (f32), wide query tile
 // 128 query columns per workgroup, 8 waves: the score tile is 64 x 128 (one 32x32 tile per wave), wave w then owns
 // value channels 64w..64w+63 for all 128 queries.  Same MFMA work per wave as memread_apply_kernel, but a key chunk
@@ -1192,12 +1199,14 @@ void memread_apply_wide_kernel(const vfn_memread_desc p) {
         qinv = 1.f / p.ml[((size_t)obj * p.HW + q0 + qcol) * 2 + 1];
     }
 
+    PH_DECL;
     for (int c = c_lo; c < c_hi; ++c) {
         const int b0 = c * CH;
         const bool more = c + 1 < c_hi;
 
         f32x16 acc;
         score_tile(sK, sQ, wr, wq, li, lh, acc);
+        PH_MARK(0);
 
         const int rloc = wr * 32 + 4 * lh;
         const int mycnt = softmax_hits(acc, p.scale, qm, qinv, p.thres, B - b0, rloc);
@@ -1211,7 +1220,9 @@ void memread_apply_wide_kernel(const vfn_memread_desc p) {
             const int row = b0 + wr * 32 + li;
             if (row < B) atomicAdd(p.cnt + (size_t)obj * p.stride_cnt + row, mycnt);
         }
+        PH_MARK(1);
         __syncthreads();                             // P^T visible; every wave is done reading sK
+        PH_MARK(2);
         if (more) chunk_load_async8(sK, K + (size_t)(b0 + CH) * DK, min(CH, B - b0 - CH), wave, lane);
 
         f32x2 vb[3][4];                              // ring: value rows two k-groups ahead of their MFMAs
@@ -1254,8 +1265,19 @@ void memread_apply_wide_kernel(const vfn_memread_desc p) {
                     o[tq][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[tq][t], vb[cur][t][1], o[tq][1], 0, 0, 0);
                 }
         }
+        PH_MARK(3);
         __syncthreads();                             // next chunk's keys visible; sP free again
+        PH_MARK(4);
     }
+#ifdef VFN_CENSUS
+    if ((threadIdx.x & 63) == 0) {
+        const int lin = (blockIdx.y * gridDim.x + blockIdx.x) * 8 + (threadIdx.x >> 6);
+        if (lin < 2048) {
+            for (int k = 0; k < 5; ++k) vfn_census_buf[lin * 8 + k] = ph_acc[k];
+            vfn_census_buf[lin * 8 + 5] = c_hi - c_lo;
+        }
+    }
+#endif
 
     float* dst = p.o_part + ((size_t)obj * p.nsplit + split) * p.HW * DV;
 #pragma unroll
