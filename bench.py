@@ -408,7 +408,9 @@ def main(argv=None):
         if apply_records:
             a_ms = sum(e0.elapsed_time(e1) for _, _, e0, e1 in apply_records)
             a_fl = sum(1280.0 * b * hw for b, hw, _, _ in apply_records)     # (2*128 + 2*512) FLOP per (entry, query): scores + P^T V
-            kn = {'fp32': 'memread_apply_wide_kernel', 'bf16': 'memread_apply_lpw_kernel<false>', 'bf16x3': 'memread_apply_lpw_kernel<true>'}[args.precision]
+            # bf16x3 reads the bank's kept split-bf16 image (FeatureBank.lp_image) unless VFN_LP_IMAGE=0
+            x3 = 'memread_apply_lpw_kernel<true>' if os.environ.get('VFN_LP_IMAGE', '1') == '0' else 'memread_apply_shw_kernel<true>'
+            kn = {'fp32': 'memread_apply_wide_kernel', 'bf16': 'memread_apply_lpw_kernel<false>', 'bf16x3': x3}[args.precision]
             cands.append((kn, a_fl, a_ms, len(apply_records)))
         tot_fl = sum(v[0] for v in per.values())
         tot_ms = sum(v[1] for v in per.values())
