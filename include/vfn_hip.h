@@ -75,6 +75,10 @@ int vfn_conv_cfg_tile(int cfg, int* bm, int* bn);
 /* tile configuration cfg: workgroup tile bm x bn, wm x wn waves, dma = 0 register-staged / 2 LDS-DMA ring;
  * the kernel it launches is conv_igemm_kernel<bm, bn, wm, wn, MODE> (conv_igemm_dma_kernel<bm, bn, wm, wn, dma>) */
 int vfn_conv_cfg_info(int cfg, int* bm, int* bn, int* wm, int* wn, int* dma);
+/* K groups per workgroup of configuration cfg: 1 for the plain ones; > 1 (f32 only): split-K inside the workgroup --
+ * that many copies of the wm x wn wave grid each take a slice of K of the same output tile and the partial sums are
+ * added through LDS in group order (conv_igemm_wk_kernel<bm, bn, wm, wn, wk>); ksplit must be <= 1 with these.  0: no such cfg */
+int vfn_conv_cfg_wk(int cfg);
 int vfn_conv2d_nhwc_f32(const vfn_conv_desc* d, int cfg, void* stream);
 /* Same convolution with both operands rounded to bf16 (nearest-even) as they are staged into LDS and multiplied
  * on v_mfma_f32_32x32x16_bf16 with f32 accumulation; tensors stay f32 in HBM.  Cin must be a multiple of 64;

@@ -100,7 +100,8 @@ __device__ __forceinline__ void splitk_finish(const vfn_conv_desc& p, int* flag,
 // Precondition: every wave has passed the barrier behind the last K tile (the staging buffers are dead).
 template <int BM, int BN, int WM, int WN, int LDS_FLOATS = 2 * (BM + BN) * BK>
 __device__ __forceinline__ bool wide_epilogue(const vfn_conv_desc& p, char* smem, f32x16 (&acc)[BM / WM / 32][BN / WN / 32],
-                                              bool split_tile, int kz, int m0, int n0, int n_tiles) {
+                                              bool split_tile, int kz, int m0, int n0, int n_tiles,
+                                              int tid_in = -1, bool active = true) {
     constexpr int NT = WM * WN * 64;
     constexpr int TM = BM / WM / 32;
     constexpr int TN = BN / WN / 32;
@@ -109,7 +110,9 @@ __device__ __forceinline__ bool wide_epilogue(const vfn_conv_desc& p, char* smem
     static_assert(ROWS * PITCH <= LDS_FLOATS, "C tile does not fit the staging LDS");
     const bool wide = (p.Cout % 4 == 0) && (p.out_ld % 4 == 0) && (!p.res || p.res_ld % 4 == 0) && !(split_tile && p.tile_counters);
     if (!wide) return false;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // (tid_in / active: the in-workgroup split-K variant runs this with its K group 0 only; the other groups keep the
+    // barriers company and touch nothing)
+    const int tid = tid_in >= 0 ? tid_in : (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
     const int li = lane & 31, lh = lane >> 5;
     float* sC = reinterpret_cast<float*>(smem);
@@ -130,12 +133,15 @@ __device__ __forceinline__ bool wide_epilogue(const vfn_conv_desc& p, char* smem
 #pragma unroll
     for (int h = 0; h < TM; ++h) {
         if (h > 0) __syncthreads();                                 // the previous round has been read back
+        if (active) {
 #pragma unroll
-        for (int j = 0; j < TN; ++j)
+            for (int j = 0; j < TN; ++j)
 #pragma unroll
-            for (int r = 0; r < 16; ++r)
-                sC[(wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh) * PITCH + (wn * TN + j) * 32 + li] = acc[h][j][r];
+                for (int r = 0; r < 16; ++r)
+                    sC[(wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh) * PITCH + (wn * TN + j) * 32 + li] = acc[h][j][r];
+        }
         __syncthreads();
+        if (!active) continue;
         for (int rr = rr0; rr < ROWS; rr += RPP) {
             const int row = m0 + (rr >> 5) * (TM * 32) + h * 32 + (rr & 31);
             if (row >= p.M || !col_ok) continue;
@@ -157,10 +163,18 @@ __device__ __forceinline__ bool wide_epilogue(const vfn_conv_desc& p, char* smem
     return true;
 }
 
-template <int BM, int BN, int WM, int WN, int MODE = 0>
-__global__ __launch_bounds__(WM * WN * 64)
-void conv_igemm_kernel(const vfn_conv_desc p) {
-    constexpr int NT = WM * WN * 64;
+// WK > 1: split-K INSIDE the workgroup.  The workgroup holds WK copies of the WM x WN wave grid ("K groups"); group g
+// stages and multiplies K tiles [g*kper, (g+1)*kper) of the same output tile in its own LDS buffers, the groups' partial
+// accumulators are summed through LDS in group order (bit-reproducible) and group 0 runs the epilogue.  For the layers
+// whose output has fewer 32x32 tiles than the chip has SIMDs (M = 1620 .. 6480 at 1/16 and 1/8 resolution): the same
+// parallelism as split-K over workgroups, without the partial slabs in HBM and without the reduce launch.
+// PD: prefetch distance of the register staging in K tiles (f32 only).  A layer with about one workgroup per CU has
+// nothing else resident to cover a global load, and a 32x64 tile computes a K tile in 0.4 us: with PD = 1 every K tile
+// waits out its own load (measured 1.5 us per tile).  PD tiles are kept in flight in registers instead.
+template <int BM, int BN, int WM, int WN, int MODE, int WK, int PD = 1>
+__device__ __forceinline__ void conv_igemm_body(const vfn_conv_desc& p) {
+    static_assert(PD == 1 || MODE == 0, "deep prefetch is implemented for the f32 path");
+    constexpr int NT = WM * WN * 64;       // threads of one K group
     constexpr int TM = BM / WM / 32;
     constexpr int TN = BN / WN / 32;
     // MODE 0: exact f32 (v_mfma_f32_32x32x2_f32).
@@ -176,11 +190,13 @@ void conv_igemm_kernel(const vfn_conv_desc p) {
     constexpr int BC = BN * CPR / NT;
     static_assert(AC >= 1 && BC >= 1, "tile too small for the thread count");
 
-    extern __shared__ __attribute__((aligned(16))) char smem[];
+    extern __shared__ __attribute__((aligned(16))) char smem_all[];
+    const int grp = WK > 1 ? (int)threadIdx.x / NT : 0;  // K group (wave-uniform)
+    char* smem = smem_all + (size_t)grp * (2 * (BM + BN) * BK * sizeof(float));
     float* sA = reinterpret_cast<float*>(smem);          // [2][BM][32]
     float* sB = sA + 2 * BM * BK;                        // [2][BN][32]
 
-    const int tid = threadIdx.x;
+    const int tid = WK > 1 ? (int)threadIdx.x % NT : (int)threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
@@ -219,9 +235,10 @@ void conv_igemm_kernel(const vfn_conv_desc p) {
     const int Ktot = p.KH * p.KW * p.Cin;
     const int nk_all = p.KH * p.KW * cblks;
     // a split tile's slice kz owns K tiles [kt_begin, kt_begin + nk)
-    const int kper = split_tile ? (nk_all + ksplit - 1) / ksplit : nk_all;
-    const int kt_begin = kz * kper;
-    const int nk = min(kper, nk_all - kt_begin);
+    const int kper = WK > 1 ? (nk_all + WK - 1) / WK : (split_tile ? (nk_all + ksplit - 1) / ksplit : nk_all);
+    const int kt_begin = (WK > 1 ? grp : kz) * kper;
+    const int nk = max(0, min(kper, nk_all - kt_begin));
+    const int nk_loop = WK > 1 ? kper : nk;               // every K group runs the same number of barriers
 
     // per-thread staging coordinates
     const int c16 = tid % CPR;             // chunk column (4 floats)
@@ -271,7 +288,7 @@ void conv_igemm_kernel(const vfn_conv_desc p) {
     for (int j = 0; j < BC; ++j)
         w_off[j] = ((n0 + r0 + j * RSTEP) * Ktot + c16 * 4) * (int)sizeof(float);
 
-    f32x4 ra[AC], rb[BC];
+    f32x4 ra[PD][AC], rb[PD][BC];
     int kh, kw, cb;                        // tap / channel block of the tile being *loaded*
     {
         const int tap = kt_begin / cblks;
@@ -279,35 +296,35 @@ void conv_igemm_kernel(const vfn_conv_desc p) {
         kh = tap / p.KW;
         kw = tap - kh * p.KW;
     }
-    auto load_a = [&]() {
+    auto load_a = [&](int slot) {
         const int tap_off = ((kh * p.W + kw) * p.in_ld + cb * BKT) * (int)sizeof(float);     // wave-uniform
 #pragma unroll
         for (int j = 0; j < AC; ++j) {
             const bool ok = (unsigned)(a_hi0[j] + kh) < (unsigned)p.H && (unsigned)(a_wi0[j] + kw) < (unsigned)p.W;
             const int off = ok ? a_off[j] + tap_off : 0x7ffffff0;
-            ra[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_in, off, 0, 0));
+            ra[slot][j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_in, off, 0, 0));
         }
     };
-    auto load_b = [&](int kt) {
+    auto load_b = [&](int kt, int slot) {
         const int k_off = kt * BKT * (int)sizeof(float);
         if (wpk) {
 #pragma unroll
             for (int j = 0; j < BCP; ++j)
-                rb[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_w, wp_off[j] + kt * 128, 0, 0));
+                rb[slot][j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_w, wp_off[j] + kt * 128, 0, 0));
         } else {
 #pragma unroll
             for (int j = 0; j < BC; ++j)
-                rb[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_w, w_off[j] + k_off, 0, 0));
+                rb[slot][j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_w, w_off[j] + k_off, 0, 0));
         }
         if (++cb == cblks) { cb = 0; if (++kw == p.KW) { kw = 0; ++kh; } }
     };
     const float relu_floor = p.relu_in ? 0.f : -INFINITY;
-    auto store_a = [&](int buf) {
+    auto store_a = [&](int buf, int slot) {
         float* dA = sA + buf * BM * BK;
 #pragma unroll
         for (int j = 0; j < AC; ++j) {
             const int r = r0 + j * RSTEP;
-            f32x4 v = ra[j];
+            f32x4 v = ra[slot][j];
             v.x = fmaxf(v.x, relu_floor); v.y = fmaxf(v.y, relu_floor);
             v.z = fmaxf(v.z, relu_floor); v.w = fmaxf(v.w, relu_floor);
             if constexpr (MODE == 1) {
@@ -324,13 +341,13 @@ void conv_igemm_kernel(const vfn_conv_desc p) {
             }
         }
     };
-    auto store_b = [&](int buf) {
+    auto store_b = [&](int buf, int slot) {
         float* dB = sB + buf * BN * BK;
         if (wpk) {
 #pragma unroll
             for (int j = 0; j < BCP; ++j) {
                 const int r = pr0 + j * (NT / 8);
-                *reinterpret_cast<f32x4*>(dB + r * BK + ((pc ^ ((r >> 1) & 7)) << 2)) = rb[j];
+                *reinterpret_cast<f32x4*>(dB + r * BK + ((pc ^ ((r >> 1) & 7)) << 2)) = rb[slot][j];
             }
             return;
         }
@@ -338,17 +355,17 @@ void conv_igemm_kernel(const vfn_conv_desc p) {
         for (int j = 0; j < BC; ++j) {
             const int r = r0 + j * RSTEP;
             if constexpr (MODE == 1) {
-                const f32x4 v = rb[j];
+                const f32x4 v = rb[slot][j];
                 const bf16x4 h = {(__bf16)v.x, (__bf16)v.y, (__bf16)v.z, (__bf16)v.w};
                 *reinterpret_cast<bf16x4*>(dB + r * BK + ((((c16 >> 1) ^ ((r >> 1) & 7)) << 2) | ((c16 & 1) << 1))) = h;
             } else if constexpr (MODE == 2) {
                 bf16x4 h, l;
-                split_bf16(rb[j], h, l);
+                split_bf16(rb[slot][j], h, l);
                 const int sw = (r >> 1) & 7, half = (c16 & 1) << 1;
                 *reinterpret_cast<bf16x4*>(dB + r * BK + ((((c16 >> 1) ^ sw) << 2) | half)) = h;
                 *reinterpret_cast<bf16x4*>(dB + r * BK + ((((4 + (c16 >> 1)) ^ sw) << 2) | half)) = l;
             } else {
-                *reinterpret_cast<f32x4*>(dB + r * BK + ((c16 ^ ((r >> 1) & 7)) << 2)) = rb[j];
+                *reinterpret_cast<f32x4*>(dB + r * BK + ((c16 ^ ((r >> 1) & 7)) << 2)) = rb[slot][j];
             }
         }
     };
@@ -361,26 +378,34 @@ void conv_igemm_kernel(const vfn_conv_desc p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
+#pragma unroll
+    for (int d = 0; d < PD; ++d)
+        if (d < nk) { load_a(d); load_b(kt_begin + d, d); }
     if (nk > 0) {
-        load_a();
-        load_b(kt_begin);
-        store_a(0);
-        store_b(0);
+        store_a(0, 0);
+        store_b(0, 0);
     }
     __syncthreads();
 
-    for (int kt = 0; kt < nk; ++kt) {
+    // (unrolled by PD so that the staging slots are compile-time registers: tile kt lives in slot kt % PD)
+    for (int kt0 = 0; kt0 < nk_loop; kt0 += PD) {
+#pragma unroll
+    for (int u = 0; u < PD; ++u) {
+        const int kt = kt0 + u;
+        if (kt >= nk_loop) break;
         const int buf = kt & 1;
-        const bool more = kt + 1 < nk;
+        const bool more = kt + 1 < nk;                 // tile kt+1 goes to LDS during this tile
+        const bool more_load = kt + PD < nk;           // tile kt+PD is requested during this tile
         const float* cA = sA + buf * BM * BK + (wm * TM * 32) * BK;
         const float* cB = sB + buf * BN * BK + (wn * TN * 32) * BK;
+        if (WK > 1 && kt >= nk) { __syncthreads(); continue; }     // (a K group with a shorter last slice)
         if constexpr (MODE == 2) {
             // two 16-channel steps per tile: hi chunk 2s+h and lo chunk 4+2s+h of every row; three MFMAs per tile pair
 #pragma unroll
             for (int st = 0; st < 2; ++st) {
                 if (more) {
-                    if (st == 0) { load_a(); load_b(kt_begin + kt + 1); }
-                    else { store_a(buf ^ 1); store_b(buf ^ 1); }
+                    if (st == 0) { load_a(0); load_b(kt_begin + kt + 1, 0); }
+                    else { store_a(buf ^ 1, 0); store_b(buf ^ 1, 0); }
                 }
                 const int lc = 2 * st + lh;
                 bf16x8 ah[TM], al[TM], bh[TN], bl[TN];
@@ -426,10 +451,10 @@ void conv_igemm_kernel(const vfn_conv_desc p) {
         read_frags(0, fa[0], fb[0]);
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) {
+            if (kk == 0 && more_load) { load_a(u); load_b(kt_begin + kt + PD, u); }       // slot u: tile kt is in LDS already
             if (more) {
-                if (kk == 0) { load_a(); load_b(kt_begin + kt + 1); }
-                if (kk == 2) store_a(buf ^ 1);
-                if (kk == 3) store_b(buf ^ 1);
+                if (kk == 2) store_a(buf ^ 1, (u + 1) % PD);
+                if (kk == 3) store_b(buf ^ 1, (u + 1) % PD);
             }
             if (kk + 1 < 4) read_frags(kk + 1, fa[(kk + 1) & 1], fb[(kk + 1) & 1]);
             f32x4 (&a)[TM] = fa[kk & 1];
@@ -455,8 +480,38 @@ void conv_igemm_kernel(const vfn_conv_desc p) {
         }
         __syncthreads();
     }
+    }
 
-    if (wide_epilogue<BM, BN, WM, WN>(p, smem, acc, split_tile, kz, m0, n0, n_tiles)) return;
+    if constexpr (WK > 1) {
+        // partial accumulators of groups 1.. -> LDS (one float per lane and register: conflict-free), summed by group 0
+        float* red = reinterpret_cast<float*>(smem_all);
+        if (grp > 0) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        red[((((grp - 1) * (WM * WN) + wave) * (TM * TN) + i * TN + j) * 16 + r) * 64 + lane] = acc[i][j][r];
+        }
+        __syncthreads();
+        if (grp == 0) {
+#pragma unroll
+            for (int g = 1; g < WK; ++g)
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r)
+                            acc[i][j][r] += red[((((g - 1) * (WM * WN) + wave) * (TM * TN) + i * TN + j) * 16 + r) * 64 + lane];
+        }
+        __syncthreads();                                   // the sums are in registers: the LDS is free for the epilogue
+        if (wide_epilogue<BM, BN, WM, WN>(p, smem_all, acc, false, 0, m0, n0, n_tiles, tid, grp == 0)) return;
+        if (grp > 0) return;
+    } else {
+        if (wide_epilogue<BM, BN, WM, WN>(p, smem, acc, split_tile, kz, m0, n0, n_tiles)) return;
+    }
 
     // split-K: raw partial sums to the workspace slab of this split; vfn_conv_splitk_reduce finishes
     if (split_tile) {
@@ -503,6 +558,15 @@ void conv_igemm_kernel(const vfn_conv_desc p) {
         }
     }
 }
+
+template <int BM, int BN, int WM, int WN, int MODE = 0>
+__global__ __launch_bounds__(WM * WN * 64)
+void conv_igemm_kernel(const vfn_conv_desc p) { conv_igemm_body<BM, BN, WM, WN, MODE, 1>(p); }
+
+// in-workgroup split-K (f32): WK K groups of WM x WN waves
+template <int BM, int BN, int WM, int WN, int WK, int PD>
+__global__ __launch_bounds__(WM * WN * WK * 64)
+void conv_igemm_wk_kernel(const vfn_conv_desc p) { conv_igemm_body<BM, BN, WM, WN, 0, WK, PD>(p); }
 
 // 128 bytes of zeros: the LDS-DMA source of every filter tap that falls outside the image
 __device__ __attribute__((aligned(128))) float vfn_zero_page[32];
@@ -834,9 +898,34 @@ int launch_cfg(const vfn_conv_desc& p, hipStream_t s) {
     return vfn_check_launch();
 }
 
+template <int BM, int BN, int WM, int WN, int WK, int PD = 3>
+int launch_wk(const vfn_conv_desc& p, hipStream_t s) {
+    constexpr int NT = WM * WN * WK * 64;
+    constexpr size_t lds = (size_t)WK * 2 * (BM + BN) * BK * sizeof(float);
+    static_assert((size_t)(WK - 1) * BM * BN * sizeof(float) <= lds, "reduce buffer does not fit the staging LDS");
+    static_assert(lds <= 160 * 1024 && NT <= 1024, "workgroup too large");
+    static bool attr_set = false;
+    if (!attr_set && lds > 64 * 1024) {
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_wk_kernel<BM, BN, WM, WN, WK, PD>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_set = true;
+    }
+    if (p.ksplit > 1) return VFN_ERR_ARG;                  // one kind of split at a time
+    const int tiles = cdiv(p.M, BM) * cdiv(p.Cout, BN);
+    hipLaunchKernelGGL((conv_igemm_wk_kernel<BM, BN, WM, WN, WK, PD>), dim3(tiles), dim3(NT), lds, s, p);
+    return vfn_check_launch();
+}
+
 }  // namespace
 
-extern "C" int vfn_conv_cfg_count(void) { return 26; }
+extern "C" int vfn_conv_cfg_count(void) { return 32; }
+
+// K groups per workgroup of a tile configuration (1 = none): configurations 26.. split K inside the workgroup
+extern "C" int vfn_conv_cfg_wk(int cfg) {
+    static const int wk[6] = {4, 2, 2, 4, 4, 2};
+    if (cfg < 0 || cfg >= 32) return 0;
+    return cfg < 26 ? 1 : wk[cfg - 26];
+}
 
 extern "C" int vfn_conv_cfg_info(int cfg, int* bm, int* bn, int* wm, int* wn, int* dma) {
     // 8..10: same tiles as 0 / 0 / 2 with twice the waves (smaller per-wave tiles, 4 waves per SIMD at 2 blocks/CU)
@@ -845,15 +934,18 @@ extern "C" int vfn_conv_cfg_info(int cfg, int* bm, int* bn, int* wm, int* wn, in
     // (must match the switch of vfn_conv2d_nhwc_f32 below)
     // 20..25 (f32 only): 32-row tiles for the 1/16-resolution layers (M = 1620: 51 x 32 rows instead of 26 x 64),
     // single-wave 32x32 tiles (most workgroups for the smallest layers), and 8-wave variants of 128x64 / 256x64
-    static const int t[26][5] = {{128, 128, 2, 2, 0}, {128, 64, 2, 2, 0}, {64, 128, 2, 2, 0}, {64, 64, 2, 2, 0}, {32, 64, 1, 2, 0},
+    // 26..31 (f32 only): in-workgroup split-K (vfn_conv_cfg_wk K groups of the WM x WN waves; ksplit must be 1)
+    static const int t[32][5] = {{128, 128, 2, 2, 0}, {128, 64, 2, 2, 0}, {64, 128, 2, 2, 0}, {64, 64, 2, 2, 0}, {32, 64, 1, 2, 0},
                                  {64, 32, 2, 1, 0}, {128, 32, 4, 1, 0}, {256, 128, 4, 2, 0},
                                  {128, 128, 2, 4, 0}, {128, 128, 4, 2, 0}, {64, 128, 2, 4, 0},
                                  {128, 128, 2, 4, 2}, {64, 128, 2, 4, 2}, {64, 64, 2, 2, 2}, {256, 128, 4, 2, 2}, {128, 32, 4, 1, 2},
                                  {64, 128, 2, 2, 2},
                                  {128, 256, 2, 4, 0}, {128, 256, 2, 4, 2}, {64, 256, 2, 4, 0},
                                  {32, 128, 1, 4, 0}, {32, 32, 1, 1, 0}, {128, 64, 4, 2, 0}, {256, 64, 4, 2, 0}, {32, 64, 1, 1, 0},
-                                 {64, 64, 1, 2, 0}};
-    if (cfg < 0 || cfg >= 26) return VFN_ERR_ARG;
+                                 {64, 64, 1, 2, 0},
+                                 {32, 64, 1, 2, 0}, {64, 64, 2, 2, 0}, {32, 64, 1, 2, 0}, {64, 64, 2, 2, 0}, {32, 32, 1, 1, 0},
+                                 {32, 128, 1, 4, 0}};
+    if (cfg < 0 || cfg >= 32) return VFN_ERR_ARG;
     if (bm) *bm = t[cfg][0];
     if (bn) *bn = t[cfg][1];
     if (wm) *wm = t[cfg][2];
@@ -914,6 +1006,12 @@ extern "C" int vfn_conv2d_nhwc_f32(const vfn_conv_desc* d, int cfg, void* stream
         case 23: return launch_cfg<256, 64, 4, 2>(*d, s);
         case 24: return launch_cfg<32, 64, 1, 1>(*d, s);
         case 25: return launch_cfg<64, 64, 1, 2>(*d, s);
+        case 26: return launch_wk<32, 64, 1, 2, 4>(*d, s);
+        case 27: return launch_wk<64, 64, 2, 2, 2>(*d, s);
+        case 28: return launch_wk<32, 64, 1, 2, 2>(*d, s);
+        case 29: return launch_wk<64, 64, 2, 2, 4>(*d, s);
+        case 30: return launch_wk<32, 32, 1, 1, 4>(*d, s);
+        case 31: return launch_wk<32, 128, 1, 4, 2>(*d, s);
     }
     return VFN_ERR_ARG;
 }

@@ -640,7 +640,11 @@ class Engine:
                     continue
                 blocks = ((d.M + bm - 1) // bm) * ((d.Cout + bn - 1) // bn)
                 options = [(c, 1, 0)]
-                if blocks < 256:
+                wk = ops.conv_cfg_wk(c)
+                if wk > 1:                                     # split-K inside the workgroup: f32, no second split,
+                    if bf or blocks > 1024 or d.KH * d.KW * d.Cin // 32 < 2 * wk:   # and only where tiles are scarce
+                        continue
+                elif blocks < 256:
                     options += [(c, k_, 0) for k_ in ops.valid_splits(d, 16, bf)[1:] if k_ * d.M * d.Cout <= WS_FLOATS]
                 else:
                     options += [(c, k_, full) for (full, k_, rows) in ops.tail_split_options(d, bm, bn, 8, bf)
