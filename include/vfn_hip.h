@@ -351,6 +351,23 @@ int vfn_png_sizes(int H, int W, int bpp, long long* work_bytes, long long* out_b
 int vfn_png_deflate_u8(const unsigned char* raw, int H, int W, int bpp, void* work, unsigned char* out, int* stats,
                        void* stream);
 
+/* ------------------------------------------------------------------ PNG frames on the input side
+ * Video_DS opens every frame with PIL (Water_DS.py:105-109 -> myutils/data.py:87-90: Image.open(p).convert('RGB')) and
+ * ToTensor divides by 255.  For PNG files a host core only inflates the IDAT stream (zlib); the scanline filters and
+ * the pixel conversion run on the device:
+ * vfn_png_unfilter_sizes  pitch (bytes per re-pitched row, a multiple of 4*bpp) and the bytes of `work` for an image.
+ * vfn_png_unfilter_u8     filtered: height x (1 + width*bpp) bytes as they come out of inflate (filter-type byte first);
+ *                         8-bit samples, bpp = 1..4 bytes per pixel, not interlaced, width <= 4096.  raw: height x pitch
+ *                         bytes.  *status (device int, zeroed by the caller) becomes 1 on a filter type outside 0..4.
+ * vfn_png_to_tensor_f32   colour type 0 grey / 2 RGB / 3 palette (palette: 256 x RGB bytes on the device) / 4 grey+alpha
+ *                         / 6 RGBA -> out float[3][H][W] = RGB / 255 exactly as PIL's convert('RGB') + ToTensor (grey
+ *                         replicated, alpha dropped), and out_u8 [H][W][3] unless NULL. */
+int vfn_png_unfilter_sizes(int width, int height, int bpp, int* pitch, long long* work_bytes);
+int vfn_png_unfilter_u8(const unsigned char* filtered, int width, int height, int bpp, void* work, unsigned char* raw,
+                        int* status, void* stream);
+int vfn_png_to_tensor_f32(const unsigned char* raw, int pitch, int width, int height, int color_type,
+                          const unsigned char* palette, float* out, unsigned char* out_u8, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -87,8 +87,8 @@ def test_device_decode_equals_pil_to_tensor(gpu, case):
 
 
 def test_video_ds_device_decode_items(tmp_path):
-    """Video_DS(decode='device'): JPEG frames come as entropy-decoded coefficients, PNG frames (and JPEG variants outside
-    the baseline subset) as uint8 images decoded by PIL."""
+    """Video_DS(decode='device'): JPEG frames come as entropy-decoded coefficients, PNG frames as inflated scanlines
+    (tests/test_png_decode.py), JPEG variants outside the baseline subset as uint8 images decoded by PIL."""
     import vfloodnet_amd  # noqa: F401
     from vfloodnet_amd.dataset import Video_DS
     from oracle import jpeg_ref
@@ -108,7 +108,11 @@ def test_video_ds_device_decode_items(tmp_path):
     assert np.array_equal(jpeg_ref.decode(coef.numpy(), qt.numpy().astype(np.uint16), info.numpy()),
                           np.array(Image.open(paths[1]).convert('RGB')))
     item, _ = ds[1]
-    assert set(item) == {'u8'} and np.array_equal(item['u8'].numpy(), np.array(Image.open(paths[2]).convert('RGB')))
+    from oracle import png_ref
+    assert set(item) == {'png'}
+    filtered, pinfo, pal = (t.numpy() for t in item['png'])
+    W, H, ctype, bpp = (int(v) for v in pinfo)
+    assert np.array_equal(png_ref.to_rgb(png_ref.unfilter(filtered, W, H, bpp), W, H, ctype, pal), np.array(Image.open(paths[2]).convert('RGB')))
     item, _ = ds[2]                                                          # progressive JPEG: PIL decodes it
     assert set(item) == {'u8'} and np.array_equal(item['u8'].numpy(), np.array(Image.open(paths[3]).convert('RGB')))
 

@@ -151,6 +151,9 @@ SIGNATURES = {
     'vfn_jpeg_to_tensor_f32': [_p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p, _p, _p],
     'vfn_png_sizes': [_i, _i, _i, C.POINTER(_ll), C.POINTER(_ll)],
     'vfn_png_deflate_u8': [_p, _i, _i, _i, _p, _p, _p, _p],
+    'vfn_png_unfilter_sizes': [_i, _i, _i, C.POINTER(_i), C.POINTER(_ll)],
+    'vfn_png_unfilter_u8': [_p, _i, _i, _i, _p, _p, _p, _p],
+    'vfn_png_to_tensor_f32': [_p, _i, _i, _i, _i, _p, _p, _p, _p],
 }
 # every symbol include/vfn_hip.h declares (checked by tests/test_abi.py)
 ALL_SYMBOLS = sorted(list(SIGNATURES) + [

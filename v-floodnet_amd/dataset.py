@@ -42,7 +42,9 @@ class Video_DS(data.Dataset):
     ``decode='device'``: baseline JPEG files are only entropy-decoded here (``jpeg_device.entropy_decode``, host C++,
     safe in worker processes); the item is a dict ``{'jpeg': (coef, qt, info)}`` and inverse DCT, chroma upsampling,
     colour conversion and ``ToTensor`` run on the GPU (``jpeg_device.to_tensor``) -- the same tensor, bit for bit.
-    PNG frames and JPEG variants outside the baseline subset (progressive, CMYK ...) are decoded by PIL as before and
+    8-bit non-interlaced PNG files are only inflated here (``png_decode.inflate``) and come as
+    ``{'png': (filtered scanlines, info, palette)}``; the scanline filters are undone on the GPU (``png_decode.to_tensor``).
+    Variants outside those subsets (progressive / CMYK JPEG, 16-bit or interlaced PNG ...) are decoded by PIL as before and
     come as ``{'u8': HWC uint8}``; use ``collate_fn=Video_DS.collate`` (batch size 1)."""
 
     def __init__(self, img_list, first_frame, first_mask, raw_u8=False, decode='pil'):
@@ -77,6 +79,16 @@ class Video_DS(data.Dataset):
                 try:
                     coef, qt, info = jpeg_device.entropy_decode(data_)
                     return {'jpeg': (torch.from_numpy(coef), torch.from_numpy(qt.astype(np.int16)), torch.from_numpy(info))}, img_name
+                except RuntimeError as e:
+                    if 'unsupported' not in str(e):
+                        raise
+            elif path.lower().endswith('.png'):
+                from . import png_decode
+                with open(path, 'rb') as f:
+                    data_ = f.read()
+                try:
+                    filtered, info, pal = png_decode.inflate(data_)
+                    return {'png': (torch.from_numpy(filtered), torch.from_numpy(info), torch.from_numpy(pal))}, img_name
                 except RuntimeError as e:
                     if 'unsupported' not in str(e):
                         raise

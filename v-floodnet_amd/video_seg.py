@@ -22,6 +22,7 @@ from . import ops
 from .data import AsyncWriter, color_palette, load_image_in_PIL, save_overlay, save_seg_mask
 from .png_device import PngSink
 from . import jpeg_device
+from . import png_decode
 from .dataset import Video_DS
 from .feature_bank import FeatureBank
 from .model import AFB_URR
@@ -249,7 +250,8 @@ def main(args, device):
 
     first_mask = load_image_in_PIL(mask_path, 'P')
     # JPEG frames: the workers undo the entropy coding only, the rest of the decode runs on the GPU (jpeg_device);
-    # PNG frames: PIL inflates them, ToTensor runs on the GPU.  Either way a frame crosses PCIe at ~1 byte per sample.
+    # PNG frames: the workers inflate them, the scanline filters are undone on the GPU (png_decode).  Either way a frame
+    # crosses PCIe at ~1 byte per sample.
     seq_dataset = Video_DS(img_list, first_frame, first_mask, decode=getattr(args, 'decode', 'device'), raw_u8=True)
     # (the reference uses one worker; the per-item hand-over costs more than the decode)
     n_load = int(getattr(args, 'load_workers', 4))
@@ -289,13 +291,18 @@ def main(args, device):
 
         # Uploads go through pinned staging buffers on their own stream: a pageable-memory ``.to(device)`` is ordered
         # behind everything already enqueued on the compute stream and blocks the host until it has run -- that would
-        # undo the launch / collect pipelining.  Three slots: frames t, t+1 (look-ahead) and the one being filled.
+        # undo the launch / collect pipelining.  The rest of the decode (JPEG: inverse DCT ..., PNG: the scanline
+        # filters, a serial recurrence that keeps ONE CU busy for ~0.8 ms per 480p frame) runs on a stream of its own, two
+        # frames ahead of the network, so that it sits underneath the kernels of the frames before it.
         copy_stream = torch.cuda.Stream(device=device)
+        decode_stream = torch.cuda.Stream(device=device)
+        main_stream = torch.cuda.current_stream()
         staging = {}
         slot = [0]
+        N_SLOTS = 5                              # frames t, t+1, t+2 in flight + the one being filled + one spare
 
         def to_device_async(t):
-            key = (tuple(t.shape), t.dtype, slot[0] % 3)
+            key = (tuple(t.shape), t.dtype, slot[0] % N_SLOTS)
             if key not in staging:
                 staging[key] = (torch.empty(t.shape, dtype=t.dtype).pin_memory(), torch.cuda.Event())
             pinned, free = staging[key]
@@ -309,21 +316,42 @@ def main(args, device):
             return d
 
         def upload(item):                        # the rest of Video_DS.__getitem__ (Water_DS.py:105-109) on the device
-            if item is None:
-                return None
             slot[0] += 1
             payload = item[0]
-            if isinstance(payload, dict) and 'jpeg' in payload:
-                coef, qt, info = payload['jpeg']
-                return jpeg_device.to_tensor(to_device_async(coef), to_device_async(qt), info, device).unsqueeze(0)
-            u8 = payload['u8'] if isinstance(payload, dict) else payload
-            return ops.to_tensor_device(to_device_async(u8)).unsqueeze(0)
+            with torch.cuda.stream(decode_stream):
+                if isinstance(payload, dict) and 'jpeg' in payload:
+                    coef, qt, info = payload['jpeg']
+                    t = jpeg_device.to_tensor(to_device_async(coef), to_device_async(qt), info, device).unsqueeze(0)
+                elif isinstance(payload, dict) and 'png' in payload:
+                    filtered, info, pal = payload['png']
+                    t = png_decode.to_tensor(to_device_async(filtered), info, to_device_async(pal), device).unsqueeze(0)
+                else:
+                    u8 = payload['u8'] if isinstance(payload, dict) else payload
+                    t = ops.to_tensor_device(to_device_async(u8)).unsqueeze(0)
+                ready = torch.cuda.Event()
+                ready.record()
+            t.record_stream(main_stream)         # allocated on the decode stream, consumed on the compute stream
+            return item, t, ready
 
-        cur = next(it, None)
-        cur_dev = upload(cur)
-        while cur is not None:
-            nxt = next(it, None)
-            nxt_dev = upload(nxt)
+        from collections import deque
+        ahead = deque()                          # (item, frame on the device, its decode-finished event)
+
+        def fill():
+            while len(ahead) < 3:
+                item = next(it, None)
+                if item is None:
+                    return
+                ahead.append(upload(item))
+
+        fill()
+        while ahead:
+            cur, cur_dev, cur_ready = ahead.popleft()
+            fill()                               # frame t+2 starts decoding now, a whole frame before it is needed
+            nxt_dev = None
+            main_stream.wait_event(cur_ready)
+            if ahead:
+                nxt_dev = ahead[0][1]
+                main_stream.wait_event(ahead[0][2])      # (its decode was enqueued one iteration ago)
             buf = runner.launch(cur_dev, next_frame=nxt_dev, want_label=False)   # postprocessing_pred (:116) runs on the GPU
             name = cur[1]
             buf['reader_done'] = sink.save(runner.label_device(), os.path.join(seg_dir, f'{name}.png'), color_palette,
@@ -331,7 +359,6 @@ def main(args, device):
                                            overlay_path=os.path.join(overlay_dir, f'{name}.png') if args.viz else None)
             if len(runner._pending) == 2:
                 runner.collect()                 # frame t-1: its bank statistics
-            cur, cur_dev = nxt, nxt_dev
         while runner._pending:
             runner.collect()
     writer.close()
