@@ -79,6 +79,9 @@ int vfn_conv_cfg_info(int cfg, int* bm, int* bn, int* wm, int* wn, int* dma);
  * that many copies of the wm x wn wave grid each take a slice of K of the same output tile and the partial sums are
  * added through LDS in group order (conv_igemm_wk_kernel<bm, bn, wm, wn, wk>); ksplit must be <= 1 with these.  0: no such cfg */
 int vfn_conv_cfg_wk(int cfg);
+/* K tiles a workgroup multiplies between two barriers: 1, or 2 (configurations with a 4-tile register prefetch and four
+ * LDS buffers, conv_igemm_wk_kernel<bm, bn, wm, wn, wk, 4, 2>; f32 only, ksplit <= 1).  0: no such cfg */
+int vfn_conv_cfg_tpb(int cfg);
 int vfn_conv2d_nhwc_f32(const vfn_conv_desc* d, int cfg, void* stream);
 /* Same convolution with both operands rounded to bf16 (nearest-even) as they are staged into LDS and multiplied
  * on v_mfma_f32_32x32x16_bf16 with f32 accumulation; tensors stay f32 in HBM.  Cin must be a multiple of 64;

@@ -31,7 +31,7 @@ for (N, H, W, Cin, Cout, k, s) in SHAPES:
     fl = 2.0 * d.M * Cout * k * k * Cin
     best = (1e9, None)
     for c, (bm, bn) in enumerate(tiles):
-        if ops.conv_cfg_wk(c) > 1 or d.cout_pad < ((Cout + bn - 1) // bn) * bn or (bn > 128 and Cout < 256): continue
+        if c >= 26 or d.cout_pad < ((Cout + bn - 1) // bn) * bn or (bn > 128 and Cout < 256): continue
         for ks in ops.valid_splits(d, 16):
             if ks * d.M * Cout > ws.numel(): continue
             ops.set_splitk(d, ks, ws if ks > 1 else None)
@@ -43,5 +43,5 @@ for (N, H, W, Cin, Cout, k, s) in SHAPES:
         bm, bn = tiles[c]
         if d.cout_pad < ((Cout + bn - 1) // bn) * bn: continue
         us = t(d, c)
-        line += f'  {bm}x{bn}/{ops.conv_cfg_wk(c)}: {us:5.1f}'
+        line += f'  {bm}x{bn}/{ops.conv_cfg_wk(c)}{"t" if ops.conv_cfg_tpb(c) > 1 else ""}: {us:5.1f}'
     print(line, flush=True)

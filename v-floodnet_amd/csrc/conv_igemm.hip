@@ -163,6 +163,12 @@ __device__ __forceinline__ bool wide_epilogue(const vfn_conv_desc& p, char* smem
     return true;
 }
 
+#ifdef VFN_CENSUS
+__device__ unsigned long long vfn_conv_census_buf[4096 * 8];
+#define CV_MARK(k) do { if (threadIdx.x == 0 && blockIdx.x < 4096) vfn_conv_census_buf[blockIdx.x * 8 + (k)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define CV_MARK(k)
+#endif
 // WK > 1: split-K INSIDE the workgroup.  The workgroup holds WK copies of the WM x WN wave grid ("K groups"); group g
 // stages and multiplies K tiles [g*kper, (g+1)*kper) of the same output tile in its own LDS buffers, the groups' partial
 // accumulators are summed through LDS in group order (bit-reproducible) and group 0 runs the epilogue.  For the layers
@@ -171,9 +177,15 @@ __device__ __forceinline__ bool wide_epilogue(const vfn_conv_desc& p, char* smem
 // PD: prefetch distance of the register staging in K tiles (f32 only).  A layer with about one workgroup per CU has
 // nothing else resident to cover a global load, and a 32x64 tile computes a K tile in 0.4 us: with PD = 1 every K tile
 // waits out its own load (measured 1.5 us per tile).  PD tiles are kept in flight in registers instead.
-template <int BM, int BN, int WM, int WN, int MODE, int WK, int PD = 1>
+// TPB: K tiles per workgroup barrier (f32 only; 2 * TPB LDS buffers).  A 32x64 or 64x64 tile gives a wave 16 MFMAs
+// (0.43 us) per K tile, and the LDS store -> barrier -> first fragment read chain behind every barrier costs about as
+// much (profiles/r02_census_conv_small_layers.txt); with TPB = 2 the waves run two tiles between barriers.
+template <int BM, int BN, int WM, int WN, int MODE, int WK, int PD = 1, int TPB = 1>
 __device__ __forceinline__ void conv_igemm_body(const vfn_conv_desc& p) {
     static_assert(PD == 1 || MODE == 0, "deep prefetch is implemented for the f32 path");
+    static_assert(TPB == 1 || (MODE == 0 && PD > TPB), "several tiles per barrier need the deep register prefetch");
+    constexpr int NBUF = 2 * TPB;          // LDS ring: the tiles being read and the tiles being staged
+    CV_MARK(0);
     constexpr int NT = WM * WN * 64;       // threads of one K group
     constexpr int TM = BM / WM / 32;
     constexpr int TN = BN / WN / 32;
@@ -192,9 +204,9 @@ __device__ __forceinline__ void conv_igemm_body(const vfn_conv_desc& p) {
 
     extern __shared__ __attribute__((aligned(16))) char smem_all[];
     const int grp = WK > 1 ? (int)threadIdx.x / NT : 0;  // K group (wave-uniform)
-    char* smem = smem_all + (size_t)grp * (2 * (BM + BN) * BK * sizeof(float));
-    float* sA = reinterpret_cast<float*>(smem);          // [2][BM][32]
-    float* sB = sA + 2 * BM * BK;                        // [2][BN][32]
+    char* smem = smem_all + (size_t)grp * (NBUF * (BM + BN) * BK * sizeof(float));
+    float* sA = reinterpret_cast<float*>(smem);          // [NBUF][BM][32]
+    float* sB = sA + NBUF * BM * BK;                     // [NBUF][BN][32]
 
     const int tid = WK > 1 ? (int)threadIdx.x % NT : (int)threadIdx.x;
     const int lane = tid & 63;
@@ -381,11 +393,11 @@ __device__ __forceinline__ void conv_igemm_body(const vfn_conv_desc& p) {
 #pragma unroll
     for (int d = 0; d < PD; ++d)
         if (d < nk) { load_a(d); load_b(kt_begin + d, d); }
-    if (nk > 0) {
-        store_a(0, 0);
-        store_b(0, 0);
-    }
+#pragma unroll
+    for (int d = 0; d < TPB; ++d)
+        if (d < nk) { store_a(d, d); store_b(d, d); }
     __syncthreads();
+    CV_MARK(1);
 
     // (unrolled by PD so that the staging slots are compile-time registers: tile kt lives in slot kt % PD)
     for (int kt0 = 0; kt0 < nk_loop; kt0 += PD) {
@@ -393,19 +405,21 @@ __device__ __forceinline__ void conv_igemm_body(const vfn_conv_desc& p) {
     for (int u = 0; u < PD; ++u) {
         const int kt = kt0 + u;
         if (kt >= nk_loop) break;
-        const int buf = kt & 1;
-        const bool more = kt + 1 < nk;                 // tile kt+1 goes to LDS during this tile
+        const int buf = kt % NBUF;
+        const int buf_st = (kt + TPB) % NBUF;          // where tile kt+TPB is staged during this tile
+        const bool more = kt + TPB < nk;               // tile kt+TPB goes to LDS during this tile
         const bool more_load = kt + PD < nk;           // tile kt+PD is requested during this tile
+        const bool sync = ((kt + 1) % TPB == 0) || kt + 1 >= nk_loop;
         const float* cA = sA + buf * BM * BK + (wm * TM * 32) * BK;
         const float* cB = sB + buf * BN * BK + (wn * TN * 32) * BK;
-        if (WK > 1 && kt >= nk) { __syncthreads(); continue; }     // (a K group with a shorter last slice)
+        if (WK > 1 && kt >= nk) { if (sync) __syncthreads(); continue; }     // (a K group with a shorter last slice)
         if constexpr (MODE == 2) {
             // two 16-channel steps per tile: hi chunk 2s+h and lo chunk 4+2s+h of every row; three MFMAs per tile pair
 #pragma unroll
             for (int st = 0; st < 2; ++st) {
                 if (more) {
                     if (st == 0) { load_a(0); load_b(kt_begin + kt + 1, 0); }
-                    else { store_a(buf ^ 1, 0); store_b(buf ^ 1, 0); }
+                    else { store_a(buf_st, 0); store_b(buf_st, 0); }
                 }
                 const int lc = 2 * st + lh;
                 bf16x8 ah[TM], al[TM], bh[TN], bl[TN];
@@ -453,8 +467,8 @@ __device__ __forceinline__ void conv_igemm_body(const vfn_conv_desc& p) {
         for (int kk = 0; kk < 4; ++kk) {
             if (kk == 0 && more_load) { load_a(u); load_b(kt_begin + kt + PD, u); }       // slot u: tile kt is in LDS already
             if (more) {
-                if (kk == 2) store_a(buf ^ 1, (u + 1) % PD);
-                if (kk == 3) store_b(buf ^ 1, (u + 1) % PD);
+                if (kk == 2) store_a(buf_st, (u + TPB) % PD);
+                if (kk == 3) store_b(buf_st, (u + TPB) % PD);
             }
             if (kk + 1 < 4) read_frags(kk + 1, fa[(kk + 1) & 1], fb[(kk + 1) & 1]);
             f32x4 (&a)[TM] = fa[kk & 1];
@@ -478,9 +492,13 @@ __device__ __forceinline__ void conv_igemm_body(const vfn_conv_desc& p) {
             }
         }
         }
-        __syncthreads();
+        if (sync) __syncthreads();
     }
     }
+    CV_MARK(2);
+#ifdef VFN_CENSUS
+    struct CvEnd { __device__ ~CvEnd() { __builtin_amdgcn_s_waitcnt(0); CV_MARK(3); } } cv_end_;       // after the last store has left
+#endif
 
     if constexpr (WK > 1) {
         // partial accumulators of groups 1.. -> LDS (one float per lane and register: conflict-free), summed by group 0
@@ -564,9 +582,9 @@ __global__ __launch_bounds__(WM * WN * 64)
 void conv_igemm_kernel(const vfn_conv_desc p) { conv_igemm_body<BM, BN, WM, WN, MODE, 1>(p); }
 
 // in-workgroup split-K (f32): WK K groups of WM x WN waves
-template <int BM, int BN, int WM, int WN, int WK, int PD>
+template <int BM, int BN, int WM, int WN, int WK, int PD, int TPB>
 __global__ __launch_bounds__(WM * WN * WK * 64)
-void conv_igemm_wk_kernel(const vfn_conv_desc p) { conv_igemm_body<BM, BN, WM, WN, 0, WK, PD>(p); }
+void conv_igemm_wk_kernel(const vfn_conv_desc p) { conv_igemm_body<BM, BN, WM, WN, 0, WK, PD, TPB>(p); }
 
 // 128 bytes of zeros: the LDS-DMA source of every filter tap that falls outside the image
 __device__ __attribute__((aligned(128))) float vfn_zero_page[32];
@@ -898,33 +916,39 @@ int launch_cfg(const vfn_conv_desc& p, hipStream_t s) {
     return vfn_check_launch();
 }
 
-template <int BM, int BN, int WM, int WN, int WK, int PD = 3>
+template <int BM, int BN, int WM, int WN, int WK, int PD = 3, int TPB = 1>
 int launch_wk(const vfn_conv_desc& p, hipStream_t s) {
     constexpr int NT = WM * WN * WK * 64;
-    constexpr size_t lds = (size_t)WK * 2 * (BM + BN) * BK * sizeof(float);
+    constexpr size_t lds = (size_t)WK * 2 * TPB * (BM + BN) * BK * sizeof(float);
     static_assert((size_t)(WK - 1) * BM * BN * sizeof(float) <= lds, "reduce buffer does not fit the staging LDS");
     static_assert(lds <= 160 * 1024 && NT <= 1024, "workgroup too large");
     static bool attr_set = false;
     if (!attr_set && lds > 64 * 1024) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_wk_kernel<BM, BN, WM, WN, WK, PD>),
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_wk_kernel<BM, BN, WM, WN, WK, PD, TPB>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = true;
     }
     if (p.ksplit > 1) return VFN_ERR_ARG;                  // one kind of split at a time
     const int tiles = cdiv(p.M, BM) * cdiv(p.Cout, BN);
-    hipLaunchKernelGGL((conv_igemm_wk_kernel<BM, BN, WM, WN, WK, PD>), dim3(tiles), dim3(NT), lds, s, p);
+    hipLaunchKernelGGL((conv_igemm_wk_kernel<BM, BN, WM, WN, WK, PD, TPB>), dim3(tiles), dim3(NT), lds, s, p);
     return vfn_check_launch();
 }
 
 }  // namespace
 
-extern "C" int vfn_conv_cfg_count(void) { return 32; }
+extern "C" int vfn_conv_cfg_count(void) { return 38; }
 
 // K groups per workgroup of a tile configuration (1 = none): configurations 26.. split K inside the workgroup
 extern "C" int vfn_conv_cfg_wk(int cfg) {
-    static const int wk[6] = {4, 2, 2, 4, 4, 2};
-    if (cfg < 0 || cfg >= 32) return 0;
+    static const int wk[12] = {4, 2, 2, 4, 4, 2, 2, 2, 1, 1, 1, 1};
+    if (cfg < 0 || cfg >= 38) return 0;
     return cfg < 26 ? 1 : wk[cfg - 26];
+}
+
+// K tiles between two workgroup barriers (1 for all but configurations 32..37, which run 2 with a 4-tile register prefetch)
+extern "C" int vfn_conv_cfg_tpb(int cfg) {
+    if (cfg < 0 || cfg >= 38) return 0;
+    return cfg < 32 ? 1 : 2;
 }
 
 extern "C" int vfn_conv_cfg_info(int cfg, int* bm, int* bn, int* wm, int* wn, int* dma) {
@@ -934,8 +958,9 @@ extern "C" int vfn_conv_cfg_info(int cfg, int* bm, int* bn, int* wm, int* wn, in
     // (must match the switch of vfn_conv2d_nhwc_f32 below)
     // 20..25 (f32 only): 32-row tiles for the 1/16-resolution layers (M = 1620: 51 x 32 rows instead of 26 x 64),
     // single-wave 32x32 tiles (most workgroups for the smallest layers), and 8-wave variants of 128x64 / 256x64
-    // 26..31 (f32 only): in-workgroup split-K (vfn_conv_cfg_wk K groups of the WM x WN waves; ksplit must be 1)
-    static const int t[32][5] = {{128, 128, 2, 2, 0}, {128, 64, 2, 2, 0}, {64, 128, 2, 2, 0}, {64, 64, 2, 2, 0}, {32, 64, 1, 2, 0},
+    // 26..37 (f32 only; ksplit must be 1): in-workgroup split-K (vfn_conv_cfg_wk K groups of the WM x WN waves) and,
+    // from 32 on, two K tiles per barrier (vfn_conv_cfg_tpb)
+    static const int t[38][5] = {{128, 128, 2, 2, 0}, {128, 64, 2, 2, 0}, {64, 128, 2, 2, 0}, {64, 64, 2, 2, 0}, {32, 64, 1, 2, 0},
                                  {64, 32, 2, 1, 0}, {128, 32, 4, 1, 0}, {256, 128, 4, 2, 0},
                                  {128, 128, 2, 4, 0}, {128, 128, 4, 2, 0}, {64, 128, 2, 4, 0},
                                  {128, 128, 2, 4, 2}, {64, 128, 2, 4, 2}, {64, 64, 2, 2, 2}, {256, 128, 4, 2, 2}, {128, 32, 4, 1, 2},
@@ -944,8 +969,10 @@ extern "C" int vfn_conv_cfg_info(int cfg, int* bm, int* bn, int* wm, int* wn, in
                                  {32, 128, 1, 4, 0}, {32, 32, 1, 1, 0}, {128, 64, 4, 2, 0}, {256, 64, 4, 2, 0}, {32, 64, 1, 1, 0},
                                  {64, 64, 1, 2, 0},
                                  {32, 64, 1, 2, 0}, {64, 64, 2, 2, 0}, {32, 64, 1, 2, 0}, {64, 64, 2, 2, 0}, {32, 32, 1, 1, 0},
+                                 {32, 128, 1, 4, 0},
+                                 {32, 64, 1, 2, 0}, {64, 64, 2, 2, 0}, {32, 64, 1, 2, 0}, {64, 64, 2, 2, 0}, {64, 128, 2, 4, 0},
                                  {32, 128, 1, 4, 0}};
-    if (cfg < 0 || cfg >= 32) return VFN_ERR_ARG;
+    if (cfg < 0 || cfg >= 38) return VFN_ERR_ARG;
     if (bm) *bm = t[cfg][0];
     if (bn) *bn = t[cfg][1];
     if (wm) *wm = t[cfg][2];
@@ -1012,6 +1039,12 @@ extern "C" int vfn_conv2d_nhwc_f32(const vfn_conv_desc* d, int cfg, void* stream
         case 29: return launch_wk<64, 64, 2, 2, 4>(*d, s);
         case 30: return launch_wk<32, 32, 1, 1, 4>(*d, s);
         case 31: return launch_wk<32, 128, 1, 4, 2>(*d, s);
+        case 32: return launch_wk<32, 64, 1, 2, 2, 4, 2>(*d, s);
+        case 33: return launch_wk<64, 64, 2, 2, 2, 4, 2>(*d, s);
+        case 34: return launch_wk<32, 64, 1, 2, 1, 4, 2>(*d, s);
+        case 35: return launch_wk<64, 64, 2, 2, 1, 4, 2>(*d, s);
+        case 36: return launch_wk<64, 128, 2, 4, 1, 4, 2>(*d, s);
+        case 37: return launch_wk<32, 128, 1, 4, 1, 4, 2>(*d, s);
     }
     return VFN_ERR_ARG;
 }
@@ -1082,3 +1115,9 @@ extern "C" int vfn_conv2d_nhwc_bf16x3(const vfn_conv_desc* d, int cfg, void* str
     }
     return VFN_ERR_ARG;
 }
+
+#ifdef VFN_CENSUS
+extern "C" int vfn_debug_conv_census(unsigned long long* host_out) {
+    return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(vfn_conv_census_buf), sizeof(unsigned long long) * 4096 * 8) == hipSuccess ? 0 : 1;
+}
+#endif

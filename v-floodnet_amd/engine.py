@@ -641,8 +641,8 @@ class Engine:
                 blocks = ((d.M + bm - 1) // bm) * ((d.Cout + bn - 1) // bn)
                 options = [(c, 1, 0)]
                 wk = ops.conv_cfg_wk(c)
-                if wk > 1:                                     # split-K inside the workgroup: f32, no second split,
-                    if bf or blocks > 1024 or d.KH * d.KW * d.Cin // 32 < 2 * wk:   # and only where tiles are scarce
+                if wk > 1 or ops.conv_cfg_tpb(c) > 1:          # split-K inside the workgroup / two tiles per barrier:
+                    if bf or blocks > 1024 or d.KH * d.KW * d.Cin // 32 < 2 * wk:   # f32, no second split, scarce tiles
                         continue
                 elif blocks < 256:
                     options += [(c, k_, 0) for k_ in ops.valid_splits(d, 16, bf)[1:] if k_ * d.M * d.Cout <= WS_FLOATS]

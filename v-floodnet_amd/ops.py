@@ -26,6 +26,11 @@ def conv_cfg_wk(cfg):
     return _lib.lib().vfn_conv_cfg_wk(int(cfg))
 
 
+def conv_cfg_tpb(cfg):
+    """K tiles per workgroup barrier of a tile configuration (vfn_conv_cfg_tpb)."""
+    return _lib.lib().vfn_conv_cfg_tpb(int(cfg))
+
+
 def conv_cfg_names(mode=0):
     """Kernel instantiation behind every tile configuration, as rocprofv3 prints it."""
     L = _lib.lib()
@@ -34,9 +39,9 @@ def conv_cfg_names(mode=0):
         v = [C.c_int() for _ in range(5)]
         L.vfn_conv_cfg_info(c, *[C.byref(x) for x in v])
         bm, bn, wm, wn, dma = [x.value for x in v]
-        wk = L.vfn_conv_cfg_wk(c)
+        wk, tpb = L.vfn_conv_cfg_wk(c), L.vfn_conv_cfg_tpb(c)
         out.append(f'conv_igemm_dma_kernel<{bm}, {bn}, {wm}, {wn}, {dma}>' if dma else
-                   f'conv_igemm_wk_kernel<{bm}, {bn}, {wm}, {wn}, {wk}, 3>' if wk > 1 else
+                   f'conv_igemm_wk_kernel<{bm}, {bn}, {wm}, {wn}, {wk}, {4 if tpb > 1 else 3}, {tpb}>' if (wk > 1 or tpb > 1) else
                    f'conv_igemm_kernel<{bm}, {bn}, {wm}, {wn}, {int(mode)}>')
     return out
 
