@@ -283,7 +283,8 @@ def main(argv=None):
         e0.record()
         rc = orig_apply(desc_ref, stream_)
         e1.record()
-        apply_records.append((cur_mem['entries'], cur_mem['HW'], e0, e1))
+        stored = bool(getattr(getattr(desc_ref, '_obj', None), 'scores', None))      # scores read back from the scan
+        apply_records.append((cur_mem['entries'], cur_mem['HW'], e0, e1, stored))
         return rc
     L_.vfn_memread_apply = timed_apply
 
@@ -406,11 +407,15 @@ def main(argv=None):
         for c, (fl, ms, n) in per.items():
             cands.append((names[c], fl, ms, n))
         if apply_records:
-            a_ms = sum(e0.elapsed_time(e1) for _, _, e0, e1 in apply_records)
-            a_fl = sum(1280.0 * b * hw for b, hw, _, _ in apply_records)     # (2*128 + 2*512) FLOP per (entry, query): scores + P^T V
+            a_ms = sum(r_[2].elapsed_time(r_[3]) for r_ in apply_records)
+            # (2*128 + 2*512) FLOP per (entry, query): scores + P^T V; with the scores read back from the statistics scan
+            # (f32 default) the kernel's own work is P^T V alone: 2*512
+            stored = all(r_[4] for r_ in apply_records)
+            a_fl = sum((1024.0 if r_[4] else 1280.0) * r_[0] * r_[1] for r_ in apply_records)
             # bf16x3 reads the bank's kept split-bf16 image (FeatureBank.lp_image) unless VFN_LP_IMAGE=0
             x3 = 'memread_apply_lpw_kernel<true>' if os.environ.get('VFN_LP_IMAGE', '1') == '0' else 'memread_apply_shw_kernel<true>'
-            kn = {'fp32': 'memread_apply_wide_kernel', 'bf16': 'memread_apply_lpw_kernel<false>', 'bf16x3': x3}[args.precision]
+            kn = {'fp32': 'memread_apply_ss_kernel' if stored else 'memread_apply_wide_kernel', 'bf16': 'memread_apply_lpw_kernel<false>',
+                  'bf16x3': x3}[args.precision]
             cands.append((kn, a_fl, a_ms, len(apply_records)))
         tot_fl = sum(v[0] for v in per.values())
         tot_ms = sum(v[1] for v in per.values())
@@ -433,7 +438,8 @@ def main(argv=None):
                                   f'FETCH doubled per MI355X_MICROARCH.md; not re-measured in this run)',
                 'launches_timed': n, 'avg_launch_us': round(ms * 1e3 / n, 2),
                 'share_of_instrumented_time': round(ms / all_ms, 4),
-                'algorithmic_flop': '2*M*Cout*K per conv launch; 1280 * bank entries * HW per memory-read apply launch (scores once + P^T V)',
+                'algorithmic_flop': '2*M*Cout*K per conv launch; memory-read apply launch: 1024 * bank entries * HW (P^T V; the scores come from the '
+                                    'statistics scan, memread_apply_ss_kernel) or 1280 * entries * HW where it recomputes them',
                 'timing': 'HIP events around every launch of frames that take no part in the side-stream overlap (kernel alone '
                           f'on the device); rocprofv3 counterpart: profiles/{PROFILE_ROUND}_kernel_stats_no_overlap.csv (--no-overlap run); '
                           f'profiles/{PROFILE_ROUND}_kernel_stats.csv is the default command, where overlapped launches run longer',
@@ -449,7 +455,9 @@ def main(argv=None):
     if mem_records:
         ms = sum(e0.elapsed_time(e1) for _, _, e0, e1 in mem_records)
         alg = sum(1280.0 * b * hw for b, hw, _, _ in mem_records)          # 2*(128+512) FLOP per (entry, query): scores once
-        done = sum(1536.0 * b * hw for b, hw, _, _ in mem_records)         # as executed: the scores are formed in both passes
+        # as executed: the scores are formed once (statistics scan) when the apply kernel reads them back, in both passes otherwise
+        twice = not (apply_records and all(r_[4] for r_ in apply_records))
+        done = sum((1536.0 if twice else 1280.0) * b * hw for b, hw, _, _ in mem_records)
         memread = {'kernels': 'bank_scan_kernel<0> + memread_apply kernel + finish', 'frames_timed': len(mem_records),
                    'ms_per_frame': round(ms / len(mem_records), 3),
                    'achieved_algorithmic': round(alg / (ms * 1e-3) / 1e12, 2), 'achieved_executed': round(done / (ms * 1e-3) / 1e12, 2),

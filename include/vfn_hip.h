@@ -27,7 +27,7 @@ extern "C" {
 /* ------------------------------------------------------------------ version
  * vfn_abi_version() == VFN_ABI_VERSION of the header the binding was written against, and
  * vfn_sizeof_desc(which) == sizeof of the binding's own struct: checked when the library is loaded. */
-#define VFN_ABI_VERSION 5
+#define VFN_ABI_VERSION 6
 enum { VFN_DESC_CONV = 0, VFN_DESC_STEM = 1, VFN_DESC_BANKSCAN = 2, VFN_DESC_MEMREAD = 3, VFN_DESC_BANK = 4 };
 int vfn_abi_version(void);
 int vfn_sizeof_desc(int which);
@@ -190,6 +190,13 @@ typedef struct vfn_bankscan_desc {
     const void* bank_k_lp; /* precision 1 / 2 only, optional: the keys' split-bf16 image kept by vfn_bank_refresh_lp
                               ([obj][cap][128 hi | 128 lo] bf16, object stride = stride_k * 4 bytes).  With it the
                               kernel reads MFMA operands directly; NULL: keys are split on the fly (same results) */
+    float* scores;         /* mode 0, optional: the raw scores <keys[b], q> are also WRITTEN here, so that vfn_memread_apply
+                              (same field) reads them back instead of multiplying keys and queries a second time.  Per
+                              object (stride_scores floats apart) one 32 KB tile per (64-entry chunk c, 128-query tile t) at
+                              tile index c * ceil(HW/128) + t, laid out [key half 2][row group 4][lane half 2][query 128][4]
+                              (= the MFMA accumulator layout, so both kernels move whole 512-byte runs).  Needs
+                              ceil(cap/64) * ceil(HW/128) * 8192 floats per object. */
+    long long stride_scores;
 } vfn_bankscan_desc;
 
 typedef struct vfn_memread_desc {
@@ -214,6 +221,10 @@ typedef struct vfn_memread_desc {
     const void* bank_k_lp; /* precision 1 / 2 with wide: the split-bf16 images of keys and values kept by         */
     const void* bank_v_lp; /* vfn_bank_refresh_lp (both or neither; same results as the on-the-fly split, without
                               the conversion work in the kernel): values [obj][cap][128 groups][4 hi | 4 lo] bf16 */
+    const float* scores;   /* precision 0 with wide, optional: the scores the mode-0 vfn_bank_scan of this frame stored
+                              (vfn_bankscan_desc.scores, same layout and stride).  The kernel then runs no score GEMM and
+                              touches neither q nor bank_k: bit-identical results (the scan forms the same sums). */
+    long long stride_scores;
 } vfn_memread_desc;
 
 int vfn_bank_scan(const vfn_bankscan_desc* d, void* stream);

@@ -45,6 +45,12 @@ for B in [int(x) for x in (sys.argv[1:] or ['56000'])]:
     d.work_counter = ptr(work)
     d.bank_k_lp = ptr(klp)
     d.ldq, d.q_per_obj, d.HW, d.obj_n, d.nsplit, d.mode, d.precision = DK + DV, 0, HW, K, nsplit_scan, 0, PREC
+    scores = None
+    if PREC == 0 and os.environ.get('SCORES', '1') != '0':
+        per_obj = ((cap + 63) // 64) * ((HW + 127) // 128) * 8192
+        if K * per_obj * 4 < 48 * 2 ** 30:
+            scores = torch.empty(K, per_obj, device=dev)
+            d.scores, d.stride_scores = ptr(scores), per_obj
     t_scan0 = timeit(lambda: check(L.vfn_bank_scan(C.byref(d), stream()), 'scan'))
     check(L.vfn_bank_scan_finish(ptr(ml_part), nsplit_scan, HW, K, 0, ptr(ml), None, None, None, stream()), 'fin')
     m = MemReadDesc()
@@ -55,6 +61,8 @@ for B in [int(x) for x in (sys.argv[1:] or ['56000'])]:
     m.scale, m.thres = scale, 1e-3
     m.ldq, m.ldqv, m.ld_out, m.HW, m.obj_n, m.nsplit, m.precision, m.wide = DK + DV, DK + DV, DV, HW, K, nsplit, PREC, int(os.environ.get('WIDE', 1))
     m.bank_k_lp, m.bank_v_lp = ptr(klp), ptr(vlp)
+    if scores is not None:
+        m.scores, m.stride_scores = ptr(scores), scores.shape[1]
     t_apply = timeit(lambda: check(L.vfn_memread_apply(C.byref(m), stream()), 'apply'))
     t_fin = timeit(lambda: check(L.vfn_memread_finish(C.byref(m), stream()), 'finish'))
     d1 = BankScanDesc()

@@ -565,3 +565,40 @@ def test_memory_read_through_split_image_is_bit_identical(gpu, sd, precision):
     assert out[0][3] and not out[1][3]
     assert torch.equal(out[0][0], out[1][0])
     assert torch.equal(out[0][1], out[1][1]) and torch.equal(out[0][2], out[1][2])
+
+
+def test_apply_from_stored_scores_is_bit_identical(gpu, sd):
+    """f32 memory read: the statistics scan stores the scores it forms and the apply kernel reads them back
+    (vfn_bankscan_desc.scores / vfn_memread_desc.scores) instead of multiplying keys and queries a second time.  Same
+    products, same order: logits and hit counts must equal the recomputing path (VFN_STORE_SCORES=0) bit for bit -- with a
+    ragged last chunk, a ragged last query tile and objects of different bank length."""
+    import os
+    from vfloodnet_amd import AFB_URR, FeatureBank
+    from tools import synth
+    model = AFB_URR(gpu, update_bank=True).to(gpu).eval()
+    model.load_state_dict(sd, strict=True)
+    H, W = 96, 272                                         # HW = 6 x 17 = 102: one ragged 128-query tile
+    hw = (H // 16) * (W // 16)
+    frames, m0 = synth.clip(5, 2, H, W)
+    out = []
+    for flag in ('1', '0'):
+        os.environ['VFN_STORE_SCORES'] = flag
+        os.environ['VFN_WIDE_APPLY'] = '1'
+        try:
+            g = torch.Generator().manual_seed(43)
+            fb = FeatureBank(2, 250000, gpu)
+            n = [64 * 29 + 17, 64 * 11 + 64]
+            keys = [torch.randn(128, max(n), generator=g) for _ in range(2)]
+            vals = [torch.randn(512, max(n), generator=g) for _ in range(2)]
+            fb.init_bank([k[:, :hw].to(gpu) for k in keys], [v[:, :hw].to(gpu) for v in vals])
+            fb.append([keys[i][:, hw:n[i]].to(gpu) for i in range(2)], [vals[i][:, hw:n[i]].to(gpu) for i in range(2)])
+            score, _ = model.segment(frames[1:2].to(gpu), fb)
+            plan = next(iter(model.engine()._plans.values())) if hasattr(model.engine(), '_plans') else None
+            out.append((score.clone(), fb.info[0].clone(), fb.info[1].clone()))
+        finally:
+            os.environ.pop('VFN_STORE_SCORES', None)
+            os.environ.pop('VFN_WIDE_APPLY', None)
+        model._invalidate()                                # fresh plan (and scores buffer) for the second pass
+    assert torch.isfinite(out[0][0]).all()
+    assert torch.equal(out[0][0], out[1][0])
+    assert torch.equal(out[0][1], out[1][1]) and torch.equal(out[0][2], out[1][2])

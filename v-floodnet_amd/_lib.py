@@ -40,7 +40,7 @@ class BankScanDesc(C.Structure):
                 ('stride_q', C.c_longlong), ('stride_k', C.c_longlong), ('stride_rs', C.c_longlong),
                 ('scale', C.c_float),
                 ('ldq', C.c_int), ('q_per_obj', C.c_int), ('HW', C.c_int), ('obj_n', C.c_int),
-                ('nsplit', C.c_int), ('mode', C.c_int), ('precision', C.c_int), ('work_counter', c_fp), ('bank_k_lp', c_fp)]
+                ('nsplit', C.c_int), ('mode', C.c_int), ('precision', C.c_int), ('work_counter', c_fp), ('bank_k_lp', c_fp), ('scores', c_fp), ('stride_scores', C.c_longlong)]
 
 
 class MemReadDesc(C.Structure):
@@ -50,7 +50,7 @@ class MemReadDesc(C.Structure):
                 ('stride_info', C.c_longlong),
                 ('scale', C.c_float), ('thres', C.c_float),
                 ('ldq', C.c_int), ('ldqv', C.c_int), ('ld_out', C.c_int), ('HW', C.c_int), ('obj_n', C.c_int),
-                ('nsplit', C.c_int), ('precision', C.c_int), ('wide', C.c_int), ('bank_k_lp', c_fp), ('bank_v_lp', c_fp)]
+                ('nsplit', C.c_int), ('precision', C.c_int), ('wide', C.c_int), ('bank_k_lp', c_fp), ('bank_v_lp', c_fp), ('scores', c_fp), ('stride_scores', C.c_longlong)]
 
 
 class BankDesc(C.Structure):
@@ -67,7 +67,7 @@ class BankDesc(C.Structure):
                 ('obj_n', C.c_int), ('cap', C.c_int), ('rm_class', C.c_int), ('rm_request', C.c_int)]
 
 
-ABI_VERSION = 5          # include/vfn_hip.h VFN_ABI_VERSION; csrc/abi.hip
+ABI_VERSION = 6          # include/vfn_hip.h VFN_ABI_VERSION; csrc/abi.hip
 DESC_IDS = {0: ConvDesc, 1: StemDesc, 2: BankScanDesc, 3: MemReadDesc, 4: BankDesc}     # vfn_sizeof_desc(which)
 
 

@@ -313,6 +313,19 @@ void bank_scan_kernel(const vfn_bankscan_desc p) {
                 }
             }
         }
+        if (MODE == 0 && p.scores) {
+            // the raw scores of this (chunk, query tile), in accumulator order: [key half i][row group g][lane half][query][4
+            // rows] -- each store instruction of a wave writes two 512-byte runs; the apply kernel reads them back the
+            // same way instead of repeating the GEMM
+            float* tile = p.scores + (size_t)obj * p.stride_scores + ((size_t)c * qtiles + qt) * (CH * QTS);
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const f32x4 v = {acc[i][4 * g], acc[i][4 * g + 1], acc[i][4 * g + 2], acc[i][4 * g + 3]};
+                    __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(tile + ((((i * 4 + g) * 2 + lh) * QTS) + wave * 32 + li) * 4));
+                }
+        }
 #ifdef VFN_ABLATE_SOFTMAX
         if (true) { run_m = fmaxf(run_m, acc[0][0] + acc[1][5]); } else
 #endif
@@ -1292,6 +1305,157 @@ void memread_apply_wide_kernel(const vfn_memread_desc p) {
         }
 }
 
+// ------------------------------------------------------------------ pass 2 (f32), wide tile, scores from the scan
+// The statistics scan has already formed every score <key, query> of the frame; with vfn_bankscan_desc.scores it also
+// stores them (HW x B floats per object: 363 MB at the C2 mean bank, written once and read once -- the bytes the key
+// chunks cost before).  This kernel then has no score GEMM, no query image and no key chunks: it loads the 16 scores of
+// its 32 x 32 tile position (a chunk ahead), runs the softmax, and goes on as memread_apply_wide_kernel.  The scan sums
+// the same products in the same order, so O^T and the hit counts are bit-identical to the recomputing kernel; the frame
+// executes F_min's 1280 B HW FLOP per object for the memory read instead of 1536.
+// LDS: two P^T buffers [128 q][64 b], 64 KB.
+__global__ __launch_bounds__(512, 1)
+void memread_apply_ss_kernel(const vfn_memread_desc p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* sP = reinterpret_cast<float*>(smem);      // [128 q][64 b]  (P^T)
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 31, lh = lane >> 5;
+    const int wr = wave >> 2, wq = wave & 3;
+    const int split = blockIdx.x % p.nsplit;
+    const int qt = blockIdx.x / p.nsplit;
+    const int obj = blockIdx.y;
+    const int q0 = qt * QTW;
+    const int qtiles = (p.HW + QTW - 1) / QTW;
+    const int B = p.bank_len[obj];
+    const float* V = p.bank_v + (size_t)obj * p.stride_v;
+    const float* S = p.scores + (size_t)obj * p.stride_scores;
+
+    int c_lo, c_hi;
+    chunk_range(B, p.nsplit, split, c_lo, c_hi);
+
+    f32x16 o[4][2];                                  // O^T tiles: [query tile][channel tile]
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[a][b][r] = 0.f;
+
+    const float* vcol = V + wave * 64 + li * 2;      // + row*512; lane li owns channels 2*li, 2*li+1 (tile tc)
+    const unsigned vlane_off = (unsigned)((4 * lh) * DV + wave * 64 + li * 2) * 4u;   // bytes, per lane
+    // this lane's 16 scores of a chunk: key rows 32wr + (r&3) + 8(r>>2) + 4lh, query column 32wq + li
+    const unsigned slane_off = (unsigned)(((wr * 4) * 2 + lh) * QTW + wq * 32 + li) * 16u;      // bytes; + g * 2 * QTW * 16
+    f32x4 sv[4];
+    auto load_scores = [&](int c) {
+        const char* tile = reinterpret_cast<const char*>(S + ((size_t)c * qtiles + qt) * (CH * QTW));
+#pragma unroll
+        for (int g = 0; g < 4; ++g) sv[g] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(tile + slane_off + g * (2 * QTW * 16)));
+    };
+    const int qcol = wq * 32 + li;
+    const bool qok = (q0 + qcol) < p.HW;
+    float qm = 1e30f, qinv = 0.f;
+    if (qok) {
+        qm = p.ml[((size_t)obj * p.HW + q0 + qcol) * 2];
+        qinv = 1.f / p.ml[((size_t)obj * p.HW + q0 + qcol) * 2 + 1];
+    }
+    const int rloc = wr * 32 + 4 * lh;
+    // softmax of chunk c from the loaded scores -> P^T buffer `buf`, hit counts
+    auto softmax_to = [&](int c, float* sPb) {
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = sv[r >> 2][r & 3];
+        const int b0 = c * CH;
+        const int mycnt = softmax_hits(acc, p.scale, qm, qinv, p.thres, B - b0, rloc);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int brow = rloc + 8 * g;
+            const f32x4 v = {acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]};
+            *reinterpret_cast<f32x4*>(sPb + swz64(qcol, brow >> 2)) = v;
+        }
+        if (p.cnt && lh == 0 && mycnt > 0) {
+            const int row = b0 + wr * 32 + li;
+            if (row < B) atomicAdd(p.cnt + (size_t)obj * p.stride_cnt + row, mycnt);
+        }
+    };
+
+    if (c_lo < c_hi) {
+        load_scores(c_lo);
+        softmax_to(c_lo, sP);
+        if (c_lo + 1 < c_hi) load_scores(c_lo + 1);
+    }
+    __syncthreads();                                 // P^T of the first chunk visible
+
+    // P^T is double-buffered: the softmax of chunk c+1 is issued in the middle of chunk c's P^T V loop (plain VALU work on
+    // registers -- the scores were loaded a chunk ahead -- that runs under the queued MFMAs) and written to the other
+    // buffer, so a chunk costs ONE barrier and the matrix pipe does not idle through the softmax
+    for (int c = c_lo; c < c_hi; ++c) {
+        const int b0 = c * CH;
+        const int buf = (c - c_lo) & 1;
+        const float* sPc = sP + buf * (QTW * CH);
+        float* sPn = sP + (buf ^ 1) * (QTW * CH);
+        const bool nxt = c + 1 < c_hi;
+
+        f32x2 vb[3][4];                              // ring: value rows two k-groups ahead of their MFMAs
+        const bool full = b0 + CH <= B;
+        const __amdgpu_buffer_rsrc_t vrsrc = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<float*>(V + (size_t)b0 * DV), 0, CH * DV * 4, 0x00020000);
+        auto load_v = [&](int kk, int slot) {
+            if (full) {
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+#ifdef VFN_ABLATE_V
+                    vb[slot][t] = f32x2{1.f * kk + lane, 2.f * t};
+#else
+                    vb[slot][t] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(vrsrc, vlane_off, (8 * kk + t) * DV * 4, 0));
+#endif
+            } else {
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const int rr = min(b0 + 8 * kk + 4 * lh + t, B - 1);  // past the end: P is exactly 0 there
+                    vb[slot][t] = *reinterpret_cast<const f32x2*>(vcol + (size_t)rr * DV);
+                }
+            }
+        };
+        load_v(0, 0);
+        load_v(1, 1);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int kk = 0; kk < CH / 8; ++kk) {
+            const int cur = kk % 3;
+            if (kk + 2 < CH / 8) load_v(kk + 2, (kk + 2) % 3);
+            __builtin_amdgcn_sched_barrier(0);
+            const int lc = 2 * kk + lh;
+            f32x4 a[4];
+#pragma unroll
+            for (int tq = 0; tq < 4; ++tq) a[tq] = *reinterpret_cast<const f32x4*>(sPc + swz64(tq * 32 + li, lc));
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int tq = 0; tq < 4; ++tq) {
+                    o[tq][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[tq][t], vb[cur][t][0], o[tq][0], 0, 0, 0);
+                    o[tq][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[tq][t], vb[cur][t][1], o[tq][1], 0, 0, 0);
+                }
+            if (kk == 2 && nxt) {
+                softmax_to(c + 1, sPn);
+                if (c + 2 < c_hi) load_scores(c + 2);
+            }
+        }
+        __syncthreads();                             // P^T of chunk c+1 visible; everyone is done with this buffer
+    }
+
+    float* dst = p.o_part + ((size_t)obj * p.nsplit + split) * p.HW * DV;
+#pragma unroll
+    for (int tq = 0; tq < 4; ++tq)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int q = q0 + tq * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+            if (q < p.HW) {
+                const f32x2 v = {o[tq][0][r], o[tq][1][r]};
+                *reinterpret_cast<f32x2*>(dst + (size_t)q * DV + wave * 64 + li * 2) = v;
+            }
+        }
+}
+
 // out[obj][q][0:512] = sum_split o_part ; out[obj][q][512:1024] = query value; then the hit-count bump
 __global__ void memread_finish_kernel(const vfn_memread_desc p) {
     const int obj = blockIdx.y;
@@ -1388,7 +1552,8 @@ extern "C" int vfn_memread_apply(const vfn_memread_desc* d, void* stream) {
         constexpr size_t LDS_WF = (size_t)(QTW * DK + CH * DK + QTW * CH) * sizeof(float);       // 128 KB
         if (!once_f) { allow_lds(memread_apply_wide_kernel, LDS_WF); once_f = true; }
         const dim3 gridw(cdiv(d->HW, QTW) * d->nsplit, d->obj_n);
-        hipLaunchKernelGGL(memread_apply_wide_kernel, gridw, dim3(512), LDS_WF, (hipStream_t)stream, *d);
+        if (d->scores) hipLaunchKernelGGL(memread_apply_ss_kernel, gridw, dim3(512), (size_t)2 * QTW * CH * sizeof(float), (hipStream_t)stream, *d);
+        else hipLaunchKernelGGL(memread_apply_wide_kernel, gridw, dim3(512), LDS_WF, (hipStream_t)stream, *d);
         return vfn_check_launch();
     }
     if (d->precision != 0 && d->wide) {

@@ -102,6 +102,23 @@ def apply_choice(desc, choice, ws, counters=None):
     return cfg
 
 
+def _scores_buffer(p, fb):
+    """[obj][ceil(cap/64) * ceil(HW/128) * 8192] floats for the scores of one frame, or None when switched off / too large
+    / the 64-query apply kernels are selected."""
+    if os.environ.get('VFN_STORE_SCORES', '1') == '0' or os.environ.get('VFN_WIDE_APPLY') == '0':
+        return None
+    if fb.len_upper() < WIDE_APPLY_FROM:
+        return None
+    per_obj = ((fb._cap + 63) // 64) * ((p.HW + 127) // 128) * 8192
+    if fb.obj_n * per_obj * 4 > float(os.environ.get('VFN_SCORES_MAX_GB', 48)) * 2 ** 30:
+        return None
+    key = (fb.obj_n, per_obj)
+    if getattr(p, '_scores_key', None) != key:
+        p._scores = torch.empty(fb.obj_n, per_obj, device=p.kv_q.device)
+        p._scores_key = key
+    return p._scores
+
+
 def choose_cfg(M, cout, K, mode=0):
     """(tile config, split-K factor, first split tile): the measured table if the shape is in it, otherwise
     minimise (rounds over 256 CUs) x (tile work / efficiency), cutting K when there are too few tiles."""
@@ -570,6 +587,12 @@ class Engine:
         d.work_counter = ptr(p.work)
         klp, vlp = fb.lp_image() if self.mode else (None, None)      # the bank's kept split-bf16 image (reduced precision)
         d.bank_k_lp = ptr(klp) if klp is not None else None
+        # f32: the scan stores the scores it forms and the apply kernel reads them back instead of repeating the
+        # keys x queries GEMM (bit-identical; HW x capacity floats per object, VFN_STORE_SCORES=0 or more than
+        # VFN_SCORES_MAX_GB switch it off)
+        scores = _scores_buffer(p, fb) if self.mode == 0 else None
+        if scores is not None:
+            d.scores, d.stride_scores = ptr(scores), scores.shape[1]
         check(L.vfn_bank_scan(_lib.C.byref(d), s), 'vfn_bank_scan')
         check(L.vfn_bank_scan_finish(ptr(p.ml_part), nsplit_scan, HW, K, 0, ptr(p.ml), None, None, None, s),
               'vfn_bank_scan_finish')
@@ -592,6 +615,8 @@ class Engine:
             m.nsplit = pick_nsplit(HW, K, fb.len_upper(), QT_SCAN, MAX_SPLIT)
         if m.wide and klp is not None:
             m.bank_k_lp, m.bank_v_lp = ptr(klp), ptr(vlp)
+        if m.wide and scores is not None:
+            m.scores, m.stride_scores = ptr(scores), scores.shape[1]
         check(L.vfn_memread_apply(_lib.C.byref(m), s), 'vfn_memread_apply')
         check(L.vfn_memread_finish(_lib.C.byref(m), s), 'vfn_memread_finish')
 
