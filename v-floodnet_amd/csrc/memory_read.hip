@@ -6,25 +6,26 @@
 //        info[:,1] += log( sum_hw [p > 1e-3] + 1 )                 (update_bank side effect, :161-174)
 //     The reference materialises p (648 MB at B = 100k) and makes >= 7 elementwise passes over it,
 //     with an out-of-memory -> CPU fallback (:147-157).  Here p is never stored:
-//        pass 1  vfn_memread_stats   per query column: running max m and sum l over the bank
-//        pass 2  vfn_memread_apply   recompute the scores, p = exp(s-m)/l in registers,
-//                                    hit counts by wave ballots, O^T += P^T V on the MFMA
+//        pass 1  vfn_bank_scan (mode 0) + _finish   per query column: running max m and sum l over the bank;
+//                                    f32: the raw scores are also stored (score tiles, one write and one read per frame)
+//        pass 2  vfn_memread_apply   scores read back (f32, memread_apply_ss_kernel) or recomputed (reduced precision,
+//                                    or no score buffer), p = exp(s-m)/l in registers, hit counts by wave ballots,
+//                                    O^T += P^T V on the MFMA
 //        finish  vfn_memread_finish  reduce the bank-split partial O, write it (and the query
 //                                    value) into the decoder input, apply the log(count+1) bump
 //
 // (2) Bank match -- FeatureBank.update, FeatureBank.py:63-68:
 //        corr = normalize(keys)^T normalize(new_keys); argmax over the bank per new feature
-//     Same GEMM with an arg-max epilogue (corr is never stored): vfn_bank_match + vfn_bank_match_finish.
+//     Same GEMM with an arg-max epilogue (corr is never stored): vfn_bank_scan (mode 1) + vfn_bank_scan_finish.
 //
-// Layout: bank entry-major K [cap][128], V [cap][512]; queries / new keys [HW][ld].
-// Tiling: one workgroup = 64 query columns x one slice of the bank, walked in chunks of
-// 64 entries; 4 waves.  Score GEMM (A = bank rows, B = queries): wave (wr, wq) owns chunk
-// rows 32wr.. x query columns 32wq...  P^T V (A = P^T read back from LDS, B = value rows
-// straight from global memory, prefetched one k-group ahead): wave w owns value channels
-// 128w..128w+127 for all 64 queries.  The next chunk's keys are fetched into registers
-// before the score GEMM and written to LDS behind it, so no load sits on the critical path.
-// 64-80 KB of LDS -> two workgroups per CU (two waves per SIMD cover each other's barriers).
-// Blocks of one bank slice share blockIdx % 8, i.e. one XCD's L2 (speed only).
+// Layout: bank entry-major K [cap][128], V [cap][512]; queries / new keys [HW][ld]; reduced precision: the bank's
+// split-bf16 image beside it (vfn_bank_refresh_lp).
+// Tiling: the bank is walked in chunks of 64 entries.  Scans: persistent workgroups (two per CU) draw (bank slice, 128-query
+// tile, object) items from a queue; a wave owns 32 query columns against all 64 rows of a chunk, key chunks arrive by
+// LDS-DMA, double-buffered.  Apply: one workgroup = 128 query columns x one slice of the bank, 8 waves; P^T goes through
+// LDS, wave w owns value channels 64w..64w+63 of all 128 queries and reads its value rows straight from global memory
+// (buffer loads, two k-groups ahead).  The 64-query kernels (memread_apply_kernel, _lp_kernel) are the first generation,
+// kept behind desc.wide = 0.
 #include "common.h"
 #include "../../include/vfn_hip.h"
 
