@@ -343,22 +343,35 @@ def main(args, device):
                     return
                 ahead.append(upload(item))
 
+        prof = [0.0, 0.0, 0.0, 0.0, 0] if os.environ.get('VFN_MAIN_TIMING') else None   # host seconds: fill, launch, save, collect
         fill()
         while ahead:
+            t0 = time.perf_counter()
             cur, cur_dev, cur_ready = ahead.popleft()
             fill()                               # frame t+2 starts decoding now, a whole frame before it is needed
+            t1 = time.perf_counter()
             nxt_dev = None
             main_stream.wait_event(cur_ready)
             if ahead:
                 nxt_dev = ahead[0][1]
                 main_stream.wait_event(ahead[0][2])      # (its decode was enqueued one iteration ago)
             buf = runner.launch(cur_dev, next_frame=nxt_dev, want_label=False)   # postprocessing_pred (:116) runs on the GPU
+            t2 = time.perf_counter()
             name = cur[1]
             buf['reader_done'] = sink.save(runner.label_device(), os.path.join(seg_dir, f'{name}.png'), color_palette,
                                            frame=cur_dev[0] if args.viz else None,
                                            overlay_path=os.path.join(overlay_dir, f'{name}.png') if args.viz else None)
+            t3 = time.perf_counter()
             if len(runner._pending) == 2:
                 runner.collect()                 # frame t-1: its bank statistics
+            if prof is not None:
+                t4 = time.perf_counter()
+                for i_, d_ in enumerate((t1 - t0, t2 - t1, t3 - t2, t4 - t3)):
+                    prof[i_] += d_
+                prof[4] += 1
+        if prof is not None and prof[4]:
+            print('main loop host time per frame: next()+upload %.2f ms, launch %.2f ms, png sink %.2f ms, collect (waits for frame t-1) %.2f ms'
+                  % tuple(1e3 * v / prof[4] for v in prof[:4]))
         while runner._pending:
             runner.collect()
     writer.close()
