@@ -1,4 +1,4 @@
-"""Debug: where a small conv layer's microseconds go (needs a -DVFN_CENSUS build: VFN_LIB_PATH=.../libvfn_census.so).
+"""Debug: where a small conv layer's microseconds go (needs the census build: make -C v-floodnet_amd/csrc census; VFN_LIB_PATH=.../libvfn_census.so).
 Per workgroup, 100 MHz timestamps at kernel entry, after the first K tile is staged, after the K loop, after the last
 store has left.  usage: census_conv.py N,H,W,Cin,Cout,k cfg [ksplit]"""
 import sys, os, ctypes
