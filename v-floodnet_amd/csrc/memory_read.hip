@@ -1419,22 +1419,26 @@ void memread_apply_ss_kernel(const vfn_memread_desc p) {
         };
         load_v(0, 0);
         load_v(1, 1);
+        f32x4 a[2][4];                               // P^T fragments, one k-group ahead of their MFMAs
+#pragma unroll
+        for (int tq = 0; tq < 4; ++tq) a[0][tq] = *reinterpret_cast<const f32x4*>(sPc + swz64(tq * 32 + li, lh));
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int kk = 0; kk < CH / 8; ++kk) {
             const int cur = kk % 3;
             if (kk + 2 < CH / 8) load_v(kk + 2, (kk + 2) % 3);
-            __builtin_amdgcn_sched_barrier(0);
-            const int lc = 2 * kk + lh;
-            f32x4 a[4];
+            if (kk + 1 < CH / 8) {
 #pragma unroll
-            for (int tq = 0; tq < 4; ++tq) a[tq] = *reinterpret_cast<const f32x4*>(sPc + swz64(tq * 32 + li, lc));
+                for (int tq = 0; tq < 4; ++tq)
+                    a[(kk + 1) & 1][tq] = *reinterpret_cast<const f32x4*>(sPc + swz64(tq * 32 + li, 2 * (kk + 1) + lh));
+            }
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int t = 0; t < 4; ++t)
 #pragma unroll
                 for (int tq = 0; tq < 4; ++tq) {
-                    o[tq][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[tq][t], vb[cur][t][0], o[tq][0], 0, 0, 0);
-                    o[tq][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[tq][t], vb[cur][t][1], o[tq][1], 0, 0, 0);
+                    o[tq][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[kk & 1][tq][t], vb[cur][t][0], o[tq][0], 0, 0, 0);
+                    o[tq][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[kk & 1][tq][t], vb[cur][t][1], o[tq][1], 0, 0, 0);
                 }
             if (kk == 2 && nxt) {
                 softmax_to(c + 1, sPn);
