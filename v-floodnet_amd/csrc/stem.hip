@@ -33,7 +33,7 @@ void stem_kernel(const vfn_stem_desc p) {
     constexpr int KP = CIN * 7 * 8;       // padded K
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* sW = reinterpret_cast<float*>(smem);        // [KP][64]
-    float* sP = sW + KP * 64;                          // [CIN][PH][2][PP]
+    float* sP = sW + KP * 64;                          // [3][PH][2][PP]: the frame planes, then (same space) an object's 2 mask planes
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
@@ -72,7 +72,7 @@ void stem_kernel(const vfn_stem_desc p) {
                     v = (c == 3) ? m : fminf(fmaxf(1.f - m, 0.f), 1.f);
                 }
             }
-            sP[(c * PH + y) * PROW + (x & 1) * PP + (x >> 1)] = v;
+            sP[((c < 3 ? c : c - 3) * PH + y) * PROW + (x & 1) * PP + (x >> 1)] = v;
         }
     };
     load_planes(0, 3, 0);
@@ -86,17 +86,29 @@ void stem_kernel(const vfn_stem_desc p) {
     f32x16 accF0, accF1;
 #pragma unroll
     for (int r = 0; r < 16; ++r) { accF0[r] = 0.f; accF1[r] = 0.f; }
+    // One filter row (kh) = 4 k-steps = 8 MFMAs.  Its 12 operand words are read a whole row ahead of the MFMAs that use
+    // them: left to itself hipcc reads each step's two filter words into the same registers right in front of its two
+    // MFMAs -- every 128 cycles of matrix work then waited out an LDS round trip (mfma_util 0.27).
     auto mac_planes = [&](f32x16& a0, f32x16& a1, int c) {
-#pragma unroll
-        for (int kh = 0; kh < 7; ++kh) {
+        float av[2][4], b0v[2][4], b1v[2][4];
+        auto fetch = [&](int kh, int slot) {
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const int s = (c * 7 + kh) * 4 + q;          // k-step: k = 2s + lh
-                const float a = pa[(c * PH + kh) * PROW + q];
-                const float b0 = pb[(2 * s) * 64];
-                const float b1 = pb[(2 * s) * 64 + 32];
-                a0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b0, a0, 0, 0, 0);
-                a1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b1, a1, 0, 0, 0);
+                av[slot][q] = pa[((c < 3 ? c : c - 3) * PH + kh) * PROW + q];
+                b0v[slot][q] = pb[(2 * s) * 64];
+                b1v[slot][q] = pb[(2 * s) * 64 + 32];
+            }
+        };
+        fetch(0, 0);
+#pragma unroll
+        for (int kh = 0; kh < 7; ++kh) {
+            if (kh + 1 < 7) fetch(kh + 1, (kh + 1) & 1);
+            __builtin_amdgcn_sched_barrier(0);               // keep the next row's reads in front of this row's MFMAs
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                a0 = __builtin_amdgcn_mfma_f32_32x32x2f32(av[kh & 1][q], b0v[kh & 1][q], a0, 0, 0, 0);
+                a1 = __builtin_amdgcn_mfma_f32_32x32x2f32(av[kh & 1][q], b1v[kh & 1][q], a1, 0, 0, 0);
             }
         }
     };
@@ -173,8 +185,11 @@ __global__ void maxpool3x3s2_kernel(const float* __restrict__ in, float* __restr
 template <int CIN>
 int launch_stem(const vfn_stem_desc& d, hipStream_t s) {
     constexpr int KP = CIN * 7 * 8;
-    const size_t lds = (size_t)(KP * 64 + CIN * PH * PROW) * sizeof(float);
+    // filters + 3 patch planes (the mask planes reuse the frame planes' space): 81 760 B for CIN = 5 -- two workgroups per
+    // CU, so that one's load / epilogue phases run under the other's MFMAs (with 5 patch planes it was one per CU)
+    const size_t lds = (size_t)(KP * 64 + 3 * PH * PROW) * sizeof(float);
     static bool attr_set = false;
+    static_assert(PH * PROW * 3 * 4 + 5 * 7 * 8 * 64 * 4 <= 81920, "two stem workgroups must fit one CU's LDS");
     if (!attr_set && lds > 64 * 1024) {
         hipFuncSetAttribute(reinterpret_cast<const void*>(&stem_kernel<CIN>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
