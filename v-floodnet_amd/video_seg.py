@@ -374,6 +374,8 @@ def main(args, device):
                   % tuple(1e3 * v / prof[4] for v in prof[:4]))
         while runner._pending:
             runner.collect()
+        if not png_decode.check_status(device):          # a filter-type byte outside 0..4 in some PNG frame (PIL raises there too)
+            raise RuntimeError('corrupt PNG frame data (invalid scanline filter type) in ' + args.test_path)
     writer.close()
 
     runner.fb.print_peak_mem()
