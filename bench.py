@@ -31,8 +31,6 @@ Prints ONE JSON line (rank 0) with the driver's contract fields plus
 import argparse
 import json
 import os
-import socket
-import subprocess
 import sys
 import time
 
@@ -104,6 +102,9 @@ def parse_args(argv=None):
     ap.add_argument('--min-warm-s', type=float, default=1.0,
                     help='keep repeating the warm-up steps until the device has been busy this long (clock ramp after the '
                          'CPU-only weight synthesis); 0 = exactly --warmup steps')
+    ap.add_argument('--min-timed-s', type=float, default=2.0,
+                    help='after the clip, keep cycling through its frames (untimed for `value`) until the GPU has run the loop '
+                         'for this long in total; reported as `sustained` (bank at its budget: the eviction regime). 0 = off')
     ap.add_argument('--budget', type=int, default=250000)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-frames', type=int, default=10, help='frames of the CPU baseline sample (after a 2-frame warm-up)')
@@ -131,38 +132,15 @@ def parse_args(argv=None):
 
 
 # ------------------------------------------------------------------------------------------------ launch
-def _free_port():
-    s = socket.socket()
-    s.bind(('127.0.0.1', 0))
-    p = s.getsockname()[1]
-    s.close()
-    return p
-
-
 def self_launch(args, argv):
     """``python bench.py --gpus N`` without torchrun: start N ranks as *child processes* (this parent never touches
     the GPU: no exec of an initialised process, see the harness notes), one per device, rank 0 prints the line.
-    The seam in the reference is the sequential loop of ``scripts/batch_test_video_seg.py:40-47``."""
-    n = args.gpus
-    port = _free_port()
-    procs = []
-    for r in range(n):
-        env = dict(os.environ)
-        env.update(RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
-                   MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
-        env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
-        env.setdefault('OMP_NUM_THREADS', str(max(1, min(16, (os.cpu_count() or 8) // (2 * n)))))
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env))
-    rc = 0
-    try:
-        for p in procs:
-            p.wait()
-            rc = rc or p.returncode
-    finally:
-        for p in procs:
-            if p.poll() is None:
-                p.kill()                              # exact PIDs we started
-    return rc
+    All children are polled: the first one that exits non-zero takes the others down (``dist.spawn_ranks``) instead of
+    leaving them in a barrier until the RCCL timeout.  The seam in the reference is the sequential loop of
+    ``scripts/batch_test_video_seg.py:40-47``."""
+    import vfloodnet_amd  # noqa: F401
+    from vfloodnet_amd import dist as vdist
+    return vdist.spawn_ranks([sys.executable, os.path.abspath(__file__)] + list(argv), args.gpus)
 
 
 def launch_check(args):
@@ -209,8 +187,14 @@ def main(argv=None):
         return self_launch(args, argv)
     if env_world is not None and int(env_world) != args.gpus and '--gpus' in ' '.join(argv):
         raise SystemExit(f'bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={env_world} ranks')
+    import vfloodnet_amd  # noqa: F401
+    from vfloodnet_amd import dist as vdist
+    # each rank keeps to its own slice of the host's CPUs (before any GPU call / thread pool): N ranks on one host otherwise
+    # wake every core with every torch CPU op and starve each other's launch threads
+    pinned = vdist.pin_rank_threads(int(os.environ.get('LOCAL_RANK', 0)), int(os.environ.get('LOCAL_WORLD_SIZE', env_world or 1)))
+    if os.environ.get('VFN_BENCH_FAIL_RANK') == os.environ.get('RANK', '0') and env_world is not None:
+        return 7                                    # (tests/test_batch_gloo.py: a rank that dies at bring-up)
     if args.launch_check:
-        import vfloodnet_amd  # noqa: F401
         return launch_check(args)
 
     H0, W0, mem_every = WORKLOADS[args.workload]
@@ -220,8 +204,7 @@ def main(argv=None):
     net_size = H0 if args.native else 480
     peak = PEAKS[args.precision]
 
-    import vfloodnet_amd  # noqa: F401
-    from vfloodnet_amd import AFB_URR, ops, dist as vdist
+    from vfloodnet_amd import AFB_URR, ops
     from vfloodnet_amd.video_seg import ClipRunner, resized_hw
     from vfloodnet_amd.engine import Engine
     from tools import synth
@@ -237,7 +220,7 @@ def main(argv=None):
     K, Wm = args.steps, args.warmup
     args.sample_every = max(1, min(args.sample_every, K))       # at least one frame is sampled for the roofline
     if world > 1:       # N ranks share the host: keep the CPU-side weight synthesis of each from waking every core
-        torch.set_num_threads(max(1, min(16, (os.cpu_count() or 8) // (2 * world))))
+        torch.set_num_threads(len(pinned) if pinned else vdist.host_threads_per_rank(world))
     sd = synth.make_state_dict(20200212)
     model = AFB_URR(dev, update_bank=True, precision=args.precision).to(dev).eval()
     model.load_state_dict(sd, strict=True)
@@ -356,11 +339,13 @@ def main(argv=None):
             timer.active = sampling and ((t - s_first + 1) % args.sample_every == 0)
             # no prefetch into / out of a sampled frame: its kernels are timed alone on the device
             sampled_next = sampling and ((t - s_first + 2) % args.sample_every == 0)
-            nxt = frame_of(t + 1) if (t < last_iter and not args.no_overlap and not timer.active and not sampled_next) else None
-            runner.launch(frames[idx:idx + 1], next_frame=frames[nxt:nxt + 1] if nxt is not None else None, want_label=False)
+            nxt = frame_of(t + 1) if (t < max(last_iter, t_to) and not args.no_overlap and not timer.active and not sampled_next) else None
+            # want_label: the frame's label map goes to pinned host memory (the reference's .cpu(), test_video_seg.py:115)
+            runner.launch(frames[idx:idx + 1], next_frame=frames[nxt:nxt + 1] if nxt is not None else None, want_label=True)
             timer.active = False
-            labels[t].copy_(runner.label_device(), non_blocking=True)
-            labels_raw[t].copy_(runner._label_dev, non_blocking=True)
+            if t < n_lab:                            # device-side copies for the parity checks after the run
+                labels[t].copy_(runner.label_device(), non_blocking=True)
+                labels_raw[t].copy_(runner._label_dev, non_blocking=True)
             if len(runner._pending) == 2:
                 collect_one()
         while runner._pending:
@@ -383,6 +368,21 @@ def main(argv=None):
     if world > 1:
         vdist.gather_masks(labels[1:].unsqueeze(0), world, rank, world)
     clip1 = bracket()
+
+    # ---- sustained rate beyond the clip: the loop keeps cycling through the clip's frames with the bank at its budget
+    # (every update evicts -- the regime a stream longer than 100 frames lives in); not part of `value`
+    sustained = None
+    if args.min_timed_s > 0 and not stream_mode and (t1 - t0) < args.min_timed_s:
+        n_extra = int(min(2000, max(K, (args.min_timed_s - (t1 - t0)) / max(1e-4, (t1 - t0) / K))))
+        n_before = len(bank_sizes)
+        run_iters(last_iter + 1, last_iter + n_extra, False)
+        s1 = bracket()
+        ext = bank_sizes[n_before:]
+        sustained = {'frames': n_extra, 'seconds': round(s1 - clip1, 3), 'fps_this_rank': round(n_extra / (s1 - clip1), 3),
+                     'mean_bank_entries_per_object': round(sum(sum(x) for x in ext) / (2.0 * len(ext)), 1),
+                     'replaced_entries_total': [int(v) for v in runner.fb.replace_n],
+                     'regime': f'frames {last_iter + 1}-{last_iter + n_extra} of the cycled clip, bank at class_budget '
+                               f'({int(runner.fb.class_budget)} entries/object): every update evicts'}
 
     def max_over_ranks(x):
         v = torch.tensor([x], dtype=torch.float64, device=dev if (world == 1 or dist.get_backend() == 'nccl') else 'cpu')
@@ -534,7 +534,7 @@ def main(argv=None):
                       'frame_mfma_frac_Fref_reference_equivalent': round(frame_frac_ref, 4) if mem_every == 1 else None},
            'full_clip_fps': round(full_clip_fps, 3),
            'full_clip_frame_mfma_frac_Fmin': round((full_clip_fps / world) * f_min_clip / (peak * 1e12), 4) if mem_every == 1 else None,
-           'frame_ms': frame_stats,
+           'frame_ms': frame_stats, 'sustained': sustained,
            'roofline': roof, 'memory_read': memread, 'cpu_baseline': cpu, 'parity': parity}
     print(json.dumps(out))
     if os.environ.get('VFN_BENCH_DUMP'):            # per-step host times of the whole run (diagnostics)

@@ -27,7 +27,7 @@ extern "C" {
 /* ------------------------------------------------------------------ version
  * vfn_abi_version() == VFN_ABI_VERSION of the header the binding was written against, and
  * vfn_sizeof_desc(which) == sizeof of the binding's own struct: checked when the library is loaded. */
-#define VFN_ABI_VERSION 6
+#define VFN_ABI_VERSION 7
 enum { VFN_DESC_CONV = 0, VFN_DESC_STEM = 1, VFN_DESC_BANKSCAN = 2, VFN_DESC_MEMREAD = 3, VFN_DESC_BANK = 4 };
 int vfn_abi_version(void);
 int vfn_sizeof_desc(int which);
@@ -92,9 +92,6 @@ int vfn_conv2d_nhwc_bf16(const vfn_conv_desc* d, int cfg, void* stream);
  * is hi*hi + hi*lo + lo*hi on the bf16 matrix cores, f32 accumulation: relative error ~2^-16 per product (bf16: 2^-9,
  * f32: 2^-24).  Cin multiple of 32, split-K slices are 32-channel tiles (as the f32 kernel); cfg as for _bf16. */
 int vfn_conv2d_nhwc_bf16x3(const vfn_conv_desc* d, int cfg, void* stream);
-/* 3x3/s1/p1 convolution with Cout == 2 and Cin in {32, 256} (Decoder.pred2 / local_pred2, AFB_URR.py:195,202,
- * 213,234): bandwidth-bound reduction kernel; same descriptor, w = [2][9*Cin]. */
-int vfn_conv3x3_cout2_f32(const vfn_conv_desc* d, void* stream);
 
 /* ------------------------------------------------------------------ encoder stems
  * vfn_stem_conv7x7_f32: pad_divide_by (myutils/data.py:132-149) + (x-mean)/std + conv1
@@ -127,7 +124,8 @@ int vfn_maxpool3x3s2_nhwc_f32(const float* in, float* out, int N, int H, int W, 
  * vfn_rough_uncertainty_f32     AFB_URR.py:214-223 + myutils/data.py:40-46
  *     p: [obj][h][w][2] -> p_up [obj][2h][2w][2], rough [obj][2h][2w], unc [2h][2w]
  * vfn_local_hpass_f32 / vfn_local_vpass_f32   AFB_URR.py:226-231 (r1*rough, AvgPool2d(7,1,3) x2,
- *     divide, MaxPool2d(7,1,3)) as a separable window; cat([r1, r1_local]) (:231) is not materialised
+ *     divide, MaxPool2d(7,1,3)) as a separable window; cat([r1, r1_local]) (:231) is not materialised.
+ *     The path for 5..8 objects (vfn_local_stats_f32 fuses both passes for up to 4) and its test reference.
  *     r1: [h][w][C] (shared by the objects), rough: [obj][h][w]
  *     scratch hs [obj][h][w][C], hr/hm [obj][h][w]; lm = r1_local: [obj][h][w][C], conf: [obj][h][w]
  * vfn_final_logits_f32          AFB_URR.py:233-237,300,309-316
@@ -146,7 +144,7 @@ int vfn_local_vpass_f32(const float* hs, const float* hr, const float* hm, float
  * vfn_pred2_gather_f32: second half of pred2 / local_pred2 (AFB_URR.py:195,202) evaluated as a tap GEMM: z [N][h][w][ldz]
  *     holds, per pixel, the 18 products of the 9 filter taps x 2 filters with relu(x) (a 1x1 vfn_conv2d over the
  *     repacked filters, which reads x once); out[n][y][x][o] = bias[o] + sum over the 3x3 neighbourhood (zero padding)
- *     of z[..][tap*2+o].  Same result as vfn_conv3x3_cout2_f32 up to summation order. */
+ *     of z[..][tap*2+o] (= the 3x3 convolution with two filters, up to summation order). */
 int vfn_local_stats_f32(const float* r1, const float* rough, float* lm, float* conf, int obj_n, int h, int w, int C,
                         void* stream);
 int vfn_pred2_gather_f32(const float* z, const float* bias, float* out, int N, int h, int w, int ldz, void* stream);
@@ -195,7 +193,8 @@ typedef struct vfn_bankscan_desc {
                               object (stride_scores floats apart) one 32 KB tile per (64-entry chunk c, 128-query tile t) at
                               tile index c * ceil(HW/128) + t, laid out [key half 2][row group 4][lane half 2][query 128][4]
                               (= the MFMA accumulator layout, so both kernels move whole 512-byte runs).  Needs
-                              ceil(cap/64) * ceil(HW/128) * 8192 floats per object. */
+                              ceil(cap/64) * ceil(HW/128) * 8192 floats per object with cap = stride_k / 128, the capacity
+                              of the key slab: vfn_bank_scan and vfn_memread_apply return VFN_ERR_ARG for less. */
     long long stride_scores;
 } vfn_bankscan_desc;
 
@@ -215,13 +214,11 @@ typedef struct vfn_memread_desc {
     float scale, thres;
     int ldq, ldqv, ld_out, HW, obj_n, nsplit;
     int precision;         /* as vfn_bankscan_desc.precision (scores, P and value operands); softmax in f32 */
-    int wide;              /* 1 = 128 query columns per workgroup (8 waves; keys and values are
-                              streamed half as often -- the large-bank / bandwidth-bound regime); the slices of
-                              o_part are then chosen for ceil(HW/128) query tiles */
-    const void* bank_k_lp; /* precision 1 / 2 with wide: the split-bf16 images of keys and values kept by         */
+                           /* (a workgroup owns 128 query columns: choose nsplit for ceil(HW/128) query tiles) */
+    const void* bank_k_lp; /* precision 1 / 2: the split-bf16 images of keys and values kept by         */
     const void* bank_v_lp; /* vfn_bank_refresh_lp (both or neither; same results as the on-the-fly split, without
                               the conversion work in the kernel): values [obj][cap][128 groups][4 hi | 4 lo] bf16 */
-    const float* scores;   /* precision 0 with wide, optional: the scores the mode-0 vfn_bank_scan of this frame stored
+    const float* scores;   /* precision 0, optional: the scores the mode-0 vfn_bank_scan of this frame stored
                               (vfn_bankscan_desc.scores, same layout and stride).  The kernel then runs no score GEMM and
                               touches neither q nor bank_k: bit-identical results (the scan forms the same sums). */
     long long stride_scores;

@@ -59,7 +59,7 @@ for B in [int(x) for x in (sys.argv[1:] or ['56000'])]:
     m.cnt, m.info, m.out = ptr(fb._cnt), ptr(fb._ibuf), ptr(dec_in)
     m.stride_k, m.stride_v, m.stride_cnt, m.stride_info = cap * DK, cap * DV, cap, cap * 2
     m.scale, m.thres = scale, 1e-3
-    m.ldq, m.ldqv, m.ld_out, m.HW, m.obj_n, m.nsplit, m.precision, m.wide = DK + DV, DK + DV, DV, HW, K, nsplit, PREC, int(os.environ.get('WIDE', 1))
+    m.ldq, m.ldqv, m.ld_out, m.HW, m.obj_n, m.nsplit, m.precision = DK + DV, DK + DV, DV, HW, K, nsplit, PREC
     m.bank_k_lp, m.bank_v_lp = ptr(klp), ptr(vlp)
     if scores is not None:
         m.scores, m.stride_scores = ptr(scores), scores.shape[1]

@@ -32,7 +32,7 @@ m.bank_k, m.bank_v, m.bank_len, m.ml, m.o_part = ptr(fb._kbuf), ptr(fb._vbuf), p
 m.cnt, m.info, m.out = ptr(fb._cnt), ptr(fb._ibuf), ptr(dec_in)
 m.stride_k, m.stride_v, m.stride_cnt, m.stride_info = cap * DK, cap * DV, cap, cap * 2
 m.scale, m.thres = 1 / math.sqrt(DK), 1e-3
-m.ldq, m.ldqv, m.ld_out, m.HW, m.obj_n, m.nsplit, m.precision, m.wide = DK + DV, DK + DV, DV, HW, K, nsplit, 0, 1
+m.ldq, m.ldqv, m.ld_out, m.HW, m.obj_n, m.nsplit, m.precision = DK + DV, DK + DV, DV, HW, K, nsplit, 0
 for _ in range(3):
     check(L.vfn_memread_apply(C.byref(m), stream()), 'apply')
 torch.cuda.synchronize()

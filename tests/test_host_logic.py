@@ -159,3 +159,33 @@ def test_bench_and_entry_modules_import_on_cpu():
     assert bench.PEAKS['fp32'] == 157.3 and abs(bench.PEAKS['bf16x3'] * 3 - bench.PEAKS['bf16']) < 1e-9
     entry = importlib.import_module('__graft_entry__')
     assert callable(entry.build) and callable(entry.smoke)
+
+
+def test_video_ds_device_decode_sniffs_content_and_defers_bad_files_to_pil(tmp_path):
+    """The reference opens every frame with PIL, which looks at the bytes (Water_DS.py:105-109): a PNG saved as .jpg (or the
+    reverse) works there and must work on the default decode path; a file the host-side decoders reject goes to PIL,
+    which either tolerates it or raises ITS error."""
+    import numpy as np
+    from PIL import Image
+    import vfloodnet_amd  # noqa: F401
+    from vfloodnet_amd.dataset import Video_DS
+    rng = np.random.RandomState(5)
+    a = rng.randint(0, 256, (24, 40, 3)).astype(np.uint8)
+    first = tmp_path / '00000.jpg'
+    Image.fromarray(a).save(first)
+    png_as_jpg, jpg_as_png, cut = tmp_path / '00001.jpg', tmp_path / '00002.png', tmp_path / '00003.jpg'
+    Image.fromarray(a).save(png_as_jpg, format='PNG')
+    Image.fromarray(a).save(jpg_as_png, format='JPEG', quality=90)
+    import io
+    buf = io.BytesIO()
+    Image.fromarray(a).save(buf, format='JPEG', quality=90)
+    cut.write_bytes(buf.getvalue()[:120])                                    # truncated inside the tables
+    ds = Video_DS([str(first), str(png_as_jpg), str(jpg_as_png), str(cut)], Image.fromarray(a),
+                  Image.fromarray((a[:, :, 0] > 100).astype(np.uint8)), decode='device')
+    item, name = ds[0]
+    assert name == '00001' and set(item) == {'png'}
+    item, _ = ds[1]
+    assert set(item) == {'jpeg'}
+    import pytest
+    with pytest.raises(OSError):                                             # PIL's own verdict on the truncated file
+        ds[2]

@@ -549,7 +549,6 @@ def test_memory_read_through_split_image_is_bit_identical(gpu, sd, precision):
     out = []
     for flag in ('1', '0'):
         os.environ['VFN_LP_IMAGE'] = flag
-        os.environ['VFN_WIDE_APPLY'] = '1'
         try:
             g.manual_seed(41)
             fb = FeatureBank(2, 250000, gpu, precision=precision)
@@ -561,7 +560,6 @@ def test_memory_read_through_split_image_is_bit_identical(gpu, sd, precision):
             out.append((score.clone(), fb.info[0].clone(), fb.info[1].clone(), fb._klp is not None))
         finally:
             os.environ.pop('VFN_LP_IMAGE', None)
-            os.environ.pop('VFN_WIDE_APPLY', None)
     assert out[0][3] and not out[1][3]
     assert torch.equal(out[0][0], out[1][0])
     assert torch.equal(out[0][1], out[1][1]) and torch.equal(out[0][2], out[1][2])
@@ -583,7 +581,6 @@ def test_apply_from_stored_scores_is_bit_identical(gpu, sd):
     out = []
     for flag in ('1', '0'):
         os.environ['VFN_STORE_SCORES'] = flag
-        os.environ['VFN_WIDE_APPLY'] = '1'
         try:
             g = torch.Generator().manual_seed(43)
             fb = FeatureBank(2, 250000, gpu)
@@ -597,7 +594,6 @@ def test_apply_from_stored_scores_is_bit_identical(gpu, sd):
             out.append((score.clone(), fb.info[0].clone(), fb.info[1].clone()))
         finally:
             os.environ.pop('VFN_STORE_SCORES', None)
-            os.environ.pop('VFN_WIDE_APPLY', None)
         model._invalidate()                                # fresh plan (and scores buffer) for the second pass
     assert torch.isfinite(out[0][0]).all()
     assert torch.equal(out[0][0], out[1][0])

@@ -169,3 +169,32 @@ def test_device_png_decode_large_and_corrupt(gpu):
     png_decode.to_tensor(bad, info, pal, gpu)
     assert not png_decode.check_status(gpu)
     assert png_decode.check_status(gpu)                                      # the flag was cleared
+
+
+def test_invalid_filter_byte_is_rejected_at_the_frame(tmp_path):
+    """A scanline filter type outside 0..4 is caught by ``inflate`` -- in the loader worker, at that frame, before the frame
+    is segmented or memorised -- and ``Video_DS`` then hands the file to PIL, whose error reaches the loop there (as in the
+    reference, which opens every frame with PIL)."""
+    import struct
+    import vfloodnet_amd  # noqa: F401
+    from vfloodnet_amd import png_decode
+    from vfloodnet_amd.dataset import Video_DS
+    a = _img(12, 20, 4)
+    W, H = 20, 12
+    raw = bytearray()
+    for y in range(H):
+        raw += bytes([0]) + a[y].tobytes()
+    raw[5 * (1 + 3 * W)] = 7                                                 # row 5: filter type 7
+
+    def chunk(t, body):
+        return struct.pack('>I', len(body)) + t + body + struct.pack('>I', zlib.crc32(t + body) & 0xffffffff)
+    data = b'\x89PNG\r\n\x1a\n' + chunk(b'IHDR', struct.pack('>IIBBBBB', W, H, 8, 2, 0, 0, 0)) + \
+        chunk(b'IDAT', zlib.compress(bytes(raw))) + chunk(b'IEND', b'')
+    with pytest.raises(RuntimeError, match='filter type'):
+        png_decode.inflate(data)
+    good, bad = tmp_path / '00000.png', tmp_path / '00001.png'
+    Image.fromarray(a).save(good)
+    bad.write_bytes(data)
+    ds = Video_DS([str(good), str(bad)], Image.fromarray(a), Image.fromarray((a[:, :, 0] > 100).astype(np.uint8)), decode='device')
+    with pytest.raises(Exception):                                          # PIL's own error for the bad file
+        ds[0]

@@ -50,7 +50,7 @@ class MemReadDesc(C.Structure):
                 ('stride_info', C.c_longlong),
                 ('scale', C.c_float), ('thres', C.c_float),
                 ('ldq', C.c_int), ('ldqv', C.c_int), ('ld_out', C.c_int), ('HW', C.c_int), ('obj_n', C.c_int),
-                ('nsplit', C.c_int), ('precision', C.c_int), ('wide', C.c_int), ('bank_k_lp', c_fp), ('bank_v_lp', c_fp), ('scores', c_fp), ('stride_scores', C.c_longlong)]
+                ('nsplit', C.c_int), ('precision', C.c_int), ('bank_k_lp', c_fp), ('bank_v_lp', c_fp), ('scores', c_fp), ('stride_scores', C.c_longlong)]
 
 
 class BankDesc(C.Structure):
@@ -67,7 +67,7 @@ class BankDesc(C.Structure):
                 ('obj_n', C.c_int), ('cap', C.c_int), ('rm_class', C.c_int), ('rm_request', C.c_int)]
 
 
-ABI_VERSION = 6          # include/vfn_hip.h VFN_ABI_VERSION; csrc/abi.hip
+ABI_VERSION = 7          # include/vfn_hip.h VFN_ABI_VERSION; csrc/abi.hip
 DESC_IDS = {0: ConvDesc, 1: StemDesc, 2: BankScanDesc, 3: MemReadDesc, 4: BankDesc}     # vfn_sizeof_desc(which)
 
 
@@ -108,7 +108,6 @@ def _declare(L):
     L.vfn_conv2d_nhwc_f32.argtypes = [C.POINTER(ConvDesc), i, p]
     L.vfn_conv2d_nhwc_bf16.argtypes = [C.POINTER(ConvDesc), i, p]
     L.vfn_conv2d_nhwc_bf16x3.argtypes = [C.POINTER(ConvDesc), i, p]
-    L.vfn_conv3x3_cout2_f32.argtypes = [C.POINTER(ConvDesc), p]
     L.vfn_stem_conv7x7_f32.argtypes = [C.POINTER(StemDesc), p]
     L.vfn_bank_scan.argtypes = [C.POINTER(BankScanDesc), p]
     L.vfn_memread_apply.argtypes = [C.POINTER(MemReadDesc), p]
@@ -159,7 +158,7 @@ SIGNATURES = {
 }
 # every symbol include/vfn_hip.h declares (checked by tests/test_abi.py)
 ALL_SYMBOLS = sorted(list(SIGNATURES) + [
-    'vfn_abi_version', 'vfn_sizeof_desc', 'vfn_conv_cfg_count', 'vfn_conv_cfg_tile', 'vfn_conv_cfg_info', 'vfn_conv_cfg_wk', 'vfn_conv_cfg_tpb', 'vfn_conv2d_nhwc_f32', 'vfn_conv2d_nhwc_bf16', 'vfn_conv2d_nhwc_bf16x3', 'vfn_conv3x3_cout2_f32',
+    'vfn_abi_version', 'vfn_sizeof_desc', 'vfn_conv_cfg_count', 'vfn_conv_cfg_tile', 'vfn_conv_cfg_info', 'vfn_conv_cfg_wk', 'vfn_conv_cfg_tpb', 'vfn_conv2d_nhwc_f32', 'vfn_conv2d_nhwc_bf16', 'vfn_conv2d_nhwc_bf16x3',
     'vfn_stem_conv7x7_f32',
     'vfn_bank_scan', 'vfn_memread_apply', 'vfn_memread_finish', 'vfn_bank_merge', 'vfn_bank_append', 'vfn_bank_remove', 'vfn_bank_refresh_norms', 'vfn_bank_refresh_lp'])
 

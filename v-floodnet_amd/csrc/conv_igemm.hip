@@ -829,62 +829,6 @@ __global__ void splitk_reduce_kernel(const vfn_conv_desc p, int m_start) {
     }
 }
 
-// 3x3 / stride 1 / pad 1 convolution with TWO filters (pred2, local_pred2: AFB_URR.py:195,202): a
-// bandwidth-bound reduction, not matrix work.  LPP = Cin/4 lanes share one output pixel (float4 of
-// channels each), the 2 x 9 x 4 filter taps of a lane live in registers, partial sums meet by shuffles.
-template <int LPP>
-__global__ __launch_bounds__(256)
-void conv3x3_cout2_kernel(const vfn_conv_desc p) {
-    constexpr int PPW = 64 / LPP;                     // pixels per wave
-    const int lane = threadIdx.x & 63;
-    const int sub = lane % LPP, pw = lane / LPP;
-    const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-    const int nwaves = (gridDim.x * blockDim.x) >> 6;
-    const int Ktot = 9 * p.Cin;
-    f32x4 w0[9], w1[9];
-#pragma unroll
-    for (int t = 0; t < 9; ++t) {
-        w0[t] = *reinterpret_cast<const f32x4*>(p.w + t * p.Cin + sub * 4);
-        w1[t] = *reinterpret_cast<const f32x4*>(p.w + Ktot + t * p.Cin + sub * 4);
-    }
-    const float s0 = p.scale ? p.scale[0] : 1.f, s1 = p.scale ? p.scale[1] : 1.f;
-    const float b0 = p.shift ? p.shift[0] : 0.f, b1 = p.shift ? p.shift[1] : 0.f;
-    const int HW = p.H * p.W;
-    for (int m0 = wave * PPW; m0 < p.M; m0 += nwaves * PPW) {
-        const int m = m0 + pw;
-        const bool live = m < p.M;
-        const int mm = live ? m : 0;
-        const int n = mm / HW, rem = mm - n * HW;
-        const int y = rem / p.W, x = rem - y * p.W;
-        float a0 = 0.f, a1 = 0.f;
-#pragma unroll
-        for (int dy = 0; dy < 3; ++dy) {
-            const int yy = y + dy - 1;
-#pragma unroll
-            for (int dx = 0; dx < 3; ++dx) {
-                const int xx = x + dx - 1;
-                const bool ok = (unsigned)yy < (unsigned)p.H && (unsigned)xx < (unsigned)p.W;
-                const int pix = ok ? (n * p.H + yy) * p.W + xx : 0;
-                f32x4 v = *reinterpret_cast<const f32x4*>(p.in + (size_t)pix * p.in_ld + sub * 4);
-                if (p.relu_in) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-                if (ok) {
-                    const f32x4 u0 = w0[dy * 3 + dx], u1 = w1[dy * 3 + dx];
-                    a0 += v.x * u0.x + v.y * u0.y + v.z * u0.z + v.w * u0.w;
-                    a1 += v.x * u1.x + v.y * u1.y + v.z * u1.z + v.w * u1.w;
-                }
-            }
-        }
-#pragma unroll
-        for (int o = LPP / 2; o > 0; o >>= 1) { a0 += __shfl_xor(a0, o, 64); a1 += __shfl_xor(a1, o, 64); }
-        if (live && sub == 0) {
-            float v0 = a0 * s0 + b0, v1 = a1 * s1 + b1;
-            if (p.relu_out) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); }
-            p.out[(size_t)m * p.out_ld] = v0;
-            p.out[(size_t)m * p.out_ld + 1] = v1;
-        }
-    }
-}
-
 template <int BM, int BN, int WM, int WN, int DMA = 0, int MODE = 0>     // DMA: 0 = register staged, 2 / 3 = LDS-DMA ring depth
 int launch_cfg(const vfn_conv_desc& p, hipStream_t s) {
     constexpr int NT = WM * WN * 64;
@@ -982,16 +926,6 @@ extern "C" int vfn_conv_cfg_info(int cfg, int* bm, int* bn, int* wm, int* wn, in
 }
 
 extern "C" int vfn_conv_cfg_tile(int cfg, int* bm, int* bn) { return vfn_conv_cfg_info(cfg, bm, bn, nullptr, nullptr, nullptr); }
-
-extern "C" int vfn_conv3x3_cout2_f32(const vfn_conv_desc* d, void* stream) {
-    if (!d || !d->in || !d->w || !d->out) return VFN_ERR_ARG;
-    if (d->Cout != 2 || d->KH != 3 || d->KW != 3 || d->stride != 1 || d->pad != 1 || d->res || d->in_ld % 4) return VFN_ERR_ARG;
-    const int blocks = 2048;
-    if (d->Cin == 256) hipLaunchKernelGGL(conv3x3_cout2_kernel<64>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, *d);
-    else if (d->Cin == 32) hipLaunchKernelGGL(conv3x3_cout2_kernel<8>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, *d);
-    else return VFN_ERR_ARG;
-    return vfn_check_launch();
-}
 
 extern "C" int vfn_conv2d_nhwc_f32(const vfn_conv_desc* d, int cfg, void* stream) {
     if (!d || !d->in || !d->w || !d->out) return VFN_ERR_ARG;

@@ -24,15 +24,13 @@
 // tile, object) items from a queue; a wave owns 32 query columns against all 64 rows of a chunk, key chunks arrive by
 // LDS-DMA, double-buffered.  Apply: one workgroup = 128 query columns x one slice of the bank, 8 waves; P^T goes through
 // LDS, wave w owns value channels 64w..64w+63 of all 128 queries and reads its value rows straight from global memory
-// (buffer loads, two k-groups ahead).  The 64-query kernels (memread_apply_kernel, _lp_kernel) are the first generation,
-// kept behind desc.wide = 0.
+// (buffer loads, two k-groups ahead).
 #include "common.h"
 #include "../../include/vfn_hip.h"
 
 namespace {
 
 constexpr int DK = 128, DV = 512;
-constexpr int QT = 64;      // query columns per workgroup
 constexpr int CH = 64;      // bank entries per chunk
 
 // [rows][128 floats] LDS image, 16-byte chunk index XOR (row & 15): conflict-free b128 fragment reads
@@ -486,308 +484,12 @@ __device__ __forceinline__ int softmax_hits(f32x16& acc, float scale, float qm, 
 }
 
 // ------------------------------------------------------------------ pass 2: P^T V and hit counts
-__global__ __launch_bounds__(256, 2)
-void memread_apply_kernel(const vfn_memread_desc p) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    float* sQ = reinterpret_cast<float*>(smem);      // [64][128]
-    float* sK = sQ + QT * DK;                        // [64][128]
-    float* sP = sK + CH * DK;                        // [64 q][64 b]  (P^T)
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int li = lane & 31, lh = lane >> 5;
-    const int wr = wave >> 1, wq = wave & 1;
-    const int sstride = p.nsplit;
-    const int split = blockIdx.x % sstride;
-    const int qt = blockIdx.x / sstride;
-    if (split >= p.nsplit) return;
-    const int obj = blockIdx.y;
-    const int q0 = qt * QT;
-    const int B = p.bank_len[obj];
-    const float* K = p.bank_k + (size_t)obj * p.stride_k;
-    const float* V = p.bank_v + (size_t)obj * p.stride_v;
-
-    stage_rows(sQ, p.q + (size_t)q0 * p.ldq, p.ldq, QT, min(QT, p.HW - q0), tid);
-
-    int c_lo, c_hi;
-    chunk_range(B, p.nsplit, split, c_lo, c_hi);
-
-    f32x16 o[2][4];                                  // O^T tiles: [tq][tc], rows = q, cols = value channel
-#pragma unroll
-    for (int a = 0; a < 2; ++a)
-#pragma unroll
-        for (int b = 0; b < 4; ++b)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) o[a][b][r] = 0.f;
-
-    // value channels of this wave: 128*wave .. +127; lane li owns the 4 consecutive channels 4*li..4*li+3, one per
-    // 32-wide MFMA tile (tile tc, column li <-> channel 4*li + tc): 16-byte loads of V and 16-byte stores of O^T
-    const float* vcol = V + wave * 128 + li * 4;     // + row*512
-
-    if (c_lo < c_hi) chunk_load_async(sK, K + (size_t)c_lo * CH * DK, min(CH, B - c_lo * CH), wave, lane);
-    __syncthreads();                                 // (drains the LDS-DMA: it is a pending LDS write)
-
-    const int qcol = wq * 32 + li;                   // this lane's query column in the score tile
-    const bool qok = (q0 + qcol) < p.HW;
-    float qm = 1e30f, qinv = 0.f;                    // softmax statistics of this lane's query (pass 1);
-    if (qok) {                                       // a column past HW gets p = exp(-big) * 0 = 0
-        qm = p.ml[((size_t)obj * p.HW + q0 + qcol) * 2];
-        qinv = 1.f / p.ml[((size_t)obj * p.HW + q0 + qcol) * 2 + 1];
-    }
-
-    for (int c = c_lo; c < c_hi; ++c) {
-        const int b0 = c * CH;
-        const bool more = c + 1 < c_hi;
-
-        f32x16 acc;
-        score_tile(sK, sQ, wr, wq, li, lh, acc);
-
-        // p = exp(s - m) / l; hit counts; P^T -> LDS
-        const int rloc = wr * 32 + 4 * lh;           // chunk-local row of register 0
-        const int mycnt = softmax_hits(acc, p.scale, qm, qinv, p.thres, B - b0, rloc);
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {                // registers 4g..4g+3 = 4 consecutive bank rows
-            const int brow = rloc + 8 * g;           // chunk-local row, multiple of 4
-            const f32x4 v = {acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]};
-            *reinterpret_cast<f32x4*>(sP + swz64(qcol, brow >> 2)) = v;
-        }
-        if (p.cnt && lh == 0 && mycnt > 0) {
-            const int row = b0 + wr * 32 + li;
-            if (row < B) atomicAdd(p.cnt + (size_t)obj * p.stride_cnt + row, mycnt);
-        }
-        __syncthreads();                             // P^T visible; every wave is done reading sK
-        if (more) chunk_load_async(sK, K + (size_t)(b0 + CH) * DK, min(CH, B - b0 - CH), wave, lane);   // lands behind P^T V
-
-        // O^T[q][c] += sum_b P^T[q][b] V[b][c];  this wave: channels 128*wave .. +127, value rows
-        // prefetched one k-group (8 bank rows) ahead of the MFMAs that use them
-        f32x4 vb[3][4];                              // ring: value rows two k-groups ahead of their MFMAs
-        auto load_v = [&](int kk, int slot) {
-#pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                // rows past the bank end are clamped to the last entry: their P is exactly 0 (masked in
-                // the softmax above) and the clamped value is a finite bank entry, so no select is needed
-                // -- a select would force a wait right behind every load
-                const int rr = min(b0 + 8 * kk + 4 * lh + t, B - 1);
-#ifdef VFN_ABLATE_V
-                vb[slot][t] = f32x4{1.f * rr, 2.f, 3.f, 4.f};
-#else
-                vb[slot][t] = *reinterpret_cast<const f32x4*>(vcol + (size_t)rr * DV);
-#endif
-            }
-        };
-        load_v(0, 0);
-        load_v(1, 1);
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int kk = 0; kk < CH / 8; ++kk) {
-            const int cur = kk % 3;
-            if (kk + 2 < CH / 8) load_v(kk + 2, (kk + 2) % 3);
-            __builtin_amdgcn_sched_barrier(0);       // keep the prefetch ahead of this k-group's MFMAs
-            const int lc = 2 * kk + lh;
-            const f32x4 a0 = *reinterpret_cast<const f32x4*>(sP + swz64(li, lc));
-            const f32x4 a1 = *reinterpret_cast<const f32x4*>(sP + swz64(32 + li, lc));
-#pragma unroll
-            for (int t = 0; t < 4; ++t)
-#pragma unroll
-                for (int tc = 0; tc < 4; ++tc) {
-                    o[0][tc] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[t], vb[cur][t][tc], o[0][tc], 0, 0, 0);
-                    o[1][tc] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[t], vb[cur][t][tc], o[1][tc], 0, 0, 0);
-                }
-        }
-        __syncthreads();                             // next chunk's keys visible; sP free again
-    }
-
-    // partial O^T -> o_part[obj][split][q][512]
-    float* dst = p.o_part + ((size_t)obj * p.nsplit + split) * p.HW * DV;
-#pragma unroll
-    for (int tq = 0; tq < 2; ++tq)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int q = q0 + tq * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-            if (q < p.HW) {
-                const f32x4 v = {o[tq][0][r], o[tq][1][r], o[tq][2][r], o[tq][3][r]};
-                *reinterpret_cast<f32x4*>(dst + (size_t)q * DV + wave * 128 + li * 4) = v;
-            }
-        }
-}
-
-
-// ------------------------------------------------------------------ pass 2 with bf16 / bf16x3 operands
-// Same tiling as memread_apply_kernel.  LDS (80 KB): query image as bf16 hi / lo [64 q][128] (converted once),
-// key chunk f32 [64][128] by LDS-DMA (fragments converted in registers), P^T as bf16 hi / lo [64 q][64 b]
-// (converted once by the wave that computed it, read by all four).  Value rows go global -> registers ->
-// bf16 fragments, one 16-row step ahead of their MFMAs.  k is in natural order everywhere: step g of a
-// 32x32x16 MFMA takes k = 16g + 8*(lane>>5) + j.
+// (The 64-query apply kernels of rounds 1-2 are gone: the 128-query kernels below measured faster at every bank size in
+// every precision mode and were the only ones the default path had selected since.)
+// LDS swizzles of the reduced-precision kernels (bytes): query image rows of 256 B, P^T rows of 128 B.  k is in natural
+// order everywhere: step g of a 32x32x16 MFMA takes k = 16g + 8*(lane>>5) + j.
 __device__ __forceinline__ int swzq(int row, int chunk) { return row * 256 + ((chunk ^ (row & 15)) << 4); }          // bytes
 __device__ __forceinline__ int swzp(int row, int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); }    // bytes
-
-template <bool X3>
-__global__ __launch_bounds__(256, 2)
-void memread_apply_lp_kernel(const vfn_memread_desc p) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    char* sQh = smem;                                        // [64][128] bf16
-    char* sQl = sQh + QT * DK * 2;
-    float* sK = reinterpret_cast<float*>(sQl + QT * DK * 2); // [64][128] f32
-    char* sPh = reinterpret_cast<char*>(sK + CH * DK);       // [64 q][64 b] bf16
-    char* sPl = sPh + QT * CH * 2;
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int li = lane & 31, lh = lane >> 5;
-    const int wr = wave >> 1, wq = wave & 1;
-    const int split = blockIdx.x % p.nsplit;
-    const int qt = blockIdx.x / p.nsplit;
-    const int obj = blockIdx.y;
-    const int q0 = qt * QT;
-    const int B = p.bank_len[obj];
-    const float* K = p.bank_k + (size_t)obj * p.stride_k;
-    const float* V = p.bank_v + (size_t)obj * p.stride_v;
-
-    {   // query image
-        const int c = tid & 31;
-        for (int r = tid >> 5; r < QT; r += 8) {
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (q0 + r < p.HW) v = *reinterpret_cast<const f32x4*>(p.q + (size_t)(q0 + r) * p.ldq + c * 4);
-            bf16x4 h, l;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) { h[e] = (__bf16)v[e]; l[e] = (__bf16)(v[e] - (float)h[e]); }
-            const int off = swzq(r, c >> 1) + (c & 1) * 8;
-            *reinterpret_cast<bf16x4*>(sQh + off) = h;
-            if constexpr (X3) *reinterpret_cast<bf16x4*>(sQl + off) = l;
-        }
-    }
-
-    int c_lo, c_hi;
-    chunk_range(B, p.nsplit, split, c_lo, c_hi);
-
-    f32x16 o[2][4];
-#pragma unroll
-    for (int a = 0; a < 2; ++a)
-#pragma unroll
-        for (int b = 0; b < 4; ++b)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) o[a][b][r] = 0.f;
-
-    const float* vcol = V + wave * 128 + li * 4;     // + row*512; lane li owns channels 4li..4li+3 (one per tile tc)
-
-    if (c_lo < c_hi) chunk_load_async(sK, K + (size_t)c_lo * CH * DK, min(CH, B - c_lo * CH), wave, lane);
-    __syncthreads();
-
-    const int qcol = wq * 32 + li;
-    const bool qok = (q0 + qcol) < p.HW;
-    float qm = 1e30f, qinv = 0.f;
-    if (qok) {
-        qm = p.ml[((size_t)obj * p.HW + q0 + qcol) * 2];
-        qinv = 1.f / p.ml[((size_t)obj * p.HW + q0 + qcol) * 2 + 1];
-    }
-
-    for (int c = c_lo; c < c_hi; ++c) {
-        const int b0 = c * CH;
-        const bool more = c + 1 < c_hi;
-
-        // value rows of step 0 (16 bank rows; this lane half: rows 8*lh .. +7) -- they land behind the score GEMM
-        f32x4 raw[8];
-        auto load_raw = [&](int st) {
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const int rr = min(b0 + 16 * st + 8 * lh + j, B - 1);      // rows past the end: P is exactly 0 there
-                raw[j] = *reinterpret_cast<const f32x4*>(vcol + (size_t)rr * DV);
-            }
-        };
-        load_raw(0);
-
-        // scores: A = key rows 32wr.., B = query columns 32wq..
-        f32x16 acc;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-        {
-            const int ra = wr * 32 + li, rq = wq * 32 + li;
-            f32x4 a[2][2];
-            a[0][0] = *reinterpret_cast<const f32x4*>(sK + swz(ra, 2 * lh));
-            a[0][1] = *reinterpret_cast<const f32x4*>(sK + swz(ra, 2 * lh + 1));
-#pragma unroll
-            for (int g = 0; g < 8; ++g) {
-                const int cur = g & 1;
-                if (g + 1 < 8) {
-                    a[cur ^ 1][0] = *reinterpret_cast<const f32x4*>(sK + swz(ra, 4 * (g + 1) + 2 * lh));
-                    a[cur ^ 1][1] = *reinterpret_cast<const f32x4*>(sK + swz(ra, 4 * (g + 1) + 2 * lh + 1));
-                }
-                const bf16x8 bh = *reinterpret_cast<const bf16x8*>(sQh + swzq(rq, 2 * g + lh));
-                bf16x8 bl = bh;
-                if constexpr (X3) bl = *reinterpret_cast<const bf16x8*>(sQl + swzq(rq, 2 * g + lh));
-                bf16x8 ah, al;
-                if constexpr (X3) split8(a[cur][0], a[cur][1], ah, al);
-                else { ah = cvt8(a[cur][0], a[cur][1]); al = ah; }
-                mfma_lp<X3>(acc, ah, al, bh, bl);
-            }
-        }
-
-        // p = exp(s - m) / l; hit counts; P^T -> LDS as bf16 (hi, lo)
-        const int rloc = wr * 32 + 4 * lh;
-        const int mycnt = softmax_hits(acc, p.scale, qm, qinv, p.thres, B - b0, rloc);
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {                // registers 4g..4g+3 = 4 consecutive bank rows of query qcol
-            const int brow = rloc + 8 * g;
-            bf16x4 h, l;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) { h[e] = (__bf16)acc[4 * g + e]; l[e] = (__bf16)(acc[4 * g + e] - (float)h[e]); }
-            const int off = swzp(qcol, brow >> 3) + ((brow >> 2) & 1) * 8;
-            *reinterpret_cast<bf16x4*>(sPh + off) = h;
-            if constexpr (X3) *reinterpret_cast<bf16x4*>(sPl + off) = l;
-        }
-        if (p.cnt && lh == 0 && mycnt > 0) {
-            const int row = b0 + wr * 32 + li;
-            if (row < B) atomicAdd(p.cnt + (size_t)obj * p.stride_cnt + row, mycnt);
-        }
-        __syncthreads();                             // P^T visible; every wave is done reading sK
-        if (more) chunk_load_async(sK, K + (size_t)(b0 + CH) * DK, min(CH, B - b0 - CH), wave, lane);
-
-        // O^T[q][ch] += sum_b P^T[q][b] V[b][ch]: A = P^T (rows q), B = value rows (cols = channel 4li + tc)
-#pragma unroll
-        for (int st = 0; st < CH / 16; ++st) {
-            __builtin_amdgcn_sched_barrier(0);       // one step at a time: hoisting the next step's operands spills
-            bf16x8 ph[2], pl[2];
-#pragma unroll
-            for (int tq = 0; tq < 2; ++tq) {
-                ph[tq] = *reinterpret_cast<const bf16x8*>(sPh + swzp(tq * 32 + li, 2 * st + lh));
-                if constexpr (X3) pl[tq] = *reinterpret_cast<const bf16x8*>(sPl + swzp(tq * 32 + li, 2 * st + lh));
-                else pl[tq] = ph[tq];
-            }
-            // two channel tiles at a time (register budget: 128 accumulators + 32 raw + 16 converted + 16 P)
-#pragma unroll
-            for (int half = 0; half < 2; ++half) {
-                __builtin_amdgcn_sched_barrier(0);
-                bf16x8 vh[2], vl[2];
-#pragma unroll
-                for (int t2 = 0; t2 < 2; ++t2)
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) {
-                        const float x = raw[j][2 * half + t2];
-                        const __bf16 hx = (__bf16)x;
-                        vh[t2][j] = hx;
-                        if constexpr (X3) vl[t2][j] = (__bf16)(x - (float)hx); else vl[t2][j] = hx;
-                    }
-                if (half == 1 && st + 1 < CH / 16) load_raw(st + 1);
-#pragma unroll
-                for (int t2 = 0; t2 < 2; ++t2)
-#pragma unroll
-                    for (int tq = 0; tq < 2; ++tq)
-                        mfma_lp<X3>(o[tq][2 * half + t2], ph[tq], pl[tq], vh[t2], vl[t2]);
-            }
-        }
-        __syncthreads();
-    }
-
-    float* dst = p.o_part + ((size_t)obj * p.nsplit + split) * p.HW * DV;
-#pragma unroll
-    for (int tq = 0; tq < 2; ++tq)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int q = q0 + tq * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-            if (q < p.HW) {
-                const f32x4 v = {o[tq][0][r], o[tq][1][r], o[tq][2][r], o[tq][3][r]};
-                *reinterpret_cast<f32x4*>(dst + (size_t)q * DV + wave * 128 + li * 4) = v;
-            }
-        }
-}
 
 // ------------------------------------------------------------------ pass 2, bf16 / bf16x3, wide query tile
 // For the bandwidth-bound regime (reduced-precision MFMAs are 5-16x faster than the f32 ones, so streaming the bank
@@ -1158,8 +860,8 @@ void memread_apply_shw_kernel(const vfn_memread_desc p) {
 #endif
 // ------------------------------------------------------------------ pass 2 (f32), wide query tile
 // 128 query columns per workgroup, 8 waves: the score tile is 64 x 128 (one 32x32 tile per wave), wave w then owns
-// value channels 64w..64w+63 for all 128 queries.  Same MFMA work per wave as memread_apply_kernel, but a key chunk
-// and a value row are fetched once per 128 queries and a chunk costs one barrier pair per 128 queries.
+// value channels 64w..64w+63 for all 128 queries: a key chunk and a value row are fetched once per 128 queries and a
+// chunk costs one barrier pair per 128 queries.
 // LDS: queries [128][128] 64 KB + key chunk 32 KB + P^T [128 q][64 b] 32 KB = 128 KB, one workgroup per CU.
 __global__ __launch_bounds__(512, 1)
 void memread_apply_wide_kernel(const vfn_memread_desc p) {
@@ -1487,7 +1189,13 @@ __global__ void memread_finish_kernel(const vfn_memread_desc p) {
 }
 
 constexpr size_t SCAN_LDS = (size_t)(2 * CH * DK) * sizeof(float);
-constexpr size_t APPLY_LDS = (size_t)(QT * DK + CH * DK + QT * CH) * sizeof(float);   // 80 KB: two per CU
+
+// The score tiles of one object: one 8192-float tile per (64-entry chunk, 128-query tile); the capacity is what the key
+// slab holds per object (stride_k / 128 entries).  An undersized buffer is refused here rather than overrun on the device.
+bool scores_fit(long long stride_scores, long long stride_k, int HW) {
+    const long long cap = stride_k / DK;
+    return stride_scores >= ((cap + CH - 1) / CH) * (long long)((HW + 127) / 128) * 8192;
+}
 
 template <typename K>
 void allow_lds(K kern, size_t bytes) {
@@ -1501,6 +1209,7 @@ extern "C" int vfn_bank_scan(const vfn_bankscan_desc* d, void* stream) {
     if (d->nsplit < 1 || d->HW < 1 || d->obj_n < 1 || d->ldq % 4) return VFN_ERR_ARG;
     if (d->mode == 1 && (!d->rowscale || d->stride_rs % 4)) return VFN_ERR_ARG;
     if (d->precision < 0 || d->precision > 2) return VFN_ERR_ARG;
+    if (d->scores && (d->mode != 0 || !scores_fit(d->stride_scores, d->stride_k, d->HW))) return VFN_ERR_ARG;
     static bool once = false;
     if (!once) {
         allow_lds(bank_scan_kernel<0, 0>, SCAN_LDS); allow_lds(bank_scan_kernel<1, 0>, SCAN_LDS);
@@ -1545,14 +1254,8 @@ extern "C" int vfn_memread_apply(const vfn_memread_desc* d, void* stream) {
     if (!d || !d->q || !d->bank_k || !d->bank_v || !d->bank_len || !d->ml || !d->o_part) return VFN_ERR_ARG;
     if (d->nsplit < 1 || d->ldq % 4) return VFN_ERR_ARG;
     if (d->precision < 0 || d->precision > 2) return VFN_ERR_ARG;
-    static bool once = false;
-    if (!once) {
-        allow_lds(memread_apply_kernel, APPLY_LDS);
-        allow_lds(memread_apply_lp_kernel<false>, APPLY_LDS);
-        allow_lds(memread_apply_lp_kernel<true>, APPLY_LDS);
-        once = true;
-    }
-    if (d->precision == 0 && d->wide) {
+    if (d->scores && !scores_fit(d->stride_scores, d->stride_k, d->HW)) return VFN_ERR_ARG;
+    if (d->precision == 0) {
         static bool once_f = false;
         constexpr size_t LDS_WF = (size_t)(QTW * DK + CH * DK + QTW * CH) * sizeof(float);       // 128 KB
         if (!once_f) { allow_lds(memread_apply_wide_kernel, LDS_WF); once_f = true; }
@@ -1561,7 +1264,7 @@ extern "C" int vfn_memread_apply(const vfn_memread_desc* d, void* stream) {
         else hipLaunchKernelGGL(memread_apply_wide_kernel, gridw, dim3(512), LDS_WF, (hipStream_t)stream, *d);
         return vfn_check_launch();
     }
-    if (d->precision != 0 && d->wide) {
+    {
         static bool once_w = false;
         constexpr size_t LDS_W1 = (size_t)QTW * DK * 2 + (size_t)CH * DK * 4 + 2 * (size_t)QTW * CH * 2;         // 80 KB
         constexpr size_t LDS_W2 = LDS_W1 + (size_t)QTW * DK * 2;                                                // 112 KB + 16
@@ -1571,20 +1274,14 @@ extern "C" int vfn_memread_apply(const vfn_memread_desc* d, void* stream) {
         // than the f32 rows rounded in registers (9.9 vs 8.9 ms at 1.2M entries)
         if (d->bank_k_lp && d->bank_v_lp && d->precision == 2) {
             static bool once_s = false;
-            if (!once_s) { allow_lds(memread_apply_shw_kernel<false>, LDS_W1); allow_lds(memread_apply_shw_kernel<true>, LDS_W2); once_s = true; }
-            if (d->precision == 1) hipLaunchKernelGGL(memread_apply_shw_kernel<false>, gridw, dim3(512), LDS_W1, (hipStream_t)stream, *d);
-            else hipLaunchKernelGGL(memread_apply_shw_kernel<true>, gridw, dim3(512), LDS_W2, (hipStream_t)stream, *d);
+            if (!once_s) { allow_lds(memread_apply_shw_kernel<true>, LDS_W2); once_s = true; }
+            hipLaunchKernelGGL(memread_apply_shw_kernel<true>, gridw, dim3(512), LDS_W2, (hipStream_t)stream, *d);
             return vfn_check_launch();
         }
         if (d->precision == 1) hipLaunchKernelGGL(memread_apply_lpw_kernel<false>, gridw, dim3(512), LDS_W1, (hipStream_t)stream, *d);
         else hipLaunchKernelGGL(memread_apply_lpw_kernel<true>, gridw, dim3(512), LDS_W2, (hipStream_t)stream, *d);
         return vfn_check_launch();
     }
-    const dim3 grid(cdiv(d->HW, QT) * d->nsplit, d->obj_n);
-    if (d->precision == 0) hipLaunchKernelGGL(memread_apply_kernel, grid, dim3(256), APPLY_LDS, (hipStream_t)stream, *d);
-    else if (d->precision == 1) hipLaunchKernelGGL(memread_apply_lp_kernel<false>, grid, dim3(256), APPLY_LDS, (hipStream_t)stream, *d);
-    else hipLaunchKernelGGL(memread_apply_lp_kernel<true>, grid, dim3(256), APPLY_LDS, (hipStream_t)stream, *d);
-    return vfn_check_launch();
 }
 
 extern "C" int vfn_memread_finish(const vfn_memread_desc* d, void* stream) {

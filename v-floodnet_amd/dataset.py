@@ -72,26 +72,23 @@ class Video_DS(data.Dataset):
         path = self.img_list[idx]
         img_name = os.path.basename(path)[:-4]
         if self.decode == 'device':
-            if path.lower().endswith(('.jpg', '.jpeg')):
-                from . import jpeg_device
-                with open(path, 'rb') as f:
-                    data_ = f.read()
-                try:
+            # Dispatch on the file's magic bytes, not its extension (PIL sniffs content too: a PNG saved as .jpg works in
+            # the reference, Water_DS.py:105-109), and hand ANY host-side decode failure to PIL -- the reference's decoder
+            # decides whether the file is really bad (it tolerates some truncated / odd files) and raises its own error.
+            import zlib
+            with open(path, 'rb') as f:
+                data_ = f.read()
+            try:
+                if data_[:2] == b'\xff\xd8':
+                    from . import jpeg_device
                     coef, qt, info = jpeg_device.entropy_decode(data_)
                     return {'jpeg': (torch.from_numpy(coef), torch.from_numpy(qt.astype(np.int16)), torch.from_numpy(info))}, img_name
-                except RuntimeError as e:
-                    if 'unsupported' not in str(e):
-                        raise
-            elif path.lower().endswith('.png'):
-                from . import png_decode
-                with open(path, 'rb') as f:
-                    data_ = f.read()
-                try:
+                if data_[:8] == b'\x89PNG\r\n\x1a\n':
+                    from . import png_decode
                     filtered, info, pal = png_decode.inflate(data_)
                     return {'png': (torch.from_numpy(filtered), torch.from_numpy(info), torch.from_numpy(pal))}, img_name
-                except RuntimeError as e:
-                    if 'unsupported' not in str(e):
-                        raise
+            except (RuntimeError, zlib.error, ValueError):
+                pass
             return {'u8': torch.from_numpy(np.array(load_image_in_PIL(path, 'RGB'), np.uint8))}, img_name
         img = load_image_in_PIL(path, 'RGB')
         frame = torch.from_numpy(np.array(img, np.uint8)) if self.raw_u8 else to_tensor(img)

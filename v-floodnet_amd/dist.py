@@ -9,6 +9,10 @@ its ``uint8[clips_per_rank, T, H, W]`` label block to a single ``all_gather`` (b
 ``bench.py --gpus N`` then runs N independent replicas.
 """
 import os
+import socket
+import subprocess
+import sys
+import time
 
 import torch
 import torch.distributed as dist
@@ -30,6 +34,92 @@ def init(backend=None):
             torch.cuda.set_device(local_rank)
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
     return rank, local_rank, world
+
+
+def free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def host_threads_per_rank(local_world):
+    """Host threads a rank may use when ``local_world`` ranks share the machine (>= 1, <= 16: more never helped the
+    CPU-side work of this path, and an idle OpenMP pool spinning on every core starves the launch threads)."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        n = os.cpu_count() or 1
+    return max(1, min(16, n // max(1, local_world)))
+
+
+def pin_rank_threads(local_rank, local_world):
+    """Give this rank its own contiguous slice of the CPUs the process may run on and cap its thread pools to it.
+    Call before anything touches the GPU or spawns threads (DataLoader workers and PNG writer threads inherit the mask).
+    Returns the CPU set (empty = affinity not available / left alone).  VFN_NO_PIN=1 switches it off."""
+    if local_world <= 1 or os.environ.get('VFN_NO_PIN') == '1':
+        return set()
+    try:
+        cpus = sorted(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        return set()
+    per = len(cpus) // local_world
+    if per < 1:
+        return set()
+    mine = set(cpus[local_rank * per:(local_rank + 1) * per])
+    try:
+        os.sched_setaffinity(0, mine)
+    except OSError:
+        return set()
+    n = str(max(1, min(16, per)))
+    for var in ('OMP_NUM_THREADS', 'MKL_NUM_THREADS', 'OPENBLAS_NUM_THREADS'):
+        os.environ[var] = n
+    torch.set_num_threads(int(n))
+    return mine
+
+
+def spawn_ranks(argv, n, poll_s=0.1, extra_env=None):
+    """Start ``n`` ranks of ``argv`` (a full command line) as CHILD processes of a parent that never touches the GPU
+    (no exec of an initialised process), one per device; wait for all of them.  The first rank that exits non-zero
+    takes the others down with it (exact PIDs we started) -- otherwise the survivors would sit in a barrier or in
+    ``init_process_group`` until the collective timeout.  Returns the first non-zero exit code, or 0."""
+    port = free_port()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ)
+        env.update(RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+        env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        env.setdefault('OMP_NUM_THREADS', str(host_threads_per_rank(n)))
+        if extra_env:
+            env.update(extra_env)
+        procs.append(subprocess.Popen(list(argv), env=env))
+    rc = 0
+    try:
+        live = list(procs)
+        while live and rc == 0:
+            for p in list(live):
+                code = p.poll()
+                if code is not None:
+                    live.remove(p)
+                    if code != 0:
+                        rc = code
+                        break
+            if live and rc == 0:
+                time.sleep(poll_s)
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.terminate()
+        deadline = time.time() + 10
+        for p in procs:
+            try:
+                p.wait(timeout=max(0.1, deadline - time.time()))
+            except subprocess.TimeoutExpired:
+                p.kill()
+                p.wait()
+    return rc
 
 
 def clips_of_rank(n_clips, rank, world):
@@ -82,3 +172,29 @@ def run_sharded(run_one_clip, n_clips, rank, world, device):
     if local is None:
         local = torch.zeros(0, *[int(x) for x in shape], dtype=torch.uint8, device=device)
     return gather_masks(local, n_clips, rank, world)
+
+
+def gather_ragged(local_labels, n_clips, rank, world, device):
+    """Clips of different length / frame size (a benchmark directory): ``local_labels`` = list of uint8 [T_c,H_c,W_c] for
+    ``clips_of_rank``.  The shapes travel first (3 integers per clip), every block is padded to the largest clip and the
+    masks then cross in the ONE all-gather of ``gather_masks``.  Returns the list of uint8 [T_c,H_c,W_c] in clip order."""
+    per = clips_per_rank(n_clips, world)
+    shp = torch.zeros(per, 3, dtype=torch.int64, device=device)
+    for i, l in enumerate(local_labels):
+        shp[i] = torch.tensor(l.shape, dtype=torch.int64)
+    if world > 1:
+        parts = [torch.empty_like(shp) for _ in range(world)]
+        dist.all_gather(parts, shp)
+        shapes = torch.stack(parts, 0).cpu()
+    else:
+        shapes = shp.unsqueeze(0).cpu()
+    T, H, W = (int(shapes[..., k].max()) for k in range(3))
+    block = torch.zeros(len(local_labels), T, H, W, dtype=torch.uint8, device=device)
+    for i, l in enumerate(local_labels):
+        block[i, :l.shape[0], :l.shape[1], :l.shape[2]] = l.to(device)
+    allm = gather_masks(block, n_clips, rank, world)
+    out = []
+    for c in range(n_clips):
+        t, h, w = (int(v) for v in shapes[c % world, c // world])
+        out.append(allm[c, :t, :h, :w])
+    return out

@@ -72,7 +72,6 @@ def pad_divide_by(h, w, d=16):
     return (lw, uw, lh, uh), new_h, new_w
 
 
-WIDE_APPLY_FROM = 0                 # bank entries / object from which the 128-query-wide apply kernels are used
 WS_FLOATS = 16 * 1024 * 1024        # split-K workspace (64 MB), shared by all launches of a plan
 _INLAUNCH_SPLITK = __import__('os').environ.get('VFN_INLAUNCH_SPLITK') == '1'
 
@@ -103,11 +102,8 @@ def apply_choice(desc, choice, ws, counters=None):
 
 
 def _scores_buffer(p, fb):
-    """[obj][ceil(cap/64) * ceil(HW/128) * 8192] floats for the scores of one frame, or None when switched off / too large
-    / the 64-query apply kernels are selected."""
-    if os.environ.get('VFN_STORE_SCORES', '1') == '0' or os.environ.get('VFN_WIDE_APPLY') == '0':
-        return None
-    if fb.len_upper() < WIDE_APPLY_FROM:
+    """[obj][ceil(cap/64) * ceil(HW/128) * 8192] floats for the scores of one frame, or None when switched off / too large."""
+    if os.environ.get('VFN_STORE_SCORES', '1') == '0':
         return None
     per_obj = ((fb._cap + 63) // 64) * ((p.HW + 127) // 128) * 8192
     if fb.obj_n * per_obj * 4 > float(os.environ.get('VFN_SCORES_MAX_GB', 48)) * 2 ** 30:
@@ -575,7 +571,6 @@ class Engine:
         L = _lib.lib()
         s = stream()
         K, HW, cap = fb.obj_n, p.HW, fb._cap
-        nsplit = pick_nsplit(HW, K, fb.len_upper())
         nsplit_scan = pick_scan_slices(HW, K, fb.len_upper())
         scale = 1.0 / math.sqrt(DK)
         d = BankScanDesc()
@@ -604,18 +599,13 @@ class Engine:
         m.info, m.out = ptr(fb._ibuf), ptr(p.dec_in)
         m.stride_k, m.stride_v, m.stride_cnt, m.stride_info = cap * DK, cap * DV, cap, cap * 2
         m.scale, m.thres = scale, 1e-3
-        m.ldq, m.ldqv, m.ld_out, m.HW, m.obj_n, m.nsplit = DK + DV, DK + DV, p.dec_in.shape[-1], HW, K, nsplit
+        m.ldq, m.ldqv, m.ld_out, m.HW, m.obj_n = DK + DV, DK + DV, p.dec_in.shape[-1], HW, K
         m.precision = self.mode
-        # 128 query columns per workgroup (8 waves): keys / values are streamed half as often, one barrier pair per 128
-        # queries and -- in the reduced-precision modes -- a value row is converted once per 128 queries.  Measured
-        # faster at every bank size in every mode (f32: -8 % at 56 k entries); VFN_WIDE_APPLY=0 selects the 64-query kernels
-        wide = os.environ.get('VFN_WIDE_APPLY')
-        m.wide = int(wide == '1' or (wide is None and fb.len_upper() >= WIDE_APPLY_FROM))
-        if m.wide:
-            m.nsplit = pick_nsplit(HW, K, fb.len_upper(), QT_SCAN, MAX_SPLIT)
-        if m.wide and klp is not None:
+        # 128 query columns per workgroup (8 waves)
+        m.nsplit = pick_nsplit(HW, K, fb.len_upper(), QT_SCAN, MAX_SPLIT)
+        if klp is not None:
             m.bank_k_lp, m.bank_v_lp = ptr(klp), ptr(vlp)
-        if m.wide and scores is not None:
+        if scores is not None:
             m.scores, m.stride_scores = ptr(scores), scores.shape[1]
         check(L.vfn_memread_apply(_lib.C.byref(m), s), 'vfn_memread_apply')
         check(L.vfn_memread_finish(_lib.C.byref(m), s), 'vfn_memread_finish')

@@ -82,6 +82,8 @@ class FeatureBank:
         self._hw = 0
         self._len_host = None        # exact lengths after the last sync
         self._len_upper = None       # upper bound valid without a sync
+        self._n_updates = 0
+        self._hist = {}
         self._dirty = False
         self._kbuf = self._vbuf = self._ibuf = None
         self._scratch = None
@@ -177,6 +179,9 @@ class FeatureBank:
         st = stats_host.numpy()
         self._len_host = [int(st[i, 0]) for i in range(self.obj_n)]
         self._len_upper = [min(n + in_flight * self._hw, self._cap) for n in self._len_host]
+        self._hist[self._n_updates - in_flight] = list(self._len_host)
+        for k in [k for k in self._hist if k < self._n_updates - 2]:
+            del self._hist[k]
         for i in range(self.obj_n):
             self.peak_n[i] = max(self.peak_n[i], float(st[i, 1]))
             self.replace_n[i] = float(st[i, 2])
@@ -194,6 +199,19 @@ class FeatureBank:
         return self._stats
 
     def len_upper(self):
+        """Upper bound of the bank lengths that is valid without a synchronisation.  The kernels read the true lengths
+        from device memory; this bound only sizes grids and picks the bank slicing of the scans / the memory read.
+        The slicing fixes the order in which partial sums meet, so the bound is made a function of the UPDATE HISTORY
+        alone, not of how far the host has got with its bookkeeping: with U updates enqueued it is (lengths after update
+        U-1) + HW -- known both to a sequential loop (which has absorbed update U) and to a pipelined one (which has
+        absorbed update U-1 while update U is in flight).  ``ClipRunner.step`` and ``launch`` / ``collect`` therefore
+        slice alike and give bit-identical results.  (Anything deeper in flight falls back to the safe running bound.)"""
+        u = self._n_updates
+        if u == 0 and 0 in self._hist:
+            return max(self._hist[0])
+        prev = self._hist.get(u - 1)
+        if prev is not None:
+            return min(max(prev) + self._hw, self._cap)
         return max(self._len_upper)
 
     # ------------------------------------------------------------------ reference attributes
@@ -258,6 +276,8 @@ class FeatureBank:
     def _set_lengths(self, lens):
         self._len_host = list(lens)
         self._len_upper = list(lens)
+        self._n_updates = 0                  # updates enqueued since the lengths were last set from the host
+        self._hist = {0: list(lens)}         # update count -> exact lengths after that update (the last three)
         for i in range(self.obj_n):
             self.peak_n[i] = max(self.peak_n[i], lens[i])
         st = torch.zeros(self.obj_n, 4, dtype=torch.int32)
@@ -386,6 +406,7 @@ class FeatureBank:
 
         self._dirty = True
         self._len_upper = [min(n + hw, cap) for n in self._len_upper]
+        self._n_updates += 1
 
     def remove(self, class_idx, request_n, frame_idx):
         """FeatureBank.py:117-143: LFU eviction of one object until ``class_budget - bank_n - request_n >= 0``;

@@ -53,7 +53,7 @@ def to_tensor(coef, qt, info, device, out=None, want_u8=False):
     planes, off = [], 0
     for c in range(ncomp):
         bpr, brows = int(info[9 + 4 * c]), int(info[10 + 4 * c])
-        key = (str(device), c, bpr, brows)
+        key = (str(device), c, bpr, brows, torch.cuda.current_stream().cuda_stream)   # per stream (see png_decode)
         if key not in _plane_cache:
             _plane_cache[key] = torch.empty(brows * 8, bpr * 8, dtype=torch.uint8, device=device)
         pl = _plane_cache[key]

@@ -150,10 +150,6 @@ def valid_splits(desc, max_split=16, mode=0):
     return out
 
 
-def conv_cout2_launch(desc):
-    check(_lib.lib().vfn_conv3x3_cout2_f32(C.byref(desc), stream()), 'vfn_conv3x3_cout2_f32')
-
-
 # arithmetic of the matrix kernels: 0 exact f32, 1 bf16 operands, 2 bf16x3 (hi/lo split operands, 3 MFMAs per product)
 MODES = {'fp32': 0, 'bf16': 1, 'bf16x3': 2}
 _CONV_FN = ('vfn_conv2d_nhwc_f32', 'vfn_conv2d_nhwc_bf16', 'vfn_conv2d_nhwc_bf16x3')

@@ -48,7 +48,12 @@ def inflate(data):
     raw = zlib.decompress(b''.join(idat))
     if len(raw) != H * (1 + W * bpp):
         raise RuntimeError('corrupt PNG data (inflated size does not match the header)')
-    return np.frombuffer(raw, np.uint8).copy(), np.array([W, H, ctype, bpp], np.int32), pal
+    out = np.frombuffer(raw, np.uint8).copy()
+    # the filter-type byte of every scanline, checked here -- at this frame, in the worker, before anything is segmented or
+    # memorised (PIL raises at the frame too); the device kernel keeps its own flag (check_status) as a second line
+    if int(out.reshape(H, 1 + W * bpp)[:, 0].max()) > 4:
+        raise RuntimeError('corrupt PNG data (scanline filter type outside 0..4)')
+    return out, np.array([W, H, ctype, bpp], np.int32), pal
 
 
 _work_cache = {}
@@ -62,7 +67,7 @@ def to_tensor(filtered, info, palette, device, want_u8=False):
     pitch, wb = _lib.C.c_int(), _lib.C.c_longlong()
     check(L.vfn_png_unfilter_sizes(W, H, bpp, _lib.C.byref(pitch), _lib.C.byref(wb)), 'vfn_png_unfilter_sizes')
     f_d = torch.as_tensor(filtered).to(device=device, dtype=torch.uint8, non_blocking=True).reshape(-1)
-    key = (str(device), W, H, bpp)
+    key = (str(device), W, H, bpp, torch.cuda.current_stream().cuda_stream)    # per stream: concurrent decodes do not share
     if key not in _work_cache:
         _work_cache[key] = (torch.empty(wb.value, dtype=torch.uint8, device=device),
                             torch.empty(H * pitch.value, dtype=torch.uint8, device=device),

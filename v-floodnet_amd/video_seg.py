@@ -272,6 +272,7 @@ def main(args, device):
     ori_first_mask = seq_dataset.first_mask.unsqueeze(0).to(device)
 
     pred = seq_dataset.first_mask.numpy().argmax(0).astype(np.uint8)          # :91
+    keep = [torch.from_numpy(pred).to(device)] if getattr(args, 'keep_labels', False) else None   # (batch_video_seg: mask gather)
     seg_path = os.path.join(seg_dir, f'{first_name}.png')
     save_seg_mask(pred, seg_path, color_palette)
     if args.viz:
@@ -358,6 +359,8 @@ def main(args, device):
             buf = runner.launch(cur_dev, next_frame=nxt_dev, want_label=False)   # postprocessing_pred (:116) runs on the GPU
             t2 = time.perf_counter()
             name = cur[1]
+            if keep is not None:
+                keep.append(runner.label_device().clone())
             buf['reader_done'] = sink.save(runner.label_device(), os.path.join(seg_dir, f'{name}.png'), color_palette,
                                            frame=cur_dev[0] if args.viz else None,
                                            overlay_path=os.path.join(overlay_dir, f'{name}.png') if args.viz else None)
@@ -374,11 +377,12 @@ def main(args, device):
                   % tuple(1e3 * v / prof[4] for v in prof[:4]))
         while runner._pending:
             runner.collect()
-        if not png_decode.check_status(device):          # a filter-type byte outside 0..4 in some PNG frame (PIL raises there too)
+        if not png_decode.check_status(device):          # second line of defence: png_decode.inflate rejects such a frame itself
             raise RuntimeError('corrupt PNG frame data (invalid scanline filter type) in ' + args.test_path)
     writer.close()
 
     runner.fb.print_peak_mem()
+    runner.kept_labels = torch.stack(keep, 0) if keep is not None else None    # uint8 [T,H0,W0] on the device, frame 0 = given mask
     return runner
 
 
