@@ -60,7 +60,10 @@ def test_c3_720p_every_5th_reduced_precision(gpu, sd, c3_oracle, precision):
         # plain bf16 operands: 2^-9 relative noise per product against logits without margin (synthetic weights):
         # several per cent of the pixels flip.  Asserted at what it reaches, not at the parity bar.
         # Measured: 0.94 on the first frame, 0.63-0.75 once its own masks have been memorised (frames 5, 10).
-        assert ious[0] >= 0.90 and min(ious) >= 0.55, ious
+        # The first frame (the bank still holds the given mask only) is asserted tightly so that a regression of the bf16
+        # kernels is visible; the later floor is what the closed loop on margin-free weights reaches, not a parity claim.
+        print('C3 bf16 per-frame mIoU: ' + ' '.join(f'{x:.4f}' for x in ious))
+        assert ious[0] >= 0.93 and min(ious) >= 0.55, ious
         drift = max(abs(a - b) for x, y in zip(out['bank_sizes'], ref['bank_sizes']) for a, b in zip(x, y))
         assert drift <= 0.05 * max(ref['bank_sizes'][-1])
 

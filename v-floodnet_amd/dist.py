@@ -179,7 +179,8 @@ def gather_ragged(local_labels, n_clips, rank, world, device):
     ``clips_of_rank``.  The shapes travel first (3 integers per clip), every block is padded to the largest clip and the
     masks then cross in the ONE all-gather of ``gather_masks``.  Returns the list of uint8 [T_c,H_c,W_c] in clip order."""
     per = clips_per_rank(n_clips, world)
-    shp = torch.zeros(per, 3, dtype=torch.int64, device=device)
+    # (gloo gathers host tensors only; RCCL device tensors only)
+    shp = torch.zeros(per, 3, dtype=torch.int64, device=device if (world > 1 and dist.get_backend() == 'nccl') else 'cpu')
     for i, l in enumerate(local_labels):
         shp[i] = torch.tensor(l.shape, dtype=torch.int64)
     if world > 1:
