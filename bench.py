@@ -271,13 +271,13 @@ def main(argv=None):
         return rc
     L_.vfn_memread_apply = timed_apply
 
-    def timed_memread(self_, p_, fb_, update_bank_):
+    def timed_memread(self_, p_, fb_, update_bank_, kv_q_=None):
         if not timer.active:
-            return orig_memread(self_, p_, fb_, update_bank_)
+            return orig_memread(self_, p_, fb_, update_bank_, kv_q_)
         cur_mem.update(entries=sum(fb_._len_host), HW=p_.HW)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        orig_memread(self_, p_, fb_, update_bank_)
+        orig_memread(self_, p_, fb_, update_bank_, kv_q_)
         e1.record()
         mem_records.append((sum(fb_._len_host), p_.HW, e0, e1))
     Engine._memory_read = timed_memread
@@ -285,7 +285,7 @@ def main(argv=None):
     Hn, Wn = resized_hw(H0, W0, net_size)            # reference semantics: the network always sees the 480p frame
     eng.autotune(Hn, Wn, 2, only_missing=not args.autotune)      # the shipped tables cover C2 / C3 / C5 at reference semantics
     plan = eng.plan(Hn, Wn, 2)
-    for lst in (plan.seg_pre, plan.seg_post, plan.mem):
+    for lst in plan.all_lists():
         for l in lst:
             if l.fn is timer.orig:
                 l.fn = timed_launch
@@ -336,12 +336,19 @@ def main(argv=None):
         last_collect[0] = time.perf_counter()
         for t in range(t_from, t_to + 1):
             idx = frame_of(t)
-            timer.active = sampling and ((t - s_first + 1) % args.sample_every == 0)
-            # no prefetch into / out of a sampled frame: its kernels are timed alone on the device
-            sampled_next = sampling and ((t - s_first + 2) % args.sample_every == 0)
-            nxt = frame_of(t + 1) if (t < max(last_iter, t_to) and not args.no_overlap and not timer.active and not sampled_next) else None
+            # no prefetch into / out of a sampled frame: its kernels are timed alone on the device.  Otherwise the query
+            # side looks up to three frames ahead (two frames per batched pass, ClipRunner._look_ahead)
+            def is_sampled(u):
+                return s_first <= u <= s_first + K - 1 and ((u - s_first + 1) % args.sample_every == 0)
+            timer.active = sampling and is_sampled(t)
+            nxt = []
+            if not args.no_overlap and not timer.active:
+                for u in range(t + 1, min(max(last_iter, t_to), t + 3) + 1):
+                    if is_sampled(u):
+                        break
+                    nxt.append(frames[frame_of(u):frame_of(u) + 1])
             # want_label: the frame's label map goes to pinned host memory (the reference's .cpu(), test_video_seg.py:115)
-            runner.launch(frames[idx:idx + 1], next_frame=frames[nxt:nxt + 1] if nxt is not None else None, want_label=True)
+            runner.launch(frames[idx:idx + 1], next_frames=nxt, want_label=True)
             timer.active = False
             if t < n_lab:                            # device-side copies for the parity checks after the run
                 labels[t].copy_(runner.label_device(), non_blocking=True)

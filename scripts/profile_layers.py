@@ -23,8 +23,10 @@ tiles = ops.conv_cfg_tiles()
 reps = 5
 tot = {}
 rows = []
-for lname in ('seg_pre', 'seg_post', 'mem'):
-    for l in getattr(p, lname):
+eng.autotune(H0, W0, 2, only_missing=True)
+lists = {'seg_pre': p.seg_pre, 'seg_post': p.seg_post, 'mem': p.mem, 'seg_pre_x2': p.qsets[0].pre[2]}
+for lname, lst in lists.items():
+    for l in lst:
         l(); torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
@@ -33,11 +35,22 @@ for lname in ('seg_pre', 'seg_post', 'mem'):
         us = e0.elapsed_time(e1) * 1e3 / reps
         cfg = ''
         if l.fn is ops.conv2d_launch:
-            cfg = '%dx%d' % tiles[l.args[1]]
+            cfg = '%dx%d' % tiles[l.args[1]] + ('/k%d' % l.args[0].ksplit if l.args[0].ksplit > 1 else '') + ('/wk%d' % ops.conv_cfg_wk(l.args[1]) if ops.conv_cfg_wk(l.args[1]) > 1 else '')
         tf = l.flops / us / 1e6 if l.flops else 0
         rows.append((lname, l.name, cfg, us, tf))
         t = tot.setdefault(lname, [0.0, 0.0]); t[0] += us; t[1] += l.flops
 for r in rows:
-    print('%-8s %-48s %-8s %8.1f us %7.1f TF' % r)
+    print('%-10s %-48s %-12s %8.1f us %7.1f TF' % r)
 for k_, (us, fl) in tot.items():
     print(k_, 'total %.1f us, %.1f GFLOP, %.1f TF' % (us, fl / 1e9, fl / us / 1e6 if us else 0))
+
+# whole lists back to back (as a frame runs them): the per-launch table above repeats each launch in isolation
+for lname, lst in lists.items():
+    for l in lst: l()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        for l in lst: l()
+    e1.record(); torch.cuda.synchronize()
+    print(lname, 'list back to back: %.1f us' % (e0.elapsed_time(e1) * 1e3 / reps))

@@ -334,19 +334,29 @@ def test_native_resolution_step(gpu, sd, model, H, W):
 def test_run_to_run_determinism(gpu, sd, model):
     """Two runs of the same clip give bit-identical labels and bank contents: split-K slabs are reduced in slice
     order, merges are summed in ascending source order, hit counts are integer atomics, the CCL root is the smallest
-    pixel index (torch_scatter's CUDA scatter_mean, by contrast, sums with float atomics)."""
+    pixel index (torch_scatter's CUDA scatter_mean, by contrast, sums with float atomics).  The look-ahead of the query
+    side changes only WHICH tile shape / K split a convolution runs with (a batch of two frames has twice the rows), i.e.
+    the summation order inside split-K layers: against a run without look-ahead the labels agree to mIoU >= 0.9999."""
     from tools import synth
     from vfloodnet_amd.video_seg import run_clip
     frames, m0 = synth.clip(9, 10, 240, 426)
     fr = frames.to(gpu)
     a = run_clip(model, fr, m0, size=240, budget=6000, postprocess=True)
-    b = run_clip(model, fr, m0, size=240, budget=6000, postprocess=True, overlap=False)
+    b = run_clip(model, fr, m0, size=240, budget=6000, postprocess=True)
     assert torch.equal(a['labels'], b['labels'])
     assert a['bank_sizes'] == b['bank_sizes']
     for i in range(2):
         assert torch.equal(a['fb'].keys[i], b['fb'].keys[i])
         assert torch.equal(a['fb'].values[i], b['fb'].values[i])
         assert torch.equal(a['fb'].info[i], b['fb'].info[i])
+    c = run_clip(model, fr, m0, size=240, budget=6000, postprocess=True, overlap=False)
+    d = run_clip(model, fr, m0, size=240, budget=6000, postprocess=True, overlap=False)
+    assert torch.equal(c['labels'], d['labels']) and c['bank_sizes'] == d['bank_sizes']
+    for t in range(1, 10):
+        la, lc = a['labels'][t], c['labels'][t]
+        inter = [((la == k) & (lc == k)).sum().item() / max(1, ((la == k) | (lc == k)).sum().item()) for k in (0, 1)]
+        assert min(inter) >= 0.9999, (t, inter)
+    assert max(abs(x - y) for s1, s2 in zip(a['bank_sizes'], c['bank_sizes']) for x, y in zip(s1, s2)) <= 2
 
 
 def test_bank_update_large_native_hw(gpu):

@@ -147,11 +147,11 @@ def test_sequential_and_pipelined_loop_are_bit_identical(gpu, sd):
         labs, sizes = [], []
         if mode == 'step':
             for t in range(1, T):
-                labs.append(torch.from_numpy(r.step(frames[t:t + 1], next_frame=frames[t + 1:t + 2] if t + 1 < T else None).numpy().copy()))
+                labs.append(torch.from_numpy(r.step(frames[t:t + 1], next_frames=[frames[u:u + 1] for u in range(t + 1, min(T, t + 4))]).numpy().copy()))
                 sizes.append(r.bank_sizes())
         else:
             for t in range(1, T):
-                r.launch(frames[t:t + 1], next_frame=frames[t + 1:t + 2] if t + 1 < T else None)
+                r.launch(frames[t:t + 1], next_frames=[frames[u:u + 1] for u in range(t + 1, min(T, t + 4))])
                 if len(r._pending) == 2:
                     labs.append(torch.from_numpy(r.collect().numpy().copy()))
                     sizes.append(r.bank_sizes())

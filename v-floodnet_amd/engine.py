@@ -110,7 +110,7 @@ def _scores_buffer(p, fb):
         return None
     key = (fb.obj_n, per_obj)
     if getattr(p, '_scores_key', None) != key:
-        p._scores = torch.empty(fb.obj_n, per_obj, device=p.kv_q.device)
+        p._scores = torch.empty(fb.obj_n, per_obj, device=p.dec_in.device)
         p._scores_key = key
     return p._scores
 
@@ -228,13 +228,10 @@ class FramePlan:
         self.HW = self.h16 * self.w16
         f = lambda *s: torch.empty(*s, device=dev, dtype=torch.float32)
         K = obj_n
-        # inputs are bound per call (pointers patched into the stem descriptors)
         self.frame_in = f(3, H0, W0)          # memorize() input
-        self.frame_q = f(3, H0, W0)           # segment() input (own buffer: the query encoder of frame t+1 may
-        self.mask_in = f(K, H0, W0)           #  run on a side stream while memorize() works on frame t)
-        # query encoder
-        self.q = self._trunk_buffers(1)
-        self.kv_q = f(1, self.HW, DK + DV)
+        self.mask_in = f(K, H0, W0)
+        # query side: two sets of frame-only state, two frames (slots) each -- see QuerySet
+        self.qsets = [QuerySet(self), QuerySet(self)]
         # memory encoder
         self.m = self._trunk_buffers(K)
         self.kv_m = f(K, self.HW, DK + DV)
@@ -244,12 +241,10 @@ class FramePlan:
         self.work = torch.zeros(4, dtype=torch.int32, device=dev)       # queue head of the persistent scan kernel
         self.o_part = f(K, MAX_SPLIT, self.HW, DV)
         self.dec_in = f(K, self.h16, self.w16, DV)          # memory read-out only; the query-value half of
-        self.fm_q = f(1, self.h16, self.w16, 256)            # cat([mem, q_out]) goes through its own conv (fm_q)
+                                                            # cat([mem, q_out]) goes through its own conv (QuerySet.fm_q)
         # decoder
         self.d16 = [f(K, self.h16, self.w16, 256) for _ in range(3)]
-        self.s8 = [f(1, self.h8, self.w8, 256) for _ in range(3)]
         self.d8 = [f(K, self.h8, self.w8, 256) for _ in range(3)]
-        self.s4 = [f(1, self.h4, self.w4, 256) for _ in range(3)]
         self.d4 = [f(K, self.h4, self.w4, 256) for _ in range(3)]
         self.pp = f(K, self.h4, self.w4, 2)
         self.z4 = f(K, self.h4, self.w4, Pred2Layer.TAPS)     # tap products of pred2 / local_pred2
@@ -262,7 +257,6 @@ class FramePlan:
         self.hr = None if fused_ok else f(K, self.h2, self.w2)
         self.hm = None if fused_ok else f(K, self.h2, self.w2)
         self.lm = f(K, self.h2, self.w2, 64)                 # r1_local
-        self.lq = f(1, self.h2, self.w2, 32)                 # local_convFM over the shared r1 half
         self.conf = f(K, self.h2, self.w2)
         self.l2 = [f(K, self.h2, self.w2, 32) for _ in range(3)]
         self.qq = f(K, self.h2, self.w2, 2)
@@ -273,10 +267,28 @@ class FramePlan:
         self.cnt_q = torch.zeros(4096, dtype=torch.int32, device=dev)
         self._ws_cur, self._cnt_cur = self.ws, self.cnt
 
-        self.seg_pre = []     # stem .. KeyValue
-        self.seg_post = []    # decoder
         self.mem = []         # memorize
         self._build()
+
+    # (single-frame views kept for tools and tests: slot 0 of set 0)
+    @property
+    def seg_pre(self):
+        return self.qsets[0].pre[1]
+
+    @property
+    def seg_post(self):
+        return self.qsets[0].post[0]
+
+    @property
+    def kv_q(self):
+        return self.qsets[0].kv_q[0:1]
+
+    def all_lists(self):
+        """Every launch list of the plan (autotune, bench instrumentation)."""
+        out = [self.mem]
+        for qs in self.qsets:
+            out += [qs.pre[1], qs.pre[2], qs.post[0], qs.post[1]]
+        return out
 
     def _trunk_buffers(self, N):
         dev = self.eng.device
@@ -347,56 +359,10 @@ class FramePlan:
     def _build(self):
         e = self.eng
         K = self.obj_n
-        # ---- segment: query encoder + KeyValue
-        self._ws_cur, self._cnt_cur = self.ws_q, self.cnt_q
-        self.stem_q = ops.make_stem_desc(self.frame_q, None, e.stem_q_w, e.stem_q_scale, e.stem_q_shift,
-                                         self.q['r1'], e.mean, e.std, 1, self.H0, self.W0, self.pad, self.Hp, self.Wp)
-        self.seg_pre.append(Launch(ops.stem_launch, (self.stem_q,), 'encoder_q.stem',
-                                   2.0 * self.h2 * self.w2 * 64 * 147))
-        r4 = self._trunk(self.seg_pre, e.enc_q, self.q, 1, 'encoder_q')
-        self._conv(self.seg_pre, e.keyval, r4, self.kv_q, 1, self.h16, self.w16, name='keyval')
-        # ---- decoder work that depends on the frame only (not on the bank): the skip-feature branches of the two
-        # Refine stages (AFB_URR.py:122-127: ResFS(convFS(f)) -- one image, shared by the objects), the query-value
-        # half of convFM and the r1 half of local_convFM.  They ride with the query encoder, i.e. on the side stream
-        # underneath memorize/update of the previous frame when the next frame is known (Engine.prefetch_query).
-        P = self.seg_pre
-        D = e.dec
-        d16, s8, d8, s4, d4 = self.d16, self.s8, self.d8, self.s4, self.d4
-        # convFM(cat([mem_i, q_out])) = convFM[:, :512](mem_i) + convFM[:, 512:](q_out): the second term is the
-        # same for every object (AFB_URR.py:159,176) -> computed once (with the bias) and added as a shared residual
-        kvq_val = self.kv_q[:, :, DK:]                          # [1, HW, 512] view, pixel stride 640
-        self._conv(P, D['convFM_q'], kvq_val, self.fm_q, 1, self.h16, self.w16, name='decoder.convFM.q',
-                   in_ld=DK + DV)
-        self._conv(P, D['RF3']['convFS'], self.q['res3']['out'], s8[0], 1, self.h8, self.w8, name='decoder.RF3.convFS')
-        self._resblock(P, D['RF3']['ResFS'], s8[0], s8[1], s8[2], 1, self.h8, self.w8, 'decoder.RF3.ResFS')
-        self._conv(P, D['RF2']['convFS'], self.q['res2']['out'], s4[0], 1, self.h4, self.w4, name='decoder.RF2.convFS')
-        self._resblock(P, D['RF2']['ResFS'], s4[0], s4[1], s4[2], 1, self.h4, self.w4, 'decoder.RF2.ResFS')
-        # local_convFM(cat([r1, r1_local])): the r1 half is shared by the objects (AFB_URR.py:231-232)
-        self._conv(P, D['local_convFM_r1'], self.q['r1'], self.lq, 1, self.h2, self.w2, name='decoder.local_convFM.r1')
-        self._ws_cur, self._cnt_cur = self.ws, self.cnt
-        # ---- decoder, bank-dependent part
-        L = self.seg_post
-        self._conv(L, D['convFM_m'], self.dec_in, d16[0], K, self.h16, self.w16, res=self.fm_q, res_mod=self.HW,
-                   name='decoder.convFM.mem')
-        self._resblock(L, D['ResMM'], d16[0], d16[1], d16[2], K, self.h16, self.w16, 'decoder.ResMM')
-        L.append(Launch(ops.upsample2x_add, (s8[2], d16[2], d8[0], True), 'decoder.RF3.up_add'))
-        self._resblock(L, D['RF3']['ResMM'], d8[0], d8[1], d8[2], K, self.h8, self.w8, 'decoder.RF3.ResMM')
-        L.append(Launch(ops.upsample2x_add, (s4[2], d8[2], d4[0], True), 'decoder.RF2.up_add'))
-        self._resblock(L, D['RF2']['ResMM'], d4[0], d4[1], d4[2], K, self.h4, self.w4, 'decoder.RF2.ResMM')
-        self._conv(L, D['pred2'], d4[2], self.z4, K, self.h4, self.w4, relu_in=True, name='decoder.pred2.taps')
-        L.append(Launch(ops.pred2_gather, (self.z4, D['pred2'].bias, self.pp), 'decoder.pred2.gather'))
-        L.append(Launch(ops.rough_uncertainty, (self.pp, self.p_up, self.rough, self.unc), 'decoder.rough_unc'))
-        L.append(Launch(ops.local_stats, (self.q['r1'], self.rough, self.hs, self.hr, self.hm, self.lm, self.conf),
-                        'decoder.local_stats'))
-        l2 = self.l2
-        self._conv(L, D['local_convFM_loc'], self.lm, l2[0], K, self.h2, self.w2, res=self.lq,
-                   res_mod=self.h2 * self.w2, name='decoder.local_convFM.local')
-        self._resblock(L, D['local_ResMM'], l2[0], l2[1], l2[2], K, self.h2, self.w2, 'decoder.local_ResMM')
-        self._conv(L, D['local_pred2'], l2[2], self.z2, K, self.h2, self.w2, relu_in=True, name='decoder.local_pred2.taps')
-        L.append(Launch(ops.pred2_gather, (self.z2, D['local_pred2'].bias, self.qq), 'decoder.local_pred2.gather'))
-        L.append(Launch(ops.final_logits, (self.p_up, self.unc, self.conf, self.qq, self.score, self.pad,
-                                           self.H0, self.W0), 'decoder.final_logits'))
+        for qs in self.qsets:
+            qs.build()
         # ---- memorize
+        self._ws_cur, self._cnt_cur = self.ws, self.cnt
         self.stem_m = ops.make_stem_desc(self.frame_in, self.mask_in, e.stem_m_w, e.stem_m_scale, e.stem_m_shift,
                                          self.m['r1'], e.mean, e.std, K, self.H0, self.W0, self.pad, self.Hp, self.Wp)
         self.mem.append(Launch(ops.stem_launch, (self.stem_m,), 'encoder_m.stem',
@@ -406,6 +372,102 @@ class FramePlan:
 
     def conv_flops(self, which):
         return sum(l.flops for l in getattr(self, which))
+
+
+class QuerySet:
+    """Frame-only state of the query side for up to TWO frames (slots 0 / 1 = the batch dimension): query encoder, KeyValue
+    and the decoder branches that depend on the frame alone (AFB_URR.py:122-127: ResFS(convFS(f)); the query-value half of
+    convFM; the r1 half of local_convFM).  None of it depends on the bank, so it is computed ahead of the loop for the NEXT
+    two frames in one pass -- every GEMM sees twice the rows (M) with the same filters -- on a side stream underneath
+    memorize / update of the frames before (Engine.prefetch_begin / prefetch_finish).  Two sets alternate: one is consumed
+    by the decoder while the other is being filled.
+
+    ``pre[n]``: launch list for n frames (n = 1: slot 0 only); ``post[slot]``: the bank-dependent decoder reading slot."""
+
+    def __init__(self, plan):
+        self.plan = plan
+        p = plan
+        f = lambda *s_: torch.empty(*s_, device=p.eng.device, dtype=torch.float32)
+        self.frames = f(2, 3, p.H0, p.W0)
+        self.q = p._trunk_buffers(2)
+        self.kv_q = f(2, p.HW, DK + DV)
+        self.fm_q = f(2, p.h16, p.w16, 256)
+        self.s8 = [f(2, p.h8, p.w8, 256) for _ in range(3)]
+        self.s4 = [f(2, p.h4, p.w4, 256) for _ in range(3)]
+        self.lq = f(2, p.h2, p.w2, 32)                       # local_convFM over the shared r1 half
+        self.pre = {1: [], 2: []}
+        self.post = [[], []]
+        self.split = {1: 0, 2: 0}                           # pre[n][:split[n]] = the first half (by estimated time)
+        # bookkeeping of Engine.prefetch_*: which frames the slots hold
+        self.keys = [None, None]
+        self.consumed = [True, True]
+        self.stage = 0                                      # 0 idle, 1 first half enqueued, 2 complete
+        self.n = 0
+        self.done = None
+
+    @staticmethod
+    def _sl(t, n):
+        return t[0:n]
+
+    def build(self):
+        p, e = self.plan, self.plan.eng
+        K = p.obj_n
+        D = e.dec
+        for n in (1, 2):
+            P = self.pre[n]
+            sl = lambda t: t[0:n]
+            q = {k: (sl(v) if torch.is_tensor(v) else {kk: ([sl(x) for x in vv] if isinstance(vv, list) else sl(vv)) for kk, vv in v.items()})
+                 for k, v in self.q.items()}
+            p._ws_cur, p._cnt_cur = p.ws_q, p.cnt_q
+            for i in range(n):                             # the stem takes one frame per launch
+                d = ops.make_stem_desc(self.frames[i], None, e.stem_q_w, e.stem_q_scale, e.stem_q_shift,
+                                       self.q['r1'][i:i + 1], e.mean, e.std, 1, p.H0, p.W0, p.pad, p.Hp, p.Wp)
+                P.append(Launch(ops.stem_launch, (d,), 'encoder_q.stem', 2.0 * p.h2 * p.w2 * 64 * 147))
+            r4 = p._trunk(P, e.enc_q, q, n, 'encoder_q')
+            p._conv(P, e.keyval, r4, sl(self.kv_q), n, p.h16, p.w16, name='keyval')
+            # convFM(cat([mem_i, q_out])) = convFM[:, :512](mem_i) + convFM[:, 512:](q_out): the second term is the
+            # same for every object (AFB_URR.py:159,176) -> computed once (with the bias) and added as a shared residual
+            kvq_val = sl(self.kv_q)[:, :, DK:]                  # [n, HW, 512] view, pixel stride 640
+            p._conv(P, D['convFM_q'], kvq_val, sl(self.fm_q), n, p.h16, p.w16, name='decoder.convFM.q', in_ld=DK + DV)
+            s8, s4 = [sl(t) for t in self.s8], [sl(t) for t in self.s4]
+            p._conv(P, D['RF3']['convFS'], q['res3']['out'], s8[0], n, p.h8, p.w8, name='decoder.RF3.convFS')
+            p._resblock(P, D['RF3']['ResFS'], s8[0], s8[1], s8[2], n, p.h8, p.w8, 'decoder.RF3.ResFS')
+            p._conv(P, D['RF2']['convFS'], q['res2']['out'], s4[0], n, p.h4, p.w4, name='decoder.RF2.convFS')
+            p._resblock(P, D['RF2']['ResFS'], s4[0], s4[1], s4[2], n, p.h4, p.w4, 'decoder.RF2.ResFS')
+            # local_convFM(cat([r1, r1_local])): the r1 half is shared by the objects (AFB_URR.py:231-232)
+            p._conv(P, D['local_convFM_r1'], q['r1'], sl(self.lq), n, p.h2, p.w2, name='decoder.local_convFM.r1')
+            est = [l.flops / 100e12 + 6e-6 for l in P]
+            half, acc = 0.5 * sum(est), 0.0
+            for i, t_ in enumerate(est):
+                acc += t_
+                if acc >= half:
+                    self.split[n] = i + 1
+                    break
+        p._ws_cur, p._cnt_cur = p.ws, p.cnt
+        # ---- decoder, bank-dependent part, once per slot
+        d16, d8, d4 = p.d16, p.d8, p.d4
+        for slot in (0, 1):
+            L = self.post[slot]
+            o = lambda t: t[slot:slot + 1]
+            p._conv(L, D['convFM_m'], p.dec_in, d16[0], K, p.h16, p.w16, res=o(self.fm_q), res_mod=p.HW,
+                    name='decoder.convFM.mem')
+            p._resblock(L, D['ResMM'], d16[0], d16[1], d16[2], K, p.h16, p.w16, 'decoder.ResMM')
+            L.append(Launch(ops.upsample2x_add, (o(self.s8[2]), d16[2], d8[0], True), 'decoder.RF3.up_add'))
+            p._resblock(L, D['RF3']['ResMM'], d8[0], d8[1], d8[2], K, p.h8, p.w8, 'decoder.RF3.ResMM')
+            L.append(Launch(ops.upsample2x_add, (o(self.s4[2]), d8[2], d4[0], True), 'decoder.RF2.up_add'))
+            p._resblock(L, D['RF2']['ResMM'], d4[0], d4[1], d4[2], K, p.h4, p.w4, 'decoder.RF2.ResMM')
+            p._conv(L, D['pred2'], d4[2], p.z4, K, p.h4, p.w4, relu_in=True, name='decoder.pred2.taps')
+            L.append(Launch(ops.pred2_gather, (p.z4, D['pred2'].bias, p.pp), 'decoder.pred2.gather'))
+            L.append(Launch(ops.rough_uncertainty, (p.pp, p.p_up, p.rough, p.unc), 'decoder.rough_unc'))
+            L.append(Launch(ops.local_stats, (self.q['r1'][slot], p.rough, p.hs, p.hr, p.hm, p.lm, p.conf),
+                            'decoder.local_stats'))
+            l2 = p.l2
+            p._conv(L, D['local_convFM_loc'], p.lm, l2[0], K, p.h2, p.w2, res=o(self.lq),
+                    res_mod=p.h2 * p.w2, name='decoder.local_convFM.local')
+            p._resblock(L, D['local_ResMM'], l2[0], l2[1], l2[2], K, p.h2, p.w2, 'decoder.local_ResMM')
+            p._conv(L, D['local_pred2'], l2[2], p.z2, K, p.h2, p.w2, relu_in=True, name='decoder.local_pred2.taps')
+            L.append(Launch(ops.pred2_gather, (p.z2, D['local_pred2'].bias, p.qq), 'decoder.local_pred2.gather'))
+            L.append(Launch(ops.final_logits, (p.p_up, p.unc, p.conf, p.qq, p.score, p.pad, p.H0, p.W0), 'decoder.final_logits'))
 
 
 class Engine:
@@ -422,8 +484,8 @@ class Engine:
         if self.precision not in ops.MODES:
             raise ValueError(f"precision must be one of {sorted(ops.MODES)}, got {self.precision!r}")
         self.mode = ops.MODES[self.precision]
-        self._side = None            # side stream for the next frame's query encoder
-        self._prefetched = None
+        self._side = None            # side stream for the query side of the next frames
+        self._side_busy = None       # event behind the last work enqueued on it
         self._pack(model)
 
     # ------------------------------------------------------------------ weights
@@ -524,57 +586,132 @@ class Engine:
             raise RuntimeError('feature bank is empty: call fb.init_bank() first')
         if fb._hw != p.HW:
             raise RuntimeError('feature bank was built for a different frame size')
-        pre = self._prefetched
-        if pre is not None:
-            # whatever the side stream was given, it has finished with the plan's buffers before this stream touches
-            # them: a prefetch for a different frame (wrong hint, skipped frame, direct segment() call) is simply redone
-            torch.cuda.current_stream().wait_event(pre[2])
-        self._prefetched = None
         out = p.score if bs == 1 else torch.empty(bs, K, H, Wd, device=self.device, dtype=torch.float32)
         for b in range(bs):
             fr = frame[b:b + 1]
-            if not (b == 0 and pre is not None and pre[0] is p and pre[1] == fr.data_ptr() and pre[3] == frame._version):
-                p.frame_q.copy_(fr[0])
-                for l in p.seg_pre:
+            qs, slot = self._take_prefetched(p, fr, frame._version) if b == 0 else (None, 0)
+            if qs is None:
+                # not prefetched (first frame of a clip, a skipped frame, a direct segment() call): the frame-only part runs
+                # here, on this stream, in a set the side stream is not filling
+                qs = self._idle_set(p)
+                if self._side_busy is not None:             # (that set's last prefetch, if any, has finished with it)
+                    torch.cuda.current_stream().wait_event(self._side_busy)
+                qs.frames[0].copy_(fr[0])
+                qs.keys, qs.consumed, qs.stage, qs.n = [None, None], [True, True], 0, 0
+                for l in qs.pre[1]:
                     l()
-            self._memory_read(p, fb, update_bank and b == 0)
-            for l in p.seg_post:
+                slot = 0
+            self._memory_read(p, fb, update_bank and b == 0, qs.kv_q[slot:slot + 1])
+            for l in qs.post[slot]:
                 l()
             if bs > 1:
                 out[b].copy_(p.score[0])
         return out
 
-    def prefetch_query(self, frame, obj_n):
-        """Run the frame-only part of ``segment`` for ``frame`` (the *next* frame of the clip: query encoder, KeyValue
-        and the decoder's skip-feature branches) on a side stream.  It depends only on that frame, so it may overlap
-        ``memorize`` / ``FeatureBank.update`` of the current frame; the next ``segment(frame, ...)`` call picks the
-        result up.  Call it after the current frame's ``segment`` (whose decoder reads the same buffers).
-        (Starting it earlier still -- second buffer set, underneath the current frame's memory read and decoder --
-        was measured slower, 104 vs 110 frames/s: the two streams then fight over the CUs on the critical path.)"""
-        self._check_frame(frame)
-        p = self.plan(frame.shape[2], frame.shape[3], obj_n)
+    # ------------------------------------------------------------------ look-ahead of the query side
+    @staticmethod
+    def _key(frame, version=None):
+        return (frame.data_ptr(), frame._version if version is None else version, tuple(frame.shape))
+
+    def _take_prefetched(self, p, fr, version):
+        """(set, slot) holding the frame-only results for ``fr`` -- finishing a prefetch that is still at its first half
+        and making this stream wait for it -- or (None, 0)."""
+        key = self._key(fr, version)
+        for qs in p.qsets:
+            for slot in range(qs.n):
+                if qs.stage > 0 and qs.keys[slot] == key and not qs.consumed[slot]:
+                    if qs.stage == 1:
+                        self.prefetch_finish(p)
+                    torch.cuda.current_stream().wait_event(qs.done)
+                    qs.consumed[slot] = True
+                    return qs, slot
+        return None, 0
+
+    def _idle_set(self, p):
+        """A set that holds no unconsumed, prefetched frame (else: the one with fewer of them -- a wrong hint is redone)."""
+        def live(qs):
+            return 0 if qs.stage == 0 else sum(1 for i in range(qs.n) if not qs.consumed[i])
+        return min(p.qsets, key=live)
+
+    def prefetched_keys(self, p):
+        """Frames whose query side is prefetched (complete or begun) and not yet consumed."""
+        return [qs.keys[i] for qs in p.qsets if qs.stage > 0 for i in range(qs.n) if not qs.consumed[i]]
+
+    def prefetch_pending(self, p):
+        return any(qs.stage == 1 for qs in p.qsets)
+
+    def prefetch_begin(self, frames, obj_n, full=False):
+        """Start the frame-only part of ``segment`` for the next ONE or TWO frames (a list of f32[1,3,h,w] tensors on
+        the GPU) on the side stream: query encoder, KeyValue and the decoder's skip-feature branches, batched over the
+        frames.  It depends only on those frames, so it may overlap ``memorize`` / ``FeatureBank.update`` of the
+        current frame; the ``segment`` calls for them pick the results up.  Call it after the current frame's
+        ``segment`` has been enqueued: the side stream starts behind everything enqueued so far, i.e. it never competes
+        with a memory read or a decoder that is already on its way (measured slower: the critical path then shares the
+        CUs).  ``full=False`` enqueues the first half of the launch list only; ``prefetch_finish`` (called after the
+        NEXT frame's ``segment``) enqueues the rest -- so one pass over two frames is spread underneath the memorize /
+        update phases of two frames.  Returns False if the set could not be claimed."""
+        for fr in frames:
+            self._check_frame(fr)
+        n = len(frames)
+        assert n in (1, 2)
+        p = self.plan(frames[0].shape[2], frames[0].shape[3], obj_n)
+        if self.prefetch_pending(p):
+            self.prefetch_finish(p)
+        qs = self._idle_set(p)
         if self._side is None:
             self._side = torch.cuda.Stream(device=self.device)
         ready = torch.cuda.Event()
-        ready.record()                                           # decoder of the current frame is enqueued
+        ready.record()                                           # everything enqueued so far (the decoder of the current frame)
         with torch.cuda.stream(self._side):
             self._side.wait_event(ready)
-            p.frame_q.copy_(frame[0])
-            for l in p.seg_pre:
+            for i, fr in enumerate(frames):
+                qs.frames[i].copy_(fr[0])
+            lst = qs.pre[n]
+            cut = len(lst) if full else qs.split[n]
+            for l in lst[:cut]:
                 l()
-            done = torch.cuda.Event()
-            done.record()
-        self._prefetched = (p, frame.data_ptr(), done, frame._version)
+            qs.done = torch.cuda.Event()
+            qs.done.record()
+        self._side_busy = qs.done
+        qs.keys = [self._key(fr) for fr in frames] + [None] * (2 - n)
+        qs.consumed = [False] * n + [True] * (2 - n)
+        qs.n = n
+        qs.stage = 2 if full else 1
+        return True
 
-    def _memory_read(self, p, fb, update_bank):
+    def prefetch_finish(self, p=None):
+        """Enqueue the second half of the prefetch begun by ``prefetch_begin(full=False)`` (behind everything enqueued so
+        far on the current stream)."""
+        plans = [p] if p is not None else list(self.plans.values())
+        for pl in plans:
+            for qs in pl.qsets:
+                if qs.stage != 1:
+                    continue
+                ready = torch.cuda.Event()
+                ready.record()
+                with torch.cuda.stream(self._side):
+                    self._side.wait_event(ready)
+                    for l in qs.pre[qs.n][qs.split[qs.n]:]:
+                        l()
+                    qs.done = torch.cuda.Event()
+                    qs.done.record()
+                self._side_busy = qs.done
+                qs.stage = 2
+
+    def prefetch_query(self, frame, obj_n):
+        """One frame of look-ahead (round-1/2 API): ``prefetch_begin([frame], full=True)``."""
+        return self.prefetch_begin([frame], obj_n, full=True)
+
+    def _memory_read(self, p, fb, update_bank, kv_q=None):
         """Matcher.forward (AFB_URR.py:136-178) on the bank slabs."""
         L = _lib.lib()
         s = stream()
+        kv_q = p.kv_q if kv_q is None else kv_q
         K, HW, cap = fb.obj_n, p.HW, fb._cap
         nsplit_scan = pick_scan_slices(HW, K, fb.len_upper())
         scale = 1.0 / math.sqrt(DK)
         d = BankScanDesc()
-        d.q, d.bank_k, d.bank_len, d.rowscale, d.part = ptr(p.kv_q), ptr(fb._kbuf), ptr(fb._len_dev), None, ptr(p.ml_part)
+        d.q, d.bank_k, d.bank_len, d.rowscale, d.part = ptr(kv_q), ptr(fb._kbuf), ptr(fb._len_dev), None, ptr(p.ml_part)
         d.stride_q, d.stride_k, d.stride_rs = 0, cap * DK, 0
         d.scale = scale
         d.ldq, d.q_per_obj, d.HW, d.obj_n, d.nsplit, d.mode = DK + DV, 0, HW, K, nsplit_scan, 0
@@ -592,7 +729,7 @@ class Engine:
         check(L.vfn_bank_scan_finish(ptr(p.ml_part), nsplit_scan, HW, K, 0, ptr(p.ml), None, None, None, s),
               'vfn_bank_scan_finish')
         m = MemReadDesc()
-        m.q = ptr(p.kv_q)
+        m.q = ptr(kv_q)
         m.qv = None                       # the query value joins through decoder.convFM.q instead of a concat
         m.bank_k, m.bank_v, m.bank_len, m.ml, m.o_part = ptr(fb._kbuf), ptr(fb._vbuf), ptr(fb._len_dev), ptr(p.ml), ptr(p.o_part)
         m.cnt = ptr(fb._cnt) if update_bank else None
@@ -617,14 +754,16 @@ class Engine:
         tables were not tuned for costs a few seconds once, e.g. at the start of ``video_seg.main``)."""
         p = self.plan(H0, W0, obj_n)
         seen = {}
-        for lst in (p.seg_pre, p.seg_post, p.mem):
+        side_lists = [id(qs.pre[n]) for qs in p.qsets for n in (1, 2)]
+        for lst in p.all_lists():
             for l in lst:
+                l_side = id(lst) in side_lists
                 if l.fn is ops.conv2d_launch:
                     d = l.args[0]
                     key = (d.M, d.Cout, d.KH * d.KW * d.Cin, int(l.args[2]))
                     if only_missing and key[:3] in _TABLES[key[3]]:
                         continue
-                    seen.setdefault(key, []).append(l)
+                    seen.setdefault(key, []).append((l, l_side))
         tiles = ops.conv_cfg_tiles()
 
         def timeit(d, c, bf):
@@ -643,7 +782,7 @@ class Engine:
             return best_ms
 
         for key, launches in seen.items():
-            d = launches[0].args[0]
+            d = launches[0][0].args[0]
             bf = key[3]
             best, best_t = None, None
             for c, (bm, bn) in enumerate(tiles):
@@ -670,7 +809,6 @@ class Engine:
                     if best_t is None or t < best_t:
                         best, best_t = opt, t
             _TABLES[bf][key[:3]] = best
-            for l in launches:
-                in_q = l in p.seg_pre
+            for l, in_q in launches:
                 l.args = (l.args[0], apply_choice(l.args[0], best, p.ws_q if in_q else p.ws, p.cnt_q if in_q else p.cnt), bf)
         return dict(_TABLES[self.mode])

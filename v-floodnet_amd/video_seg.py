@@ -84,8 +84,8 @@ class ClipRunner:
         self.t = 0
         self._pinned = None
         self._stats_pinned = None
-        self._next_net = None
-        self._next_src = None
+        self._net_cache = {}                 # source frame (data_ptr, version) -> its network-resolution tensor
+        self.lookahead = int(os.environ.get('VFN_LOOKAHEAD', 3))    # frames of look-ahead the query side may use (0..3)
 
     def _net_frame(self, frame):
         """TF.resize(ori_frame, 480, BICUBIC) (:88,:107); identity when the short edge already matches."""
@@ -109,8 +109,7 @@ class ClipRunner:
         k, v = self.model.memorize(f, m)
         self.fb.init_bank(k, v)
         self.t = 0
-        self._next_net = None                                    # no look-ahead carried over from a previous clip
-        self._next_src = None
+        self._net_cache = {}                                     # no look-ahead carried over from a previous clip
         # two sets of per-frame outputs: frame t+1 may be enqueued (launch) before the host has looked at frame t
         # (collect), and a side stream may still be compressing frame t's label map while frame t+1 runs
         self._bufs = [dict(label=torch.empty(H0, W0, dtype=torch.uint8, device=self.device),
@@ -123,15 +122,50 @@ class ClipRunner:
         self._ccl_scratch = torch.empty(2 * H0 * W0 + 8, dtype=torch.int32, device=self.device)
         self._pending = []
 
-    def launch(self, frame, next_frame=None, want_label=True):
+    def _net_cached(self, frame):
+        key = (frame.data_ptr(), frame._version, tuple(frame.shape))
+        f = self._net_cache.get(key)
+        if f is None:
+            f = self._net_frame(frame)
+            if len(self._net_cache) >= 8:
+                self._net_cache.pop(next(iter(self._net_cache)))
+            self._net_cache[key] = f
+        return f
+
+    def _look_ahead(self, nxt):
+        """The query side of the coming frames (``nxt``: network-resolution tensors of frames t+1, t+2, ...), which depends
+        on nothing but those frames: batched over TWO frames and spread over the side stream underneath memorize / update
+        of two loop iterations (Engine.prefetch_begin / prefetch_finish)."""
+        eng = self.model.engine()
+        p = eng.plan(nxt[0].shape[2], nxt[0].shape[3], self.obj_n)
+        have = set(eng.prefetched_keys(p))
+        keys = [eng._key(f) for f in nxt]
+        if keys[0] not in have:
+            # frame t+1 is needed next: everything for it (and, batched with it, for t+2) goes out now
+            if eng.prefetch_pending(p):
+                eng.prefetch_finish(p)
+                have = set(eng.prefetched_keys(p))
+            if keys[0] not in have:
+                pair = [f for f, k in zip(nxt[:2], keys[:2]) if k not in have]
+                eng.prefetch_begin(pair, self.obj_n, full=True)
+        elif eng.prefetch_pending(p):
+            eng.prefetch_finish(p)
+        elif len(nxt) >= 2 and keys[1] not in have:
+            # t+1 is ready; start on (t+2, t+3): first half now, the rest after the next frame's decoder is on its way
+            pair = [f for f, k in zip(nxt[1:3], keys[1:3]) if k not in have]
+            eng.prefetch_begin(pair, self.obj_n, full=False)
+
+    def launch(self, frame, next_frame=None, want_label=True, next_frames=None):
         """Enqueue one iteration of the hot loop (:105-116) for ``frame`` f32[1,3,H0,W0] (on the GPU) and return
         without waiting.  ``collect()`` later waits for it and absorbs the bank bookkeeping.  At most two launches may
         be outstanding (the kernels read the true bank lengths from device memory; the host only needs upper bounds
         to size the grids, ``FeatureBank.len_upper``).
 
-        ``next_frame`` (optional, already on the GPU): lets the query encoder of frame t+1 -- which depends
-        on nothing but that frame -- run on a side stream underneath memorize/update of frame t.  Results
-        are identical with or without it."""
+        ``next_frames`` (optional, already on the GPU: frames t+1, t+2, t+3; ``next_frame`` = just t+1): lets the query
+        side of the coming frames -- which depends on nothing but those frames -- run on a side stream underneath
+        memorize / update, two frames per pass.  The labels do not depend on how far the loop looks ahead up to the
+        summation order inside the split-K convolutions (the batch of two picks other tile shapes than a single
+        frame)."""
         if len(self._pending) >= 2:
             raise RuntimeError('ClipRunner: two frames already in flight; collect() first')
         self.t += 1
@@ -141,17 +175,13 @@ class ClipRunner:
             buf['reader_done'] = None
         self._cur = buf
         self._label_dev, self._post_dev, self._pinned = buf['label'], buf['post'], buf['pinned']
-        if self._next_net is not None and self._next_src == frame.data_ptr():
-            f = self._next_net                                    # resized when it was prefetched
-        else:
-            f = self._net_frame(frame)
-        self._next_net = None
+        f = self._net_cached(frame)                               # (resized when it was prefetched)
         score, _ = self.model.segment(f, self.fb)                 # :108
         pred_mask = ops.softmax_objects(score)                    # :109
-        if next_frame is not None:
-            self._next_net = self._net_frame(next_frame)
-            self._next_src = next_frame.data_ptr()
-            self.model.engine().prefetch_query(self._next_net, self.obj_n)
+        nxt = list(next_frames) if next_frames is not None else ([next_frame] if next_frame is not None else [])
+        nxt = [x for x in nxt if x is not None and x.shape[0] == 1][:max(0, self.lookahead)]
+        if nxt:
+            self._look_ahead([self._net_cached(x) for x in nxt])
         if self.t % self.mem_every == 0:
             k, v = self.model.memorize(f, pred_mask)              # :111 (soft masks are memorised)
             self.fb.update(k, v, self.t)                          # :112
@@ -176,10 +206,10 @@ class ClipRunner:
         self.fb.absorb_stats(buf['stats'], in_flight=len(self._pending))
         return buf['pinned']
 
-    def step(self, frame, want_label=True, next_frame=None):
+    def step(self, frame, want_label=True, next_frame=None, next_frames=None):
         """``launch`` + ``collect``: one iteration of the hot loop, synchronised (one host synchronisation per frame,
         the one the reference also has at ``.cpu()``, test_video_seg.py:115)."""
-        self.launch(frame, next_frame, want_label)
+        self.launch(frame, next_frame, want_label, next_frames)
         lab = self.collect()
         return lab if want_label else None
 
@@ -205,7 +235,7 @@ def run_clip(model, frames, first_mask_u8, budget=250000, update_rate=0.1, thres
     labels[0] = m.cpu()
     sizes = []
     for t in range(1, T):
-        lab = runner.step(frames[t:t + 1], next_frame=frames[t + 1:t + 2] if (overlap and t + 1 < T) else None)
+        lab = runner.step(frames[t:t + 1], next_frames=[frames[u:u + 1] for u in range(t + 1, min(T, t + 4))] if overlap else None)
         # plain memcpy: a torch CPU copy_ wakes the whole OpenMP pool (128 threads on the MI355X hosts), whose
         # spinning starves this launch thread -- measured 41 instead of 7.9 ms per frame
         np.copyto(labels_np[t], lab.numpy())
@@ -300,7 +330,7 @@ def main(args, device):
         main_stream = torch.cuda.current_stream()
         staging = {}
         slot = [0]
-        N_SLOTS = 5                              # frames t, t+1, t+2 in flight + the one being filled + one spare
+        N_SLOTS = 6                              # frames t .. t+3 in flight + the one being filled + one spare
 
         def to_device_async(t):
             key = (tuple(t.shape), t.dtype, slot[0] % N_SLOTS)
@@ -338,7 +368,7 @@ def main(args, device):
         ahead = deque()                          # (item, frame on the device, its decode-finished event)
 
         def fill():
-            while len(ahead) < 3:
+            while len(ahead) < 4:
                 item = next(it, None)
                 if item is None:
                     return
@@ -351,12 +381,10 @@ def main(args, device):
             cur, cur_dev, cur_ready = ahead.popleft()
             fill()                               # frame t+2 starts decoding now, a whole frame before it is needed
             t1 = time.perf_counter()
-            nxt_dev = None
             main_stream.wait_event(cur_ready)
-            if ahead:
-                nxt_dev = ahead[0][1]
-                main_stream.wait_event(ahead[0][2])      # (its decode was enqueued one iteration ago)
-            buf = runner.launch(cur_dev, next_frame=nxt_dev, want_label=False)   # postprocessing_pred (:116) runs on the GPU
+            for a_ in ahead:
+                main_stream.wait_event(a_[2])            # (their decodes were enqueued one to three iterations ago)
+            buf = runner.launch(cur_dev, next_frames=[a_[1] for a_ in ahead], want_label=False)   # postprocessing_pred (:116) runs on the GPU
             t2 = time.perf_counter()
             name = cur[1]
             if keep is not None:
