@@ -27,7 +27,7 @@ extern "C" {
 /* ------------------------------------------------------------------ version
  * vfn_abi_version() == VFN_ABI_VERSION of the header the binding was written against, and
  * vfn_sizeof_desc(which) == sizeof of the binding's own struct: checked when the library is loaded. */
-#define VFN_ABI_VERSION 7
+#define VFN_ABI_VERSION 8
 enum { VFN_DESC_CONV = 0, VFN_DESC_STEM = 1, VFN_DESC_BANKSCAN = 2, VFN_DESC_MEMREAD = 3, VFN_DESC_BANK = 4 };
 int vfn_abi_version(void);
 int vfn_sizeof_desc(int which);
@@ -68,6 +68,15 @@ typedef struct vfn_conv_desc {
                              per filter row and K tile in (kh,kw,cin) order -- bf16: [cout_pad][K] bf16 (tiles of 64);
                              bf16x3: [cout_pad][K/32][hi 32 bf16 | lo 32 bf16] -- so they are staged without
                              conversion; 0 = w is the f32 [cout_pad][K] array and is converted on the fly */
+    /* --- the activations' split-bf16 image (vfn_conv2d_nhwc_bf16x3 only; ABI 8) ---------------------------------------
+     * A tensor's image has the SAME size and pixel stride as the f32 tensor: per pixel and 32-channel block 128 bytes =
+     * [32 hi bf16 | 32 lo bf16], x = hi + lo with hi = bf16(x), lo = bf16(x - hi) -- exactly one LDS row of the kernel's
+     * A tile, so a consumer stages it with plain 16-byte copies and no conversion work.  A producer writes the image of
+     * its result (optionally of relu(result): the consumer's "ReLU on the input" moves here) from its epilogue. */
+    int in_lp;            /* 1: `in` points at such an image (relu_in must be 0; same in_ld; Cin multiple of 32) */
+    int out_lp_relu;      /* the image written to out_lp is that of max(y, 0) */
+    void* out_lp;         /* optional: image of y (pixel stride out_ld * 4 bytes; Cout, out_ld multiples of 32 / 4);
+                             `out` may then be NULL when no consumer wants the f32 tensor */
 } vfn_conv_desc;
 
 int vfn_conv_cfg_count(void);
@@ -75,12 +84,12 @@ int vfn_conv_cfg_tile(int cfg, int* bm, int* bn);
 /* tile configuration cfg: workgroup tile bm x bn, wm x wn waves, dma = 0 register-staged / 2 LDS-DMA ring;
  * the kernel it launches is conv_igemm_kernel<bm, bn, wm, wn, MODE> (conv_igemm_dma_kernel<bm, bn, wm, wn, dma>) */
 int vfn_conv_cfg_info(int cfg, int* bm, int* bn, int* wm, int* wn, int* dma);
-/* K groups per workgroup of configuration cfg: 1 for the plain ones; > 1 (f32 only): split-K inside the workgroup --
+/* K groups per workgroup of configuration cfg: 1 for the plain ones; > 1: split-K inside the workgroup --
  * that many copies of the wm x wn wave grid each take a slice of K of the same output tile and the partial sums are
  * added through LDS in group order (conv_igemm_wk_kernel<bm, bn, wm, wn, wk>); ksplit must be <= 1 with these.  0: no such cfg */
 int vfn_conv_cfg_wk(int cfg);
 /* K tiles a workgroup multiplies between two barriers: 1, or 2 (configurations with a 4-tile register prefetch and four
- * LDS buffers, conv_igemm_wk_kernel<bm, bn, wm, wn, wk, 4, 2>; f32 only, ksplit <= 1).  0: no such cfg */
+ * LDS buffers, conv_igemm_wk_kernel<bm, bn, wm, wn, wk, 4, 2, mode>; ksplit <= 1).  0: no such cfg */
 int vfn_conv_cfg_tpb(int cfg);
 int vfn_conv2d_nhwc_f32(const vfn_conv_desc* d, int cfg, void* stream);
 /* Same convolution with both operands rounded to bf16 (nearest-even) as they are staged into LDS and multiplied
@@ -133,6 +142,10 @@ int vfn_maxpool3x3s2_nhwc_f32(const float* in, float* out, int N, int H, int W, 
  */
 int vfn_upsample2x_add_nhwc_f32(const float* s, const float* pm, float* out, int N, int h, int w, int C,
                                 int s_bcast, void* stream);
+/* the same, also writing the split-bf16 image of the result (of max(result, 0) with lp_relu) for a vfn_conv2d_nhwc_bf16x3
+ * consumer with in_lp (vfn_conv_desc); C multiple of 32 */
+int vfn_upsample2x_add_lp_nhwc_f32(const float* s, const float* pm, float* out, void* out_lp, int lp_relu,
+                                   int N, int h, int w, int C, int s_bcast, void* stream);
 int vfn_rough_uncertainty_f32(const float* p, float* p_up, float* rough, float* unc, int obj_n, int h, int w,
                               void* stream);
 int vfn_local_hpass_f32(const float* r1, const float* rough, float* hs, float* hr, float* hm, int obj_n,

@@ -164,3 +164,85 @@ def test_conv_reduced_precision_matches_emulation(gpu, case, mode):
         torch.cuda.synchronize()
         err = (y.permute(0, 3, 1, 2).cpu() - ref).abs().max().item()
         assert err < tol, f'split {ks}: max err {err}'
+
+
+@pytest.mark.parametrize('shape', [(2, 12, 20, 64, 128, 3, 1), (1, 13, 19, 128, 64, 3, 2), (2, 9, 14, 256, 256, 1, 1), (1, 24, 40, 32, 32, 3, 1)])
+@pytest.mark.parametrize('relu', [False, True])
+def test_split_bf16_activation_image_round_trip(gpu, shape, relu):
+    """bf16x3 with the activations' split-bf16 image (vfn_conv_desc.out_lp / in_lp): a producer writes the image of (the ReLU
+    of) its result from its epilogue -- with and without the f32 tensor, through the plain, the split-K and the in-workgroup
+    split-K epilogues -- and a consumer stages it without conversion.  The image must hold exactly hi = bf16(y),
+    lo = bf16(y - hi); the consumer must give the SAME BITS as the on-the-fly split of the f32 tensor (same operands, same
+    order of MFMAs)."""
+    from vfloodnet_amd import ops, weights
+    from vfloodnet_amd._lib import ptr
+    N, H, W, Cin, Cmid, k, s = shape
+    g = torch.Generator().manual_seed(sum(shape) + relu)
+    x = torch.randn(N, H, W, Cin, generator=g).to(gpu)
+    w1 = torch.randn(Cmid, Cin, k, k, generator=g) / (Cin * k * k) ** 0.5
+    w2 = torch.randn(96, Cmid, 3, 3, generator=g) / (Cmid * 9) ** 0.5
+    wp1 = ops.pad_rows(weights.pack_conv_weight(w1)).to(gpu)
+    wp2 = ops.pad_rows(weights.pack_conv_weight(w2)).to(gpu)
+    sc = (1 + 0.1 * torch.randn(Cmid, generator=g)).to(gpu)
+    sh = (0.1 * torch.randn(Cmid, generator=g)).to(gpu)
+    Ho, Wo = (H + 2 * (k // 2) - k) // s + 1, (W + 2 * (k // 2) - k) // s + 1
+    res = torch.randn(N, Ho, Wo, Cmid, generator=g).to(gpu)
+    # reference: f32 tensor y from the plain bf16x3 kernel, consumer with on-the-fly split (+ ReLU on the input)
+    y = torch.empty(N, Ho, Wo, Cmid, device=gpu)
+    d1 = ops.make_conv_desc(x, wp1, Cmid, k, k, s, k // 2, y, sc, sh, res, False, False)
+    ops.conv2d_launch(d1, 3, 2)
+    z_ref = torch.empty(N, Ho, Wo, 96, device=gpu)
+    d2 = ops.make_conv_desc(y, wp2, 96, 3, 3, 1, 1, z_ref, None, None, None, relu, False)
+    ops.conv2d_launch(d2, 3, 2)
+    torch.cuda.synchronize()
+    yr = torch.relu(y) if relu else y
+    hi = yr.bfloat16()
+    lo = (yr - hi.float()).bfloat16()
+    want = torch.cat([hi.view(-1, Cmid // 32, 32), lo.view(-1, Cmid // 32, 32)], dim=2).reshape(N, Ho, Wo, Cmid * 2)
+    ws = torch.empty(8 * y.numel(), device=gpu)
+    for variant in ('plain', 'image_only', 'split_k', 'wk'):
+        img = torch.zeros(N, Ho, Wo, Cmid, device=gpu)                       # the twin: same bytes as y
+        y2 = torch.full_like(y, float('nan'))
+        d = ops.make_conv_desc(x, wp1, Cmid, k, k, s, k // 2, y2, sc, sh, res, False, False)
+        d.out_lp, d.out_lp_relu = ptr(img), int(relu)
+        cfg = 3
+        if variant == 'image_only':
+            d.out = None
+        elif variant == 'split_k':
+            splits = ops.valid_splits(d, 8, mode=2)
+            if len(splits) < 2:
+                continue
+            ops.set_splitk(d, splits[1], ws)
+        elif variant == 'wk':
+            cfg = 27                                                        # 64x64 tile, two K groups, deep prefetch
+        ops.conv2d_launch(d, cfg, 2)
+        torch.cuda.synchronize()
+        got = img.view(torch.bfloat16)
+        if variant == 'plain':
+            assert torch.equal(y2, y)
+            assert torch.equal(got, want), variant
+        elif variant == 'image_only':
+            assert torch.isnan(y2).all() and torch.equal(got, want)
+        else:                                                               # another summation order: compare the values
+            back = got.view(-1, Cmid // 32, 2, 32).float().sum(2).reshape(N, Ho, Wo, Cmid)
+            assert (back - yr).abs().max() < 2e-4 * max(1.0, yr.abs().max().item()), variant
+            continue
+        z = torch.empty_like(z_ref)
+        dc = ops.make_conv_desc(y, wp2, 96, 3, 3, 1, 1, z, None, None, None, False, False)
+        dc.inp, dc.in_lp = ptr(img), 1
+        for ccfg in (3, 10, 27, 36):
+            z.zero_()
+            ops.conv2d_launch(dc, ccfg, 2)
+            zr = torch.empty_like(z_ref)
+            dr = ops.make_conv_desc(y, wp2, 96, 3, 3, 1, 1, zr, None, None, None, relu, False)
+            ops.conv2d_launch(dr, ccfg, 2)
+            torch.cuda.synchronize()
+            assert torch.equal(z, zr), (variant, ccfg)
+    # refused: ReLU on an image input, an image from the f32 / bf16 entry points
+    dbad = ops.make_conv_desc(y, wp2, 96, 3, 3, 1, 1, z_ref, None, None, None, True, False)
+    dbad.in_lp = 1
+    with pytest.raises(RuntimeError):
+        ops.conv2d_launch(dbad, 3, 2)
+    dbad.relu_in = 0
+    with pytest.raises(RuntimeError):
+        ops.conv2d_launch(dbad, 3, 0)

@@ -24,7 +24,7 @@ class ConvDesc(C.Structure):
                 ('KH', C.c_int), ('KW', C.c_int), ('stride', C.c_int), ('pad', C.c_int),
                 ('relu_in', C.c_int), ('relu_out', C.c_int), ('M', C.c_int), ('ksplit', C.c_int),
                 ('split_from', C.c_int), ('res_mod', C.c_int), ('partial', c_fp), ('tile_counters', c_fp),
-                ('w_packed', C.c_int)]
+                ('w_packed', C.c_int), ('in_lp', C.c_int), ('out_lp_relu', C.c_int), ('out_lp', c_fp)]
 
 
 class StemDesc(C.Structure):
@@ -67,7 +67,7 @@ class BankDesc(C.Structure):
                 ('obj_n', C.c_int), ('cap', C.c_int), ('rm_class', C.c_int), ('rm_request', C.c_int)]
 
 
-ABI_VERSION = 7          # include/vfn_hip.h VFN_ABI_VERSION; csrc/abi.hip
+ABI_VERSION = 8          # include/vfn_hip.h VFN_ABI_VERSION; csrc/abi.hip
 DESC_IDS = {0: ConvDesc, 1: StemDesc, 2: BankScanDesc, 3: MemReadDesc, 4: BankDesc}     # vfn_sizeof_desc(which)
 
 
@@ -129,6 +129,7 @@ _ll = C.c_longlong
 SIGNATURES = {
     'vfn_maxpool3x3s2_nhwc_f32': [_p, _p, _i, _i, _i, _i, _p],
     'vfn_upsample2x_add_nhwc_f32': [_p, _p, _p, _i, _i, _i, _i, _i, _p],
+    'vfn_upsample2x_add_lp_nhwc_f32': [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p],
     'vfn_rough_uncertainty_f32': [_p, _p, _p, _p, _i, _i, _i, _p],
     'vfn_local_hpass_f32': [_p, _p, _p, _p, _p, _i, _i, _i, _i, _p],
     'vfn_local_vpass_f32': [_p, _p, _p, _p, _p, _i, _i, _i, _i, _p],

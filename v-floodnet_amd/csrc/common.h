@@ -37,3 +37,27 @@ __device__ __forceinline__ int wave_sum_i(int v) {
 }
 
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+
+// ---- the activations' split-bf16 image (vfn_conv_desc.in_lp / out_lp, include/vfn_hip.h)
+typedef __attribute__((ext_vector_type(4))) __bf16 vfn_bf16x4;
+// x = hi + lo with hi = bf16(x), lo = bf16(x - hi): 16 significant bits in two bf16 (the "bf16x3" operands)
+__device__ __forceinline__ void vfn_split_bf16(const f32x4& v, vfn_bf16x4& h, vfn_bf16x4& l) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        h[e] = (__bf16)v[e];
+        l[e] = (__bf16)(v[e] - (float)h[e]);
+    }
+}
+// image of 4 consecutive channels (col .. col+3) of pixel `row`: hi at byte (col % 32) * 2 of the pixel's 128-byte block
+// col / 32, lo 64 bytes behind it; pixel stride ld_floats * 4 bytes (the twin of an f32 tensor with that stride)
+__device__ __forceinline__ void vfn_store_lp4(void* base, size_t row, int ld_floats, int col, f32x4 v, bool relu) {
+    if (relu) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+    }
+    vfn_bf16x4 h, l;
+    vfn_split_bf16(v, h, l);
+    char* dst = reinterpret_cast<char*>(base) + (row * (size_t)ld_floats) * 4 + (col >> 5) * 128 + (col & 31) * 2;
+    *reinterpret_cast<vfn_bf16x4*>(dst) = h;
+    *reinterpret_cast<vfn_bf16x4*>(dst + 64) = l;
+}

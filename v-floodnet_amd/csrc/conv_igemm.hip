@@ -88,7 +88,8 @@ __device__ __forceinline__ void splitk_finish(const vfn_conv_desc& p, int* flag,
 #pragma unroll
             for (int k = 0; k < 4; ++k) v[k] = fmaxf(v[k], 0.f);
         }
-        *reinterpret_cast<f32x4*>(p.out + (size_t)row * p.out_ld + col) = v;
+        if (p.out) *reinterpret_cast<f32x4*>(p.out + (size_t)row * p.out_ld + col) = v;
+        if (p.out_lp) vfn_store_lp4(p.out_lp, row, p.out_ld, col, v, p.out_lp_relu);
     }
 }
 
@@ -157,7 +158,8 @@ __device__ __forceinline__ bool wide_epilogue(const vfn_conv_desc& p, char* smem
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
             }
-            *reinterpret_cast<f32x4*>(p.out + (size_t)row * p.out_ld + col) = v;
+            if (p.out) *reinterpret_cast<f32x4*>(p.out + (size_t)row * p.out_ld + col) = v;
+            if (p.out_lp) vfn_store_lp4(p.out_lp, row, p.out_ld, col, v, p.out_lp_relu);
         }
     }
     return true;
@@ -174,16 +176,15 @@ __device__ unsigned long long vfn_conv_census_buf[4096 * 8];
 // accumulators are summed through LDS in group order (bit-reproducible) and group 0 runs the epilogue.  For the layers
 // whose output has fewer 32x32 tiles than the chip has SIMDs (M = 1620 .. 6480 at 1/16 and 1/8 resolution): the same
 // parallelism as split-K over workgroups, without the partial slabs in HBM and without the reduce launch.
-// PD: prefetch distance of the register staging in K tiles (f32 only).  A layer with about one workgroup per CU has
+// PD: prefetch distance of the register staging in K tiles.  A layer with about one workgroup per CU has
 // nothing else resident to cover a global load, and a 32x64 tile computes a K tile in 0.4 us: with PD = 1 every K tile
 // waits out its own load (measured 1.5 us per tile).  PD tiles are kept in flight in registers instead.
-// TPB: K tiles per workgroup barrier (f32 only; 2 * TPB LDS buffers).  A 32x64 or 64x64 tile gives a wave 16 MFMAs
+// TPB: K tiles per workgroup barrier (2 * TPB LDS buffers).  A 32x64 or 64x64 tile gives a wave 16 MFMAs
 // (0.43 us) per K tile, and the LDS store -> barrier -> first fragment read chain behind every barrier costs about as
 // much (profiles/r02_census_conv_small_layers.txt); with TPB = 2 the waves run two tiles between barriers.
 template <int BM, int BN, int WM, int WN, int MODE, int WK, int PD = 1, int TPB = 1>
 __device__ __forceinline__ void conv_igemm_body(const vfn_conv_desc& p) {
-    static_assert(PD == 1 || MODE == 0, "deep prefetch is implemented for the f32 path");
-    static_assert(TPB == 1 || (MODE == 0 && PD > TPB), "several tiles per barrier need the deep register prefetch");
+    static_assert(TPB == 1 || PD > TPB, "several tiles per barrier need the deep register prefetch");
     constexpr int NBUF = 2 * TPB;          // LDS ring: the tiles being read and the tiles being staged
     CV_MARK(0);
     constexpr int NT = WM * WN * 64;       // threads of one K group
@@ -331,12 +332,19 @@ __device__ __forceinline__ void conv_igemm_body(const vfn_conv_desc& p) {
         if (++cb == cblks) { cb = 0; if (++kw == p.KW) { kw = 0; ++kh; } }
     };
     const float relu_floor = p.relu_in ? 0.f : -INFINITY;
+    const bool a_lp = (MODE == 2) && p.in_lp;            // A rows arrive as the split-bf16 image (vfn_conv_desc.in_lp)
     auto store_a = [&](int buf, int slot) {
         float* dA = sA + buf * BM * BK;
 #pragma unroll
         for (int j = 0; j < AC; ++j) {
             const int r = r0 + j * RSTEP;
             f32x4 v = ra[slot][j];
+            if constexpr (MODE == 2) {
+                if (a_lp) {                              // the tensor IS the operand image: 16 bytes in, 16 bytes out
+                    *reinterpret_cast<f32x4*>(dA + r * BK + ((c16 ^ ((r >> 1) & 7)) << 2)) = v;
+                    continue;
+                }
+            }
             v.x = fmaxf(v.x, relu_floor); v.y = fmaxf(v.y, relu_floor);
             v.z = fmaxf(v.z, relu_floor); v.w = fmaxf(v.w, relu_floor);
             if constexpr (MODE == 1) {
@@ -417,10 +425,11 @@ __device__ __forceinline__ void conv_igemm_body(const vfn_conv_desc& p) {
             // two 16-channel steps per tile: hi chunk 2s+h and lo chunk 4+2s+h of every row; three MFMAs per tile pair
 #pragma unroll
             for (int st = 0; st < 2; ++st) {
-                if (more) {
-                    if (st == 0) { load_a(0); load_b(kt_begin + kt + 1, 0); }
-                    else { store_a(buf_st, 0); store_b(buf_st, 0); }
-                }
+                // (tile kt+PD is requested in the first step, tile kt+TPB goes to LDS in the second: as the f32 path.  In the
+                // reduced-precision modes a K tile is a fraction of a microsecond of matrix time, so the K loop of a small
+                // layer runs at the speed of its loads: PD tiles in flight, not one)
+                if (st == 0) { if (more_load) { load_a(u); load_b(kt_begin + kt + PD, u); } }
+                else if (more) { store_a(buf_st, (u + TPB) % PD); store_b(buf_st, (u + TPB) % PD); }
                 const int lc = 2 * st + lh;
                 bf16x8 ah[TM], al[TM], bh[TN], bl[TN];
 #pragma unroll
@@ -581,10 +590,10 @@ template <int BM, int BN, int WM, int WN, int MODE = 0>
 __global__ __launch_bounds__(WM * WN * 64)
 void conv_igemm_kernel(const vfn_conv_desc p) { conv_igemm_body<BM, BN, WM, WN, MODE, 1>(p); }
 
-// in-workgroup split-K (f32): WK K groups of WM x WN waves
-template <int BM, int BN, int WM, int WN, int WK, int PD, int TPB>
+// in-workgroup split-K: WK K groups of WM x WN waves; PD K tiles in flight, TPB K tiles per barrier
+template <int BM, int BN, int WM, int WN, int WK, int PD, int TPB, int MODE = 0>
 __global__ __launch_bounds__(WM * WN * WK * 64)
-void conv_igemm_wk_kernel(const vfn_conv_desc p) { conv_igemm_body<BM, BN, WM, WN, 0, WK, PD, TPB>(p); }
+void conv_igemm_wk_kernel(const vfn_conv_desc p) { conv_igemm_body<BM, BN, WM, WN, MODE, WK, PD, TPB>(p); }
 
 // 128 bytes of zeros: the LDS-DMA source of every filter tap that falls outside the image
 __device__ __attribute__((aligned(128))) float vfn_zero_page[32];
@@ -825,7 +834,8 @@ __global__ void splitk_reduce_kernel(const vfn_conv_desc p, int m_start) {
 #pragma unroll
             for (int k = 0; k < 4; ++k) v[k] = fmaxf(v[k], 0.f);
         }
-        *reinterpret_cast<f32x4*>(p.out + row * p.out_ld + c4 * 4) = v;
+        if (p.out) *reinterpret_cast<f32x4*>(p.out + row * p.out_ld + c4 * 4) = v;
+        if (p.out_lp) vfn_store_lp4(p.out_lp, row, p.out_ld, c4 * 4, v, p.out_lp_relu);
     }
 }
 
@@ -860,7 +870,7 @@ int launch_cfg(const vfn_conv_desc& p, hipStream_t s) {
     return vfn_check_launch();
 }
 
-template <int BM, int BN, int WM, int WN, int WK, int PD = 3, int TPB = 1>
+template <int BM, int BN, int WM, int WN, int WK, int PD = 3, int TPB = 1, int MODE = 0>
 int launch_wk(const vfn_conv_desc& p, hipStream_t s) {
     constexpr int NT = WM * WN * WK * 64;
     constexpr size_t lds = (size_t)WK * 2 * TPB * (BM + BN) * BK * sizeof(float);
@@ -868,13 +878,13 @@ int launch_wk(const vfn_conv_desc& p, hipStream_t s) {
     static_assert(lds <= 160 * 1024 && NT <= 1024, "workgroup too large");
     static bool attr_set = false;
     if (!attr_set && lds > 64 * 1024) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_wk_kernel<BM, BN, WM, WN, WK, PD, TPB>),
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_wk_kernel<BM, BN, WM, WN, WK, PD, TPB, MODE>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = true;
     }
     if (p.ksplit > 1) return VFN_ERR_ARG;                  // one kind of split at a time
     const int tiles = cdiv(p.M, BM) * cdiv(p.Cout, BN);
-    hipLaunchKernelGGL((conv_igemm_wk_kernel<BM, BN, WM, WN, WK, PD, TPB>), dim3(tiles), dim3(NT), lds, s, p);
+    hipLaunchKernelGGL((conv_igemm_wk_kernel<BM, BN, WM, WN, WK, PD, TPB, MODE>), dim3(tiles), dim3(NT), lds, s, p);
     return vfn_check_launch();
 }
 
@@ -902,7 +912,7 @@ extern "C" int vfn_conv_cfg_info(int cfg, int* bm, int* bn, int* wm, int* wn, in
     // (must match the switch of vfn_conv2d_nhwc_f32 below)
     // 20..25 (f32 only): 32-row tiles for the 1/16-resolution layers (M = 1620: 51 x 32 rows instead of 26 x 64),
     // single-wave 32x32 tiles (most workgroups for the smallest layers), and 8-wave variants of 128x64 / 256x64
-    // 26..37 (f32 only; ksplit must be 1): in-workgroup split-K (vfn_conv_cfg_wk K groups of the WM x WN waves) and,
+    // 26..37 (any arithmetic mode; ksplit must be 1): in-workgroup split-K (vfn_conv_cfg_wk K groups of the WM x WN waves) and,
     // from 32 on, two K tiles per barrier (vfn_conv_cfg_tpb)
     static const int t[38][5] = {{128, 128, 2, 2, 0}, {128, 64, 2, 2, 0}, {64, 128, 2, 2, 0}, {64, 64, 2, 2, 0}, {32, 64, 1, 2, 0},
                                  {64, 32, 2, 1, 0}, {128, 32, 4, 1, 0}, {256, 128, 4, 2, 0},
@@ -927,8 +937,28 @@ extern "C" int vfn_conv_cfg_info(int cfg, int* bm, int* bn, int* wm, int* wn, in
 
 extern "C" int vfn_conv_cfg_tile(int cfg, int* bm, int* bn) { return vfn_conv_cfg_info(cfg, bm, bn, nullptr, nullptr, nullptr); }
 
+// configurations 26..37 (in-workgroup split-K / deep prefetch / two tiles per barrier) in any arithmetic mode
+template <int MODE>
+int launch_wk_cfg(const vfn_conv_desc& d, int cfg, hipStream_t s) {
+    switch (cfg) {
+        case 26: return launch_wk<32, 64, 1, 2, 4, 3, 1, MODE>(d, s);
+        case 27: return launch_wk<64, 64, 2, 2, 2, 3, 1, MODE>(d, s);
+        case 28: return launch_wk<32, 64, 1, 2, 2, 3, 1, MODE>(d, s);
+        case 29: return launch_wk<64, 64, 2, 2, 4, 3, 1, MODE>(d, s);
+        case 30: return launch_wk<32, 32, 1, 1, 4, 3, 1, MODE>(d, s);
+        case 31: return launch_wk<32, 128, 1, 4, 2, 3, 1, MODE>(d, s);
+        case 32: return launch_wk<32, 64, 1, 2, 2, 4, 2, MODE>(d, s);
+        case 33: return launch_wk<64, 64, 2, 2, 2, 4, 2, MODE>(d, s);
+        case 34: return launch_wk<32, 64, 1, 2, 1, 4, 2, MODE>(d, s);
+        case 35: return launch_wk<64, 64, 2, 2, 1, 4, 2, MODE>(d, s);
+        case 36: return launch_wk<64, 128, 2, 4, 1, 4, 2, MODE>(d, s);
+        case 37: return launch_wk<32, 128, 1, 4, 1, 4, 2, MODE>(d, s);
+    }
+    return VFN_ERR_ARG;
+}
+
 extern "C" int vfn_conv2d_nhwc_f32(const vfn_conv_desc* d, int cfg, void* stream) {
-    if (!d || !d->in || !d->w || !d->out) return VFN_ERR_ARG;
+    if (!d || !d->in || !d->w || !d->out || d->in_lp || d->out_lp) return VFN_ERR_ARG;
     if (d->Cin % BK != 0 || d->in_ld % 4 != 0 || d->M <= 0) return VFN_ERR_ARG;
     int bm, bn;
     if (vfn_conv_cfg_tile(cfg, &bm, &bn) != VFN_OK) return VFN_ERR_ARG;
@@ -967,18 +997,7 @@ extern "C" int vfn_conv2d_nhwc_f32(const vfn_conv_desc* d, int cfg, void* stream
         case 23: return launch_cfg<256, 64, 4, 2>(*d, s);
         case 24: return launch_cfg<32, 64, 1, 1>(*d, s);
         case 25: return launch_cfg<64, 64, 1, 2>(*d, s);
-        case 26: return launch_wk<32, 64, 1, 2, 4>(*d, s);
-        case 27: return launch_wk<64, 64, 2, 2, 2>(*d, s);
-        case 28: return launch_wk<32, 64, 1, 2, 2>(*d, s);
-        case 29: return launch_wk<64, 64, 2, 2, 4>(*d, s);
-        case 30: return launch_wk<32, 32, 1, 1, 4>(*d, s);
-        case 31: return launch_wk<32, 128, 1, 4, 2>(*d, s);
-        case 32: return launch_wk<32, 64, 1, 2, 2, 4, 2>(*d, s);
-        case 33: return launch_wk<64, 64, 2, 2, 2, 4, 2>(*d, s);
-        case 34: return launch_wk<32, 64, 1, 2, 1, 4, 2>(*d, s);
-        case 35: return launch_wk<64, 64, 2, 2, 1, 4, 2>(*d, s);
-        case 36: return launch_wk<64, 128, 2, 4, 1, 4, 2>(*d, s);
-        case 37: return launch_wk<32, 128, 1, 4, 1, 4, 2>(*d, s);
+        default: if (cfg >= 26 && cfg <= 37) return launch_wk_cfg<0>(*d, cfg, s);
     }
     return VFN_ERR_ARG;
 }
@@ -986,7 +1005,7 @@ extern "C" int vfn_conv2d_nhwc_f32(const vfn_conv_desc* d, int cfg, void* stream
 // Same convolution with bf16 operands (rounded to nearest-even as they are staged; f32 accumulate, f32
 // tensors in HBM): BASELINE configs C3 / C5.  Register-staged tile configurations only (LDS-DMA cannot convert).
 extern "C" int vfn_conv2d_nhwc_bf16(const vfn_conv_desc* d, int cfg, void* stream) {
-    if (!d || !d->in || !d->w || !d->out) return VFN_ERR_ARG;
+    if (!d || !d->in || !d->w || !d->out || d->in_lp || d->out_lp) return VFN_ERR_ARG;
     if (d->Cin % 64 != 0 || d->in_ld % 4 != 0 || d->M <= 0) return VFN_ERR_ARG;
     int bm, bn;
     if (vfn_conv_cfg_tile(cfg, &bm, &bn) != VFN_OK) return VFN_ERR_ARG;
@@ -1012,6 +1031,7 @@ extern "C" int vfn_conv2d_nhwc_bf16(const vfn_conv_desc* d, int cfg, void* strea
         case 10: return launch_cfg<64, 128, 2, 4, 0, 1>(*d, s);
         case 17: return launch_cfg<128, 256, 2, 4, 0, 1>(*d, s);
         case 19: return launch_cfg<64, 256, 2, 4, 0, 1>(*d, s);
+        default: if (cfg >= 26 && cfg <= 37) return launch_wk_cfg<1>(*d, cfg, s);
     }
     return VFN_ERR_ARG;
 }
@@ -1020,7 +1040,10 @@ extern "C" int vfn_conv2d_nhwc_bf16(const vfn_conv_desc* d, int cfg, void* strea
 // product (hi*hi + hi*lo + lo*hi), f32 accumulate: relative error ~2^-16 per product, against 2^-9 for plain bf16
 // and 2^-24 for f32.  Same tile configurations and K tiling (32 channels) as the f32 kernel's register-staged ones.
 extern "C" int vfn_conv2d_nhwc_bf16x3(const vfn_conv_desc* d, int cfg, void* stream) {
-    if (!d || !d->in || !d->w || !d->out) return VFN_ERR_ARG;
+    if (!d || !d->in || !d->w || (!d->out && !d->out_lp)) return VFN_ERR_ARG;
+    if (d->in_lp && (d->relu_in || d->in_ld % 32)) return VFN_ERR_ARG;            // ReLU belongs to the image's producer
+    // the image is written by the 16-byte epilogue only (4 channels per lane): shapes that fall back to the dword form are refused
+    if (d->out_lp && (d->Cout % 32 || d->out_ld % 32 || (d->res && d->res_ld % 4) || d->tile_counters)) return VFN_ERR_ARG;
     if (d->Cin % BK != 0 || d->in_ld % 4 != 0 || d->M <= 0) return VFN_ERR_ARG;
     int bm, bn;
     if (vfn_conv_cfg_tile(cfg, &bm, &bn) != VFN_OK) return VFN_ERR_ARG;
@@ -1046,6 +1069,7 @@ extern "C" int vfn_conv2d_nhwc_bf16x3(const vfn_conv_desc* d, int cfg, void* str
         case 10: return launch_cfg<64, 128, 2, 4, 0, 2>(*d, s);
         case 17: return launch_cfg<128, 256, 2, 4, 0, 2>(*d, s);
         case 19: return launch_cfg<64, 256, 2, 4, 0, 2>(*d, s);
+        default: if (cfg >= 26 && cfg <= 37) return launch_wk_cfg<2>(*d, cfg, s);
     }
     return VFN_ERR_ARG;
 }

@@ -28,8 +28,10 @@ __device__ __forceinline__ Lerp lerp2x(int dst, int in_size) {
     return L;
 }
 
+// out_lp (optional): the split-bf16 image of the result (of its ReLU with lp_relu), for a bf16x3 consumer (common.h)
 __global__ void upsample2x_add_kernel(const float* __restrict__ s, const float* __restrict__ pm,
-                                      float* __restrict__ out, int N, int h, int w, int C, int s_bcast) {
+                                      float* __restrict__ out, int N, int h, int w, int C, int s_bcast,
+                                      void* __restrict__ out_lp, int lp_relu) {
     const int c4n = C / 4;
     const int hi = h / 2, wi = w / 2;
     const size_t total = (size_t)N * h * w * c4n;
@@ -52,6 +54,7 @@ __global__ void upsample2x_add_kernel(const float* __restrict__ s, const float* 
         for (int k = 0; k < 4; ++k)
             o[k] = sv[k] + (ly.l0 * (lx.l0 * a[k] + lx.l1 * b[k]) + ly.l1 * (lx.l0 * c[k] + lx.l1 * d[k]));
         *reinterpret_cast<f32x4*>(out + i * 4) = o;
+        if (out_lp) vfn_store_lp4(out_lp, i / c4n, C, c4 * 4, o, lp_relu);
     }
 }
 
@@ -410,7 +413,16 @@ extern "C" int vfn_upsample2x_add_nhwc_f32(const float* s, const float* pm, floa
     if (!s || !pm || !out || C % 4 || h % 2 || w % 2) return VFN_ERR_ARG;
     const size_t total = (size_t)N * h * w * (C / 4);
     hipLaunchKernelGGL(upsample2x_add_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream,
-                       s, pm, out, N, h, w, C, s_bcast);
+                       s, pm, out, N, h, w, C, s_bcast, (void*)nullptr, 0);
+    return vfn_check_launch();
+}
+
+extern "C" int vfn_upsample2x_add_lp_nhwc_f32(const float* s, const float* pm, float* out, void* out_lp, int lp_relu,
+                                              int N, int h, int w, int C, int s_bcast, void* stream) {
+    if (!s || !pm || !out || C % 4 || h % 2 || w % 2 || (out_lp && C % 32)) return VFN_ERR_ARG;
+    const size_t total = (size_t)N * h * w * (C / 4);
+    hipLaunchKernelGGL(upsample2x_add_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream,
+                       s, pm, out, N, h, w, C, s_bcast, out_lp, lp_relu);
     return vfn_check_launch();
 }
 

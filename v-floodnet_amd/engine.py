@@ -261,6 +261,8 @@ class FramePlan:
         self.l2 = [f(K, self.h2, self.w2, 32) for _ in range(3)]
         self.qq = f(K, self.h2, self.w2, 2)
         self.score = f(1, K, H0, W0)
+        self._twins = {}                      # storage -> split-bf16 image buffer (bf16x3 mode)
+        self._lp_state = {}                   # (ptr, shape) of an f32 view -> its twin holds the image of relu(x)? (True / False)
         self.ws = f(WS_FLOATS)
         self.ws_q = f(WS_FLOATS)              # split-K workspace of the query-encoder list (side stream)
         self.cnt = torch.zeros(4096, dtype=torch.int32, device=dev)      # split-tile arrival counters (zero at rest)
@@ -306,13 +308,46 @@ class FramePlan:
         return b
 
     # ------------------------------------------------------------------ builders
+    def _lp_args(self, out):
+        """Extra arguments of ops.upsample2x_add in bf16x3 mode: the image of relu(out) for the ResBlock behind it."""
+        if self.eng.mode != 2 or out.shape[-1] % 32:
+            return ()
+        self._lp_state[(out.data_ptr(), tuple(out.shape))] = True
+        return (self.lp_twin(out), True)
+
+    def lp_twin(self, t):
+        """The split-bf16 image that travels with an f32 activation buffer in bf16x3 mode (vfn_conv_desc.in_lp / out_lp):
+        same bytes, same strides -- a view of ``t`` maps onto the same view of the twin."""
+        st = t.untyped_storage()
+        key = st.data_ptr()
+        if key not in self._twins:
+            self._twins[key] = torch.empty(st.nbytes() // 4, dtype=torch.float32, device=t.device)
+        return torch.as_strided(self._twins[key], t.size(), t.stride(), t.storage_offset())
+
+    def has_lp(self, t, relu):
+        """Does the twin of ``t`` hold the image of t (relu=False) / of relu(t) (relu=True)?"""
+        return self._lp_state.get((t.data_ptr(), tuple(t.shape))) == bool(relu)
+
     def _conv(self, lst, layer, x, out, N, H, Wd, res=None, relu_in=False, relu_out=False, name='conv',
-              in_ld=None, out_ld=None, res_mod=0):
+              in_ld=None, out_ld=None, res_mod=0, lp_out=None, f32_out=True):
+        """``lp_out`` ('plain' / 'relu', bf16x3 mode only): the epilogue also writes the split-bf16 image of the result (of
+        its ReLU) into the twin of ``out``; ``f32_out=False`` then drops the f32 tensor when only convolutions consume
+        it.  An input whose twin holds the image this layer needs (has_lp) is staged from the twin without conversion."""
+        lp = self.eng.mode == 2
         d = ops.make_conv_desc(x, layer.w, layer.cout, layer.k, layer.k, layer.stride, layer.pad, out,
                                layer.scale, layer.shift, res, relu_in, relu_out,
                                cin=layer.cin, in_ld=in_ld if in_ld is not None else x.shape[-1],
                                out_ld=out_ld, N=N, H=H, W=Wd)
         d.res_mod = int(res_mod)
+        if lp and in_ld is None and layer.cin % 32 == 0 and self.has_lp(x, relu_in):
+            d.inp, d.in_lp, d.relu_in = ptr(self.lp_twin(x)), 1, 0
+        if lp and lp_out and layer.cout % 32 == 0 and d.out_ld % 32 == 0:
+            d.out_lp, d.out_lp_relu = ptr(self.lp_twin(out)), int(lp_out == 'relu')
+            self._lp_state[(out.data_ptr(), tuple(out.shape))] = (lp_out == 'relu')
+            if not f32_out:
+                d.out = None
+        else:
+            self._lp_state.pop((out.data_ptr(), tuple(out.shape)), None)      # (an f32-only producer: the twin is stale)
         K = layer.k * layer.k * layer.cin
         bf = self.eng.mode
         if bf == 1 and layer.cin % 64:                     # (the 32-channel local head: no 64-channel K tile)
@@ -338,21 +373,26 @@ class FramePlan:
                 Ho, Wo = H // s, Wd // s
                 t1 = lb['t1a'] if (s == 2) else lb['t1']
                 nm = f'{prefix}.{lname}.{bi}'
-                self._conv(lst, blk['conv1'], x, t1, N, H, Wd, relu_out=True, name=nm + '.conv1')
-                self._conv(lst, blk['conv2'], t1, lb['t2'], N, H, Wd, relu_out=True, name=nm + '.conv2')
+                # (bf16x3: t1 / t2 feed one convolution each -> image only; a block's output is the next block's residual
+                # (f32) and the next convolutions' operand (image))
+                self._conv(lst, blk['conv1'], x, t1, N, H, Wd, relu_out=True, name=nm + '.conv1', lp_out='plain', f32_out=False)
+                self._conv(lst, blk['conv2'], t1, lb['t2'], N, H, Wd, relu_out=True, name=nm + '.conv2', lp_out='plain',
+                           f32_out=False)
                 if 'down' in blk:
                     self._conv(lst, blk['down'], x, lb['ds'], N, H, Wd, name=nm + '.down')
                     idn = lb['ds']
                 else:
                     idn = x
                 out = lb['out'] if bi == len(blocks) - 1 else lb['o'][bi % 2]
-                self._conv(lst, blk['conv3'], lb['t2'], out, N, Ho, Wo, res=idn, relu_out=True, name=nm + '.conv3')
+                self._conv(lst, blk['conv3'], lb['t2'], out, N, Ho, Wo, res=idn, relu_out=True, name=nm + '.conv3',
+                           lp_out='plain')
                 x = out
                 H, Wd = Ho, Wo
         return x
 
     def _resblock(self, lst, rb, x, t, out, N, H, Wd, name):
-        self._conv(lst, rb['conv1'], x, t, N, H, Wd, relu_in=True, name=name + '.conv1')
+        # (bf16x3: t feeds conv2 only, through its ReLU -> the image of relu(t) and no f32 tensor)
+        self._conv(lst, rb['conv1'], x, t, N, H, Wd, relu_in=True, name=name + '.conv1', lp_out='relu', f32_out=False)
         self._conv(lst, rb['conv2'], t, out, N, H, Wd, res=x, relu_in=True, name=name + '.conv2')
         return out
 
@@ -430,9 +470,9 @@ class QuerySet:
             kvq_val = sl(self.kv_q)[:, :, DK:]                  # [n, HW, 512] view, pixel stride 640
             p._conv(P, D['convFM_q'], kvq_val, sl(self.fm_q), n, p.h16, p.w16, name='decoder.convFM.q', in_ld=DK + DV)
             s8, s4 = [sl(t) for t in self.s8], [sl(t) for t in self.s4]
-            p._conv(P, D['RF3']['convFS'], q['res3']['out'], s8[0], n, p.h8, p.w8, name='decoder.RF3.convFS')
+            p._conv(P, D['RF3']['convFS'], q['res3']['out'], s8[0], n, p.h8, p.w8, name='decoder.RF3.convFS', lp_out='relu')
             p._resblock(P, D['RF3']['ResFS'], s8[0], s8[1], s8[2], n, p.h8, p.w8, 'decoder.RF3.ResFS')
-            p._conv(P, D['RF2']['convFS'], q['res2']['out'], s4[0], n, p.h4, p.w4, name='decoder.RF2.convFS')
+            p._conv(P, D['RF2']['convFS'], q['res2']['out'], s4[0], n, p.h4, p.w4, name='decoder.RF2.convFS', lp_out='relu')
             p._resblock(P, D['RF2']['ResFS'], s4[0], s4[1], s4[2], n, p.h4, p.w4, 'decoder.RF2.ResFS')
             # local_convFM(cat([r1, r1_local])): the r1 half is shared by the objects (AFB_URR.py:231-232)
             p._conv(P, D['local_convFM_r1'], q['r1'], sl(self.lq), n, p.h2, p.w2, name='decoder.local_convFM.r1')
@@ -450,11 +490,11 @@ class QuerySet:
             L = self.post[slot]
             o = lambda t: t[slot:slot + 1]
             p._conv(L, D['convFM_m'], p.dec_in, d16[0], K, p.h16, p.w16, res=o(self.fm_q), res_mod=p.HW,
-                    name='decoder.convFM.mem')
+                    name='decoder.convFM.mem', lp_out='relu')
             p._resblock(L, D['ResMM'], d16[0], d16[1], d16[2], K, p.h16, p.w16, 'decoder.ResMM')
-            L.append(Launch(ops.upsample2x_add, (o(self.s8[2]), d16[2], d8[0], True), 'decoder.RF3.up_add'))
+            L.append(Launch(ops.upsample2x_add, (o(self.s8[2]), d16[2], d8[0], True) + p._lp_args(d8[0]), 'decoder.RF3.up_add'))
             p._resblock(L, D['RF3']['ResMM'], d8[0], d8[1], d8[2], K, p.h8, p.w8, 'decoder.RF3.ResMM')
-            L.append(Launch(ops.upsample2x_add, (o(self.s4[2]), d8[2], d4[0], True), 'decoder.RF2.up_add'))
+            L.append(Launch(ops.upsample2x_add, (o(self.s4[2]), d8[2], d4[0], True) + p._lp_args(d4[0]), 'decoder.RF2.up_add'))
             p._resblock(L, D['RF2']['ResMM'], d4[0], d4[1], d4[2], K, p.h4, p.w4, 'decoder.RF2.ResMM')
             p._conv(L, D['pred2'], d4[2], p.z4, K, p.h4, p.w4, relu_in=True, name='decoder.pred2.taps')
             L.append(Launch(ops.pred2_gather, (p.z4, D['pred2'].bias, p.pp), 'decoder.pred2.gather'))
@@ -463,7 +503,7 @@ class QuerySet:
                             'decoder.local_stats'))
             l2 = p.l2
             p._conv(L, D['local_convFM_loc'], p.lm, l2[0], K, p.h2, p.w2, res=o(self.lq),
-                    res_mod=p.h2 * p.w2, name='decoder.local_convFM.local')
+                    res_mod=p.h2 * p.w2, name='decoder.local_convFM.local', lp_out='relu')
             p._resblock(L, D['local_ResMM'], l2[0], l2[1], l2[2], K, p.h2, p.w2, 'decoder.local_ResMM')
             p._conv(L, D['local_pred2'], l2[2], p.z2, K, p.h2, p.w2, relu_in=True, name='decoder.local_pred2.taps')
             L.append(Launch(ops.pred2_gather, (p.z2, D['local_pred2'].bias, p.qq), 'decoder.local_pred2.gather'))
@@ -796,7 +836,7 @@ class Engine:
                 options = [(c, 1, 0)]
                 wk = ops.conv_cfg_wk(c)
                 if wk > 1 or ops.conv_cfg_tpb(c) > 1:          # split-K inside the workgroup / two tiles per barrier:
-                    if bf or blocks > 1024 or d.KH * d.KW * d.Cin // 32 < 2 * wk:   # f32, no second split, scarce tiles
+                    if blocks > 1024 or d.KH * d.KW * d.Cin // (64 if bf == 1 else 32) < 2 * wk:   # no second split, scarce tiles
                         continue
                 elif blocks < 256:
                     options += [(c, k_, 0) for k_ in ops.valid_splits(d, 16, bf)[1:] if k_ * d.M * d.Cout <= WS_FLOATS]

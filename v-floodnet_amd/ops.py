@@ -22,7 +22,7 @@ def conv_cfg_tiles():
 
 
 def conv_cfg_wk(cfg):
-    """K groups per workgroup of a tile configuration (vfn_conv_cfg_wk): > 1 = split-K inside the workgroup (f32 only)."""
+    """K groups per workgroup of a tile configuration (vfn_conv_cfg_wk): > 1 = split-K inside the workgroup."""
     return _lib.lib().vfn_conv_cfg_wk(int(cfg))
 
 
@@ -41,7 +41,7 @@ def conv_cfg_names(mode=0):
         bm, bn, wm, wn, dma = [x.value for x in v]
         wk, tpb = L.vfn_conv_cfg_wk(c), L.vfn_conv_cfg_tpb(c)
         out.append(f'conv_igemm_dma_kernel<{bm}, {bn}, {wm}, {wn}, {dma}>' if dma else
-                   f'conv_igemm_wk_kernel<{bm}, {bn}, {wm}, {wn}, {wk}, {4 if tpb > 1 else 3}, {tpb}>' if (wk > 1 or tpb > 1) else
+                   f'conv_igemm_wk_kernel<{bm}, {bn}, {wm}, {wn}, {wk}, {4 if tpb > 1 else 3}, {tpb}, {int(mode)}>' if (wk > 1 or tpb > 1) else
                    f'conv_igemm_kernel<{bm}, {bn}, {wm}, {wn}, {int(mode)}>')
     return out
 
@@ -80,7 +80,7 @@ def make_conv_desc(x, wp, cout, kh, kw, stride, pad, out, scale=None, shift=None
     cin = cin if cin is not None else in_ld
     Ho = (H + 2 * pad - kh) // stride + 1
     Wo = (W + 2 * pad - kw) // stride + 1
-    out_ld = out_ld if out_ld is not None else out.shape[-1]
+    out_ld = out_ld if out_ld is not None else out.shape[-1]       # (out may be None with an image-only producer: pass out_ld)
     d = ConvDesc()
     d.inp, d.w, d.scale, d.shift, d.res, d.out = ptr(x), ptr(wp), ptr(scale), ptr(shift), ptr(res), ptr(out)
     d.N, d.H, d.W, d.Cin, d.in_ld = N, H, W, cin, in_ld
@@ -94,6 +94,7 @@ def make_conv_desc(x, wp, cout, kh, kw, stride, pad, out, scale=None, shift=None
     d.tile_counters = None
     d.res_mod = 0
     d.w_packed = 0
+    d.in_lp, d.out_lp_relu, d.out_lp = 0, 0, None
     assert wp.shape[1] == kh * kw * cin
     return d
 
@@ -160,7 +161,7 @@ def conv2d_launch(desc, cfg, mode=0):
     check(getattr(_lib.lib(), name)(C.byref(desc), int(cfg), stream()), name)
 
 
-BF16_CFGS = (0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 17, 19)
+BF16_CFGS = (0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 17, 19) + tuple(range(26, 38))     # (no LDS-DMA variants: the DMA cannot convert)
 
 
 def conv2d_nhwc(x, wp, cout, kh, kw, stride, pad, scale=None, shift=None, res=None,
@@ -212,8 +213,13 @@ def maxpool3x3s2(x, out):
 
 
 # --------------------------------------------------------------------------- decoder pointwise
-def upsample2x_add(s, pm, out, s_bcast):
+def upsample2x_add(s, pm, out, s_bcast, out_lp=None, lp_relu=False):
+    """out = s + bilinear_x2(pm); ``out_lp``: also the split-bf16 image of (relu of) the result (a bf16x3 conv consumes it)."""
     N, h, w, Cc = out.shape
+    if out_lp is not None:
+        check(_lib.lib().vfn_upsample2x_add_lp_nhwc_f32(ptr(s), ptr(pm), ptr(out), ptr(out_lp), int(lp_relu), N, h, w, Cc,
+                                                        int(s_bcast), stream()), 'vfn_upsample2x_add_lp_nhwc_f32')
+        return out
     check(_lib.lib().vfn_upsample2x_add_nhwc_f32(ptr(s), ptr(pm), ptr(out), N, h, w, Cc, int(s_bcast), stream()),
           'vfn_upsample2x_add_nhwc_f32')
     return out
