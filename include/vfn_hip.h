@@ -77,6 +77,11 @@ typedef struct vfn_conv_desc {
     int out_lp_relu;      /* the image written to out_lp is that of max(y, 0) */
     void* out_lp;         /* optional: image of y (pixel stride out_ld * 4 bytes; Cout, out_ld multiples of 32 / 4);
                              `out` may then be NULL when no consumer wants the f32 tensor */
+    /* --- backward passes (f32; ABI 8): a data-gradient convolution runs this same kernel over the flipped, transposed
+     * filters; the ReLU that preceded the forward convolution is undone in the epilogue -------------------------------- */
+    const float* mask;    /* optional [M, mask_ld]: y = (mask[m, c] > 0 ? acc * scale + shift : 0) + res -- the gradient of
+                             conv(relu(x)) w.r.t. x with mask = x, plus the gradient arriving over the skip connection */
+    int mask_ld;
 } vfn_conv_desc;
 
 int vfn_conv_cfg_count(void);
@@ -168,6 +173,25 @@ int vfn_final_logits_f32(const float* p_up, const float* unc, const float* conf,
  *     loss at train_video_seg.py:73-74): mean over the batch of ||calc_uncertainty(softmax_objects(prob))||_2 / sqrt(n).
  *     logit: [bs][obj][n] as returned by segment (n = H*W); partial: scratch float[bs*64]; out: one float. */
 int vfn_segment_uncertainty_f32(const float* logit, int bs, int obj_n, int n, float* partial, float* out, void* stream);
+
+/* ------------------------------------------------------------------ backward pass, first slice (csrc/backward_ops.hip)
+ * train_video_seg.py:65-74 runs loss.backward() through AFB_URR.segment; the convolutions' gradients reuse
+ * vfn_conv2d_nhwc_f32 (data gradient: flipped / transposed filters + vfn_conv_desc.mask / res; weight gradient: a GEMM over
+ * the pixels on transposed operands, cut along K), these entry points are the HBM-bound pieces around them.
+ *
+ * vfn_transpose_taps_f32   out[(tap*C + c)][m] = act(x[n][y+dy][x+dx][c]), 0 outside the image; m = (n,y,x) flattened,
+ *     columns N*H*W .. Mpad-1 zero; taps = 1 (a transposition) or 9 (the transposed im2col image of a 3x3 / pad 1
+ *     convolution, tap = 3*(dy+1) + (dx+1)); relu: act = max(., 0).  x pixel stride ld_x floats.
+ * vfn_colsum_f32           out[c] = sum_m x[m][c] (bias gradient); partial: scratch nb * C floats, nb <= 1024 blocks;
+ *     two stages in fixed order (deterministic).
+ * vfn_upsample2x_add_backward_f32   adjoint of vfn_upsample2x_add_nhwc_f32 (Refine, AFB_URR.py:124): gm [N][h][w][C] ->
+ *     gs = sum over n (s_bcast = 1: the objects share s; gs may be NULL otherwise: ds = dm) and
+ *     gpm [N][h/2][w/2][C] = interpolate^T(gm). */
+int vfn_transpose_taps_f32(const float* x, int N, int H, int W, int C, int ld_x, int relu, int taps, float* out, int Mpad,
+                           void* stream);
+int vfn_colsum_f32(const float* x, int M, int C, int ld, float* partial, int nb, float* out, void* stream);
+int vfn_upsample2x_add_backward_f32(const float* gm, float* gs, float* gpm, int N, int h, int w, int C, int s_bcast,
+                                    void* stream);
 
 /* ------------------------------------------------------------------ feature-bank contractions (f32 MFMA)
  * Bank layout: entry-major, keys [obj][cap][128], values [obj][cap][512], info [obj][cap][2]

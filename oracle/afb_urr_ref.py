@@ -135,13 +135,20 @@ def matcher(fb, q_in, q_out, update_bank=True, thres_valid=1e-3):
     return torch.stack(outs, dim=0).transpose(0, 1)
 
 
-def decoder(sd, patch_match, r3, r2, r1, feature_shape, return_parts=False):
-    """AFB_URR.py:208-239."""
+def decoder_global(sd, patch_match, r3, r2):
+    """AFB_URR.py:209-212: the decoder's global branch, p = pred2(relu(RF2(r2, RF3(r3, ResMM(convFM(patch_match)))))), before
+    the interpolation and the local refinement (differentiated by tests/test_backward_gpu.py with torch.autograd)."""
     D = 'decoder'
     p = _resblock(sd, D + '.ResMM', _conv3(sd, D + '.convFM', patch_match))
     p = _refine(sd, D + '.RF3', r3, p)
     p = _refine(sd, D + '.RF2', r2, p)
-    p = _conv3(sd, D + '.pred2', F.relu(p))
+    return _conv3(sd, D + '.pred2', F.relu(p))
+
+
+def decoder(sd, patch_match, r3, r2, r1, feature_shape, return_parts=False):
+    """AFB_URR.py:208-239."""
+    D = 'decoder'
+    p = decoder_global(sd, patch_match, r3, r2)
     p = F.interpolate(p, scale_factor=2, mode='bilinear', align_corners=False)
 
     bs, obj_n, h, w = feature_shape

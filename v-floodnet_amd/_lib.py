@@ -24,7 +24,7 @@ class ConvDesc(C.Structure):
                 ('KH', C.c_int), ('KW', C.c_int), ('stride', C.c_int), ('pad', C.c_int),
                 ('relu_in', C.c_int), ('relu_out', C.c_int), ('M', C.c_int), ('ksplit', C.c_int),
                 ('split_from', C.c_int), ('res_mod', C.c_int), ('partial', c_fp), ('tile_counters', c_fp),
-                ('w_packed', C.c_int), ('in_lp', C.c_int), ('out_lp_relu', C.c_int), ('out_lp', c_fp)]
+                ('w_packed', C.c_int), ('in_lp', C.c_int), ('out_lp_relu', C.c_int), ('out_lp', c_fp), ('mask', c_fp), ('mask_ld', C.c_int)]
 
 
 class StemDesc(C.Structure):
@@ -131,6 +131,9 @@ SIGNATURES = {
     'vfn_upsample2x_add_nhwc_f32': [_p, _p, _p, _i, _i, _i, _i, _i, _p],
     'vfn_upsample2x_add_lp_nhwc_f32': [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p],
     'vfn_rough_uncertainty_f32': [_p, _p, _p, _p, _i, _i, _i, _p],
+    'vfn_transpose_taps_f32': [_p, _i, _i, _i, _i, _i, _i, _i, _p, _i, _p],
+    'vfn_colsum_f32': [_p, _i, _i, _i, _p, _i, _p, _p],
+    'vfn_upsample2x_add_backward_f32': [_p, _p, _p, _i, _i, _i, _i, _i, _p],
     'vfn_local_hpass_f32': [_p, _p, _p, _p, _p, _i, _i, _i, _i, _p],
     'vfn_local_vpass_f32': [_p, _p, _p, _p, _p, _i, _i, _i, _i, _p],
     'vfn_local_stats_f32': [_p, _p, _p, _p, _i, _i, _i, _i, _p],

@@ -83,6 +83,11 @@ __device__ __forceinline__ void splitk_finish(const vfn_conv_desc& p, int* flag,
         f32x4 v;
 #pragma unroll
         for (int k = 0; k < 4; ++k) v[k] = a[k] * sc[k] + sh[k];
+        if (p.mask) {
+            const f32x4 mk = *reinterpret_cast<const f32x4*>(p.mask + (size_t)row * p.mask_ld + col);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) v[k] = mk[k] > 0.f ? v[k] : 0.f;
+        }
         if (p.res) v += *reinterpret_cast<const f32x4*>(p.res + (size_t)(p.res_mod > 0 ? row % p.res_mod : row) * p.res_ld + col);
         if (p.relu_out) {
 #pragma unroll
@@ -109,7 +114,8 @@ __device__ __forceinline__ bool wide_epilogue(const vfn_conv_desc& p, char* smem
     constexpr int ROWS = WM * 32;                                   // tile rows handled per round
     constexpr int PITCH = (ROWS * (BN + 4) <= LDS_FLOATS) ? BN + 4 : BN;
     static_assert(ROWS * PITCH <= LDS_FLOATS, "C tile does not fit the staging LDS");
-    const bool wide = (p.Cout % 4 == 0) && (p.out_ld % 4 == 0) && (!p.res || p.res_ld % 4 == 0) && !(split_tile && p.tile_counters);
+    const bool wide = (p.Cout % 4 == 0) && (p.out_ld % 4 == 0) && (!p.res || p.res_ld % 4 == 0) && (!p.mask || p.mask_ld % 4 == 0) &&
+                      !(split_tile && p.tile_counters);
     if (!wide) return false;
     // (tid_in / active: the in-workgroup split-K variant runs this with its K group 0 only; the other groups keep the
     // barriers company and touch nothing)
@@ -153,6 +159,11 @@ __device__ __forceinline__ bool wide_epilogue(const vfn_conv_desc& p, char* smem
             }
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] = v[e] * sc[e] + sh[e];
+            if (p.mask) {
+                const f32x4 mk = *reinterpret_cast<const f32x4*>(p.mask + (size_t)row * p.mask_ld + col);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = mk[e] > 0.f ? v[e] : 0.f;
+            }
             if (p.res) v += *reinterpret_cast<const f32x4*>(p.res + (size_t)(p.res_mod > 0 ? row % p.res_mod : row) * p.res_ld + col);
             if (p.relu_out) {
 #pragma unroll
@@ -577,6 +588,7 @@ __device__ __forceinline__ void conv_igemm_body(const vfn_conv_desc& p) {
                 const int row = rbase + (r & 3) + 8 * (r >> 2);
                 if (row < p.M) {
                     float v = acc[i][j][r] * sc + sh;
+                    if (p.mask) v = p.mask[(size_t)row * p.mask_ld + col] > 0.f ? v : 0.f;
                     if (p.res) v += p.res[(size_t)(p.res_mod > 0 ? row % p.res_mod : row) * p.res_ld + col];
                     if (p.relu_out) v = fmaxf(v, 0.f);
                     p.out[(size_t)row * p.out_ld + col] = v;
@@ -801,6 +813,7 @@ void conv_igemm_dma_kernel(const vfn_conv_desc p) {
                 const int row = rbase + (r & 3) + 8 * (r >> 2);
                 if (row < p.M) {
                     float v = acc[i][j][r] * sc + sh;
+                    if (p.mask) v = p.mask[(size_t)row * p.mask_ld + col] > 0.f ? v : 0.f;
                     if (p.res) v += p.res[(size_t)(p.res_mod > 0 ? row % p.res_mod : row) * p.res_ld + col];
                     if (p.relu_out) v = fmaxf(v, 0.f);
                     p.out[(size_t)row * p.out_ld + col] = v;
@@ -829,6 +842,11 @@ __global__ void splitk_reduce_kernel(const vfn_conv_desc p, int m_start) {
         f32x4 v;
 #pragma unroll
         for (int k = 0; k < 4; ++k) v[k] = a[k] * sc[k] + sh[k];
+        if (p.mask) {
+            const f32x4 mk = *reinterpret_cast<const f32x4*>(p.mask + row * p.mask_ld + c4 * 4);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) v[k] = mk[k] > 0.f ? v[k] : 0.f;
+        }
         if (p.res) v += *reinterpret_cast<const f32x4*>(p.res + (p.res_mod > 0 ? row % p.res_mod : row) * p.res_ld + c4 * 4);
         if (p.relu_out) {
 #pragma unroll
@@ -965,7 +983,7 @@ extern "C" int vfn_conv2d_nhwc_f32(const vfn_conv_desc* d, int cfg, void* stream
     if (d->cout_pad < cdiv(d->Cout, bn) * bn) return VFN_ERR_ARG;
     if (d->ksplit > 1) {
         const int nk_all = d->KH * d->KW * (d->Cin / BK);
-        if (!d->partial || d->Cout % 4 || d->out_ld % 4 || (d->res && d->res_ld % 4)) return VFN_ERR_ARG;
+        if (!d->partial || d->Cout % 4 || d->out_ld % 4 || (d->res && d->res_ld % 4) || (d->mask && d->mask_ld % 4)) return VFN_ERR_ARG;
         if (d->tile_counters && d->Cout % bn) return VFN_ERR_ARG;      // in-launch finish works on whole filter tiles
         if (cdiv(nk_all, d->ksplit) * (d->ksplit - 1) >= nk_all) return VFN_ERR_ARG;   // every split non-empty
     }

@@ -644,6 +644,7 @@ class Engine:
             self._memory_read(p, fb, update_bank and b == 0, qs.kv_q[slot:slot + 1])
             for l in qs.post[slot]:
                 l()
+            self.last_query = (p, qs, slot)                 # (where the backward slice finds this frame's activations)
             if bs > 1:
                 out[b].copy_(p.score[0])
         return out
