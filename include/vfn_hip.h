@@ -192,6 +192,23 @@ int vfn_transpose_taps_f32(const float* x, int N, int H, int W, int C, int ld_x,
 int vfn_colsum_f32(const float* x, int M, int C, int ld, float* partial, int nb, float* out, void* stream);
 int vfn_upsample2x_add_backward_f32(const float* gm, float* gs, float* gpm, int N, int h, int w, int C, int s_bcast,
                                     void* stream);
+/* The decoder's tail backwards (AFB_URR.py:214-237,300,309-316), in the stages the host threads the local head's convolution
+ * gradients through (backward.py::DecoderBackward.run_tail):
+ * vfn_tail_grad_o_f32   G = dL/dscore [obj][H0][W0] (the logits segment returns) -> g_o [obj][2h][2w][4]: gradient w.r.t. the
+ *     two channels of interpolate(p2) in the PADDED frame (channels 2, 3 and the padding stay as the caller zeroed them);
+ *     zero where the clamp of :309 is active.  The adjoint of the interpolation is vfn_upsample2x_add_backward_f32 (C = 4).
+ * vfn_tail_split_f32    p2 = p_up + unc * conf * q: g_p2 [obj][pix][4] -> g_q [obj][pix][32] (channels 0, 1 written: the
+ *     32-channel gradient tensor the data-gradient convolution of local_pred2 reads), g_cf [obj][pix], g_u [pix].
+ * vfn_local_stats_backward_f32   through r1_local = avg7(r1*rough)/(avg7(rough)+1e-8), conf = max7(rough), the uncertainty's
+ *     top-2 and the two softmaxes: g_lm = dL/dr1_local [obj][pix][C], g_cf, g_u, g_p2 -> g_r1 [pix][C] (ACCUMULATED) and
+ *     g_pup [obj][pix][4] = dL/d interpolate(p).  Scratch: dA [obj][pix][C], dBv [obj][pix], amax int[obj][pix]. */
+int vfn_tail_grad_o_f32(const float* G, const float* p_up, const float* unc, const float* conf, const float* q, float* g_o,
+                        int obj_n, int h, int w, int pad_top, int pad_left, int H0, int W0, void* stream);
+int vfn_tail_split_f32(const float* g_p2, const float* unc, const float* conf, const float* q, float* g_q, float* g_cf, float* g_u,
+                       int obj_n, int npix, void* stream);
+int vfn_local_stats_backward_f32(const float* g_lm, const float* lm, const float* g_cf, const float* g_u, const float* g_p2,
+                                 const float* r1, const float* rough, const float* p_up, float* dA, float* dBv, int* amax,
+                                 float* g_r1, float* g_pup, int obj_n, int h, int w, int C, void* stream);
 
 /* ------------------------------------------------------------------ feature-bank contractions (f32 MFMA)
  * Bank layout: entry-major, keys [obj][cap][128], values [obj][cap][512], info [obj][cap][2]

@@ -67,6 +67,83 @@ def test_decoder_global_branch_backward_vs_autograd(gpu, H, W):
     assert set(grads) == want, want ^ set(grads)
 
 
+@pytest.mark.parametrize('H,W', [(96, 160), (90, 150)])
+def test_whole_decoder_backward_vs_autograd(gpu, H, W):
+    """dL/dscore -> every ``decoder.*`` parameter and (mem, q_out, r3, r2, r1): the tail (interpolations, clamp / logit, the
+    two softmaxes, top-2 uncertainty, 7x7 average / max windows), the local refinement head and the global branch, against
+    float64 autograd through the oracle's ``decoder`` + the logit tail of ``segment`` (AFB_URR.py:208-239,300,309-316).
+    90x150 is padded to 96x160 (pad_divide_by): the gradient of the cropped border is zero."""
+    import torch.nn.functional as F
+    from tools import synth
+    from vfloodnet_amd import AFB_URR, FeatureBank
+    from vfloodnet_amd.backward import DecoderBackward
+    from oracle import afb_urr_ref as O
+    sd = synth.make_state_dict(SEED)
+    model = AFB_URR(gpu, update_bank=False).to(gpu).eval()
+    model.load_state_dict(sd, strict=True)
+    frames, m0 = synth.clip(4, 2, H, W)
+    oh = synth.onehot(m0).unsqueeze(0)
+    k, v = model.memorize(frames[0:1].to(gpu), oh.to(gpu))
+    fb = FeatureBank(2, 250000, gpu)
+    fb.init_bank(k, v)
+    score, _ = model.segment(frames[1:2].to(gpu), fb)
+    eng = model.engine()
+    plan, qs, slot = eng.last_query
+    K = 2
+    g = torch.Generator().manual_seed(H + W)
+    G = torch.randn(K, H, W, generator=g).to(gpu)
+    grads, gin = DecoderBackward(eng).run_tail(plan, G, qs, slot)
+    torch.cuda.synchronize()
+
+    nchw = lambda t: t.permute(0, 3, 1, 2).contiguous().cpu().double()
+    mem = nchw(plan.dec_in).requires_grad_()
+    q_out = qs.kv_q[slot, :, 128:].t().reshape(1, 512, plan.h16, plan.w16).cpu().double().requires_grad_()
+    r3 = nchw(qs.q['res3']['out'][slot:slot + 1]).requires_grad_()
+    r2 = nchw(qs.q['res2']['out'][slot:slot + 1]).requires_grad_()
+    r1 = nchw(qs.q['r1'][slot:slot + 1]).requires_grad_()
+    sd64 = {n: t.double().clone().requires_grad_() for n, t in sd.items() if n.startswith('decoder.') and t.is_floating_point()}
+    patch_match = torch.cat([mem, q_out.expand(K, -1, -1, -1)], dim=1)
+    e = lambda t: t.expand(K, -1, -1, -1)
+    # ReLU is not differentiable at 0: a pre-activation within rounding of 0 may sit on different sides in the f32 HIP forward and
+    # the float64 oracle, and the gradient through that ONE element can be a visible fraction of a filter's gradient (measured:
+    # 1 element of 245 760, 1 % of local_ResMM.conv1).  The comparison is made well-posed by differentiating the oracle at the
+    # HIP forward's activation pattern: its ReLUs (called in a fixed order, AFB_URR.py:208-239) take their masks from the HIP
+    # buffers; how many elements that changes is asserted to be a handful.
+    sl = lambda t: t[slot:slot + 1].expand(K, -1, -1, -1)
+    order = [plan.d16[0], plan.d16[1], sl(qs.s8[0]), sl(qs.s8[1]), plan.d8[0], plan.d8[1], sl(qs.s4[0]), sl(qs.s4[1]),
+             plan.d4[0], plan.d4[1], plan.d4[2], plan.l2[0], plan.l2[1], plan.l2[2]]
+    masks = iter([(t.permute(0, 3, 1, 2) > 0).cpu() for t in order])
+    flips = []
+    real_relu = F.relu
+
+    def relu_at_hip_pattern(x, *a, **k):
+        m = next(masks)
+        flips.append(int(((x.detach() > 0) != m).sum()))
+        return x * m.to(x.dtype)
+    O.F.relu = relu_at_hip_pattern
+    try:
+        out = O.decoder(sd64, patch_match, e(r3), e(r2), e(r1), (1, K, plan.h2, plan.w2))   # [K, Hp, Wp]
+    finally:
+        O.F.relu = real_relu
+    assert next(masks, None) is None and sum(flips) <= 8, flips
+    sc = torch.clamp(out, 1e-7, 1 - 1e-7)
+    sc = torch.log(sc / (1 - sc))
+    lw, uw, lh, uh = plan.pad
+    sc = sc[:, lh:sc.shape[1] - uh, lw:sc.shape[2] - uw]                                    # AFB_URR.py:312-316
+    assert (sc.detach() - score[0].cpu().double()).abs().max() < 2e-3                       # same forward
+    (sc * G.cpu().double()).sum().backward()
+
+    worst = {}
+    for name, got in grads.items():
+        worst[name] = _rel(got.cpu(), sd64[name].grad)
+    for name, ref in (('mem', mem.grad), ('q_out', q_out.grad), ('r3', r3.grad), ('r2', r2.grad), ('r1', r1.grad)):
+        worst['input.' + name] = _rel(nchw(gin[name]), ref)
+    print('whole decoder backward, relative errors:', {n: f'{e_:.1e}' for n, e_ in sorted(worst.items(), key=lambda kv: -kv[1])})
+    bad = {n: e_ for n, e_ in worst.items() if not e_ < 1e-4}
+    assert not bad, bad
+    assert set(grads) == set(sd64), set(sd64) ^ set(grads)
+
+
 def test_transposed_im2col_and_adjoint_kernels(gpu):
     """vfn_transpose_taps_f32 against unfold, vfn_colsum_f32 against sum, vfn_upsample2x_add_backward_f32 against autograd
     of interpolate, on ragged shapes."""

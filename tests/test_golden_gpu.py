@@ -31,9 +31,9 @@ def test_blocks(gpu, model, tag):
     score, _ = model.segment(frames[1:2], fb)
     ok, dl, dp = close_logits(score.cpu(), t(g['score']), 1e-3)
     assert ok, (dl, dp)
-    p = model.engine().plan(H, W, 2)
-    for n, buf in dict(r1=p.q['r1'], r2=p.q['res2']['out'], r3=p.q['res3']['out'], r4=p.q['res4']['out']).items():
-        x = buf.permute(0, 3, 1, 2).contiguous().cpu()
+    p, qs, slot = model.engine().last_query                 # the query set / slot this frame's features live in
+    for n, buf in dict(r1=qs.q['r1'], r2=qs.q['res2']['out'], r3=qs.q['res3']['out'], r4=qs.q['res4']['out']).items():
+        x = buf[slot:slot + 1].permute(0, 3, 1, 2).contiguous().cpu()
         assert (x.flatten()[t(g[n + '_idx'])] - t(g[n + '_val'])).abs().max() < 5e-4, n
     # info[:,1] = log(hit count + 1) (AFB_URR.py:161-174): the counts are integers, so an entry either agrees to the
     # rounding of log() or one probability sat on the 1e-3 threshold and its count moved by one -- at most a couple of

@@ -134,6 +134,9 @@ SIGNATURES = {
     'vfn_transpose_taps_f32': [_p, _i, _i, _i, _i, _i, _i, _i, _p, _i, _p],
     'vfn_colsum_f32': [_p, _i, _i, _i, _p, _i, _p, _p],
     'vfn_upsample2x_add_backward_f32': [_p, _p, _p, _i, _i, _i, _i, _i, _p],
+    'vfn_tail_grad_o_f32': [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p],
+    'vfn_tail_split_f32': [_p, _p, _p, _p, _p, _p, _p, _i, _i, _p],
+    'vfn_local_stats_backward_f32': [_p] * 13 + [_i, _i, _i, _i, _p],
     'vfn_local_hpass_f32': [_p, _p, _p, _p, _p, _i, _i, _i, _i, _p],
     'vfn_local_vpass_f32': [_p, _p, _p, _p, _p, _i, _i, _i, _i, _p],
     'vfn_local_stats_f32': [_p, _p, _p, _p, _i, _i, _i, _i, _p],

@@ -52,6 +52,15 @@ class DecoderBackward:
         wp = torch.zeros(32, d.pred2.weight.shape[1], 3, 3)                 # pred2 has 2 filters: its gradient arrives in a
         wp[:2] = d.pred2.weight.detach().float()                           # 32-channel tensor (channels 2.. are zero)
         self.f['pred2'] = (_dgrad_filters(wp).to(dev), d.pred2.weight.shape[1])
+        # the local refinement head (AFB_URR.py:231-234)
+        for name, conv in (('local_ResMM.conv1', d.local_ResMM.conv1), ('local_ResMM.conv2', d.local_ResMM.conv2)):
+            self.f[name] = (_dgrad_filters(conv.weight).to(dev), conv.weight.shape[1])
+        wl = d.local_convFM.weight                                           # input = cat([r1, r1_local]): 64 + 64 channels
+        self.f['local_convFM.r1'] = (_dgrad_filters(wl[:, :64]).to(dev), 64)
+        self.f['local_convFM.loc'] = (_dgrad_filters(wl[:, 64:]).to(dev), 64)
+        wp = torch.zeros(32, d.local_pred2.weight.shape[1], 3, 3)
+        wp[:2] = d.local_pred2.weight.detach().float()
+        self.f['local_pred2'] = (_dgrad_filters(wp).to(dev), d.local_pred2.weight.shape[1])
         self._scratch = {}
 
     # ------------------------------------------------------------------ pieces
@@ -80,11 +89,12 @@ class DecoderBackward:
         self._launch(d, plan)
         return out
 
-    def wgrad(self, plan, x, gy, relu, x_ld=None, x_c=None):
-        """(dL/dW [Cout,Cin,3,3], dL/db [Cout]) of y = conv3x3(act(x)) + b given gy [N,H,W,Cout]."""
+    def wgrad(self, plan, x, gy, relu, x_ld=None, x_c=None, gy_c=None):
+        """(dL/dW [Cout,Cin,3,3], dL/db [Cout]) of y = conv3x3(act(x)) + b given gy [N,H,W,Cout] (``gy_c``: the first gy_c
+        channels of a wider gradient tensor)."""
         L = _lib.lib()
         N, H, Wd = gy.shape[0], gy.shape[1], gy.shape[2]
-        cout = gy.shape[-1]
+        cout = gy_c if gy_c is not None else gy.shape[-1]
         cin = x_c if x_c is not None else x.shape[-1]
         ld_x = x_ld if x_ld is not None else x.shape[-1]
         M = N * H * Wd
@@ -168,6 +178,59 @@ class DecoderBackward:
         grads['decoder.convFM.bias'] = db
         # patch_match[i] = cat([mem_i, q_out]) (AFB_URR.py:159): dL/dmem per object, dL/dq_out summed over the objects
         return grads, {'mem': g_mem, 'q_out': g_qv, 'r3': g_r3, 'r2': g_r2}
+
+    @torch.no_grad()
+    def run_tail(self, plan, grad_score, qs=None, slot=0):
+        """The whole decoder backwards: ``grad_score`` = dL/d(logits ``segment`` returned) f32 [obj_n, H0, W0] for the frame
+        ``segment`` ran last (AFB_URR.py:208-239 + :300,309-316).  Runs the tail and the local refinement head, then
+        ``run`` for the global branch.  Returns (dict state-dict name -> gradient for every ``decoder.*`` parameter, dict of
+        input gradients: mem, q_out, r3, r2, r1)."""
+        L = _lib.lib()
+        p = plan
+        qs = qs or p.qsets[0]
+        K, h2, w2 = p.obj_n, p.h2, p.w2
+        npix = h2 * w2
+        dev = self.dev
+        s = stream()
+        r1 = qs.q['r1'][slot:slot + 1]                                         # [1,h2,w2,64]
+        G = grad_score.contiguous()
+        g_o = torch.zeros(K, 2 * h2, 2 * w2, 4, device=dev)
+        check(L.vfn_tail_grad_o_f32(ptr(G), ptr(p.p_up), ptr(p.unc), ptr(p.conf), ptr(p.qq), ptr(g_o), K, h2, w2,
+                                    p.pad[2], p.pad[0], p.H0, p.W0, s), 'vfn_tail_grad_o_f32')
+        g_p2 = torch.empty(K, h2, w2, 4, device=dev)
+        check(L.vfn_upsample2x_add_backward_f32(ptr(g_o), None, ptr(g_p2), K, 2 * h2, 2 * w2, 4, 0, s), 'vfn_upsample2x_add_backward_f32')
+        g_q = torch.zeros(K, h2, w2, 32, device=dev)
+        g_cf = torch.empty(K, h2, w2, device=dev)
+        g_u = torch.empty(h2, w2, device=dev)
+        check(L.vfn_tail_split_f32(ptr(g_p2), ptr(p.unc), ptr(p.conf), ptr(p.qq), ptr(g_q), ptr(g_cf), ptr(g_u), K, npix, s),
+              'vfn_tail_split_f32')
+        grads = {}
+        # q = conf * local_pred2(relu(local_ResMM(local_convFM(cat([r1, r1_local])))))   (AFB_URR.py:231-234)
+        l2 = p.l2
+        g = self.dgrad(p, 'local_pred2', g_q, K, h2, w2, mask=l2[2])
+        grads['decoder.local_pred2.weight'], grads['decoder.local_pred2.bias'] = self.wgrad(p, l2[2], g_q, True, gy_c=2)
+        g = self.resblock(p, grads, 'local_ResMM', l2[0], l2[1], g, K, h2, w2)
+        g_lm = self.dgrad(p, 'local_convFM.loc', g, K, h2, w2)
+        dw_loc, _ = self.wgrad(p, p.lm, g, False)
+        g_lq = self._sum_objects(g)                                            # the r1 half is shared by the objects (:231)
+        dw_r1, db = self.wgrad(p, r1, g_lq, False)
+        g_r1 = self.dgrad(p, 'local_convFM.r1', g_lq, 1, h2, w2)
+        grads['decoder.local_convFM.weight'] = torch.cat([dw_r1, dw_loc], dim=1)
+        grads['decoder.local_convFM.bias'] = db
+        # r1_local, conf, uncertainty, the two softmaxes -> interpolate(p)
+        dA = torch.empty(K, h2, w2, 64, device=dev)
+        dBv = torch.empty(K, h2, w2, device=dev)
+        amax = torch.empty(K, h2, w2, dtype=torch.int32, device=dev)
+        g_pup = torch.empty(K, h2, w2, 4, device=dev)
+        check(L.vfn_local_stats_backward_f32(ptr(g_lm), ptr(p.lm), ptr(g_cf), ptr(g_u), ptr(g_p2), ptr(r1), ptr(p.rough), ptr(p.p_up),
+                                             ptr(dA), ptr(dBv), ptr(amax), ptr(g_r1), ptr(g_pup), K, h2, w2, 64, s),
+              'vfn_local_stats_backward_f32')
+        g_p4 = torch.empty(K, p.h4, p.w4, 4, device=dev)
+        check(L.vfn_upsample2x_add_backward_f32(ptr(g_pup), None, ptr(g_p4), K, h2, w2, 4, 0, s), 'vfn_upsample2x_add_backward_f32')
+        g2, inputs = self.run(p, g_p4[..., :2].contiguous(), qs, slot)
+        grads.update(g2)
+        inputs['r1'] = g_r1
+        return grads, inputs
 
     def _sum_objects(self, g):
         """[N,h,w,C] -> [1,h,w,C], summed over the objects in index order."""

@@ -130,6 +130,193 @@ __global__ void upsample2x_adjoint_kernel(const float* __restrict__ gm, float* _
     }
 }
 
+// ------------------------------------------------------------------ the decoder's tail, backwards (AFB_URR.py:214-237,300,309-316)
+// forward (decoder_ops.hip): p_up = up2(p); rp = softmax_c(p_up)[1]; rough = softmax_k(rp); unc = exp(1 - top1/(top2+1e-8));
+//   r1_local = box7(r1 * rough)/49 / (box7(rough)/49 + 1e-8); conf = max7(rough); q = local head(cat[r1, r1_local]);
+//   p2 = p_up + unc * conf * q; o = up2(p2); s = softmax_c(o)[1]; score = logit(clamp(s, 1e-7, 1-1e-7)), un-padded.
+constexpr int MAX_OBJ = 8;
+
+// T1: g_o[n][Y][X][0..3] (padded frame, channels 2, 3 and the padding stay zero) from G = dL/dscore [n][H0][W0]:
+// score = o1 - o0 where the clamp is inactive, constant otherwise
+__global__ void tail_grad_o_kernel(const float* __restrict__ G, const float* __restrict__ p_up, const float* __restrict__ unc,
+                                   const float* __restrict__ conf, const float* __restrict__ q, float* __restrict__ g_o,
+                                   int obj_n, int h, int w, int pad_top, int pad_left, int H0, int W0) {
+    const size_t total = (size_t)obj_n * H0 * W0;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int x0 = i % W0;
+        size_t t = i / W0;
+        const int y0 = t % H0;
+        const int n = t / H0;
+        const int y = y0 + pad_top, x = x0 + pad_left;
+        const Lerp ly = lerp2x(y, h), lx = lerp2x(x, w);
+        float v[2][4];
+        const int ys[2] = {ly.i0, ly.i1}, xs[2] = {lx.i0, lx.i1};
+        for (int a = 0; a < 2; ++a)
+            for (int b = 0; b < 2; ++b) {
+                const size_t pix = (size_t)ys[a] * w + xs[b];
+                const size_t pn = (size_t)n * h * w + pix;
+                const float u = unc[pix], cf = conf[pn];
+                v[0][a * 2 + b] = p_up[pn * 2] + u * (cf * q[pn * 2]);
+                v[1][a * 2 + b] = p_up[pn * 2 + 1] + u * (cf * q[pn * 2 + 1]);
+            }
+        const float o0 = ly.l0 * (lx.l0 * v[0][0] + lx.l1 * v[0][1]) + ly.l1 * (lx.l0 * v[0][2] + lx.l1 * v[0][3]);
+        const float o1 = ly.l0 * (lx.l0 * v[1][0] + lx.l1 * v[1][1]) + ly.l1 * (lx.l0 * v[1][2] + lx.l1 * v[1][3]);
+        const float m = fmaxf(o0, o1);
+        const float e0 = expf(o0 - m), e1 = expf(o1 - m);
+        const float sft = e1 / (e0 + e1);
+        const float g = (sft > 1e-7f && sft < 1.f - 1e-7f) ? G[i] : 0.f;
+        float* dst = g_o + (((size_t)n * 2 * h + y) * (2 * w) + x) * 4;
+        dst[0] = -g;
+        dst[1] = g;
+    }
+}
+
+// T2: p2 = p_up + unc * conf * q.  g_p2 [n][pix][4] (2 used) -> g_q [n][pix][32] (2 used, rest zero), g_cf [n][pix], g_u [pix]
+__global__ void tail_split_kernel(const float* __restrict__ g_p2, const float* __restrict__ unc, const float* __restrict__ conf,
+                                  const float* __restrict__ q, float* __restrict__ g_q, float* __restrict__ g_cf,
+                                  float* __restrict__ g_u, int obj_n, int npix) {
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < npix; i += gridDim.x * blockDim.x) {
+        const float u = unc[i];
+        float gu = 0.f;
+        for (int n = 0; n < obj_n; ++n) {
+            const size_t pn = (size_t)n * npix + i;
+            const float g0 = g_p2[pn * 4], g1 = g_p2[pn * 4 + 1];
+            const float cf = conf[pn], q0 = q[pn * 2], q1 = q[pn * 2 + 1];
+            g_q[pn * 32] = g0 * u * cf;
+            g_q[pn * 32 + 1] = g1 * u * cf;
+            const float dot = g0 * q0 + g1 * q1;
+            g_cf[pn] = u * dot;
+            gu += cf * dot;
+        }
+        g_u[i] = gu;
+    }
+}
+
+// arg-max position of the 7x7 window of rough around every pixel (first maximum in row-major order, as MaxPool2d)
+__global__ void window_argmax_kernel(const float* __restrict__ rough, int* __restrict__ amax, int obj_n, int h, int w) {
+    const int total = obj_n * h * w;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+        const int x = i % w, y = (i / w) % h, n = i / (h * w);
+        const float* r = rough + (size_t)n * h * w;
+        float best = -INFINITY;
+        int arg = y * w + x;
+        for (int dy = -3; dy <= 3; ++dy) {
+            const int yy = y + dy;
+            if ((unsigned)yy >= (unsigned)h) continue;
+            for (int dx = -3; dx <= 3; ++dx) {
+                const int xx = x + dx;
+                if ((unsigned)xx >= (unsigned)w) continue;
+                const float v = r[yy * w + xx];
+                if (v > best) { best = v; arg = yy * w + xx; }
+            }
+        }
+        amax[i] = arg;
+    }
+}
+
+// T4a: dA [n][pix][C] = g_lm / Bv,  dBv [n][pix] = -sum_c g_lm * r1_local / Bv, Bv = box7(rough)/49 + 1e-8 (recomputed)
+__global__ void local_ratio_bwd_kernel(const float* __restrict__ g_lm, const float* __restrict__ lm, const float* __restrict__ rough,
+                                       float* __restrict__ dA, float* __restrict__ dBv, int obj_n, int h, int w, int C) {
+    const int total = obj_n * h * w;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+        const int x = i % w, y = (i / w) % h, n = i / (h * w);
+        const float* r = rough + (size_t)n * h * w;
+        float sr = 0.f;
+        for (int dy = -3; dy <= 3; ++dy) {
+            const int yy = y + dy;
+            if ((unsigned)yy >= (unsigned)h) continue;
+            for (int dx = -3; dx <= 3; ++dx) {
+                const int xx = x + dx;
+                if ((unsigned)xx < (unsigned)w) sr += r[yy * w + xx];
+            }
+        }
+        const float bv = sr / 49.f + 1e-8f;
+        float acc = 0.f;
+        for (int c = 0; c < C; ++c) {
+            const float g = g_lm[(size_t)i * C + c];
+            dA[(size_t)i * C + c] = g / bv;
+            acc += g * lm[(size_t)i * C + c];
+        }
+        dBv[i] = -acc / bv;
+    }
+}
+
+// T4b: everything that reaches rough, then back through the two softmaxes to p_up (out [n][pix][4], 2 used), and the part
+// of dL/dr1 that comes through r1 * rough (g_r1 [pix][C], added to what is there)
+__global__ void local_stats_bwd_kernel(const float* __restrict__ dA, const float* __restrict__ dBv, const float* __restrict__ g_cf,
+                                       const int* __restrict__ amax, const float* __restrict__ g_u, const float* __restrict__ g_p2,
+                                       const float* __restrict__ r1, const float* __restrict__ rough, const float* __restrict__ p_up,
+                                       float* __restrict__ g_r1, float* __restrict__ g_pup, int obj_n, int h, int w, int C) {
+    const int npix = h * w;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < npix; i += gridDim.x * blockDim.x) {
+        const int x = i % w, y = i / w;
+        float g_rough[MAX_OBJ], rg[MAX_OBJ];
+        for (int n = 0; n < obj_n; ++n) { g_rough[n] = 0.f; rg[n] = rough[(size_t)n * npix + i]; }
+        // box filters of dA (per channel) and dBv; max-pool routing of g_cf
+        for (int n = 0; n < obj_n; ++n) {
+            float sb = 0.f, gmax = 0.f;
+            for (int dy = -3; dy <= 3; ++dy) {
+                const int yy = y + dy;
+                if ((unsigned)yy >= (unsigned)h) continue;
+                for (int dx = -3; dx <= 3; ++dx) {
+                    const int xx = x + dx;
+                    if ((unsigned)xx >= (unsigned)w) continue;
+                    const size_t pn = (size_t)n * npix + yy * w + xx;
+                    sb += dBv[pn];
+                    if (amax[pn] == i) gmax += g_cf[pn];
+                }
+            }
+            g_rough[n] += sb / 49.f + gmax;
+        }
+        for (int c = 0; c < C; ++c) {
+            const float rv = r1[(size_t)i * C + c];
+            float gr1 = 0.f;
+            for (int n = 0; n < obj_n; ++n) {
+                float sa = 0.f;
+                for (int dy = -3; dy <= 3; ++dy) {
+                    const int yy = y + dy;
+                    if ((unsigned)yy >= (unsigned)h) continue;
+                    for (int dx = -3; dx <= 3; ++dx) {
+                        const int xx = x + dx;
+                        if ((unsigned)xx < (unsigned)w) sa += dA[((size_t)n * npix + yy * w + xx) * C + c];
+                    }
+                }
+                sa /= 49.f;
+                gr1 += rg[n] * sa;
+                g_rough[n] += rv * sa;
+            }
+            g_r1[(size_t)i * C + c] += gr1;
+        }
+        // uncertainty: u = exp(1 - t1 / (t2 + 1e-8)) with (t1, t2) the two largest rough values (first maximum wins ties)
+        int k1 = 0, k2 = -1;
+        float t1 = -INFINITY, t2 = -INFINITY;
+        for (int n = 0; n < obj_n; ++n) {
+            if (rg[n] > t1) { t2 = t1; k2 = k1; t1 = rg[n]; k1 = n; }
+            else if (rg[n] > t2) { t2 = rg[n]; k2 = n; }
+        }
+        const float u = expf(1.f - t1 / (t2 + 1e-8f));
+        const float gu = g_u[i];
+        g_rough[k1] += gu * (-u / (t2 + 1e-8f));
+        if (k2 >= 0) g_rough[k2] += gu * (u * t1 / ((t2 + 1e-8f) * (t2 + 1e-8f)));
+        // rough = softmax_k(rp); rp = sigmoid(p_up1 - p_up0)
+        float dot = 0.f;
+        for (int n = 0; n < obj_n; ++n) dot += g_rough[n] * rg[n];
+        for (int n = 0; n < obj_n; ++n) {
+            const size_t pn = (size_t)n * npix + i;
+            const float g_rp = rg[n] * (g_rough[n] - dot);
+            const float v0 = p_up[pn * 2], v1 = p_up[pn * 2 + 1];
+            const float m = fmaxf(v0, v1);
+            const float e0 = expf(v0 - m), e1 = expf(v1 - m);
+            const float rp = e1 / (e0 + e1);
+            const float d = g_rp * rp * (1.f - rp);
+            g_pup[pn * 4] = g_p2[pn * 4] - d;
+            g_pup[pn * 4 + 1] = g_p2[pn * 4 + 1] + d;
+            g_pup[pn * 4 + 2] = 0.f;
+            g_pup[pn * 4 + 3] = 0.f;
+        }
+    }
+}
+
 }  // namespace
 
 extern "C" int vfn_transpose_taps_f32(const float* x, int N, int H, int W, int C, int ld_x, int relu, int taps, float* out,
@@ -157,5 +344,41 @@ extern "C" int vfn_upsample2x_add_backward_f32(const float* gm, float* gs, float
     }
     const size_t total = (size_t)N * (h / 2) * (w / 2) * (C / 4);
     hipLaunchKernelGGL(upsample2x_adjoint_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, gm, gpm, N, h, w, C);
+    return vfn_check_launch();
+}
+
+// Decoder tail backwards, stage by stage (the host runs the local head's convolution gradients between T2 and T4):
+//   vfn_tail_grad_o_f32        G [obj][H0][W0] -> g_o [obj][2h][2w][4] (zero-initialised by the caller; channels 0, 1 written)
+//   vfn_tail_split_f32         g_p2 [obj][pix][4] -> g_q [obj][pix][32] (zero-initialised; channels 0, 1 written), g_cf, g_u
+//   vfn_local_stats_backward_f32   g_lm, g_cf, g_u, g_p2 + forward tensors -> g_r1 (accumulated) and g_pup [obj][pix][4]
+//                              scratch: dA [obj][pix][C], dBv [obj][pix], amax int[obj][pix]
+extern "C" int vfn_tail_grad_o_f32(const float* G, const float* p_up, const float* unc, const float* conf, const float* q, float* g_o,
+                                   int obj_n, int h, int w, int pad_top, int pad_left, int H0, int W0, void* stream) {
+    if (!G || !p_up || !unc || !conf || !q || !g_o || obj_n < 1 || obj_n > MAX_OBJ) return VFN_ERR_ARG;
+    if (pad_top + H0 > 2 * h || pad_left + W0 > 2 * w) return VFN_ERR_ARG;
+    hipLaunchKernelGGL(tail_grad_o_kernel, dim3(grid_for((size_t)obj_n * H0 * W0)), dim3(256), 0, (hipStream_t)stream,
+                       G, p_up, unc, conf, q, g_o, obj_n, h, w, pad_top, pad_left, H0, W0);
+    return vfn_check_launch();
+}
+
+extern "C" int vfn_tail_split_f32(const float* g_p2, const float* unc, const float* conf, const float* q, float* g_q, float* g_cf,
+                                  float* g_u, int obj_n, int npix, void* stream) {
+    if (!g_p2 || !unc || !conf || !q || !g_q || !g_cf || !g_u || obj_n < 1 || obj_n > MAX_OBJ) return VFN_ERR_ARG;
+    hipLaunchKernelGGL(tail_split_kernel, dim3(grid_for(npix)), dim3(256), 0, (hipStream_t)stream, g_p2, unc, conf, q, g_q, g_cf, g_u,
+                       obj_n, npix);
+    return vfn_check_launch();
+}
+
+extern "C" int vfn_local_stats_backward_f32(const float* g_lm, const float* lm, const float* g_cf, const float* g_u, const float* g_p2,
+                                            const float* r1, const float* rough, const float* p_up, float* dA, float* dBv, int* amax,
+                                            float* g_r1, float* g_pup, int obj_n, int h, int w, int C, void* stream) {
+    if (!g_lm || !lm || !g_cf || !g_u || !g_p2 || !r1 || !rough || !p_up || !dA || !dBv || !amax || !g_r1 || !g_pup) return VFN_ERR_ARG;
+    if (obj_n < 1 || obj_n > MAX_OBJ || C < 1) return VFN_ERR_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    const int total = obj_n * h * w;
+    hipLaunchKernelGGL(window_argmax_kernel, dim3(grid_for(total)), dim3(256), 0, s, rough, amax, obj_n, h, w);
+    hipLaunchKernelGGL(local_ratio_bwd_kernel, dim3(grid_for(total)), dim3(256), 0, s, g_lm, lm, rough, dA, dBv, obj_n, h, w, C);
+    hipLaunchKernelGGL(local_stats_bwd_kernel, dim3(grid_for(h * w)), dim3(256), 0, s, dA, dBv, g_cf, amax, g_u, g_p2, r1, rough, p_up,
+                       g_r1, g_pup, obj_n, h, w, C);
     return vfn_check_launch();
 }
