@@ -202,6 +202,12 @@ int vfn_upsample2x_add_backward_f32(const float* gm, float* gs, float* gpm, int 
  * vfn_local_stats_backward_f32   through r1_local = avg7(r1*rough)/(avg7(rough)+1e-8), conf = max7(rough), the uncertainty's
  *     top-2 and the two softmaxes: g_lm = dL/dr1_local [obj][pix][C], g_cf, g_u, g_p2 -> g_r1 [pix][C] (ACCUMULATED) and
  *     g_pup [obj][pix][4] = dL/d interpolate(p).  Scratch: dA [obj][pix][C], dBv [obj][pix], amax int[obj][pix]. */
+/* vfn_segment_loss_f32   train_video_seg.py:72-74: loss = CrossEntropyLoss(scores, label) + lu * uncertainty on the logits
+ *     segment returns (scores [bs][obj][n], label int32 [bs][n]; uncertainty as vfn_segment_uncertainty_f32) and, with grad
+ *     != NULL, dloss/dscores [bs][obj][n] -- the input of the decoder's backward.  partial: scratch 2*bs*64 floats;
+ *     stats: 3 + bs floats = (loss, cross entropy, uncertainty, ||u|| per sample).  Deterministic two-stage sums. */
+int vfn_segment_loss_f32(const float* logit, const int* label, int bs, int obj_n, int n, float lu, float* partial, float* stats,
+                         float* grad, void* stream);
 int vfn_tail_grad_o_f32(const float* G, const float* p_up, const float* unc, const float* conf, const float* q, float* g_o,
                         int obj_n, int h, int w, int pad_top, int pad_left, int H0, int W0, void* stream);
 int vfn_tail_split_f32(const float* g_p2, const float* unc, const float* conf, const float* q, float* g_q, float* g_cf, float* g_u,

@@ -179,3 +179,29 @@ def test_transposed_im2col_and_adjoint_kernels(gpu):
         check(L.vfn_upsample2x_add_backward_f32(ptr(gm.to(gpu)), ptr(gs), ptr(gpm), n, h, w, c, 1, stream()), 'adjoint')
         assert (gpm.cpu().permute(0, 3, 1, 2).double() - pm.grad).abs().max() < 1e-5
         assert (gs.cpu() - gm.sum(0, keepdim=True)).abs().max() < 1e-5
+
+
+@pytest.mark.parametrize('bs,K,H,W', [(1, 2, 48, 80), (3, 3, 40, 56)])
+def test_training_loss_and_its_gradient(gpu, bs, K, H, W):
+    """vfn_segment_loss_f32 = CrossEntropyLoss(scores, label) + lu * uncertainty (train_video_seg.py:72-74, AFB_URR.py:302-305)
+    and dloss/dscores, against torch autograd in float64 (the uncertainty is a function of the decoder's probability
+    s = sigmoid(score), as in the reference where the logit is taken after it)."""
+    import torch.nn.functional as F
+    from vfloodnet_amd import ops
+    from oracle import afb_urr_ref as O
+    g = torch.Generator().manual_seed(bs * 100 + K)
+    score = (2.5 * torch.randn(bs, K, H, W, generator=g))
+    label = torch.randint(0, K, (bs, H, W), generator=g)
+    lu = 0.5
+    stats, grad = ops.segment_loss(score.to(gpu), label.to(gpu), lu)
+    torch.cuda.synchronize()
+    z = score.double().requires_grad_()
+    s = torch.sigmoid(z)
+    u = O.calc_uncertainty(F.softmax(s, dim=1))
+    unc = (u.view(bs, -1).norm(p=2, dim=1) / (H * W) ** 0.5).mean()
+    ce = F.cross_entropy(z, label)
+    loss = ce + lu * unc
+    loss.backward()
+    st = stats.cpu().double()
+    assert abs(st[0] - loss.item()) < 1e-5 * abs(loss.item()) and abs(st[1] - ce.item()) < 1e-5 and abs(st[2] - unc.item()) < 1e-5
+    assert _rel(grad.cpu(), z.grad) < 1e-4

@@ -317,6 +317,112 @@ __global__ void local_stats_bwd_kernel(const float* __restrict__ dA, const float
     }
 }
 
+// ------------------------------------------------------------------ the training loss and its gradient
+// train_video_seg.py:72-74: loss = CrossEntropyLoss(scores, label) + lu * uncertainty, scores = the logits segment returns
+// [bs][obj][n], label [bs][n], uncertainty = AFB_URR.py:302-305 (vfn_segment_uncertainty_f32: mean over the batch of
+// ||calc_uncertainty(softmax_obj(s))||_2 / sqrt(n), s = sigmoid(logit) = the decoder's probability).
+constexpr int LOSS_BLOCKS = 64;
+
+// stage 1: per (block, sample): sum of -log softmax_obj(logit)[label] and of u^2
+__global__ __launch_bounds__(256)
+void loss_partial_kernel(const float* __restrict__ logit, const int* __restrict__ label, int obj_n, int n,
+                         float* __restrict__ part_ce, float* __restrict__ part_u2) {
+    __shared__ float red[2][4];
+    const int b = blockIdx.y;
+    const float* src = logit + (size_t)b * obj_n * n;
+    float ce = 0.f, u2 = 0.f;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        float z[MAX_OBJ], s[MAX_OBJ], zmax = -INFINITY, smax = -INFINITY;
+        for (int k = 0; k < obj_n; ++k) {
+            z[k] = src[(size_t)k * n + i];
+            s[k] = 1.f / (1.f + expf(-z[k]));
+            zmax = fmaxf(zmax, z[k]);
+            smax = fmaxf(smax, s[k]);
+        }
+        float zden = 0.f, sden = 0.f;
+        for (int k = 0; k < obj_n; ++k) { zden += expf(z[k] - zmax); s[k] = expf(s[k] - smax); sden += s[k]; }
+        const int lab = label[(size_t)b * n + i];
+        ce += logf(zden) + zmax - z[lab];
+        float t1 = -1.f, t2 = -1.f;
+        for (int k = 0; k < obj_n; ++k) {
+            const float pk = s[k] / sden;
+            if (pk > t1) { t2 = t1; t1 = pk; } else if (pk > t2) t2 = pk;
+        }
+        const float u = expf(1.f - t1 / (t2 + 1e-8f));
+        u2 += u * u;
+    }
+    ce = wave_sum(ce);
+    u2 = wave_sum(u2);
+    if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = ce; red[1][threadIdx.x >> 6] = u2; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        part_ce[b * LOSS_BLOCKS + blockIdx.x] = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]);
+        part_u2[b * LOSS_BLOCKS + blockIdx.x] = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
+    }
+}
+
+// stage 2: out[0] = loss, out[1] = CE, out[2] = uncertainty, out[3 + b] = sqrt(sum u^2) of sample b
+__global__ void loss_finish_kernel(const float* __restrict__ part_ce, const float* __restrict__ part_u2, int bs, int n, float lu,
+                                   float* __restrict__ out) {
+    if (blockIdx.x != 0 || threadIdx.x != 0) return;
+    float ce = 0.f, unc = 0.f;
+    for (int b = 0; b < bs; ++b) {
+        float c = 0.f, q = 0.f;
+        for (int j = 0; j < LOSS_BLOCKS; ++j) { c += part_ce[b * LOSS_BLOCKS + j]; q += part_u2[b * LOSS_BLOCKS + j]; }
+        ce += c;
+        out[3 + b] = sqrtf(q);
+        unc += sqrtf(q) / sqrtf((float)n);
+    }
+    ce /= (float)bs * (float)n;
+    unc /= (float)bs;
+    out[0] = ce + lu * unc;
+    out[1] = ce;
+    out[2] = unc;
+}
+
+// dloss/dlogit.  The uncertainty term reaches the logit through s = sigmoid(logit) (ds/dlogit = s (1 - s); where the clamp of
+// AFB_URR.py:309 is active that factor is below 1e-7 and the term is dropped with the rest of that pixel's gradient).
+__global__ void loss_grad_kernel(const float* __restrict__ logit, const int* __restrict__ label, const float* __restrict__ stats,
+                                 int bs, int obj_n, int n, float lu, float* __restrict__ grad) {
+    const int b = blockIdx.y;
+    const float* src = logit + (size_t)b * obj_n * n;
+    float* dst = grad + (size_t)b * obj_n * n;
+    const float norm = stats[3 + b];
+    const float cu = norm > 0.f ? lu / ((float)bs * sqrtf((float)n) * norm) : 0.f;      // dU/du_i = cu * u_i
+    const float cce = 1.f / ((float)bs * (float)n);
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        float z[MAX_OBJ], s[MAX_OBJ], e[MAX_OBJ], zmax = -INFINITY, smax = -INFINITY;
+        for (int k = 0; k < obj_n; ++k) {
+            z[k] = src[(size_t)k * n + i];
+            s[k] = 1.f / (1.f + expf(-z[k]));
+            zmax = fmaxf(zmax, z[k]);
+            smax = fmaxf(smax, s[k]);
+        }
+        float zden = 0.f, sden = 0.f;
+        for (int k = 0; k < obj_n; ++k) { zden += expf(z[k] - zmax); e[k] = expf(s[k] - smax); sden += e[k]; }
+        int k1 = 0, k2 = -1;
+        float t1 = -1.f, t2 = -1.f;
+        for (int k = 0; k < obj_n; ++k) {
+            const float pk = e[k] / sden;
+            if (pk > t1) { t2 = t1; k2 = k1; t1 = pk; k1 = k; } else if (pk > t2) { t2 = pk; k2 = k; }
+        }
+        const float u = expf(1.f - t1 / (t2 + 1e-8f));
+        float gP[MAX_OBJ];
+        for (int k = 0; k < obj_n; ++k) gP[k] = 0.f;
+        gP[k1] = cu * u * (-u / (t2 + 1e-8f));
+        if (k2 >= 0) gP[k2] = cu * u * (u * t1 / ((t2 + 1e-8f) * (t2 + 1e-8f)));
+        float dot = 0.f;
+        for (int k = 0; k < obj_n; ++k) dot += gP[k] * (e[k] / sden);
+        const int lab = label[(size_t)b * n + i];
+        for (int k = 0; k < obj_n; ++k) {
+            const float P = e[k] / sden;
+            const float g_s = P * (gP[k] - dot);
+            const float ce_g = (expf(z[k] - zmax) / zden - (k == lab ? 1.f : 0.f)) * cce;
+            dst[(size_t)k * n + i] = ce_g + g_s * s[k] * (1.f - s[k]);
+        }
+    }
+}
+
 }  // namespace
 
 extern "C" int vfn_transpose_taps_f32(const float* x, int N, int H, int W, int C, int ld_x, int relu, int taps, float* out,
@@ -380,5 +486,19 @@ extern "C" int vfn_local_stats_backward_f32(const float* g_lm, const float* lm, 
     hipLaunchKernelGGL(local_ratio_bwd_kernel, dim3(grid_for(total)), dim3(256), 0, s, g_lm, lm, rough, dA, dBv, obj_n, h, w, C);
     hipLaunchKernelGGL(local_stats_bwd_kernel, dim3(grid_for(h * w)), dim3(256), 0, s, dA, dBv, g_cf, amax, g_u, g_p2, r1, rough, p_up,
                        g_r1, g_pup, obj_n, h, w, C);
+    return vfn_check_launch();
+}
+
+// loss = CrossEntropyLoss(logit [bs][obj][n], label int32 [bs][n]) + lu * uncertainty (train_video_seg.py:72-74) and dloss/dlogit.
+// partial: scratch 2 * bs * 64 floats; stats: 3 + bs floats (loss, CE, uncertainty, per-sample ||u||); grad (optional): [bs][obj][n]
+extern "C" int vfn_segment_loss_f32(const float* logit, const int* label, int bs, int obj_n, int n, float lu, float* partial,
+                                    float* stats, float* grad, void* stream) {
+    if (!logit || !label || !partial || !stats || bs < 1 || obj_n < 2 || obj_n > MAX_OBJ || n < 1) return VFN_ERR_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    float* pce = partial;
+    float* pu2 = partial + (size_t)bs * LOSS_BLOCKS;
+    hipLaunchKernelGGL(loss_partial_kernel, dim3(LOSS_BLOCKS, bs), dim3(256), 0, s, logit, label, obj_n, n, pce, pu2);
+    hipLaunchKernelGGL(loss_finish_kernel, dim3(1), dim3(64), 0, s, pce, pu2, bs, n, lu, stats);
+    if (grad) hipLaunchKernelGGL(loss_grad_kernel, dim3(256, bs), dim3(256), 0, s, logit, label, stats, bs, obj_n, n, lu, grad);
     return vfn_check_launch();
 }

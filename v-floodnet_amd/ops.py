@@ -280,6 +280,20 @@ def segment_uncertainty(score):
     return out[0]
 
 
+def segment_loss(score, label, lu, want_grad=True):
+    """train_video_seg.py:72-74 on the logits ``segment`` returns: score f32 [bs,obj,H,W], label int [bs,H,W] ->
+    (stats f32[3+bs] = loss, cross entropy, uncertainty, ||u|| per sample; dloss/dscore [bs,obj,H,W] or None)."""
+    bs, obj_n, H, W = score.shape
+    assert score.is_contiguous()
+    lab = label.to(device=score.device, dtype=torch.int32).contiguous()
+    partial = torch.empty(2 * bs * 64, device=score.device, dtype=torch.float32)
+    stats = torch.empty(3 + bs, device=score.device, dtype=torch.float32)
+    grad = torch.empty_like(score) if want_grad else None
+    check(_lib.lib().vfn_segment_loss_f32(ptr(score), ptr(lab), bs, obj_n, H * W, float(lu), ptr(partial), ptr(stats), ptr(grad),
+                                          stream()), 'vfn_segment_loss_f32')
+    return stats, grad
+
+
 # --------------------------------------------------------------------------- loop operators
 def resize_bicubic(x, Ho, Wo, out=None):
     """x [C,Hi,Wi] (or [1,C,Hi,Wi]) float32 -> [.., Ho, Wo]."""
