@@ -364,6 +364,9 @@ def main(argv=None):
             dist.barrier()
         return time.perf_counter()
 
+    import gc
+    gc.collect()
+    gc.disable()            # a cyclic collection in the middle of the timed frames is a 10-70 ms hiccup of the launch thread
     clip0 = bracket()
     run_iters(1, s_first - 1, False)                                       # untimed pre-roll
     t0 = bracket()
@@ -390,6 +393,8 @@ def main(argv=None):
                      'replaced_entries_total': [int(v) for v in runner.fb.replace_n],
                      'regime': f'frames {last_iter + 1}-{last_iter + n_extra} of the cycled clip, bank at class_budget '
                                f'({int(runner.fb.class_budget)} entries/object): every update evicts'}
+
+    gc.enable()
 
     def max_over_ranks(x):
         v = torch.tensor([x], dtype=torch.float64, device=dev if (world == 1 or dist.get_backend() == 'nccl') else 'cpu')

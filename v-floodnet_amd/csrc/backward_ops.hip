@@ -39,26 +39,30 @@ inline int grid_for(size_t total) {
     return (int)(b < 8192 ? (b ? b : 1) : 8192);
 }
 
-// out[(tap * C + c)][m] = act(x[n][y + dy][x + dx][c]) (0 outside the image), m = (n, y, x) flattened; columns M .. Mpad-1
-// are written as zeros.  32 x 32 tiles through LDS: reads run along the channels, writes along the pixels.
+// out[(tap * C + c)][m] = cs[c] * act(x[n][yo * stride - pad + kh][xo * stride - pad + kw][c]) (0 outside the image), tap = kh * k + kw,
+// m = (n, yo, xo) flattened over the OUTPUT pixels of a k x k / stride / pad convolution; columns M .. Mpad-1 are written as
+// zeros.  k = 1, stride = 1, pad = 0 is a plain transposition.  32 x 32 tiles through LDS: reads run along the channels,
+// writes along the pixels.
 __global__ __launch_bounds__(256)
-void transpose_taps_kernel(const float* __restrict__ x, int N, int H, int W, int C, int ld_x, int relu, int taps,
-                           float* __restrict__ out, int Mpad) {
+void transpose_taps_kernel(const float* __restrict__ x, int N, int H, int W, int C, int ld_x, int relu, int k, int stride, int pad,
+                           int Ho, int Wo, const float* __restrict__ colscale, float* __restrict__ out, int Mpad) {
     __shared__ float tile[32][33];
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;          // 32 x 8
     const int m0 = blockIdx.x * 32, c0 = blockIdx.y * 32, tap = blockIdx.z;
-    const int dy = taps == 9 ? tap / 3 - 1 : 0, dx = taps == 9 ? tap % 3 - 1 : 0;
-    const int M = N * H * W;
+    const int dy = tap / k - pad, dx = tap % k - pad;
+    const int M = N * Ho * Wo;
+    const float cs = (colscale && c0 + tx < C) ? colscale[c0 + tx] : 1.f;
 #pragma unroll
     for (int r = ty; r < 32; r += 8) {
         const int m = m0 + r;
         float v = 0.f;
         if (m < M && c0 + tx < C) {
-            const int n = m / (H * W), rem = m - n * H * W;
-            const int yy = rem / W + dy, xx = rem % W + dx;
+            const int n = m / (Ho * Wo), rem = m - n * Ho * Wo;
+            const int yy = (rem / Wo) * stride + dy, xx = (rem % Wo) * stride + dx;
             if ((unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W) {
                 v = x[((size_t)(n * H + yy) * W + xx) * ld_x + c0 + tx];
                 if (relu) v = fmaxf(v, 0.f);
+                v *= cs;
             }
         }
         tile[r][tx] = v;
@@ -423,13 +427,131 @@ __global__ void loss_grad_kernel(const float* __restrict__ logit, const int* __r
     }
 }
 
+// ------------------------------------------------------------------ encoder pieces (ResNet trunks with frozen BatchNorm)
+// zero insertion: out[n][2y][2x][c] = g[n][y][x][c], 0 elsewhere -- a stride-2 convolution's data gradient is the stride-1
+// data-gradient convolution of this
+__global__ void dilate2_kernel(const float* __restrict__ g, float* __restrict__ out, int N, int Ho, int Wo, int H, int W, int C) {
+    const int c4n = C / 4;
+    const size_t total = (size_t)N * H * W * c4n;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int c4 = i % c4n;
+        size_t t = i / c4n;
+        const int x = t % W; t /= W;
+        const int y = t % H;
+        const int n = t / H;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (!(y & 1) && !(x & 1) && (y >> 1) < Ho && (x >> 1) < Wo)
+            v = *reinterpret_cast<const f32x4*>(g + (((size_t)n * Ho + (y >> 1)) * Wo + (x >> 1)) * C + c4 * 4);
+        *reinterpret_cast<f32x4*>(out + i * 4) = v;
+    }
+}
+
+// eval-mode BatchNorm y = gamma * xhat + beta (xhat from the frozen running statistics): dbeta = sum_m g, dgamma = sum_m g * xhat
+// with xhat = (y - idn - beta) / gamma, where y is what the forward stored (after the residual add `idn` and the ReLU: wherever the
+// ReLU clipped, g is zero, so the clipped value is never used).  Stage 1 per block, stage 2 in block order.
+__global__ void bn_grads_partial_kernel(const float* __restrict__ g, const float* __restrict__ y, const float* __restrict__ idn,
+                                        const float* __restrict__ beta, const float* __restrict__ gamma, int M, int C,
+                                        float* __restrict__ partial) {
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+        const float b = beta[c], ig = 1.f / gamma[c];
+        float sg = 0.f, sx = 0.f;
+        for (int m = blockIdx.x; m < M; m += gridDim.x) {
+            const float gv = g[(size_t)m * C + c];
+            const float yv = y[(size_t)m * C + c] - (idn ? idn[(size_t)m * C + c] : 0.f);
+            sg += gv;
+            sx += gv * (yv - b) * ig;
+        }
+        partial[((size_t)blockIdx.x * 2) * C + c] = sg;
+        partial[((size_t)blockIdx.x * 2 + 1) * C + c] = sx;
+    }
+}
+__global__ void bn_grads_final_kernel(const float* __restrict__ partial, int nb, int C, float* __restrict__ dgamma, float* __restrict__ dbeta) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    float sg = 0.f, sx = 0.f;
+    for (int b = 0; b < nb; ++b) { sg += partial[((size_t)b * 2) * C + c]; sx += partial[((size_t)b * 2 + 1) * C + c]; }
+    dbeta[c] = sg;
+    dgamma[c] = sx;
+}
+
+// MaxPool2d(3, 2, 1) backwards: gx[n][y][x][c] = sum of g[n][yo][xo][c] over the output windows whose FIRST maximum (row-major, as
+// PyTorch) is (y, x).  A gather: the <= 2 x 2 windows that contain the input pixel are re-evaluated.
+__global__ void maxpool3x3s2_bwd_kernel(const float* __restrict__ x, const float* __restrict__ g, float* __restrict__ gx,
+                                        int N, int H, int W, int C, int Ho, int Wo) {
+    const size_t total = (size_t)N * H * W * C;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int c = i % C;
+        size_t t = i / C;
+        const int xx = t % W; t /= W;
+        const int yy = t % H;
+        const int n = t / H;
+        float acc = 0.f;
+        for (int yo = (yy >= 1 ? (yy - 1 + 1) / 2 : 0); yo <= (yy + 1) / 2 && yo < Ho; ++yo)
+            for (int xo = (xx >= 1 ? (xx - 1 + 1) / 2 : 0); xo <= (xx + 1) / 2 && xo < Wo; ++xo) {
+                float best = -INFINITY;
+                int by = -1, bx = -1;
+                for (int dy = -1; dy <= 1; ++dy) {
+                    const int y2 = 2 * yo + dy;
+                    if ((unsigned)y2 >= (unsigned)H) continue;
+                    for (int dx = -1; dx <= 1; ++dx) {
+                        const int x2 = 2 * xo + dx;
+                        if ((unsigned)x2 >= (unsigned)W) continue;
+                        const float v = x[(((size_t)n * H + y2) * W + x2) * C + c];
+                        if (v > best) { best = v; by = y2; bx = x2; }
+                    }
+                }
+                if (by == yy && bx == xx) acc += g[(((size_t)n * Ho + yo) * Wo + xo) * C + c];
+            }
+        gx[i] = acc;
+    }
+}
+
+// ------------------------------------------------------------------ memory read, backwards (training: the bank is one frame)
+// P[b][q] = softmax over b of scale * S[b][q] (AFB_URR.py:144-145); one thread per query column, rows strided by ld
+__global__ void softmax_cols_kernel(const float* __restrict__ S, int B, int Q, int ld, float scale, float* __restrict__ P) {
+    const int q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= Q) return;
+    float m = -INFINITY;
+    for (int b = 0; b < B; ++b) m = fmaxf(m, S[(size_t)b * ld + q] * scale);
+    float l = 0.f;
+    for (int b = 0; b < B; ++b) l += expf(S[(size_t)b * ld + q] * scale - m);
+    for (int b = 0; b < B; ++b) P[(size_t)b * ld + q] = expf(S[(size_t)b * ld + q] * scale - m) / l;
+}
+// dS[b][q] = scale * P (dP - sum_b' P dP)
+__global__ void softmax_cols_bwd_kernel(const float* __restrict__ P, const float* __restrict__ dP, int B, int Q, int ld, float scale,
+                                        float* __restrict__ dS) {
+    const int q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= Q) return;
+    float dot = 0.f;
+    for (int b = 0; b < B; ++b) dot += P[(size_t)b * ld + q] * dP[(size_t)b * ld + q];
+    for (int b = 0; b < B; ++b) dS[(size_t)b * ld + q] = scale * P[(size_t)b * ld + q] * (dP[(size_t)b * ld + q] - dot);
+}
+
+// ------------------------------------------------------------------ AdamW (torch.optim.AdamW defaults' arithmetic)
+__global__ void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v, size_t n,
+                             float lr, float b1, float b2, float eps, float wd, float bc1, float bc2) {
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        float pv = p[i];
+        const float gv = g[i];
+        pv *= 1.f - lr * wd;                                           // decoupled weight decay
+        const float mv = b1 * m[i] + (1.f - b1) * gv;
+        const float vv = b2 * v[i] + (1.f - b2) * gv * gv;
+        m[i] = mv;
+        v[i] = vv;
+        const float denom = sqrtf(vv) / sqrtf(bc2) + eps;
+        p[i] = pv - (lr / bc1) * (mv / denom);
+    }
+}
+
 }  // namespace
 
-extern "C" int vfn_transpose_taps_f32(const float* x, int N, int H, int W, int C, int ld_x, int relu, int taps, float* out,
-                                      int Mpad, void* stream) {
-    if (!x || !out || N < 1 || H < 1 || W < 1 || C < 1 || ld_x < C || (taps != 1 && taps != 9) || Mpad < N * H * W) return VFN_ERR_ARG;
-    const dim3 grid(cdiv(Mpad, 32), cdiv(C, 32), taps);
-    hipLaunchKernelGGL(transpose_taps_kernel, grid, dim3(256), 0, (hipStream_t)stream, x, N, H, W, C, ld_x, relu, taps, out, Mpad);
+extern "C" int vfn_transpose_taps_f32(const float* x, int N, int H, int W, int C, int ld_x, int relu, int k, int stride, int pad,
+                                      int Ho, int Wo, const float* colscale, float* out, int Mpad, void* stream) {
+    if (!x || !out || N < 1 || H < 1 || W < 1 || C < 1 || ld_x < C || k < 1 || k > 7 || stride < 1 || pad < 0 || Ho < 1 || Wo < 1 ||
+        Mpad < N * Ho * Wo) return VFN_ERR_ARG;
+    const dim3 grid(cdiv(Mpad, 32), cdiv(C, 32), k * k);
+    hipLaunchKernelGGL(transpose_taps_kernel, grid, dim3(256), 0, (hipStream_t)stream, x, N, H, W, C, ld_x, relu, k, stride, pad, Ho, Wo,
+                       colscale, out, Mpad);
     return vfn_check_launch();
 }
 
@@ -500,5 +622,48 @@ extern "C" int vfn_segment_loss_f32(const float* logit, const int* label, int bs
     hipLaunchKernelGGL(loss_partial_kernel, dim3(LOSS_BLOCKS, bs), dim3(256), 0, s, logit, label, obj_n, n, pce, pu2);
     hipLaunchKernelGGL(loss_finish_kernel, dim3(1), dim3(64), 0, s, pce, pu2, bs, n, lu, stats);
     if (grad) hipLaunchKernelGGL(loss_grad_kernel, dim3(256, bs), dim3(256), 0, s, logit, label, stats, bs, obj_n, n, lu, grad);
+    return vfn_check_launch();
+}
+
+extern "C" int vfn_dilate2_f32(const float* g, float* out, int N, int Ho, int Wo, int H, int W, int C, void* stream) {
+    if (!g || !out || C % 4 || N < 1 || H < 2 * Ho - 1 || W < 2 * Wo - 1) return VFN_ERR_ARG;
+    hipLaunchKernelGGL(dilate2_kernel, dim3(grid_for((size_t)N * H * W * (C / 4))), dim3(256), 0, (hipStream_t)stream, g, out, N, Ho, Wo, H, W, C);
+    return vfn_check_launch();
+}
+
+extern "C" int vfn_bn_param_grads_f32(const float* g, const float* y, const float* idn, const float* beta, const float* gamma, int M,
+                                      int C, float* partial, int nb, float* dgamma, float* dbeta, void* stream) {
+    if (!g || !y || !beta || !gamma || !partial || !dgamma || !dbeta || M < 1 || C < 1 || nb < 1 || nb > 1024) return VFN_ERR_ARG;
+    hipLaunchKernelGGL(bn_grads_partial_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, g, y, idn, beta, gamma, M, C, partial);
+    hipLaunchKernelGGL(bn_grads_final_kernel, dim3(cdiv(C, 256)), dim3(256), 0, (hipStream_t)stream, partial, nb, C, dgamma, dbeta);
+    return vfn_check_launch();
+}
+
+extern "C" int vfn_maxpool3x3s2_backward_f32(const float* x, const float* g, float* gx, int N, int H, int W, int C, void* stream) {
+    if (!x || !g || !gx || N < 1 || H < 1 || W < 1 || C < 1) return VFN_ERR_ARG;
+    const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
+    hipLaunchKernelGGL(maxpool3x3s2_bwd_kernel, dim3(grid_for((size_t)N * H * W * C)), dim3(256), 0, (hipStream_t)stream, x, g, gx, N, H, W, C, Ho, Wo);
+    return vfn_check_launch();
+}
+
+extern "C" int vfn_softmax_cols_f32(const float* S, int B, int Q, int ld, float scale, float* P, void* stream) {
+    if (!S || !P || B < 1 || Q < 1 || ld < Q) return VFN_ERR_ARG;
+    hipLaunchKernelGGL(softmax_cols_kernel, dim3(cdiv(Q, 64)), dim3(64), 0, (hipStream_t)stream, S, B, Q, ld, scale, P);
+    return vfn_check_launch();
+}
+
+extern "C" int vfn_softmax_cols_backward_f32(const float* P, const float* dP, int B, int Q, int ld, float scale, float* dS, void* stream) {
+    if (!P || !dP || !dS || B < 1 || Q < 1 || ld < Q) return VFN_ERR_ARG;
+    hipLaunchKernelGGL(softmax_cols_bwd_kernel, dim3(cdiv(Q, 64)), dim3(64), 0, (hipStream_t)stream, P, dP, B, Q, ld, scale, dS);
+    return vfn_check_launch();
+}
+
+// one AdamW step on n floats: step >= 1 (bias corrections 1 - beta^step); torch.optim.AdamW arithmetic (decoupled decay first)
+extern "C" int vfn_adamw_f32(float* p, const float* g, float* m, float* v, long long n, float lr, float beta1, float beta2, float eps,
+                             float weight_decay, int step, void* stream) {
+    if (!p || !g || !m || !v || n < 1 || step < 1) return VFN_ERR_ARG;
+    const float bc1 = 1.f - powf(beta1, (float)step), bc2 = 1.f - powf(beta2, (float)step);
+    hipLaunchKernelGGL(adamw_kernel, dim3(grid_for((size_t)n)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, (size_t)n, lr, beta1, beta2,
+                       eps, weight_decay, bc1, bc2);
     return vfn_check_launch();
 }
