@@ -27,7 +27,7 @@ extern "C" {
 /* ------------------------------------------------------------------ version
  * vfn_abi_version() == VFN_ABI_VERSION of the header the binding was written against, and
  * vfn_sizeof_desc(which) == sizeof of the binding's own struct: checked when the library is loaded. */
-#define VFN_ABI_VERSION 8
+#define VFN_ABI_VERSION 9
 enum { VFN_DESC_CONV = 0, VFN_DESC_STEM = 1, VFN_DESC_BANKSCAN = 2, VFN_DESC_MEMREAD = 3, VFN_DESC_BANK = 4 };
 int vfn_abi_version(void);
 int vfn_sizeof_desc(int which);
@@ -82,6 +82,8 @@ typedef struct vfn_conv_desc {
     const float* mask;    /* optional [M, mask_ld]: y = (mask[m, c] > 0 ? acc * scale + shift : 0) + res -- the gradient of
                              conv(relu(x)) w.r.t. x with mask = x, plus the gradient arriving over the skip connection */
     int mask_ld;
+    int mask_after;       /* 1: the mask is applied AFTER the residual add: y = mask > 0 ? acc * scale + shift + res : 0 (a block's
+                             input gradient = its two branches summed, then the ReLU that produced that input) */
 } vfn_conv_desc;
 
 int vfn_conv_cfg_count(void);
@@ -179,16 +181,37 @@ int vfn_segment_uncertainty_f32(const float* logit, int bs, int obj_n, int n, fl
  * vfn_conv2d_nhwc_f32 (data gradient: flipped / transposed filters + vfn_conv_desc.mask / res; weight gradient: a GEMM over
  * the pixels on transposed operands, cut along K), these entry points are the HBM-bound pieces around them.
  *
- * vfn_transpose_taps_f32   out[(tap*C + c)][m] = act(x[n][y+dy][x+dx][c]), 0 outside the image; m = (n,y,x) flattened,
- *     columns N*H*W .. Mpad-1 zero; taps = 1 (a transposition) or 9 (the transposed im2col image of a 3x3 / pad 1
- *     convolution, tap = 3*(dy+1) + (dx+1)); relu: act = max(., 0).  x pixel stride ld_x floats.
+ * vfn_transpose_taps_f32   out[(tap*C + c)][m] = colscale[c] * act(x[n][yo*stride - pad + kh][xo*stride - pad + kw][c]), 0 outside
+ *     the image; tap = kh*k + kw, m = (n,yo,xo) flattened over the Ho x Wo output pixels of a k x k / stride / pad convolution,
+ *     columns N*Ho*Wo .. Mpad-1 zero: the transposed im2col image (k = 1, stride 1, pad 0: a transposition).  relu: act =
+ *     max(., 0); colscale optional (a frozen BatchNorm's scale applied to the gradient tensor).  x pixel stride ld_x floats.
  * vfn_colsum_f32           out[c] = sum_m x[m][c] (bias gradient); partial: scratch nb * C floats, nb <= 1024 blocks;
  *     two stages in fixed order (deterministic).
  * vfn_upsample2x_add_backward_f32   adjoint of vfn_upsample2x_add_nhwc_f32 (Refine, AFB_URR.py:124): gm [N][h][w][C] ->
  *     gs = sum over n (s_bcast = 1: the objects share s; gs may be NULL otherwise: ds = dm) and
  *     gpm [N][h/2][w/2][C] = interpolate^T(gm). */
-int vfn_transpose_taps_f32(const float* x, int N, int H, int W, int C, int ld_x, int relu, int taps, float* out, int Mpad,
-                           void* stream);
+int vfn_transpose_taps_f32(const float* x, int N, int H, int W, int C, int ld_x, int relu, int k, int stride, int pad, int Ho, int Wo,
+                           const float* colscale, float* out, int Mpad, void* stream);
+/* Encoder pieces (ResNet trunks, BatchNorm frozen as train_video_seg.py:103-106 sets it), memory read, optimiser:
+ * vfn_dilate2_f32          out[n][2y][2x][c] = g[n][y][x][c], 0 elsewhere ([N][H][W][C] from [N][Ho][Wo][C]): the data gradient of a
+ *     stride-2 convolution is the stride-1 data-gradient convolution of this.
+ * vfn_bn_param_grads_f32   dbeta[c] = sum_m g, dgamma[c] = sum_m g * (y - idn - beta) / gamma for y = gamma * xhat + beta (+ idn,
+ *     then ReLU) as the forward stored it; g = the gradient w.r.t. the BatchNorm's output (zero wherever the ReLU clipped).
+ *     partial: scratch 2 * nb * C floats, nb <= 1024.
+ * vfn_maxpool3x3s2_backward_f32   MaxPool2d(3,2,1): gx [N][H][W][C] from g [N][Ho][Wo][C], first maximum of a window wins;
+ *     add (optional, shape of x): a second gradient arriving at x; relu_mask: x is a ReLU's output, the sum is zeroed where x <= 0.
+ * vfn_softmax_cols_f32 / _backward_f32   P = softmax over the rows of scale * S [B][ld] per column (AFB_URR.py:144-145 with the
+ *     bank of one frame materialised, as training has it); dS = scale * P (dP - sum_b P dP).
+ * vfn_adamw_f32            one torch.optim.AdamW step on n floats (decoupled decay, bias corrections 1 - beta^step). */
+int vfn_dilate2_f32(const float* g, float* out, int N, int Ho, int Wo, int H, int W, int C, void* stream);
+int vfn_bn_param_grads_f32(const float* g, const float* y, const float* idn, const float* beta, const float* gamma, int M, int C,
+                           float* partial, int nb, float* dgamma, float* dbeta, void* stream);
+int vfn_maxpool3x3s2_backward_f32(const float* x, const float* g, float* gx, int N, int H, int W, int C, const float* add, int relu_mask,
+                                  void* stream);
+int vfn_softmax_cols_f32(const float* S, int B, int Q, int ld, float scale, float* P, void* stream);
+int vfn_softmax_cols_backward_f32(const float* P, const float* dP, int B, int Q, int ld, float scale, float* dS, void* stream);
+int vfn_adamw_f32(float* p, const float* g, float* m, float* v, long long n, float lr, float beta1, float beta2, float eps,
+                  float weight_decay, int step, void* stream);
 int vfn_colsum_f32(const float* x, int M, int C, int ld, float* partial, int nb, float* out, void* stream);
 int vfn_upsample2x_add_backward_f32(const float* gm, float* gs, float* gpm, int N, int h, int w, int C, int s_bcast,
                                     void* stream);

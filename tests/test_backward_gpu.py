@@ -158,7 +158,7 @@ def test_transposed_im2col_and_adjoint_kernels(gpu):
     Mpad = (M + 31) // 32 * 32
     for relu in (0, 1):
         out = torch.full((9 * C, Mpad), float('nan'), device=gpu)
-        check(L.vfn_transpose_taps_f32(ptr(x.to(gpu)), N, H, W, C, ld, relu, 9, ptr(out), Mpad, stream()), 'taps')
+        check(L.vfn_transpose_taps_f32(ptr(x.to(gpu)), N, H, W, C, ld, relu, 3, 1, 1, H, W, None, ptr(out), Mpad, stream()), 'taps')
         xc = x[..., :C].permute(0, 3, 1, 2)
         xc = F.relu(xc) if relu else xc
         cols = F.unfold(xc, 3, padding=1).view(N, C, 9, H * W)                  # [N, C, tap, HW]
@@ -205,3 +205,88 @@ def test_training_loss_and_its_gradient(gpu, bs, K, H, W):
     st = stats.cpu().double()
     assert abs(st[0] - loss.item()) < 1e-5 * abs(loss.item()) and abs(st[1] - ce.item()) < 1e-5 and abs(st[2] - unc.item()) < 1e-5
     assert _rel(grad.cpu(), z.grad) < 1e-4
+
+
+def test_whole_model_backward_vs_autograd(gpu):
+    """One training sample end to end (train_video_seg.py:65-74): memorize -> bank -> segment (training branch) -> loss on the HIP
+    path, then ``ModelBackward``: decoder, memory read, KeyValue, query encoder, and -- through the bank's keys / values --
+    KeyValue and the memory encoder again.  EVERY trainable parameter's gradient (convolutions, frozen-BatchNorm weights and
+    biases, the three stems) against float64 autograd through the oracle's memorize / segment / loss, differentiated at the HIP
+    forward's activation pattern (see test_whole_decoder_backward_vs_autograd)."""
+    import torch.nn.functional as F
+    from tools import synth
+    from vfloodnet_amd import AFB_URR, FeatureBank, ops
+    from vfloodnet_amd.backward import ModelBackward
+    from oracle import afb_urr_ref as O
+    H, W, K, lu = 96, 160, 2, 0.5
+    sd = synth.make_state_dict(SEED)
+    model = AFB_URR(gpu, update_bank=False).to(gpu)
+    model.load_state_dict(sd, strict=True)
+    model.train()
+    frames, m0 = synth.clip(6, 2, H, W)
+    oh = synth.onehot(m0).unsqueeze(0)
+    k, v = model.memorize(frames[0:1].to(gpu), oh.to(gpu))
+    fb = FeatureBank(K, 250000, gpu)
+    fb.init_bank(k, v)
+    scores, unc = model.segment(frames[1:2].to(gpu), fb)
+    label = torch.randint(0, K, (1, H, W), generator=torch.Generator().manual_seed(9))
+    stats, dscores = ops.segment_loss(scores.contiguous(), label.to(gpu), lu)
+    eng = model.engine()
+    mb = ModelBackward(eng)
+    g_bk, g_bv = mb.segment_sample(fb, dscores[0])
+    mb.finish_memorize(frames[0:1].to(gpu), oh.to(gpu), g_bk, g_bv)
+    torch.cuda.synchronize()
+
+    # ---- the oracle, float64, its ReLUs at the HIP pattern
+    plan, qs, slot = eng.last_query
+    pm = eng.last_memorize
+    nchw_mask = lambda t: (t.permute(0, 3, 1, 2) > 0).cpu()
+    order = [pm.m['r1']]
+    for lname, nb in (('res2', 3), ('res3', 4), ('res4', 6)):
+        for bi in range(nb):
+            a = pm.acts_m[(lname, bi)]
+            order += [a['t1'], a['t2'], a['out']]
+    order.append(qs.q['r1'][0:1])
+    for lname, nb in (('res2', 3), ('res3', 4), ('res4', 6)):
+        for bi in range(nb):
+            a = qs.acts[1][(lname, bi)]
+            order += [a['t1'], a['t2'], a['out']]
+    ex = lambda t: t[0:1].expand(K, -1, -1, -1)
+    order += [plan.d16[0], plan.d16[1], ex(qs.s8[0]), ex(qs.s8[1]), plan.d8[0], plan.d8[1], ex(qs.s4[0]), ex(qs.s4[1]),
+              plan.d4[0], plan.d4[1], plan.d4[2], plan.l2[0], plan.l2[1], plan.l2[2]]
+    masks = iter([nchw_mask(t) for t in order])
+    flips = []
+    real_relu = F.relu
+
+    def relu_at_hip_pattern(x, *a_, **k_):
+        mk = next(masks)
+        flips.append(int(((x.detach() > 0) != mk).sum()))
+        return x * mk.to(x.dtype)
+    sd64 = {n: (t.double().clone().requires_grad_() if (t.is_floating_point() and not n.endswith(('running_mean', 'running_var', '.mean', '.std')))
+                else (t.double() if t.is_floating_point() else t)) for n, t in sd.items()}
+    O.F.relu = relu_at_hip_pattern
+    try:
+        k_ref, v_ref = O.memorize(sd64, frames[0:1].double(), oh)
+        fbr = O.FeatureBankRef(K, 250000)
+        fbr.init_bank(k_ref, v_ref)
+        sc, un = O.segment(sd64, frames[1:2].double(), fbr, update_bank=False, training=True)
+    finally:
+        O.F.relu = real_relu
+    assert next(masks, None) is None and sum(flips) <= 40, (sum(flips), len(flips))
+    assert (sc.detach() - scores.cpu().double()).abs().max() < 5e-3
+    loss = F.cross_entropy(sc, label) + lu * un
+    assert abs(loss.item() - stats[0].item()) < 1e-4 * abs(loss.item())
+    loss.backward()
+
+    worst = {}
+    for name, t in sd64.items():
+        if not (torch.is_tensor(t) and t.requires_grad):
+            continue
+        assert t.grad is not None, name
+        assert name in mb.grads, f'no HIP gradient for {name}'
+        worst[name] = _rel(mb.grads[name].cpu(), t.grad)
+    top = sorted(worst.items(), key=lambda kv: -kv[1])[:8]
+    print(f'whole model backward: {len(worst)} parameter tensors, worst relative errors:', {n: f'{e:.1e}' for n, e in top})
+    bad = {n: e for n, e in worst.items() if not e < 2e-4}
+    assert not bad, dict(sorted(bad.items(), key=lambda kv: -kv[1])[:12])
+    assert set(mb.grads) == set(worst)

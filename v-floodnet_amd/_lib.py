@@ -24,7 +24,7 @@ class ConvDesc(C.Structure):
                 ('KH', C.c_int), ('KW', C.c_int), ('stride', C.c_int), ('pad', C.c_int),
                 ('relu_in', C.c_int), ('relu_out', C.c_int), ('M', C.c_int), ('ksplit', C.c_int),
                 ('split_from', C.c_int), ('res_mod', C.c_int), ('partial', c_fp), ('tile_counters', c_fp),
-                ('w_packed', C.c_int), ('in_lp', C.c_int), ('out_lp_relu', C.c_int), ('out_lp', c_fp), ('mask', c_fp), ('mask_ld', C.c_int)]
+                ('w_packed', C.c_int), ('in_lp', C.c_int), ('out_lp_relu', C.c_int), ('out_lp', c_fp), ('mask', c_fp), ('mask_ld', C.c_int), ('mask_after', C.c_int)]
 
 
 class StemDesc(C.Structure):
@@ -67,7 +67,7 @@ class BankDesc(C.Structure):
                 ('obj_n', C.c_int), ('cap', C.c_int), ('rm_class', C.c_int), ('rm_request', C.c_int)]
 
 
-ABI_VERSION = 8          # include/vfn_hip.h VFN_ABI_VERSION; csrc/abi.hip
+ABI_VERSION = 9          # include/vfn_hip.h VFN_ABI_VERSION; csrc/abi.hip
 DESC_IDS = {0: ConvDesc, 1: StemDesc, 2: BankScanDesc, 3: MemReadDesc, 4: BankDesc}     # vfn_sizeof_desc(which)
 
 
@@ -131,7 +131,13 @@ SIGNATURES = {
     'vfn_upsample2x_add_nhwc_f32': [_p, _p, _p, _i, _i, _i, _i, _i, _p],
     'vfn_upsample2x_add_lp_nhwc_f32': [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p],
     'vfn_rough_uncertainty_f32': [_p, _p, _p, _p, _i, _i, _i, _p],
-    'vfn_transpose_taps_f32': [_p, _i, _i, _i, _i, _i, _i, _i, _p, _i, _p],
+    'vfn_transpose_taps_f32': [_p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p, _p, _i, _p],
+    'vfn_dilate2_f32': [_p, _p, _i, _i, _i, _i, _i, _i, _p],
+    'vfn_bn_param_grads_f32': [_p, _p, _p, _p, _p, _i, _i, _p, _i, _p, _p, _p],
+    'vfn_maxpool3x3s2_backward_f32': [_p, _p, _p, _i, _i, _i, _i, _p, _i, _p],
+    'vfn_softmax_cols_f32': [_p, _i, _i, _i, _f, _p, _p],
+    'vfn_softmax_cols_backward_f32': [_p, _p, _i, _i, _i, _f, _p, _p],
+    'vfn_adamw_f32': [_p, _p, _p, _p, _ll, _f, _f, _f, _f, _f, _i, _p],
     'vfn_colsum_f32': [_p, _i, _i, _i, _p, _i, _p, _p],
     'vfn_upsample2x_add_backward_f32': [_p, _p, _p, _i, _i, _i, _i, _i, _p],
     'vfn_tail_grad_o_f32': [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p],

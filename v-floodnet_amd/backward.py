@@ -104,8 +104,8 @@ class DecoderBackward:
         if rows > 9 * cin:
             xt[9 * cin:].zero_()
         gt = self._buf('gt', max(cout, 32) * Mpad).view(-1, Mpad)[:cout]
-        check(L.vfn_transpose_taps_f32(ptr(x), N, H, Wd, cin, ld_x, int(relu), 9, ptr(xt), Mpad, stream()), 'vfn_transpose_taps_f32')
-        check(L.vfn_transpose_taps_f32(ptr(gy), N, H, Wd, cout, gy.shape[-1], 0, 1, ptr(gt), Mpad, stream()), 'vfn_transpose_taps_f32')
+        check(L.vfn_transpose_taps_f32(ptr(x), N, H, Wd, cin, ld_x, int(relu), 3, 1, 1, H, Wd, None, ptr(xt), Mpad, stream()), 'vfn_transpose_taps_f32')
+        check(L.vfn_transpose_taps_f32(ptr(gy), N, H, Wd, cout, gy.shape[-1], 0, 1, 1, 0, H, Wd, None, ptr(gt), Mpad, stream()), 'vfn_transpose_taps_f32')
         dw = torch.empty(cout, 9 * cin, device=self.dev)
         # the forward kernel on a 1x1 problem: 'pixels' = the Cout rows of dY^T, 'channels' = the padded pixel axis, filters =
         # the rows of the transposed im2col image
@@ -238,3 +238,307 @@ class DecoderBackward:
         for n in range(1, g.shape[0]):
             out += g[n:n + 1]
         return out
+
+
+# =====================================================================================================================
+# The rest of the model: memory read, KeyValue, the two ResNet trunks (BatchNorm frozen, train_video_seg.py:103-106), stems
+# =====================================================================================================================
+class _ConvBwd:
+    """One forward convolution seen from the backward pass: the packed filters of its data-gradient convolution (a frozen
+    BatchNorm's scale folded in: d/dx of scale * conv(x) is conv(g * scale, flipped filters)) and its geometry."""
+
+    def __init__(self, weight, stride, pad, dev, scale=None):
+        w = weight.detach().float()
+        self.cout, self.cin, self.k, _ = w.shape
+        self.stride, self.pad = int(stride), int(pad)
+        ws = w if scale is None else w * scale.detach().float().view(-1, 1, 1, 1).to(w.device)
+        self.wp = _dgrad_filters(ws).to(dev)
+        self.scale = None if scale is None else scale.detach().float().to(dev).contiguous()
+
+
+def _bn_scale(bn):
+    return bn.weight.detach().float() / torch.sqrt(bn.running_var.detach().float() + bn.eps)
+
+
+class ModelBackward:
+    """dL/dscores -> the gradient of EVERY parameter of AFB_URR for one training sample (train_video_seg.py:65-74):
+    decoder (DecoderBackward), memory read, KeyValue, query encoder; ``finish_memorize`` then carries the gradients that
+    arrived at the bank's keys / values back through KeyValue and the memory encoder.  Gradients accumulate in ``self.grads``
+    (state-dict name -> tensor)."""
+    NB = 256
+
+    def __init__(self, engine):
+        self.eng = engine
+        self.dev = engine.device
+        self.dec = DecoderBackward(engine)
+        m = engine.model
+        dev = self.dev
+        self.cb = {}
+        for enc_name, enc in (('encoder_q', m.encoder_q), ('encoder_m', m.encoder_m)):
+            for lname in ('res2', 'res3', 'res4'):
+                for bi, blk in enumerate(getattr(enc, lname)):
+                    pre = f'{enc_name}.{lname}.{bi}'
+                    self.cb[pre + '.conv1'] = _ConvBwd(blk.conv1.weight, 1, 0, dev, _bn_scale(blk.bn1))
+                    self.cb[pre + '.conv2'] = _ConvBwd(blk.conv2.weight, blk.conv2.stride[0], 1, dev, _bn_scale(blk.bn2))
+                    self.cb[pre + '.conv3'] = _ConvBwd(blk.conv3.weight, 1, 0, dev, _bn_scale(blk.bn3))
+                    if hasattr(blk, 'downsample'):
+                        self.cb[pre + '.downsample.0'] = _ConvBwd(blk.downsample[0].weight, blk.downsample[0].stride[0], 0, dev,
+                                                                  _bn_scale(blk.downsample[1]))
+        kv = m.keyval_r4
+        wkv = torch.cat([kv.Key.weight.detach().float(), kv.Value.weight.detach().float()], 0)      # one 640-filter conv
+        self.cb['keyval'] = _ConvBwd(wkv, 1, 1, dev)
+        self.grads = {}
+
+    # ------------------------------------------------------------------ generic pieces
+    def _acc(self, name, g):
+        g = g.contiguous()
+        if name in self.grads:
+            self.grads[name] += g
+        else:
+            self.grads[name] = g.clone()
+
+    def _dgrad(self, plan, cb, gy, N, H, Wd, mask=None, res=None, mask_after=False):
+        """Data gradient of a k x k convolution at input resolution H x W (``gy`` already zero-inserted for stride 2)."""
+        out = torch.empty(N, H, Wd, cb.cin, device=self.dev)
+        d = ops.make_conv_desc(gy, cb.wp, cb.cin, cb.k, cb.k, 1, cb.k // 2, out, None, None, res, False, False, N=N, H=H, W=Wd)
+        if mask is not None:
+            d.mask, d.mask_ld, d.mask_after = ptr(mask), mask.shape[-1], int(mask_after)
+        self.dec._launch(d, plan)
+        return out
+
+    def _dilate(self, g, H, Wd):
+        N, Ho, Wo, C = g.shape
+        out = torch.empty(N, H, Wd, C, device=self.dev)
+        check(_lib.lib().vfn_dilate2_f32(ptr(g), ptr(out), N, Ho, Wo, H, Wd, C, stream()), 'vfn_dilate2_f32')
+        return out
+
+    def _wgrad(self, plan, x, gy, cb, N, H, Wd, relu=False, ld_x=None, cin=None):
+        """dL/dW [Cout,Cin,k,k] of y = conv(act(x)) (k, stride, pad of ``cb``; x [N,H,W,*]) given gy [N,Ho,Wo,Cout]; a frozen
+        BatchNorm's scale is applied to gy on the way (cb.scale)."""
+        L = _lib.lib()
+        k, s, pad = cb.k, cb.stride, cb.pad
+        cin = cin if cin is not None else cb.cin
+        cout = gy.shape[-1]
+        Ho, Wo = gy.shape[1], gy.shape[2]
+        M = N * Ho * Wo
+        Mpad = (M + 31) // 32 * 32
+        kk = k * k * cin
+        rows = (kk + 255) // 256 * 256
+        xt = self.dec._buf('xt', rows * Mpad).view(rows, Mpad)
+        if rows > kk:
+            xt[kk:].zero_()
+        gt = self.dec._buf('gt', max(cout, 32) * Mpad).view(-1, Mpad)[:cout]
+        check(L.vfn_transpose_taps_f32(ptr(x), N, H, Wd, cin, ld_x if ld_x is not None else x.shape[-1], int(relu), k, s, pad, Ho, Wo,
+                                       None, ptr(xt), Mpad, stream()), 'vfn_transpose_taps_f32')
+        check(L.vfn_transpose_taps_f32(ptr(gy), N, Ho, Wo, cout, gy.shape[-1], 0, 1, 1, 0, Ho, Wo, ptr(cb.scale), ptr(gt), Mpad, stream()),
+              'vfn_transpose_taps_f32')
+        dw = torch.empty(cout, kk, device=self.dev)
+        d = ops.make_conv_desc(gt.view(1, 1, cout, Mpad), xt, kk, 1, 1, 1, 0, dw.view(1, 1, cout, kk), None, None, None, False, False,
+                               N=1, H=1, W=cout)
+        tiles = ops.conv_cfg_tiles()
+        cfg = 0 if cout >= 128 else (3 if cout >= 64 else 4)                   # 128x128 / 64x64 / 32x64 tiles
+        bm, bn = tiles[cfg]
+        blocks = ((cout + bm - 1) // bm) * ((kk + bn - 1) // bn)
+        splits = [q for q in ops.valid_splits(d, 16) if q * cout * kk <= plan.ws.numel()]
+        want = max(1, 512 // max(1, blocks))
+        ks = max([q for q in splits if q <= want] or [1])
+        if kk % 4:
+            ks = 1
+        apply_choice(d, (cfg, ks, 0), plan.ws, None)
+        ops.conv2d_launch(d, cfg, 0)
+        return dw.view(cout, k, k, cin).permute(0, 3, 1, 2)
+
+    def _colsum(self, g, C=None):
+        C = C if C is not None else g.shape[-1]
+        M = g.numel() // g.shape[-1]
+        out = torch.empty(C, device=self.dev)
+        part = self.dec._buf('colsum', self.NB * C)
+        check(_lib.lib().vfn_colsum_f32(ptr(g), M, C, g.shape[-1], ptr(part), self.NB, ptr(out), stream()), 'vfn_colsum_f32')
+        return out
+
+    def _bn_grads(self, name, bn, g, y, idn=None):
+        """Gradients of a frozen BatchNorm's weight / bias (they stay trainable: only the statistics are frozen)."""
+        C = g.shape[-1]
+        M = g.numel() // C
+        dg, db = torch.empty(C, device=self.dev), torch.empty(C, device=self.dev)
+        part = self.dec._buf('bn', 2 * self.NB * C)
+        check(_lib.lib().vfn_bn_param_grads_f32(ptr(g), ptr(y), ptr(idn), ptr(bn.bias.detach().float().contiguous()),
+                                                ptr(bn.weight.detach().float().contiguous()), M, C, ptr(part), self.NB, ptr(dg), ptr(db),
+                                                stream()), 'vfn_bn_param_grads_f32')
+        self._acc(name + '.weight', dg)
+        self._acc(name + '.bias', db)
+
+    # ------------------------------------------------------------------ ResNet bottleneck / trunk
+    def _bottleneck(self, plan, pre, blk, a, N, g_pre, extra, mask_x):
+        """torchvision Bottleneck (v1.5: the stride sits on conv2) backwards.  ``g_pre``: dL/d(out), already zero where the final
+        ReLU clipped.  ``extra``: a further gradient arriving at the block's input (decoder skip connections).  Returns dL/dx,
+        masked by x > 0 when x is itself a ReLU output (``mask_x``)."""
+        x, t1, t2, out, s, H, Wd = a['x'], a['t1'], a['t2'], a['out'], a['stride'], a['H'], a['W']
+        c1, c2, c3 = self.cb[pre + '.conv1'], self.cb[pre + '.conv2'], self.cb[pre + '.conv3']
+        Ho, Wo = H // s, Wd // s
+        idn = a['ds'] if a['ds'] is not None else x
+        # conv3 + bn3 (+ idn) + relu
+        self._bn_grads(pre + '.bn3', blk.bn3, g_pre, out, idn)
+        self._acc(pre + '.conv3.weight', self._wgrad(plan, t2, g_pre, c3, N, Ho, Wo))
+        g_t2 = self._dgrad(plan, c3, g_pre, N, Ho, Wo, mask=t2)
+        # conv2 + bn2 + relu
+        self._bn_grads(pre + '.bn2', blk.bn2, g_t2, t2)
+        self._acc(pre + '.conv2.weight', self._wgrad(plan, t1, g_t2, c2, N, H, Wd))
+        g_t1 = self._dgrad(plan, c2, self._dilate(g_t2, H, Wd) if s == 2 else g_t2, N, H, Wd, mask=t1)
+        # identity branch
+        if a['ds'] is not None:
+            cd = self.cb[pre + '.downsample.0']
+            self._bn_grads(pre + '.downsample.1', blk.downsample[1], g_pre, a['ds'])
+            self._acc(pre + '.downsample.0.weight', self._wgrad(plan, x, g_pre, cd, N, H, Wd))
+            side = self._dgrad(plan, cd, self._dilate(g_pre, H, Wd) if s == 2 else g_pre, N, H, Wd, res=extra)
+        else:
+            side = g_pre if extra is None else g_pre + extra
+        # conv1 + bn1 + relu, joined with the identity branch; then the ReLU that produced x
+        self._bn_grads(pre + '.bn1', blk.bn1, g_t1, t1)
+        self._acc(pre + '.conv1.weight', self._wgrad(plan, x, g_t1, c1, N, H, Wd))
+        return self._dgrad(plan, c1, g_t1, N, H, Wd, mask=x if mask_x else None, res=side, mask_after=True)
+
+    def _trunk(self, plan, enc_name, enc, acts, bufs, N, g_r4, extras):
+        """res4 .. res2, max-pool, back to dL/d(bn1 output) of the stem.  ``g_r4`` is masked by r4 > 0 already; ``extras``:
+        gradients the decoder sends to r3 / r2 / r1 ([1,...] tensors or None)."""
+        g = g_r4
+        prev = {'res4': 'res3', 'res3': 'res2', 'res2': None}
+        for lname in ('res4', 'res3', 'res2'):
+            blocks = getattr(enc, lname)
+            for bi in reversed(range(len(blocks))):
+                extra = extras.get(prev[lname]) if bi == 0 and prev[lname] else None
+                g = self._bottleneck(plan, f'{enc_name}.{lname}.{bi}', blocks[bi], acts[(lname, bi)], N, g, extra,
+                                     mask_x=not (lname == 'res2' and bi == 0))
+        r1 = bufs['r1']
+        g_r1 = torch.empty_like(r1)
+        check(_lib.lib().vfn_maxpool3x3s2_backward_f32(ptr(r1), ptr(g), ptr(g_r1), N, plan.h2, plan.w2, 64, ptr(extras.get('r1')), 1,
+                                                       stream()), 'vfn_maxpool3x3s2_backward_f32')
+        return g_r1
+
+    def _stem(self, plan, enc_name, enc, xn, g_c1, r1, N, names):
+        """conv1 (7x7, stride 2, pad 3; + conv1_m / conv1_o for the memory encoder: one convolution over the concatenated
+        planes) + bn1.  xn: the padded, normalised input planes [N,Hp,Wp,C]; g_c1: dL/d(bn1 output), masked."""
+        self._bn_grads(enc_name + '.bn1', enc.bn1, g_c1, r1)
+        C = xn.shape[-1]
+        cb = _ConvBwd(torch.zeros(64, C, 7, 7), 2, 3, self.dev, _bn_scale(enc.bn1))
+        dw = self._wgrad(plan, xn, g_c1, cb, N, plan.Hp, plan.Wp)              # [64, C, 7, 7]
+        c0 = 0
+        for name, nc in names:
+            self._acc(name, dw[:, c0:c0 + nc])
+            c0 += nc
+
+    def _normalised_input(self, plan, frame, mask=None):
+        """pad_divide_by (myutils/data.py:132-149: zeros, BEFORE the normalisation) + (x - mean) / std, NHWC.  Data preparation
+        for the stem's weight gradient; plain tensor ops."""
+        lw, uw, lh, uh = plan.pad
+        e = self.eng
+        mean = torch.tensor(e.mean, device=self.dev).view(1, 3, 1, 1)
+        std = torch.tensor(e.std, device=self.dev).view(1, 3, 1, 1)
+        f = torch.nn.functional.pad(frame, (lw, uw, lh, uh))
+        f = (f - mean) / std
+        if mask is None:
+            return f.permute(0, 2, 3, 1).contiguous()
+        K = mask.shape[1]
+        mk = torch.nn.functional.pad(mask.float(), (lw, uw, lh, uh))[0]        # [K,Hp,Wp], zero in the padding
+        inv = (1.0 - mk).clamp(0, 1)                                           # AFB_URR.py:262-264 (one in the padding)
+        planes = [torch.cat([f[0], mk[k:k + 1], inv[k:k + 1]], 0) for k in range(K)]
+        return torch.stack(planes, 0).permute(0, 2, 3, 1).contiguous()
+
+    # ------------------------------------------------------------------ memory read (the bank = one frame, materialised P)
+    def _gemm_nt(self, plan, A, Bm, M, Nn, Kd):
+        """C [M,Nn] = A [M,Kd] @ Bm [Nn,Kd]^T through the forward kernel (a 1x1 problem); operands zero-padded to its granules."""
+        Kp = (Kd + 31) // 32 * 32
+        rows = (Nn + 255) // 256 * 256
+        Ap = torch.zeros(M, Kp, device=self.dev)
+        Ap[:, :Kd] = A
+        Bp = torch.zeros(rows, Kp, device=self.dev)
+        Bp[:Nn, :Kd] = Bm
+        ldo = (Nn + 3) // 4 * 4
+        Cm = torch.empty(M, ldo, device=self.dev)
+        d = ops.make_conv_desc(Ap.view(1, 1, M, Kp), Bp, Nn, 1, 1, 1, 0, Cm.view(1, 1, M, ldo), None, None, None, False, False, N=1, H=1, W=M)
+        d.out_ld = ldo
+        cfg = 3
+        apply_choice(d, (cfg, 1, 0), plan.ws, None)
+        ops.conv2d_launch(d, cfg, 0)
+        return Cm[:, :Nn]
+
+    def memory_read(self, plan, fb, q, g_mem):
+        """Matcher.forward backwards (AFB_URR.py:136-146) for a bank that holds one frame (training: init_bank only).
+        q [HW,128] query keys, g_mem [K,HW,512] = dL/d(mem).  Returns dL/dq [HW,128], dL/d(bank keys) [K,B,128],
+        dL/d(bank values) [K,B,512]."""
+        L = _lib.lib()
+        K = fb.obj_n
+        lens = fb._sync_len()
+        HW = q.shape[0]
+        scale = 1.0 / (DK ** 0.5)
+        g_q = torch.zeros(HW, DK, device=self.dev)
+        g_k, g_v = [], []
+        for k in range(K):
+            B = lens[k]
+            Kb, Vb = fb._kbuf[k, :B], fb._vbuf[k, :B]
+            g = g_mem[k]                                                       # [HW,512]
+            S = self._gemm_nt(plan, Kb, q, B, HW, DK).contiguous()             # [B,HW]
+            P = torch.empty_like(S)
+            check(L.vfn_softmax_cols_f32(ptr(S), B, HW, HW, scale, ptr(P), stream()), 'vfn_softmax_cols_f32')
+            g_v.append(self._gemm_nt(plan, P, g.t(), B, DV, HW))               # dV = P dO
+            dP = self._gemm_nt(plan, Vb, g, B, HW, DV).contiguous()            # dP = V dO^T
+            dS = torch.empty_like(S)
+            check(L.vfn_softmax_cols_backward_f32(ptr(P), ptr(dP), B, HW, HW, scale, ptr(dS), stream()), 'vfn_softmax_cols_backward_f32')
+            g_q += self._gemm_nt(plan, dS.t(), Kb.t(), HW, DK, B)              # dq = dS^T K
+            g_k.append(self._gemm_nt(plan, dS, q.t(), B, DK, HW))              # dK = dS q
+        return g_q, g_k, g_v
+
+    # ------------------------------------------------------------------ one sample
+    @torch.no_grad()
+    def segment_sample(self, fb, grad_score):
+        """Backward of the sample ``segment`` ran last (its activations are in the training plan).  grad_score = dloss/dscores
+        [obj_n,H0,W0].  Accumulates parameter gradients; returns (dL/d bank keys, dL/d bank values) for ``finish_memorize``."""
+        plan, qs, slot = self.eng.last_query
+        if not plan.keep_acts:
+            raise RuntimeError('backward needs the training plan: call model.train() before memorize / segment')
+        m = self.eng.model
+        K = plan.obj_n
+        g_dec, gin = self.dec.run_tail(plan, grad_score, qs, slot)
+        for n_, g_ in g_dec.items():
+            self._acc(n_, g_)
+        kvq = qs.kv_q[slot]                                                   # [HW,640]
+        g_qk, g_bk, g_bv = self.memory_read(plan, fb, kvq[:, :DK].contiguous(), gin['mem'].reshape(K, plan.HW, DV))
+        # KeyValue on the query side: dL/d[key | value]
+        g_kv = torch.cat([g_qk, gin['q_out'].reshape(plan.HW, DV)], dim=1).view(1, plan.h16, plan.w16, DK + DV).contiguous()
+        if slot != 0 or qs.stage != 0:
+            raise RuntimeError('backward expects the frame-only part of segment to have run in place (no look-ahead in training)')
+        acts = qs.acts[1]
+        bufs = {'r1': qs.q['r1'][0:1]}
+        r4 = acts[('res4', len(m.encoder_q.res4) - 1)]['out']
+        self._keyval(plan, r4, g_kv, 1)
+        g_r4 = self._dgrad(plan, self.cb['keyval'], g_kv, 1, plan.h16, plan.w16, mask=r4)
+        g_c1 = self._trunk(plan, 'encoder_q', m.encoder_q, acts, bufs, 1, g_r4, {'res3': gin['r3'], 'res2': gin['r2'], 'r1': gin['r1']})
+        xn = self._normalised_input(plan, qs.frames[slot:slot + 1])
+        self._stem(plan, 'encoder_q', m.encoder_q, xn, g_c1, bufs['r1'], 1, [('encoder_q.conv1.weight', 3)])
+        return g_bk, g_bv
+
+    def _keyval(self, plan, r4, g_kv, N):
+        m = self.eng.model
+        dw = self._wgrad(plan, r4, g_kv, self.cb['keyval'], N, plan.h16, plan.w16)            # [640,1024,3,3]
+        db = self._colsum(g_kv)
+        self._acc('keyval_r4.Key.weight', dw[:DK])
+        self._acc('keyval_r4.Value.weight', dw[DK:])
+        self._acc('keyval_r4.Key.bias', db[:DK])
+        self._acc('keyval_r4.Value.bias', db[DK:])
+
+    @torch.no_grad()
+    def finish_memorize(self, frame, mask, g_bank_k, g_bank_v):
+        """The gradients that reached the bank's keys / values (summed over the samples) back through ``memorize``
+        (AFB_URR.py:255-272): KeyValue and the memory encoder.  frame [1,3,H0,W0], mask [1,K,H0,W0] as given to memorize."""
+        plan = self.eng.last_memorize
+        m = self.eng.model
+        K = plan.obj_n
+        g_kv = torch.stack([torch.cat([g_bank_k[k], g_bank_v[k]], dim=1) for k in range(K)], 0).view(K, plan.h16, plan.w16, DK + DV).contiguous()
+        acts = plan.acts_m
+        r4 = acts[('res4', len(m.encoder_m.res4) - 1)]['out']
+        self._keyval(plan, r4, g_kv, K)
+        g_r4 = self._dgrad(plan, self.cb['keyval'], g_kv, K, plan.h16, plan.w16, mask=r4)
+        g_c1 = self._trunk(plan, 'encoder_m', m.encoder_m, acts, plan.m, K, g_r4, {})
+        xn = self._normalised_input(plan, frame, mask)
+        self._stem(plan, 'encoder_m', m.encoder_m, xn, g_c1, plan.m['r1'], K,
+                   [('encoder_m.conv1.weight', 3), ('encoder_m.conv1_m.weight', 1), ('encoder_m.conv1_o.weight', 1)])

@@ -476,8 +476,9 @@ __global__ void bn_grads_final_kernel(const float* __restrict__ partial, int nb,
 
 // MaxPool2d(3, 2, 1) backwards: gx[n][y][x][c] = sum of g[n][yo][xo][c] over the output windows whose FIRST maximum (row-major, as
 // PyTorch) is (y, x).  A gather: the <= 2 x 2 windows that contain the input pixel are re-evaluated.
+// add (optional): a second gradient arriving at x (the decoder reads r1 too); relu_mask: x is a ReLU's output, the sum is masked
 __global__ void maxpool3x3s2_bwd_kernel(const float* __restrict__ x, const float* __restrict__ g, float* __restrict__ gx,
-                                        int N, int H, int W, int C, int Ho, int Wo) {
+                                        int N, int H, int W, int C, int Ho, int Wo, const float* __restrict__ add, int relu_mask) {
     const size_t total = (size_t)N * H * W * C;
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
         const int c = i % C;
@@ -502,6 +503,8 @@ __global__ void maxpool3x3s2_bwd_kernel(const float* __restrict__ x, const float
                 }
                 if (by == yy && bx == xx) acc += g[(((size_t)n * Ho + yo) * Wo + xo) * C + c];
             }
+        if (add) acc += add[i];
+        if (relu_mask && !(x[i] > 0.f)) acc = 0.f;
         gx[i] = acc;
     }
 }
@@ -639,10 +642,12 @@ extern "C" int vfn_bn_param_grads_f32(const float* g, const float* y, const floa
     return vfn_check_launch();
 }
 
-extern "C" int vfn_maxpool3x3s2_backward_f32(const float* x, const float* g, float* gx, int N, int H, int W, int C, void* stream) {
+extern "C" int vfn_maxpool3x3s2_backward_f32(const float* x, const float* g, float* gx, int N, int H, int W, int C, const float* add,
+                                             int relu_mask, void* stream) {
     if (!x || !g || !gx || N < 1 || H < 1 || W < 1 || C < 1) return VFN_ERR_ARG;
     const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
-    hipLaunchKernelGGL(maxpool3x3s2_bwd_kernel, dim3(grid_for((size_t)N * H * W * C)), dim3(256), 0, (hipStream_t)stream, x, g, gx, N, H, W, C, Ho, Wo);
+    hipLaunchKernelGGL(maxpool3x3s2_bwd_kernel, dim3(grid_for((size_t)N * H * W * C)), dim3(256), 0, (hipStream_t)stream, x, g, gx, N, H, W, C, Ho, Wo,
+                       add, relu_mask);
     return vfn_check_launch();
 }
 

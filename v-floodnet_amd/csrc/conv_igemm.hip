@@ -83,12 +83,17 @@ __device__ __forceinline__ void splitk_finish(const vfn_conv_desc& p, int* flag,
         f32x4 v;
 #pragma unroll
         for (int k = 0; k < 4; ++k) v[k] = a[k] * sc[k] + sh[k];
-        if (p.mask) {
-            const f32x4 mk = *reinterpret_cast<const f32x4*>(p.mask + (size_t)row * p.mask_ld + col);
+        f32x4 mk = {1.f, 1.f, 1.f, 1.f};
+        if (p.mask) mk = *reinterpret_cast<const f32x4*>(p.mask + (size_t)row * p.mask_ld + col);
+        if (p.mask && !p.mask_after) {
 #pragma unroll
             for (int k = 0; k < 4; ++k) v[k] = mk[k] > 0.f ? v[k] : 0.f;
         }
         if (p.res) v += *reinterpret_cast<const f32x4*>(p.res + (size_t)(p.res_mod > 0 ? row % p.res_mod : row) * p.res_ld + col);
+        if (p.mask && p.mask_after) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) v[k] = mk[k] > 0.f ? v[k] : 0.f;
+        }
         if (p.relu_out) {
 #pragma unroll
             for (int k = 0; k < 4; ++k) v[k] = fmaxf(v[k], 0.f);
@@ -159,12 +164,17 @@ __device__ __forceinline__ bool wide_epilogue(const vfn_conv_desc& p, char* smem
             }
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] = v[e] * sc[e] + sh[e];
-            if (p.mask) {
-                const f32x4 mk = *reinterpret_cast<const f32x4*>(p.mask + (size_t)row * p.mask_ld + col);
+            f32x4 mk = {1.f, 1.f, 1.f, 1.f};
+            if (p.mask) mk = *reinterpret_cast<const f32x4*>(p.mask + (size_t)row * p.mask_ld + col);
+            if (p.mask && !p.mask_after) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[e] = mk[e] > 0.f ? v[e] : 0.f;
             }
             if (p.res) v += *reinterpret_cast<const f32x4*>(p.res + (size_t)(p.res_mod > 0 ? row % p.res_mod : row) * p.res_ld + col);
+            if (p.mask && p.mask_after) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = mk[e] > 0.f ? v[e] : 0.f;
+            }
             if (p.relu_out) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
@@ -588,8 +598,10 @@ __device__ __forceinline__ void conv_igemm_body(const vfn_conv_desc& p) {
                 const int row = rbase + (r & 3) + 8 * (r >> 2);
                 if (row < p.M) {
                     float v = acc[i][j][r] * sc + sh;
-                    if (p.mask) v = p.mask[(size_t)row * p.mask_ld + col] > 0.f ? v : 0.f;
+                    const bool live = !p.mask || p.mask[(size_t)row * p.mask_ld + col] > 0.f;
+                    if (!p.mask_after && !live) v = 0.f;
                     if (p.res) v += p.res[(size_t)(p.res_mod > 0 ? row % p.res_mod : row) * p.res_ld + col];
+                    if (p.mask_after && !live) v = 0.f;
                     if (p.relu_out) v = fmaxf(v, 0.f);
                     p.out[(size_t)row * p.out_ld + col] = v;
                 }
@@ -813,8 +825,10 @@ void conv_igemm_dma_kernel(const vfn_conv_desc p) {
                 const int row = rbase + (r & 3) + 8 * (r >> 2);
                 if (row < p.M) {
                     float v = acc[i][j][r] * sc + sh;
-                    if (p.mask) v = p.mask[(size_t)row * p.mask_ld + col] > 0.f ? v : 0.f;
+                    const bool live = !p.mask || p.mask[(size_t)row * p.mask_ld + col] > 0.f;
+                    if (!p.mask_after && !live) v = 0.f;
                     if (p.res) v += p.res[(size_t)(p.res_mod > 0 ? row % p.res_mod : row) * p.res_ld + col];
+                    if (p.mask_after && !live) v = 0.f;
                     if (p.relu_out) v = fmaxf(v, 0.f);
                     p.out[(size_t)row * p.out_ld + col] = v;
                 }
@@ -842,12 +856,17 @@ __global__ void splitk_reduce_kernel(const vfn_conv_desc p, int m_start) {
         f32x4 v;
 #pragma unroll
         for (int k = 0; k < 4; ++k) v[k] = a[k] * sc[k] + sh[k];
-        if (p.mask) {
-            const f32x4 mk = *reinterpret_cast<const f32x4*>(p.mask + row * p.mask_ld + c4 * 4);
+        f32x4 mk = {1.f, 1.f, 1.f, 1.f};
+        if (p.mask) mk = *reinterpret_cast<const f32x4*>(p.mask + row * p.mask_ld + c4 * 4);
+        if (p.mask && !p.mask_after) {
 #pragma unroll
             for (int k = 0; k < 4; ++k) v[k] = mk[k] > 0.f ? v[k] : 0.f;
         }
         if (p.res) v += *reinterpret_cast<const f32x4*>(p.res + (p.res_mod > 0 ? row % p.res_mod : row) * p.res_ld + c4 * 4);
+        if (p.mask && p.mask_after) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) v[k] = mk[k] > 0.f ? v[k] : 0.f;
+        }
         if (p.relu_out) {
 #pragma unroll
             for (int k = 0; k < 4; ++k) v[k] = fmaxf(v[k], 0.f);

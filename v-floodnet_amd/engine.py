@@ -216,8 +216,10 @@ class Launch:
 class FramePlan:
     """Buffers + launch lists for one (H0, W0, obj_n)."""
 
-    def __init__(self, eng, H0, W0, obj_n):
+    def __init__(self, eng, H0, W0, obj_n, keep_acts=False):
         self.eng = eng
+        self.keep_acts = keep_acts            # training: every bottleneck keeps its own activation buffers (the backward reads them)
+        self.acts_m = {}                      # memory encoder: (stage, block) -> dict(x, t1, t2, ds, out, stride, H, W)
         self.H0, self.W0, self.obj_n = H0, W0, obj_n
         self.pad, self.Hp, self.Wp = pad_divide_by(H0, W0)
         dev = eng.device
@@ -361,7 +363,7 @@ class FramePlan:
         lst.append(Launch(ops.conv2d_launch, (d, cfg, bf), f'{name}[{d.M}x{layer.cout}x{K}]', 2.0 * d.M * layer.cout * K))
         return out
 
-    def _trunk(self, lst, enc, bufs, N, prefix):
+    def _trunk(self, lst, enc, bufs, N, prefix, acts=None):
         x = bufs['x4']
         lst.append(Launch(ops.maxpool3x3s2, (bufs['r1'], x), prefix + '.maxpool'))
         H, Wd = self.h4, self.w4
@@ -372,20 +374,28 @@ class FramePlan:
                 s = blk['conv2'].stride
                 Ho, Wo = H // s, Wd // s
                 t1 = lb['t1a'] if (s == 2) else lb['t1']
+                t2, ds_buf = lb['t2'], lb['ds']
+                if self.keep_acts:                        # own buffers per block (sliced like the shared ones)
+                    t1, t2 = torch.empty_like(t1), torch.empty_like(lb['t2'])
+                    ds_buf = torch.empty_like(lb['ds'])
                 nm = f'{prefix}.{lname}.{bi}'
                 # (bf16x3: t1 / t2 feed one convolution each -> image only; a block's output is the next block's residual
                 # (f32) and the next convolutions' operand (image))
                 self._conv(lst, blk['conv1'], x, t1, N, H, Wd, relu_out=True, name=nm + '.conv1', lp_out='plain', f32_out=False)
-                self._conv(lst, blk['conv2'], t1, lb['t2'], N, H, Wd, relu_out=True, name=nm + '.conv2', lp_out='plain',
+                self._conv(lst, blk['conv2'], t1, t2, N, H, Wd, relu_out=True, name=nm + '.conv2', lp_out='plain',
                            f32_out=False)
                 if 'down' in blk:
-                    self._conv(lst, blk['down'], x, lb['ds'], N, H, Wd, name=nm + '.down')
-                    idn = lb['ds']
+                    self._conv(lst, blk['down'], x, ds_buf, N, H, Wd, name=nm + '.down')
+                    idn = ds_buf
                 else:
                     idn = x
                 out = lb['out'] if bi == len(blocks) - 1 else lb['o'][bi % 2]
-                self._conv(lst, blk['conv3'], lb['t2'], out, N, Ho, Wo, res=idn, relu_out=True, name=nm + '.conv3',
+                if self.keep_acts and bi != len(blocks) - 1:
+                    out = torch.empty_like(out)
+                self._conv(lst, blk['conv3'], t2, out, N, Ho, Wo, res=idn, relu_out=True, name=nm + '.conv3',
                            lp_out='plain')
+                if self.keep_acts and acts is not None:
+                    acts[(lname, bi)] = dict(x=x, t1=t1, t2=t2, ds=ds_buf if 'down' in blk else None, out=out, stride=s, H=H, W=Wd)
                 x = out
                 H, Wd = Ho, Wo
         return x
@@ -407,7 +417,7 @@ class FramePlan:
                                          self.m['r1'], e.mean, e.std, K, self.H0, self.W0, self.pad, self.Hp, self.Wp)
         self.mem.append(Launch(ops.stem_launch, (self.stem_m,), 'encoder_m.stem',
                                2.0 * K * self.h2 * self.w2 * 64 * 245))
-        r4m = self._trunk(self.mem, e.enc_m, self.m, K, 'encoder_m')
+        r4m = self._trunk(self.mem, e.enc_m, self.m, K, 'encoder_m', acts=self.acts_m)
         self._conv(self.mem, e.keyval, r4m, self.kv_m, K, self.h16, self.w16, name='keyval')
 
     def conv_flops(self, which):
@@ -436,6 +446,7 @@ class QuerySet:
         self.s4 = [f(2, p.h4, p.w4, 256) for _ in range(3)]
         self.lq = f(2, p.h2, p.w2, 32)                       # local_convFM over the shared r1 half
         self.pre = {1: [], 2: []}
+        self.acts = {1: {}, 2: {}}                          # training plans: the bottlenecks' activations per launch list
         self.post = [[], []]
         self.split = {1: 0, 2: 0}                           # pre[n][:split[n]] = the first half (by estimated time)
         # bookkeeping of Engine.prefetch_*: which frames the slots hold
@@ -463,7 +474,7 @@ class QuerySet:
                 d = ops.make_stem_desc(self.frames[i], None, e.stem_q_w, e.stem_q_scale, e.stem_q_shift,
                                        self.q['r1'][i:i + 1], e.mean, e.std, 1, p.H0, p.W0, p.pad, p.Hp, p.Wp)
                 P.append(Launch(ops.stem_launch, (d,), 'encoder_q.stem', 2.0 * p.h2 * p.w2 * 64 * 147))
-            r4 = p._trunk(P, e.enc_q, q, n, 'encoder_q')
+            r4 = p._trunk(P, e.enc_q, q, n, 'encoder_q', acts=self.acts[n])
             p._conv(P, e.keyval, r4, sl(self.kv_q), n, p.h16, p.w16, name='keyval')
             # convFM(cat([mem_i, q_out])) = convFM[:, :512](mem_i) + convFM[:, 512:](q_out): the second term is the
             # same for every object (AFB_URR.py:159,176) -> computed once (with the bias) and added as a shared residual
@@ -579,13 +590,14 @@ class Engine:
                             local_pred2=Pred2Layer(d.local_pred2, dev))
 
     # ------------------------------------------------------------------ plans
-    def plan(self, H0, W0, obj_n):
-        key = (H0, W0, obj_n)
+    def plan(self, H0, W0, obj_n, keep_acts=False):
+        """``keep_acts`` (training): a plan whose bottlenecks keep their activations for the backward pass."""
+        key = (H0, W0, obj_n, bool(keep_acts))
         p = self.plans.get(key)
         if p is None:
             if len(self.plans) >= 4:
                 self.plans.pop(next(iter(self.plans)))
-            p = FramePlan(self, H0, W0, obj_n)
+            p = FramePlan(self, H0, W0, obj_n, keep_acts=bool(keep_acts))
             self.plans[key] = p
         return p
 
@@ -596,10 +608,11 @@ class Engine:
         _lib.require_gpu(frame, 'frame')
 
     # ------------------------------------------------------------------ API
-    def memorize(self, frame, mask):
+    def memorize(self, frame, mask, training=False):
         self._check_frame(frame)
         _, K, H, Wd = mask.shape
-        p = self.plan(frame.shape[2], frame.shape[3], K)
+        p = self.plan(frame.shape[2], frame.shape[3], K, keep_acts=training)
+        self.last_memorize = p
         p.frame_in.copy_(frame[0])
         p.mask_in.copy_(mask[0])                       # uint8 / float -> float32 (mask.float(), AFB_URR.py:262)
         for l in p.mem:
@@ -621,7 +634,7 @@ class Engine:
         H, Wd = frame.shape[2], frame.shape[3]
         if training and (H % 16 or Wd % 16):
             raise RuntimeError(f'training-mode segment does not pad (AFB_URR.py:278): {H}x{Wd} is not a multiple of 16')
-        p = self.plan(H, Wd, K)
+        p = self.plan(H, Wd, K, keep_acts=training)
         if fb._kbuf is None:
             raise RuntimeError('feature bank is empty: call fb.init_bank() first')
         if fb._hw != p.HW:

@@ -73,7 +73,7 @@ class AFB_URR(nn.Module):
         """AFB_URR.py:255-272.  frame f32[1,3,h,w] in [0,1]; mask [1,K,h,w] (u8 or float).  Identical in eval and in
         training mode (the reference pads here in both, :259); BatchNorm always uses its running statistics -- in
         training mode that is the frozen-BN setting of train_video_seg.py:103-106."""
-        return self.engine().memorize(frame, mask)
+        return self.engine().memorize(frame, mask, training=self.training)
 
     @torch.no_grad()
     def segment(self, frame, fb_global):

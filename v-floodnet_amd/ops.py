@@ -95,7 +95,7 @@ def make_conv_desc(x, wp, cout, kh, kw, stride, pad, out, scale=None, shift=None
     d.res_mod = 0
     d.w_packed = 0
     d.in_lp, d.out_lp_relu, d.out_lp = 0, 0, None
-    d.mask, d.mask_ld = None, 0
+    d.mask, d.mask_ld, d.mask_after = None, 0, 0
     assert wp.shape[1] == kh * kw * cin
     return d
 
