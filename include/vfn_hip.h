@@ -202,7 +202,8 @@ int vfn_transpose_taps_f32(const float* x, int N, int H, int W, int C, int ld_x,
  *     add (optional, shape of x): a second gradient arriving at x; relu_mask: x is a ReLU's output, the sum is zeroed where x <= 0.
  * vfn_softmax_cols_f32 / _backward_f32   P = softmax over the rows of scale * S [B][ld] per column (AFB_URR.py:144-145 with the
  *     bank of one frame materialised, as training has it); dS = scale * P (dP - sum_b P dP).
- * vfn_adamw_f32            one torch.optim.AdamW step on n floats (decoupled decay, bias corrections 1 - beta^step). */
+ * vfn_adamw_f32            one torch.optim.AdamW step on n floats (decoupled decay, bias corrections 1 - beta^step; the hyper-parameters
+ *     are doubles: 1 - beta and the corrections are formed in double as torch forms its python scalars, then rounded to f32). */
 int vfn_dilate2_f32(const float* g, float* out, int N, int Ho, int Wo, int H, int W, int C, void* stream);
 int vfn_bn_param_grads_f32(const float* g, const float* y, const float* idn, const float* beta, const float* gamma, int M, int C,
                            float* partial, int nb, float* dgamma, float* dbeta, void* stream);
@@ -210,8 +211,8 @@ int vfn_maxpool3x3s2_backward_f32(const float* x, const float* g, float* gx, int
                                   void* stream);
 int vfn_softmax_cols_f32(const float* S, int B, int Q, int ld, float scale, float* P, void* stream);
 int vfn_softmax_cols_backward_f32(const float* P, const float* dP, int B, int Q, int ld, float scale, float* dS, void* stream);
-int vfn_adamw_f32(float* p, const float* g, float* m, float* v, long long n, float lr, float beta1, float beta2, float eps,
-                  float weight_decay, int step, void* stream);
+int vfn_adamw_f32(float* p, const float* g, float* m, float* v, long long n, double lr, double beta1, double beta2, double eps,
+                  double weight_decay, int step, void* stream);
 int vfn_colsum_f32(const float* x, int M, int C, int ld, float* partial, int nb, float* out, void* stream);
 int vfn_upsample2x_add_backward_f32(const float* gm, float* gs, float* gpm, int N, int h, int w, int C, int s_bcast,
                                     void* stream);

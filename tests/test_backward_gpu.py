@@ -207,17 +207,71 @@ def test_training_loss_and_its_gradient(gpu, bs, K, H, W):
     assert _rel(grad.cpu(), z.grad) < 1e-4
 
 
+def _hip_relu_masks(eng, K, memorize_only=False):
+    """The ReLU activation patterns of the HIP forward (memorize, then the sample segment ran last), in the order the oracle
+    calls F.relu; NCHW bool on the CPU."""
+    pm = eng.last_memorize
+    nchw_mask = lambda t: (t.permute(0, 3, 1, 2) > 0).cpu()
+    order = [pm.m['r1']]
+    for lname, nb in (('res2', 3), ('res3', 4), ('res4', 6)):
+        for bi in range(nb):
+            a = pm.acts_m[(lname, bi)]
+            order += [a['t1'], a['t2'], a['out']]
+    mem_masks = [nchw_mask(t) for t in order]
+    if memorize_only:
+        return mem_masks
+    plan, qs, slot = eng.last_query
+    order = [qs.q['r1'][0:1]]
+    for lname, nb in (('res2', 3), ('res3', 4), ('res4', 6)):
+        for bi in range(nb):
+            a = qs.acts[1][(lname, bi)]
+            order += [a['t1'], a['t2'], a['out']]
+    ex = lambda t: t[0:1].expand(K, -1, -1, -1)
+    order += [plan.d16[0], plan.d16[1], ex(qs.s8[0]), ex(qs.s8[1]), plan.d8[0], plan.d8[1], ex(qs.s4[0]), ex(qs.s4[1]),
+              plan.d4[0], plan.d4[1], plan.d4[2], plan.l2[0], plan.l2[1], plan.l2[2]]
+    return mem_masks, [nchw_mask(t) for t in order]
+
+
+def _sd64(sd):
+    return {n: (t.double().clone().requires_grad_() if (t.is_floating_point() and not n.endswith(('running_mean', 'running_var', '.mean', '.std')))
+                else (t.double() if t.is_floating_point() else t)) for n, t in sd.items()}
+
+
+def _oracle_sample(sd64, frame0, oh, frame_i, label_i, K, lu, masks):
+    """float64 autograd through the oracle's memorize / segment / loss for one sample, its ReLUs at the HIP pattern ``masks``
+    (a list in call order).  Returns (scores, loss); gradients accumulate in sd64's leaves after ``loss.backward()``."""
+    import torch.nn.functional as F
+    from oracle import afb_urr_ref as O
+    it = iter(masks)
+    flips = []
+    real_relu = F.relu
+
+    def relu_at_hip_pattern(x, *a_, **k_):
+        mk = next(it)
+        flips.append(int(((x.detach() > 0) != mk).sum()))
+        return x * mk.to(x.dtype)
+    O.F.relu = relu_at_hip_pattern
+    try:
+        k_ref, v_ref = O.memorize(sd64, frame0.double(), oh)
+        fbr = O.FeatureBankRef(K, 250000)
+        fbr.init_bank(k_ref, v_ref)
+        sc, un = O.segment(sd64, frame_i.double(), fbr, update_bank=False, training=True)
+    finally:
+        O.F.relu = real_relu
+    assert next(it, None) is None and sum(flips) <= 40, (sum(flips), len(flips))
+    loss = F.cross_entropy(sc, label_i) + lu * un
+    return sc, un, loss
+
+
 def test_whole_model_backward_vs_autograd(gpu):
     """One training sample end to end (train_video_seg.py:65-74): memorize -> bank -> segment (training branch) -> loss on the HIP
     path, then ``ModelBackward``: decoder, memory read, KeyValue, query encoder, and -- through the bank's keys / values --
     KeyValue and the memory encoder again.  EVERY trainable parameter's gradient (convolutions, frozen-BatchNorm weights and
     biases, the three stems) against float64 autograd through the oracle's memorize / segment / loss, differentiated at the HIP
     forward's activation pattern (see test_whole_decoder_backward_vs_autograd)."""
-    import torch.nn.functional as F
     from tools import synth
     from vfloodnet_amd import AFB_URR, FeatureBank, ops
     from vfloodnet_amd.backward import ModelBackward
-    from oracle import afb_urr_ref as O
     H, W, K, lu = 96, 160, 2, 0.5
     sd = synth.make_state_dict(SEED)
     model = AFB_URR(gpu, update_bank=False).to(gpu)
@@ -238,43 +292,10 @@ def test_whole_model_backward_vs_autograd(gpu):
     torch.cuda.synchronize()
 
     # ---- the oracle, float64, its ReLUs at the HIP pattern
-    plan, qs, slot = eng.last_query
-    pm = eng.last_memorize
-    nchw_mask = lambda t: (t.permute(0, 3, 1, 2) > 0).cpu()
-    order = [pm.m['r1']]
-    for lname, nb in (('res2', 3), ('res3', 4), ('res4', 6)):
-        for bi in range(nb):
-            a = pm.acts_m[(lname, bi)]
-            order += [a['t1'], a['t2'], a['out']]
-    order.append(qs.q['r1'][0:1])
-    for lname, nb in (('res2', 3), ('res3', 4), ('res4', 6)):
-        for bi in range(nb):
-            a = qs.acts[1][(lname, bi)]
-            order += [a['t1'], a['t2'], a['out']]
-    ex = lambda t: t[0:1].expand(K, -1, -1, -1)
-    order += [plan.d16[0], plan.d16[1], ex(qs.s8[0]), ex(qs.s8[1]), plan.d8[0], plan.d8[1], ex(qs.s4[0]), ex(qs.s4[1]),
-              plan.d4[0], plan.d4[1], plan.d4[2], plan.l2[0], plan.l2[1], plan.l2[2]]
-    masks = iter([nchw_mask(t) for t in order])
-    flips = []
-    real_relu = F.relu
-
-    def relu_at_hip_pattern(x, *a_, **k_):
-        mk = next(masks)
-        flips.append(int(((x.detach() > 0) != mk).sum()))
-        return x * mk.to(x.dtype)
-    sd64 = {n: (t.double().clone().requires_grad_() if (t.is_floating_point() and not n.endswith(('running_mean', 'running_var', '.mean', '.std')))
-                else (t.double() if t.is_floating_point() else t)) for n, t in sd.items()}
-    O.F.relu = relu_at_hip_pattern
-    try:
-        k_ref, v_ref = O.memorize(sd64, frames[0:1].double(), oh)
-        fbr = O.FeatureBankRef(K, 250000)
-        fbr.init_bank(k_ref, v_ref)
-        sc, un = O.segment(sd64, frames[1:2].double(), fbr, update_bank=False, training=True)
-    finally:
-        O.F.relu = real_relu
-    assert next(masks, None) is None and sum(flips) <= 40, (sum(flips), len(flips))
+    mem_masks, q_masks = _hip_relu_masks(eng, K)
+    sd64 = _sd64(sd)
+    sc, un, loss = _oracle_sample(sd64, frames[0:1], oh, frames[1:2], label, K, lu, mem_masks + q_masks)
     assert (sc.detach() - scores.cpu().double()).abs().max() < 5e-3
-    loss = F.cross_entropy(sc, label) + lu * un
     assert abs(loss.item() - stats[0].item()) < 1e-4 * abs(loss.item())
     loss.backward()
 
@@ -290,3 +311,119 @@ def test_whole_model_backward_vs_autograd(gpu):
     bad = {n: e for n, e in worst.items() if not e < 2e-4}
     assert not bad, dict(sorted(bad.items(), key=lambda kv: -kv[1])[:12])
     assert set(mb.grads) == set(worst)
+
+
+def test_adamw_kernel_vs_torch_optim(gpu):
+    """vfn_adamw_f32 through ``train.AdamW`` against torch.optim.AdamW (train_video_seg.py:109: defaults, lr 1e-5) on the CPU:
+    three steps with fresh random gradients, parameters and both moment buffers."""
+    from vfloodnet_amd.train import AdamW
+    g = torch.Generator().manual_seed(3)
+    shapes = {'a.weight': (64, 3, 7, 7), 'b.bias': (5,), 'c.weight': (130, 67)}
+    ref = {n: torch.nn.Parameter(torch.randn(*s, generator=g)) for n, s in shapes.items()}
+    mine = {n: torch.nn.Parameter(p.detach().clone().to(gpu)) for n, p in ref.items()}
+    for lr, wd in ((1e-5, 1e-2), (3e-3, 0.1)):
+        o_ref = torch.optim.AdamW(list(ref.values()), lr=lr, weight_decay=wd)
+        o = AdamW(mine.items(), lr=lr, weight_decay=wd)
+        for step in range(3):
+            grads = {n: torch.randn(*s, generator=g) * 10.0 ** (step - 2) for n, s in shapes.items()}
+            for n, p in ref.items():
+                p.grad = grads[n].clone()
+            o_ref.step()
+            o.zero_grad()
+            o.set_grads({n: t.to(gpu) for n, t in grads.items()})
+            o.step()
+            for n in shapes:
+                assert (mine[n].detach().cpu() - ref[n].detach()).abs().max() <= 4e-7 * max(1.0, lr / 1e-5) * max(1.0, ref[n].abs().max().item()), (n, step)
+                st = o_ref.state[ref[n]]
+                sd_ = o.state_dict()
+                assert _rel(sd_['exp_avg'][n].cpu(), st['exp_avg']) < 1e-6 and _rel(sd_['exp_avg_sq'][n].cpu(), st['exp_avg_sq']) < 1e-6
+    with pytest.raises(KeyError):
+        o.set_grads({'a.weight': torch.zeros(shapes['a.weight'], device=gpu)})
+
+
+def test_train_step_vs_reference_loop(gpu):
+    """``train.train_step`` = the loop body of train_video_seg.py:56-76 for a 3-frame sample (reference frame + a batch of two):
+    loss / uncertainty against the oracle, the batch gradient of every parameter against float64 autograd (mean over the two
+    samples, each differentiated at its HIP activation pattern), the parameters after ``optimizer.step()`` against
+    torch.optim.AdamW fed the same gradients, and the next step sees the new parameters (the loss on the same sample falls)."""
+    from tools import synth
+    from vfloodnet_amd import AFB_URR
+    from vfloodnet_amd import train as T
+    from vfloodnet_amd.backward import ModelBackward
+    H, W, K, lu, lr = 96, 160, 2, 0.5, 1e-5
+    sd = synth.make_state_dict(SEED)
+    model = AFB_URR(gpu, update_bank=False).to(gpu)
+    model.load_state_dict(sd, strict=True)
+    model.train()
+    frames, m0 = synth.clip(6, 3, H, W)
+    gen = torch.Generator().manual_seed(11)
+    lab = torch.stack([m0.long()] + [torch.roll(m0.long(), (2 * t, 5 * t), (0, 1)) for t in (1, 2)], 0)       # [3,H,W]
+    flip = torch.rand(3, H, W, generator=gen) < 0.05
+    lab = torch.where(flip, 1 - lab, lab)
+    masks = torch.nn.functional.one_hot(lab, K).permute(0, 3, 1, 2).float()                                    # [3,K,H,W]
+
+    # record the activation patterns of every sample as the step passes through it
+    pats = []
+    orig = ModelBackward.segment_sample
+
+    def spy(self, fb, grad_score):
+        pats.append(_hip_relu_masks(self.eng, K)[1])
+        return orig(self, fb, grad_score)
+    ModelBackward.segment_sample = spy
+    try:
+        loss, unc, grads = T.forward_backward(model, frames, masks, lu)
+    finally:
+        ModelBackward.segment_sample = orig
+    mem_masks = _hip_relu_masks(model.engine(), K, memorize_only=True)
+    assert len(pats) == 2
+
+    sd64 = _sd64(sd)
+    tot, unc_ref = 0.0, 0.0
+    for i in range(2):
+        sc, un, l_i = _oracle_sample(sd64, frames[0:1], masks[0:1], frames[1 + i:2 + i], lab[1 + i:2 + i], K, lu, mem_masks + pats[i])
+        (l_i / 2).backward()
+        tot += l_i.item() / 2
+        unc_ref += un.item() / 2
+    assert abs(loss - tot) < 1e-4 * abs(tot) and abs(unc - unc_ref) < 1e-4 * abs(unc_ref), (loss, tot, unc, unc_ref)
+    worst = {}
+    for name, t in sd64.items():
+        if torch.is_tensor(t) and t.requires_grad:
+            worst[name] = _rel(grads[name].cpu(), t.grad)
+    bad = {n: e for n, e in worst.items() if not e < 2e-4}
+    print('train step: batch gradient, worst relative errors:', {n: f'{e:.1e}' for n, e in sorted(worst.items(), key=lambda kv: -kv[1])[:5]})
+    assert not bad, dict(sorted(bad.items(), key=lambda kv: -kv[1])[:12])
+
+    # the optimiser step on those gradients
+    opt = T.AdamW(model.named_parameters(), lr=lr)
+    assert set(opt.names) == set(worst)
+    before = {n: p.detach().cpu().clone() for n, p in model.named_parameters()}
+    for n, p in model.named_parameters():                                   # moving into the flat buffer changes no value
+        assert torch.equal(p.detach().cpu(), sd[n].float())
+    losses = [T.train_step(model, opt, frames, masks, lu)[0] for _ in range(3)]
+    assert abs(losses[0] - loss) < 1e-6 * abs(loss)
+    ref_p = {n: torch.nn.Parameter(before[n].clone()) for n in before}
+    o_ref = torch.optim.AdamW(list(ref_p.values()), lr=lr)
+    for n in ref_p:
+        ref_p[n].grad = grads[n].cpu().reshape(ref_p[n].shape).clone()
+    o_ref.step()
+    model2 = AFB_URR(gpu, update_bank=False).to(gpu)
+    model2.load_state_dict(sd, strict=True)
+    model2.train()
+    opt2 = T.AdamW(model2.named_parameters(), lr=lr)
+    T.train_step(model2, opt2, frames, masks, lu)
+    for n, p in model2.named_parameters():
+        assert (p.detach().cpu() - ref_p[n].detach()).abs().max() <= 4e-7 * max(1.0, ref_p[n].abs().max().item()), n
+    print('train step: losses over three steps on one sample', [f'{x:.6f}' for x in losses])
+    assert losses[2] < losses[1] < losses[0]
+
+    # the epoch loop (train_video_seg.py:51-89) and the scheduler (:146-147): a single-object sample is skipped
+    sched = T.StepLR(opt, step_size=1, gamma=0.5)
+    assert sched.get_last_lr() == [lr]
+    seen = []
+    loader = [(frames[None], masks[None], torch.tensor([K]), {}), (frames[None], masks[None, :, :1], torch.tensor([1]), {})]
+    avg = T.train_model(model, loader, opt, lu, progress=lambda n, l, a, u: seen.append((n, l)))
+    assert len(seen) == 1 and avg == seen[0][1] and avg < losses[2]
+    sched.step()
+    assert sched.get_last_lr() == [lr * 0.5] and opt.lr == lr * 0.5
+    sdo = opt.state_dict()
+    assert sdo['step'] == 4 and set(sdo['exp_avg']) == set(opt.names)

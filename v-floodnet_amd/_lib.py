@@ -137,7 +137,7 @@ SIGNATURES = {
     'vfn_maxpool3x3s2_backward_f32': [_p, _p, _p, _i, _i, _i, _i, _p, _i, _p],
     'vfn_softmax_cols_f32': [_p, _i, _i, _i, _f, _p, _p],
     'vfn_softmax_cols_backward_f32': [_p, _p, _i, _i, _i, _f, _p, _p],
-    'vfn_adamw_f32': [_p, _p, _p, _p, _ll, _f, _f, _f, _f, _f, _i, _p],
+    'vfn_adamw_f32': [_p, _p, _p, _p, _ll, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, _i, _p],
     'vfn_colsum_f32': [_p, _i, _i, _i, _p, _i, _p, _p],
     'vfn_upsample2x_add_backward_f32': [_p, _p, _p, _i, _i, _i, _i, _i, _p],
     'vfn_tail_grad_o_f32': [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p],

@@ -532,13 +532,13 @@ __global__ void softmax_cols_bwd_kernel(const float* __restrict__ P, const float
 
 // ------------------------------------------------------------------ AdamW (torch.optim.AdamW defaults' arithmetic)
 __global__ void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v, size_t n,
-                             float lr, float b1, float b2, float eps, float wd, float bc1, float bc2) {
+                             float lr, float b1, float b2, float omb1, float omb2, float eps, float wd, float bc1, float bc2) {
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
         float pv = p[i];
         const float gv = g[i];
         pv *= 1.f - lr * wd;                                           // decoupled weight decay
-        const float mv = b1 * m[i] + (1.f - b1) * gv;
-        const float vv = b2 * v[i] + (1.f - b2) * gv * gv;
+        const float mv = b1 * m[i] + omb1 * gv;
+        const float vv = b2 * v[i] + omb2 * gv * gv;
         m[i] = mv;
         v[i] = vv;
         const float denom = sqrtf(vv) / sqrtf(bc2) + eps;
@@ -664,11 +664,13 @@ extern "C" int vfn_softmax_cols_backward_f32(const float* P, const float* dP, in
 }
 
 // one AdamW step on n floats: step >= 1 (bias corrections 1 - beta^step); torch.optim.AdamW arithmetic (decoupled decay first)
-extern "C" int vfn_adamw_f32(float* p, const float* g, float* m, float* v, long long n, float lr, float beta1, float beta2, float eps,
-                             float weight_decay, int step, void* stream) {
+extern "C" int vfn_adamw_f32(float* p, const float* g, float* m, float* v, long long n, double lr, double beta1, double beta2, double eps,
+                             double weight_decay, int step, void* stream) {
     if (!p || !g || !m || !v || n < 1 || step < 1) return VFN_ERR_ARG;
-    const float bc1 = 1.f - powf(beta1, (float)step), bc2 = 1.f - powf(beta2, (float)step);
-    hipLaunchKernelGGL(adamw_kernel, dim3(grid_for((size_t)n)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, (size_t)n, lr, beta1, beta2,
-                       eps, weight_decay, bc1, bc2);
+    // 1 - beta and the bias corrections are formed in double on the host, as torch.optim forms its python scalars
+    const float bc1 = (float)(1.0 - pow(beta1, (double)step)), bc2 = (float)(1.0 - pow(beta2, (double)step));
+    const float omb1 = (float)(1.0 - beta1), omb2 = (float)(1.0 - beta2);
+    hipLaunchKernelGGL(adamw_kernel, dim3(grid_for((size_t)n)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, (size_t)n, (float)lr,
+                       (float)beta1, (float)beta2, omb1, omb2, (float)eps, (float)weight_decay, bc1, bc2);
     return vfn_check_launch();
 }

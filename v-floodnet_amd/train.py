@@ -1,0 +1,194 @@
+"""One optimisation step of ``train_video_seg.py`` on the HIP path.
+
+The reference's inner loop (``train_video_seg.py:56-76``):
+
+    fb_global = FeatureBank(obj_n, budget, device)
+    k4_list, v4_list = model.memorize(frames[0:1], masks[0:1]);  fb_global.init_bank(k4_list, v4_list)
+    scores, uncertainty = model.segment(frames[1:], fb_global)
+    label = torch.argmax(masks[1:], dim=1).long()
+    optimizer.zero_grad();  loss = criterion(scores, label) + lu * uncertainty;  loss.backward();  optimizer.step()
+
+with ``criterion = CrossEntropyLoss()`` (:162), ``optimizer = torch.optim.AdamW(params, lr)`` (:109), BatchNorm frozen
+(:103-106, ``myutils.set_bn_eval``: running statistics, affine parameters still trained), ``update_bank=False`` (:101).
+
+Here: ``train_step`` runs that body.  The bank is fixed while the batch is segmented, so the batch's samples are independent
+given the bank: each sample is segmented, its loss gradient formed (``ops.segment_loss``; the batch means of the cross entropy
+and of the uncertainty become a factor 1/bs on every sample's gradient) and carried back to the parameters and to the
+bank's keys / values (``backward.ModelBackward.segment_sample``) before the next sample reuses the activation buffers; the
+gradients that reached the bank are summed over the samples and go through ``memorize`` once (``finish_memorize``).
+``AdamW`` keeps every parameter of the model in ONE flat f32 buffer (the ``nn.Parameter``s become views of it) next to
+flat ``exp_avg`` / ``exp_avg_sq`` buffers, so a step is one ``vfn_adamw_f32`` launch over 38 M floats (HBM-bound: 5 floats
+moved per parameter).  All arithmetic runs in the HIP library; there is no autograd graph and no eager fallback.
+"""
+import torch
+
+from . import _lib, ops
+from ._lib import ptr, stream, check
+from .feature_bank import FeatureBank
+from .backward import ModelBackward
+
+
+class AdamW:
+    """``torch.optim.AdamW(params, lr, betas, eps, weight_decay)`` (train_video_seg.py:109; torch defaults: betas (0.9, 0.999),
+    eps 1e-8, weight_decay 1e-2, no amsgrad) over the parameters of one ``AFB_URR``.
+
+    ``named_params``: iterable of (state-dict name, nn.Parameter) -- ``model.named_parameters()``.  The parameters are moved
+    into one flat device buffer (their ``.data`` become views of it, values unchanged)."""
+
+    def __init__(self, named_params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2):
+        items = [(n, p) for n, p in named_params if p.requires_grad]
+        if not items:
+            raise ValueError('optimizer got an empty parameter list')
+        dev = items[0][1].device
+        if dev.type != 'cuda':
+            raise RuntimeError('AdamW runs on the HIP device only (no CPU fallback): move the model to the GPU first')
+        self.lr, self.betas, self.eps, self.weight_decay = float(lr), (float(betas[0]), float(betas[1])), float(eps), float(weight_decay)
+        self.names = [n for n, _ in items]
+        self.offsets = {}
+        off = 0
+        for n, p in items:
+            if p.dtype != torch.float32:
+                raise TypeError(f'{n}: f32 parameters only')
+            self.offsets[n] = (off, p.numel(), tuple(p.shape))
+            off += (p.numel() + 3) // 4 * 4                                # 16-byte aligned views
+        self.n = off
+        self.flat = torch.zeros(off, device=dev, dtype=torch.float32)
+        for n, p in items:
+            o, k, shp = self.offsets[n]
+            view = self.flat[o:o + k].view(shp)
+            view.copy_(p.data)
+            p.data = view
+        self.grad = torch.zeros_like(self.flat)
+        self.exp_avg = torch.zeros_like(self.flat)
+        self.exp_avg_sq = torch.zeros_like(self.flat)
+        self.step_count = 0
+
+    def zero_grad(self):
+        self.grad.zero_()
+
+    def grad_view(self, name):
+        o, k, shp = self.offsets[name]
+        return self.grad[o:o + k].view(shp)
+
+    def param_view(self, name):
+        o, k, shp = self.offsets[name]
+        return self.flat[o:o + k].view(shp)
+
+    def set_grads(self, grads):
+        """grads: state-dict name -> tensor (``ModelBackward.grads``).  Every optimised parameter must have one."""
+        missing = [n for n in self.names if n not in grads]
+        if missing:
+            raise KeyError(f'no gradient for {missing[:4]} ({len(missing)} parameters)')
+        for n in self.names:
+            self.grad_view(n).copy_(grads[n].reshape(self.offsets[n][2]))
+
+    def step(self):
+        self.step_count += 1
+        check(_lib.lib().vfn_adamw_f32(ptr(self.flat), ptr(self.grad), ptr(self.exp_avg), ptr(self.exp_avg_sq), self.n, self.lr,
+                                       self.betas[0], self.betas[1], self.eps, self.weight_decay, self.step_count, stream()),
+              'vfn_adamw_f32')
+
+    # checkpoint pieces of train_video_seg.py:186-193 ('optimizer': optimizer.state_dict())
+    def state_dict(self):
+        return {'step': self.step_count, 'lr': self.lr, 'betas': self.betas, 'eps': self.eps, 'weight_decay': self.weight_decay,
+                'exp_avg': {n: self.exp_avg[o:o + k].view(s).clone() for n, (o, k, s) in self.offsets.items()},
+                'exp_avg_sq': {n: self.exp_avg_sq[o:o + k].view(s).clone() for n, (o, k, s) in self.offsets.items()}}
+
+    def load_state_dict(self, sd):
+        self.step_count = int(sd['step'])
+        self.lr, self.betas, self.eps, self.weight_decay = float(sd['lr']), tuple(sd['betas']), float(sd['eps']), float(sd['weight_decay'])
+        for n, (o, k, s) in self.offsets.items():
+            self.exp_avg[o:o + k].view(s).copy_(sd['exp_avg'][n])
+            self.exp_avg_sq[o:o + k].view(s).copy_(sd['exp_avg_sq'][n])
+
+
+@torch.no_grad()
+def forward_backward(model, frames, masks, lu=0.5, budget=300000):
+    """The loop body of train_video_seg.py:56-74 up to and including ``loss.backward()``.
+
+    frames f32 [T,3,H,W] in [0,1], masks [T,obj_n,H,W] one-hot (the dataset's sample with the leading 1 removed, :63);
+    the model must be on the GPU and in training mode (``model.train()``, update_bank False).
+    Returns (loss, uncertainty, grads): python floats as ``loss.item()`` / ``uncertainty.item()`` give them, and
+    state-dict name -> gradient tensor for every parameter."""
+    if not model.training:
+        raise RuntimeError('forward_backward needs model.train() (the training branch of segment keeps its activations)')
+    if model.update_bank:
+        raise RuntimeError('training runs with update_bank=False (train_video_seg.py:101)')
+    T, obj_n = frames.shape[0], masks.shape[1]
+    if T < 2:
+        raise ValueError('a training sample needs a reference frame and at least one frame to segment')
+    dev = model.device
+    frames, masks = frames.to(dev), masks.to(dev)
+    bs = T - 1
+    fb = FeatureBank(obj_n, budget, dev)
+    k4_list, v4_list = model.memorize(frames[0:1], masks[0:1])
+    fb.init_bank(k4_list, v4_list)
+    label = torch.argmax(masks[1:], dim=1)
+    mb = ModelBackward(model.engine())
+    g_bk = g_bv = None
+    stats_sum = torch.zeros(3, device=dev)
+    for i in range(bs):
+        score, _ = model.segment(frames[1 + i:2 + i], fb)
+        stats, dscore = ops.segment_loss(score.contiguous(), label[i:i + 1], lu)
+        stats_sum += stats[:3]
+        if bs > 1:
+            dscore *= 1.0 / bs                                              # mean over the batch: CE over bs*H*W pixels, uncertainty.mean()
+        bk, bv = mb.segment_sample(fb, dscore[0])
+        if g_bk is None:
+            g_bk, g_bv = bk, bv
+        else:
+            g_bk = [a + b for a, b in zip(g_bk, bk)]
+            g_bv = [a + b for a, b in zip(g_bv, bv)]
+    mb.finish_memorize(frames[0:1], masks[0:1], g_bk, g_bv)
+    st = (stats_sum / bs).tolist()                                          # one D2H per step, as loss.item() is
+    return st[0], st[2], mb.grads
+
+
+@torch.no_grad()
+def train_step(model, optimizer, frames, masks, lu=0.5, budget=300000):
+    """train_video_seg.py:56-76 for one sample of the dataloader.  Returns (loss, uncertainty) as python floats."""
+    optimizer.zero_grad()
+    loss, unc, grads = forward_backward(model, frames, masks, lu, budget)
+    optimizer.set_grads(grads)
+    optimizer.step()
+    model._invalidate()              # the engine's packed filters / folded BatchNorm constants are rebuilt from the new parameters
+    return loss, unc
+
+
+class StepLR:
+    """``torch.optim.lr_scheduler.StepLR(optimizer, step_size, gamma, last_epoch)`` for ``AdamW`` above
+    (train_video_seg.py:146-147,181): lr = initial_lr * gamma ** (epoch // step_size)."""
+
+    def __init__(self, optimizer, step_size, gamma=0.1, last_epoch=-1):
+        self.opt, self.step_size, self.gamma = optimizer, int(step_size), float(gamma)
+        self.base_lr = optimizer.lr
+        self.epoch = last_epoch + 1
+        self._set()
+
+    def _set(self):
+        self.opt.lr = self.base_lr * self.gamma ** (self.epoch // self.step_size)
+
+    def get_last_lr(self):
+        return [self.opt.lr]
+
+    def step(self):
+        self.epoch += 1
+        self._set()
+
+
+def train_model(model, dataloader, optimizer, lu=0.5, budget=300000, progress=None):
+    """``train_model`` of train_video_seg.py:51-89: one pass over the dataloader; samples are
+    (frames [1,T,3,H,W], masks [1,T,obj_n,H,W], obj_n, info) as ``Water_Image_Train_DS`` yields them; single-object samples are
+    skipped (:61-62).  Returns the mean loss (``stats.avg``)."""
+    n, loss_sum = 0, 0.0
+    for sample in dataloader:
+        frames, masks, obj_n = sample[0], sample[1], sample[2]
+        obj_n = int(obj_n.item() if torch.is_tensor(obj_n) else obj_n)
+        if obj_n == 1:
+            continue
+        loss, unc = train_step(model, optimizer, frames[0], masks[0], lu, budget)
+        n += 1
+        loss_sum += loss
+        if progress is not None:
+            progress(n, loss, loss_sum / n, unc)
+    return loss_sum / max(n, 1)
