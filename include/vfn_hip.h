@@ -301,7 +301,8 @@ typedef struct vfn_memread_desc {
                            /* (a workgroup owns 128 query columns: choose nsplit for ceil(HW/128) query tiles) */
     const void* bank_k_lp; /* precision 1 / 2: the split-bf16 images of keys and values kept by         */
     const void* bank_v_lp; /* vfn_bank_refresh_lp (both or neither; same results as the on-the-fly split, without
-                              the conversion work in the kernel): values [obj][cap][128 groups][4 hi | 4 lo] bf16 */
+                              the conversion work in the kernel): values [obj][cap / 8 blocks][hi | lo plane][512
+                              channels][8 rows] bf16 -- 16 bytes = one lane's B operand of a P^T V MFMA (cap % 8 == 0) */
     const float* scores;   /* precision 0, optional: the scores the mode-0 vfn_bank_scan of this frame stored
                               (vfn_bankscan_desc.scores, same layout and stride).  The kernel then runs no score GEMM and
                               touches neither q nor bank_k: bit-identical results (the scan forms the same sums). */
@@ -358,8 +359,9 @@ typedef struct vfn_bank_desc {
 } vfn_bank_desc;
 
 /* Split-bf16 image of the bank for the reduced-precision contractions (precision 1 / 2): per entry the keys as
- * [128 hi | 128 lo] bf16 and the values as 128 groups of [4 hi | 4 lo] bf16 (hi = RNE bf16 of x, lo = RNE bf16 of
- * x - hi): the same bytes per entry as the f32 rows, object strides stride_k / stride_v * 4 bytes.
+ * [128 hi | 128 lo] bf16; the values in blocks of 8 entries as [hi plane | lo plane][512 channels][8 entries] bf16 (16 KB per
+ * block; 16 bytes = 8 consecutive entries of one channel = one lane's B operand of a P^T V MFMA) (hi = RNE bf16 of x, lo = RNE
+ * bf16 of x - hi): the same bytes per entry as the f32 rows, object strides stride_k / stride_v * 4 bytes, cap % 8 == 0.
  * all_rows = 0: after vfn_bank_merge + vfn_bank_append of the same descriptor, re-split only the entries that update
  * changed (merged or appended; every entry when it compacted the bank).  all_rows = 1: every live entry. */
 int vfn_bank_refresh_lp(const vfn_bank_desc* d, void* bank_k_lp, void* bank_v_lp, int all_rows, void* stream);

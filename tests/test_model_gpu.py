@@ -520,24 +520,25 @@ def test_carried_split_image_equals_full_rebuild(gpu, precision):
         fb = banks[0]
         cap = fb._cap
         klp = fb._klp[:2 * cap * 256].view(2, cap, 256).clone()
-        vlp = fb._vlp[:2 * cap * 1024].view(2, cap, 128, 8).clone()
+        # values: blocks of 8 rows, [block][hi | lo plane][channel][8 rows] (bank.hip) -> [obj][row][plane][channel]
+        rows_of = lambda img: img[:2 * cap * 1024].view(2, cap // 8, 2, 512, 8).permute(0, 1, 4, 2, 3).reshape(2, cap, 2, 512)
+        vlp = rows_of(fb._vlp).clone()
         fb._lp_valid = False
         fb.lp_image()                                                          # full rebuild
         for i in range(2):
             assert torch.equal(banks[0]._kbuf[i, :n[i]], banks[1]._kbuf[i, :n[i]]), (t, i)
             assert torch.equal(banks[0]._vbuf[i, :n[i]], banks[1]._vbuf[i, :n[i]]), (t, i)
             assert torch.equal(klp[i, :n[i]], fb._klp[:2 * cap * 256].view(2, cap, 256)[i, :n[i]]), (t, i)
-            assert torch.equal(vlp[i, :n[i]], fb._vlp[:2 * cap * 1024].view(2, cap, 128, 8)[i, :n[i]]), (t, i)
+            assert torch.equal(vlp[i, :n[i]], rows_of(fb._vlp)[i, :n[i]]), (t, i)
+            xv = fb._vbuf[i, :n[i]]
+            hv = xv.to(torch.bfloat16)
+            assert torch.equal(vlp[i, :n[i], 0].view(torch.bfloat16), hv)
+            assert torch.equal(vlp[i, :n[i], 1].view(torch.bfloat16), (xv - hv.float()).to(torch.bfloat16))
             x = fb._kbuf[i, :n[i]]
             hi = x.to(torch.bfloat16)
             lo = (x - hi.float()).to(torch.bfloat16)
             assert torch.equal(klp[i, :n[i], :128].view(torch.bfloat16), hi)
             assert torch.equal(klp[i, :n[i], 128:].view(torch.bfloat16), lo)
-            x = fb._vbuf[i, :n[i]].view(-1, 128, 4)
-            hi = x.to(torch.bfloat16)
-            lo = (x - hi.float()).to(torch.bfloat16)
-            assert torch.equal(vlp[i, :n[i], :, :4].view(torch.bfloat16), hi)
-            assert torch.equal(vlp[i, :n[i], :, 4:].view(torch.bfloat16), lo)
     assert banks[0].replace_n.sum() > 0
 
 

@@ -364,9 +364,13 @@ __global__ void bank_refresh_norms_kernel(const vfn_bank_desc p, float* __restri
 // bf16 hi + lo in the consuming kernel costs as many vector-ALU cycles as its MFMAs.  The split is kept beside the
 // bank instead and re-done only for the entries an update changed (same row walk as bank_refresh_norms_kernel).
 // keys:   [row][128 hi | 128 lo] bf16           -- a chunk lands in LDS as the MFMA operand image
-// values: [row][group g of 4 channels][4 hi | 4 lo] bf16 -- one 16-byte load per lane and bank row in P^T V
+// values: blocks of 8 bank rows, [block][hi plane | lo plane][channel 0..511][8 rows] bf16 (a block = 16 KB = its 8 f32 rows'
+// bytes): 16 bytes = one channel's 8 consecutive bank rows = one lane's B operand of v_mfma_f32_32x32x16_bf16 in P^T V
+// (k = bank rows), 32 lanes = 32 consecutive channels = 512 contiguous bytes.  The apply kernels load their operands straight
+// from the image: no transposition in registers, no second register set.
 typedef __bf16 bf16x4_t __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
 __global__ void bank_refresh_lp_kernel(const vfn_bank_desc p, char* __restrict__ klp, char* __restrict__ vlp, int all_rows) {
     const int obj = blockIdx.y;
     bool all = all_rows != 0;
@@ -378,7 +382,6 @@ __global__ void bank_refresh_lp_kernel(const vfn_bank_desc p, char* __restrict__
         newlen = p.stats[obj * 4];
         base = plan[2];
     }
-    const int items = all ? newlen : p.HW;
     const int* idx = p.match_idx + (size_t)obj * p.HW;
     const float* corr = p.match_corr + (size_t)obj * p.HW;
     const int* pos = p.app_pos + (size_t)obj * p.HW;
@@ -387,28 +390,49 @@ __global__ void bank_refresh_lp_kernel(const vfn_bank_desc p, char* __restrict__
     char* KL = klp + (size_t)obj * p.stride_k * 4;
     char* VL = vlp + (size_t)obj * p.stride_v * 4;
     const int lane = threadIdx.x & 63, wpb = blockDim.x >> 6;
-    for (int it = blockIdx.x * wpb + (threadIdx.x >> 6); it < items; it += gridDim.x * wpb) {
-        int row = it;
-        if (!all) row = (corr[it] > p.thres_close) ? idx[it] : base + pos[it];
-        if (row < 0 || row >= newlen) continue;
-        {   // keys: lane l splits k = 2l, 2l+1
-            const float2 v = *reinterpret_cast<const float2*>(K + (size_t)row * DK + 2 * lane);
-            bf16x2_t h, l;
-            h[0] = (__bf16)v.x; h[1] = (__bf16)v.y;
-            l[0] = (__bf16)(v.x - (float)h[0]); l[1] = (__bf16)(v.y - (float)h[1]);
-            char* dst = KL + (size_t)row * (DK * 4);
-            *reinterpret_cast<bf16x2_t*>(dst + 4 * lane) = h;
-            *reinterpret_cast<bf16x2_t*>(dst + DK * 2 + 4 * lane) = l;
+    auto split_key_row = [&](int row) {                           // keys: lane l splits k = 2l, 2l+1
+        const float2 v = *reinterpret_cast<const float2*>(K + (size_t)row * DK + 2 * lane);
+        bf16x2_t h, l;
+        h[0] = (__bf16)v.x; h[1] = (__bf16)v.y;
+        l[0] = (__bf16)(v.x - (float)h[0]); l[1] = (__bf16)(v.y - (float)h[1]);
+        char* dst = KL + (size_t)row * (DK * 4);
+        *reinterpret_cast<bf16x2_t*>(dst + 4 * lane) = h;
+        *reinterpret_cast<bf16x2_t*>(dst + DK * 2 + 4 * lane) = l;
+    };
+    if (all) {
+        // whole blocks: a wave takes a block of 8 rows, a lane 8 channels (one at a time): 8 row reads of 256 contiguous
+        // bytes per wave, 16-byte image stores.  Rows >= newlen of the last block are written as 0.
+        const int nblk = (newlen + 7) >> 3;
+        for (int blk = blockIdx.x * wpb + (threadIdx.x >> 6); blk < nblk; blk += gridDim.x * wpb) {
+#pragma unroll
+            for (int r = 0; r < 8; ++r)
+                if (blk * 8 + r < newlen) split_key_row(blk * 8 + r);
+            char* dst = VL + (size_t)blk * (8 * DV * 4);
+            for (int c = lane; c < DV; c += 64) {
+                bf16x8_t h, l;
+#pragma unroll
+                for (int r = 0; r < 8; ++r) {
+                    const int row = blk * 8 + r;
+                    const float x = row < newlen ? V[(size_t)row * DV + c] : 0.f;
+                    h[r] = (__bf16)x;
+                    l[r] = (__bf16)(x - (float)h[r]);
+                }
+                *reinterpret_cast<bf16x8_t*>(dst + c * 16) = h;
+                *reinterpret_cast<bf16x8_t*>(dst + DV * 16 + c * 16) = l;
+            }
         }
-#pragma unroll
-        for (int g = lane; g < DV / 4; g += 64) {                 // values: channel groups g = lane, lane + 64
-            const f32x4 v = *reinterpret_cast<const f32x4*>(V + (size_t)row * DV + 4 * g);
-            bf16x4_t h, l;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) { h[e] = (__bf16)v[e]; l[e] = (__bf16)(v[e] - (float)h[e]); }
-            char* dst = VL + (size_t)row * (DV * 4) + 16 * g;
-            *reinterpret_cast<bf16x4_t*>(dst) = h;
-            *reinterpret_cast<bf16x4_t*>(dst + 8) = l;
+        return;
+    }
+    for (int it = blockIdx.x * wpb + (threadIdx.x >> 6); it < p.HW; it += gridDim.x * wpb) {
+        const int row = (corr[it] > p.thres_close) ? idx[it] : base + pos[it];
+        if (row < 0 || row >= newlen) continue;
+        split_key_row(row);
+        char* dst = VL + (size_t)(row >> 3) * (8 * DV * 4) + (row & 7) * 2;
+        for (int c = lane; c < DV; c += 64) {                     // one row of a block: 2-byte stores, 16 bytes apart
+            const float x = V[(size_t)row * DV + c];
+            const __bf16 h = (__bf16)x;
+            *reinterpret_cast<__bf16*>(dst + c * 16) = h;
+            *reinterpret_cast<__bf16*>(dst + DV * 16 + c * 16) = (__bf16)(x - (float)h);
         }
     }
 }

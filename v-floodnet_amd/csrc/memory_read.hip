@@ -483,6 +483,27 @@ __device__ __forceinline__ int softmax_hits(f32x16& acc, float scale, float qm, 
     return cnt;                                       // lane i (0..31) holds the hits of chunk-local row 32*wr + i
 }
 
+// Workgroup -> (bank slice, query tile, object) of the apply kernels.  Workgroups are dealt round-robin over the 8 XCDs, each with
+// a private L2: the query tiles of one (object, slice) pair stream the SAME value rows, so they are given to ONE XCD as a
+// contiguous run of workgroup slots (they start together and advance in step: the first reader of a chunk brings it into that
+// L2, the other tiles hit it).  With query tiles scattered over the XCDs (the linear order of rounds 1-2) every chunk was
+// fetched from beyond L2 by up to 8 XCDs -- at C5 sizes (GBs of values per object) that is the kernel's bandwidth.  Bijective
+// for any grid; affects speed only.  VFN_APPLY_XCD=0 (read once by the host) restores the linear order.
+__device__ int vfn_apply_linear_order = 0;
+__device__ __forceinline__ void apply_item(const vfn_memread_desc& p, int& split, int& qt, int& obj) {
+    const int qtiles = (int)gridDim.x / p.nsplit;
+    if (vfn_apply_linear_order) { split = blockIdx.x % p.nsplit; qt = blockIdx.x / p.nsplit; obj = blockIdx.y; return; }
+    const int total = (int)(gridDim.x * gridDim.y);
+    const int id = (int)(blockIdx.y * gridDim.x + blockIdx.x);
+    const int q = total >> 3, r = total & 7;
+    const int xcd = id & 7, slot = id >> 3;
+    const int L = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
+    const int pair = L / qtiles;
+    qt = L - pair * qtiles;
+    obj = pair / p.nsplit;
+    split = pair - obj * p.nsplit;
+}
+
 // ------------------------------------------------------------------ pass 2: P^T V and hit counts
 // (The 64-query apply kernels of rounds 1-2 are gone: the 128-query kernels below measured faster at every bank size in
 // every precision mode and were the only ones the default path had selected since.)
@@ -524,9 +545,8 @@ void memread_apply_lpw_kernel(const vfn_memread_desc p) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 31, lh = lane >> 5;
     const int wr = wave >> 2, wq = wave & 3;                  // score tile: key rows 32wr.., query columns 32wq..
-    const int split = blockIdx.x % p.nsplit;
-    const int qt = blockIdx.x / p.nsplit;
-    const int obj = blockIdx.y;
+    int split, qt, obj;
+    apply_item(p, split, qt, obj);
     const int q0 = qt * QTW;
     const int B = p.bank_len[obj];
     const float* K = p.bank_k + (size_t)obj * p.stride_k;
@@ -680,13 +700,14 @@ void memread_apply_lpw_kernel(const vfn_memread_desc p) {
 
 // ------------------------------------------------------------------ pass 2, bf16 / bf16x3, wide tile, kept split image
 // As memread_apply_lpw_kernel, for a bank that carries its split-bf16 image (vfn_bank_refresh_lp): no operand is
-// converted in the loop except P.  The key chunk lands in LDS as the hi | lo operand image; value rows are read as
-// [group of 4 channels][4 hi | 4 lo] -- one 16-byte buffer load per lane and bank row -- and transposed into the
-// K-contiguous B operand with byte permutes (32 v_perm per 16 bank rows; the split cost ~110 VALU instructions).
-// P^T V mapping: wave = (query half qh, channel quarter cq): 2 query tiles x 4 channel tiles (channel = 128cq + 4li + tc),
+// converted in the loop except P.  The key chunk lands in LDS as the hi | lo operand image; the value image is stored
+// operand-ready (bank.hip: blocks of 8 rows, [hi | lo plane][channel][8 rows]): a lane's B operand of a 16-row step is one
+// 16-byte buffer load per channel tile and plane, 32 lanes = 512 contiguous bytes -- no transposition in registers.
+// P^T V mapping: wave = (query half qh, channel quarter cq): 2 query tiles x 4 channel tiles (channel = 128cq + 32tc + li),
 // so P^T fragments are read from LDS half as often as with 4 query tiles x 2 channel tiles.
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+constexpr unsigned VBLK = 8 * DV * 4;       // bytes of one 8-row block of the value image
 
 template <bool X3>
 __global__ __launch_bounds__(512, 1)
@@ -702,13 +723,12 @@ void memread_apply_shw_kernel(const vfn_memread_desc p) {
     const int li = lane & 31, lh = lane >> 5;
     const int wr = wave >> 2, wq = wave & 3;                  // score tile: key rows 32wr.., query columns 32wq..
     const int qhalf = wave >> 2, cq = wave & 3;               // P^T V: queries 64qhalf.., channels 128cq..
-    const int split = blockIdx.x % p.nsplit;
-    const int qt = blockIdx.x / p.nsplit;
-    const int obj = blockIdx.y;
+    int split, qt, obj;
+    apply_item(p, split, qt, obj);
     const int q0 = qt * QTW;
     const int B = p.bank_len[obj];
     const float* K = reinterpret_cast<const float*>(p.bank_k_lp) + (size_t)obj * p.stride_k;     // image rows are 512 B too
-    const char* V = reinterpret_cast<const char*>(p.bank_v_lp) + (size_t)obj * p.stride_v * 4;   // rows of 2048 B
+    const char* V = reinterpret_cast<const char*>(p.bank_v_lp) + (size_t)obj * p.stride_v * 4;   // blocks of 8 rows, 16 KB
 
     {   // query image
         const int c = tid & 31;
@@ -735,7 +755,7 @@ void memread_apply_shw_kernel(const vfn_memread_desc p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) o[a][b][r] = 0.f;
 
-    const unsigned vlane_off = (unsigned)(8 * lh) * (DV * 4) + (unsigned)(cq * 32 + li) * 16u;   // bytes, per lane
+    const unsigned vlane_off = (unsigned)lh * VBLK + (unsigned)(cq * 128 + li) * 16u;   // bytes, per lane: row block lh of a step
 
     if (c_lo < c_hi) chunk_load_async8(sK, K + (size_t)c_lo * CH * DK, min(CH, B - c_lo * CH), wave, lane);
     __syncthreads();
@@ -751,25 +771,26 @@ void memread_apply_shw_kernel(const vfn_memread_desc p) {
     for (int c = c_lo; c < c_hi; ++c) {
         const int b0 = c * CH;
         const bool more = c + 1 < c_hi;
-        // buffer descriptor over this chunk's live value rows; the row goes into the per-lane offset (a constant add,
-        // folded into the instruction offset where it fits), which the hardware range check covers: rows past the bank
-        // end read 0 -- their P is exactly 0 as well -- so the last chunk needs no clamp and no branch
+        // buffer descriptor over this chunk's live row blocks: blocks past the bank end read 0 through the range check; rows
+        // past the end inside the last live block hold zeros or stale (finite) values -- their P is exactly 0
         const int live = min(CH, B - b0);
         const __amdgpu_buffer_rsrc_t vrsrc = __builtin_amdgcn_make_buffer_rsrc(
-            const_cast<char*>(V + (size_t)b0 * (DV * 4)), 0, live * DV * 4, 0x00020000);
+            const_cast<char*>(V + (size_t)(b0 >> 3) * VBLK), 0, ((live + 7) >> 3) * VBLK, 0x00020000);
 
-        u32x4 raw[8];                                // 8 bank rows x [4 hi | 4 lo] of this lane's channel group
-        auto load_raw = [&](int st) {
+        u32x4 vop[2][8];                             // two steps of operands: [tc][hi, lo]
+        auto load_v = [&](int st, u32x4 (&dst)[8]) {
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                if constexpr (X3) raw[j] = __builtin_amdgcn_raw_buffer_load_b128(vrsrc, vlane_off + (16 * st + j) * DV * 4, 0, 0);
-                else {
-                    const u32x2 h = __builtin_amdgcn_raw_buffer_load_b64(vrsrc, vlane_off + (16 * st + j) * DV * 4, 0, 0);
-                    raw[j][0] = h[0]; raw[j][1] = h[1];
-                }
+            for (int tc = 0; tc < 4; ++tc) {
+#ifdef VFN_ABLATE_V
+                dst[2 * tc] = u32x4{(unsigned)lane, (unsigned)st, 0x3f803f80u, 0x3f803f80u};
+                dst[2 * tc + 1] = u32x4{0x3f803f80u, (unsigned)tc, 0u, 0u};
+#else
+                dst[2 * tc] = __builtin_amdgcn_raw_buffer_load_b128(vrsrc, vlane_off, 2 * st * VBLK + tc * 512, 0);
+                if constexpr (X3) dst[2 * tc + 1] = __builtin_amdgcn_raw_buffer_load_b128(vrsrc, vlane_off, 2 * st * VBLK + DV * 16 + tc * 512, 0);
+#endif
             }
         };
-        load_raw(0);                                 // lands behind the score GEMM
+        load_v(0, vop[0]);                           // lands behind the score GEMM
 
         f32x16 acc;
 #pragma unroll
@@ -811,20 +832,8 @@ void memread_apply_shw_kernel(const vfn_memread_desc p) {
         // O^T[q][ch] += sum_b P^T[q][b] V[b][ch]: A = P^T (2 query tiles), B = value rows (4 channel tiles)
 #pragma unroll
         for (int st = 0; st < CH / 16; ++st) {
-            bf16x8 vh[4], vl[4];
-#pragma unroll
-            for (int tc = 0; tc < 4; ++tc) {
-                const unsigned sel = (tc & 1) ? 0x07060302u : 0x05040100u;   // high / low halves of two dwords
-                u32x4 th, tl;
-#pragma unroll
-                for (int m = 0; m < 4; ++m) {        // dword m = rows 2m, 2m+1 of channel tc
-                    th[m] = __builtin_amdgcn_perm(raw[2 * m + 1][tc >> 1], raw[2 * m][tc >> 1], sel);
-                    if constexpr (X3) tl[m] = __builtin_amdgcn_perm(raw[2 * m + 1][2 + (tc >> 1)], raw[2 * m][2 + (tc >> 1)], sel);
-                }
-                vh[tc] = __builtin_bit_cast(bf16x8, th);
-                if constexpr (X3) vl[tc] = __builtin_bit_cast(bf16x8, tl); else vl[tc] = vh[tc];
-            }
-            if (st + 1 < CH / 16) load_raw(st + 1);
+            if (st + 1 < CH / 16) load_v(st + 1, vop[(st + 1) & 1]);
+            const u32x4 (&vv)[8] = vop[st & 1];
 #pragma unroll
             for (int tq = 0; tq < 2; ++tq) {
                 const int prow = qhalf * 64 + tq * 32 + li;
@@ -832,7 +841,11 @@ void memread_apply_shw_kernel(const vfn_memread_desc p) {
                 bf16x8 pl = ph;
                 if constexpr (X3) pl = *reinterpret_cast<const bf16x8*>(sPl + swzp(prow, 2 * st + lh));
 #pragma unroll
-                for (int tc = 0; tc < 4; ++tc) mfma_lp<X3>(o[tq][tc], ph, pl, vh[tc], vl[tc]);
+                for (int tc = 0; tc < 4; ++tc) {
+                    const bf16x8 vh = __builtin_bit_cast(bf16x8, vv[2 * tc]);
+                    const bf16x8 vl = X3 ? __builtin_bit_cast(bf16x8, vv[2 * tc + 1]) : vh;
+                    mfma_lp<X3>(o[tq][tc], ph, pl, vh, vl);
+                }
             }
         }
         __syncthreads();
@@ -845,8 +858,8 @@ void memread_apply_shw_kernel(const vfn_memread_desc p) {
         for (int r = 0; r < 16; ++r) {
             const int q = q0 + qhalf * 64 + tq * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
             if (q < p.HW) {
-                const f32x4 v = {o[tq][0][r], o[tq][1][r], o[tq][2][r], o[tq][3][r]};
-                *reinterpret_cast<f32x4*>(dst + (size_t)q * DV + cq * 128 + li * 4) = v;
+#pragma unroll
+                for (int tc = 0; tc < 4; ++tc) dst[(size_t)q * DV + cq * 128 + tc * 32 + li] = o[tq][tc][r];
             }
         }
 }
@@ -873,9 +886,8 @@ void memread_apply_wide_kernel(const vfn_memread_desc p) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 31, lh = lane >> 5;
     const int wr = wave >> 2, wq = wave & 3;
-    const int split = blockIdx.x % p.nsplit;
-    const int qt = blockIdx.x / p.nsplit;
-    const int obj = blockIdx.y;
+    int split, qt, obj;
+    apply_item(p, split, qt, obj);
     const int q0 = qt * QTW;
     const int B = p.bank_len[obj];
     const float* K = p.bank_k + (size_t)obj * p.stride_k;
@@ -1024,9 +1036,8 @@ void memread_apply_ss_kernel(const vfn_memread_desc p) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 31, lh = lane >> 5;
     const int wr = wave >> 2, wq = wave & 3;
-    const int split = blockIdx.x % p.nsplit;
-    const int qt = blockIdx.x / p.nsplit;
-    const int obj = blockIdx.y;
+    int split, qt, obj;
+    apply_item(p, split, qt, obj);
     const int q0 = qt * QTW;
     const int qtiles = (p.HW + QTW - 1) / QTW;
     const int B = p.bank_len[obj];
@@ -1255,6 +1266,15 @@ extern "C" int vfn_memread_apply(const vfn_memread_desc* d, void* stream) {
     if (d->nsplit < 1 || d->ldq % 4) return VFN_ERR_ARG;
     if (d->precision < 0 || d->precision > 2) return VFN_ERR_ARG;
     if (d->scores && !scores_fit(d->stride_scores, d->stride_k, d->HW)) return VFN_ERR_ARG;
+    {
+        static bool once_x = false;
+        if (!once_x) {
+            const char* e = getenv("VFN_APPLY_XCD");
+            const int lin = (e && atoi(e) == 0) ? 1 : 0;
+            if (lin && hipMemcpyToSymbol(HIP_SYMBOL(vfn_apply_linear_order), &lin, sizeof(int)) != hipSuccess) return VFN_ERR_LAUNCH;
+            once_x = true;
+        }
+    }
     if (d->precision == 0) {
         static bool once_f = false;
         constexpr size_t LDS_WF = (size_t)(QTW * DK + CH * DK + QTW * CH) * sizeof(float);       // 128 KB
@@ -1272,11 +1292,21 @@ extern "C" int vfn_memread_apply(const vfn_memread_desc* d, void* stream) {
         const dim3 gridw(cdiv(d->HW, QTW) * d->nsplit, d->obj_n);
         // bf16x3 only: in plain bf16 the image's 8-byte hi halves sit 16 bytes apart and the kernel measured 11 % slower
         // than the f32 rows rounded in registers (9.9 vs 8.9 ms at 1.2M entries)
-        if (d->bank_k_lp && d->bank_v_lp && d->precision == 2) {
+        // the kept split image: keys land in LDS as the operand image, value operands come straight from the 8-row-blocked
+        // image (bank.hip) -- in plain bf16 only its hi plane is read (2 bytes per element instead of the f32 rows' 4)
+        static int img_bf16 = 1;
+        if (d->bank_k_lp && d->bank_v_lp && (d->precision == 2 || img_bf16)) {
             static bool once_s = false;
-            if (!once_s) { allow_lds(memread_apply_shw_kernel<true>, LDS_W2); once_s = true; }
-            hipLaunchKernelGGL(memread_apply_shw_kernel<true>, gridw, dim3(512), LDS_W2, (hipStream_t)stream, *d);
-            return vfn_check_launch();
+            if (!once_s) {
+                allow_lds(memread_apply_shw_kernel<true>, LDS_W2);
+                allow_lds(memread_apply_shw_kernel<false>, LDS_W1);
+                const char* e = getenv("VFN_APPLY_IMG_BF16");
+                if (e) img_bf16 = atoi(e);
+                once_s = true;
+            }
+            if (d->precision == 2) hipLaunchKernelGGL(memread_apply_shw_kernel<true>, gridw, dim3(512), LDS_W2, (hipStream_t)stream, *d);
+            else if (img_bf16) hipLaunchKernelGGL(memread_apply_shw_kernel<false>, gridw, dim3(512), LDS_W1, (hipStream_t)stream, *d);
+            if (d->precision == 2 || img_bf16) return vfn_check_launch();
         }
         if (d->precision == 1) hipLaunchKernelGGL(memread_apply_lpw_kernel<false>, gridw, dim3(512), LDS_W1, (hipStream_t)stream, *d);
         else hipLaunchKernelGGL(memread_apply_lpw_kernel<true>, gridw, dim3(512), LDS_W2, (hipStream_t)stream, *d);

@@ -144,7 +144,8 @@ class FeatureBank:
 
     def lp_image(self):
         """Device pointers (keys, values) of the bank's split-bf16 image for the reduced-precision kernels
-        (``vfn_bank_refresh_lp``: per entry keys [128 hi | 128 lo], values 128 x [4 hi | 4 lo] bf16 -- the bytes of the f32
+        (``vfn_bank_refresh_lp``: per entry keys [128 hi | 128 lo] bf16; values in blocks of 8 entries,
+        [hi | lo plane][512 channels][8 entries] bf16, the B operand of the P^T V MFMAs as it is loaded -- the bytes of the f32
         rows again), brought up to date first.  ``update`` re-splits only the entries it changed; anything else that
         touches the bank (``keys`` / ``values`` views, ``append``, ``remove``) makes the next call rebuild it.
         ``VFN_LP_IMAGE=0``: (None, None) -- the kernels then split their operands on the fly (same results, slower)."""
