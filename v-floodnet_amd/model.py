@@ -81,7 +81,8 @@ class AFB_URR(nn.Module):
         eval: pads to a multiple of 16, uncertainty is None (test_video_seg.py:108).  After ``model.train()``: the
         training branch -- no padding (:278) and the scalar uncertainty of :302-305 as a 0-dim tensor
         (train_video_seg.py:69,73-74) -- with BatchNorm frozen as train_video_seg.py:103-106 sets it.  There is no
-        backward pass: the HIP path is inference / forward evaluation only."""
+        autograd graph: the backward pass and the optimiser step of the training loop are ``vfloodnet_amd.train``
+        (``train_step``), which differentiates the activations this call keeps."""
         if fb_global.obj_n < 2:
             # the reference fails here as well: calc_uncertainty takes the top-2 over the object axis
             # (myutils/data.py:40-46, `score.topk(k=2, dim=1)` -> "selected index k out of range")
