@@ -207,7 +207,7 @@ def test_training_loss_and_its_gradient(gpu, bs, K, H, W):
     assert _rel(grad.cpu(), z.grad) < 1e-4
 
 
-def _hip_relu_masks(eng, K, memorize_only=False):
+def _hip_relu_masks(eng, K, memorize_only=False, query=None):
     """The ReLU activation patterns of the HIP forward (memorize, then the sample segment ran last), in the order the oracle
     calls F.relu; NCHW bool on the CPU."""
     pm = eng.last_memorize
@@ -220,7 +220,7 @@ def _hip_relu_masks(eng, K, memorize_only=False):
     mem_masks = [nchw_mask(t) for t in order]
     if memorize_only:
         return mem_masks
-    plan, qs, slot = eng.last_query
+    plan, qs, slot = query if query is not None else eng.last_query
     order = [qs.q['r1'][0:1]]
     for lname, nb in (('res2', 3), ('res3', 4), ('res4', 6)):
         for bi in range(nb):
@@ -366,9 +366,9 @@ def test_train_step_vs_reference_loop(gpu):
     pats = []
     orig = ModelBackward.segment_sample
 
-    def spy(self, fb, grad_score):
-        pats.append(_hip_relu_masks(self.eng, K)[1])
-        return orig(self, fb, grad_score)
+    def spy(self, fb, grad_score, query=None):
+        pats.append(_hip_relu_masks(self.eng, K, query=query)[1])
+        return orig(self, fb, grad_score, query)
     ModelBackward.segment_sample = spy
     try:
         loss, unc, grads = T.forward_backward(model, frames, masks, lu)

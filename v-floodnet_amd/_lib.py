@@ -189,7 +189,13 @@ def ptr(t):
     return C.c_void_p(t.data_ptr())
 
 
+_raw_stream = getattr(torch._C, '_cuda_getCurrentRawStream', None)
+
+
 def stream():
+    """hipStream_t of torch's current stream on the current device (one C call: this runs before every kernel launch)."""
+    if _raw_stream is not None:
+        return C.c_void_p(_raw_stream(torch.cuda.current_device()))
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 

@@ -490,10 +490,11 @@ class ModelBackward:
 
     # ------------------------------------------------------------------ one sample
     @torch.no_grad()
-    def segment_sample(self, fb, grad_score):
-        """Backward of the sample ``segment`` ran last (its activations are in the training plan).  grad_score = dloss/dscores
+    def segment_sample(self, fb, grad_score, query=None):
+        """Backward of the sample ``segment`` ran last (its activations are in the training plan; ``query``: the (plan, query
+        set, slot) triple of another segment call, ``engine.last_query`` right after it).  grad_score = dloss/dscores
         [obj_n,H0,W0].  Accumulates parameter gradients; returns (dL/d bank keys, dL/d bank values) for ``finish_memorize``."""
-        plan, qs, slot = self.eng.last_query
+        plan, qs, slot = query if query is not None else self.eng.last_query
         if not plan.keep_acts:
             raise RuntimeError('backward needs the training plan: call model.train() before memorize / segment')
         m = self.eng.model

@@ -11,14 +11,21 @@ from . import _lib
 from ._lib import ptr, stream, check, ConvDesc
 
 
+_cfg_tiles = None
+
+
 def conv_cfg_tiles():
-    L = _lib.lib()
-    out = []
-    for c in range(L.vfn_conv_cfg_count()):
-        bm, bn = C.c_int(), C.c_int()
-        L.vfn_conv_cfg_tile(c, C.byref(bm), C.byref(bn))
-        out.append((bm.value, bn.value))
-    return out
+    """(BM, BN) of every tile configuration of the library (a constant of the build: asked once)."""
+    global _cfg_tiles
+    if _cfg_tiles is None:
+        L = _lib.lib()
+        out = []
+        for c in range(L.vfn_conv_cfg_count()):
+            bm, bn = C.c_int(), C.c_int()
+            L.vfn_conv_cfg_tile(c, C.byref(bm), C.byref(bn))
+            out.append((bm.value, bn.value))
+        _cfg_tiles = tuple(out)
+    return _cfg_tiles
 
 
 def conv_cfg_wk(cfg):

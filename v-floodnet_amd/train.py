@@ -117,6 +117,14 @@ def forward_backward(model, frames, masks, lu=0.5, budget=300000):
     T, obj_n = frames.shape[0], masks.shape[1]
     if T < 2:
         raise ValueError('a training sample needs a reference frame and at least one frame to segment')
+    if obj_n < 2:      # as model.segment: the reference fails in calc_uncertainty's top-2 (myutils/data.py:40-46)
+        raise RuntimeError('segment needs at least two objects (background + 1): selected index k out of range')
+    with _host_single_threaded():
+        return _forward_backward(model, frames, masks, lu, budget)
+
+
+def _forward_backward(model, frames, masks, lu, budget):
+    T, obj_n = frames.shape[0], masks.shape[1]
     dev = model.device
     frames, masks = frames.to(dev), masks.to(dev)
     bs = T - 1
@@ -144,14 +152,33 @@ def forward_backward(model, frames, masks, lu=0.5, budget=300000):
     return st[0], st[2], mb.grads
 
 
+class _host_single_threaded:
+    """The step's host side is ~6 700 kernel launches and a few hundred tiny CPU tensor operations (filter packing after every
+    optimiser step).  One CPU tensor operation above torch's parallel grain wakes the whole OpenMP pool (256 threads on the GPU
+    box), whose spinning starves the launching thread: 230-390 ms per step against 116 ms with intra-op parallelism off.  Nothing
+    in the step has CPU work worth a second thread, so it runs with torch.set_num_threads(1) and restores the setting."""
+
+    def __enter__(self):
+        self.n = torch.get_num_threads()
+        if self.n != 1:
+            torch.set_num_threads(1)
+
+    def __exit__(self, *exc):
+        if self.n != 1:
+            torch.set_num_threads(self.n)
+        return False
+
+
 @torch.no_grad()
 def train_step(model, optimizer, frames, masks, lu=0.5, budget=300000):
     """train_video_seg.py:56-76 for one sample of the dataloader.  Returns (loss, uncertainty) as python floats."""
-    optimizer.zero_grad()
-    loss, unc, grads = forward_backward(model, frames, masks, lu, budget)
-    optimizer.set_grads(grads)
-    optimizer.step()
-    model._invalidate()              # the engine's packed filters / folded BatchNorm constants are rebuilt from the new parameters
+    with _host_single_threaded():
+        optimizer.zero_grad()
+        loss, unc, grads = forward_backward(model, frames, masks, lu, budget)
+        optimizer.set_grads(grads)
+        optimizer.step()
+        model._invalidate()          # the engine's packed filters / folded BatchNorm constants are rebuilt from the new parameters
+        model.engine()               # (rebuilt here, inside the single-threaded region)
     return loss, unc
 
 
