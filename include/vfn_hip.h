@@ -465,6 +465,31 @@ int vfn_png_unfilter_u8(const unsigned char* filtered, int width, int height, in
 int vfn_png_to_tensor_f32(const unsigned char* raw, int pitch, int width, int height, int color_type,
                           const unsigned char* palette, float* out, unsigned char* out_u8, void* stream);
 
+/* ------------------------------------------------------------------ first-frame bootstrap model
+ * test_video_seg.py:67-69 calls test_image_seg.test_waterseg (:133: a pickled smp.Linknet over EfficientNet-B4) when a clip has
+ * no first-frame mask.  Its 1x1 convolutions and the decoder's 4x4 transposed convolutions (stride-1 convolution of the
+ * zero-inserted input, vfn_dilate2_f32) run through vfn_conv2d_nhwc_f32 on channel-padded NHWC tensors; these are the rest
+ * (the architecture is restated in oracle/linknet_ref.py -- third-party packages, parity unpinned):
+ * vfn_ln_stem_f32       x [N][3][H][W] -> out [N][Ho][Wo][ld] = swish(BN(conv 3x3 / stride 2 (x))), 48 filters [48][3][3][3],
+ *                       pad_before rows / columns of zeros before the image (TensorFlow-style "same" padding: the rest after),
+ *                       channels 48..ld-1 = 0 (ld % 16 == 0)
+ * vfn_ln_dwconv_f32     depthwise k x k (3 / 5), stride 1 / 2: out = swish(scale * conv(act(x)) + shift), act = swish when
+ *                       swish_in; w [k*k][C] tap-major; C % 4 == 0 (padded channels: zero filters, scale, shift)
+ * vfn_ln_se_gate_f32    squeeze-excite gate from the per-channel pixel sums (vfn_colsum_f32): gate[c] = sigmoid(b2 + w2 .
+ *                       swish(b1 + w1 . (sum_px * inv_hw))), w1 [sq][C], w2 [C][sq]; gate[C..Cpad-1] = 0; sq <= 256
+ * vfn_ln_scale_cols_f32 out[r][k] = w[r][k] * g[k]: the gate applied to the project convolution's packed filter matrix
+ * vfn_ln_add_f32        out = a + b (n % 4 == 0): the decoder's skip connections (added AFTER the block's last ReLU)
+ * vfn_ln_head_f32       out[m] = sigmoid(bias + sum_c x[m][c] w[c]) (prob = 1) or the logit (prob = 0) */
+int vfn_ln_stem_f32(const float* x, const float* w, const float* scale, const float* shift, float* out, int N, int H, int W, int Ho,
+                    int Wo, int ld, int pad_before, void* stream);
+int vfn_ln_dwconv_f32(const float* x, const float* w, const float* scale, const float* shift, float* out, int N, int H, int W, int C,
+                      int ld_x, int ld_out, int k, int stride, int pad_before, int Ho, int Wo, int swish_in, void* stream);
+int vfn_ln_se_gate_f32(const float* sum_px, float inv_hw, const float* w1, const float* b1, const float* w2, const float* b2,
+                       float* gate, int C, int sq, int Cpad, void* stream);
+int vfn_ln_scale_cols_f32(const float* w, const float* g, float* out, int rows, int K, void* stream);
+int vfn_ln_add_f32(const float* a, const float* b, float* out, long long n, void* stream);
+int vfn_ln_head_f32(const float* x, const float* w, float bias, float* out, long long M, int C, int ld, int prob, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,149 @@
+"""First-frame bootstrap model: ``smp.Linknet`` over EfficientNet-B4 (test_image_seg.py:133,
+test_video_seg.py:67-69).  PARITY UNPINNED: segmentation_models_pytorch / efficientnet-pytorch and the trained weights are
+not available, the reference has no golden output; the oracle (oracle/linknet_ref.py) restates the packages' published
+architecture and the HIP path (vfloodnet_amd.linknet) is compared with it on synthetic weights.
+
+CPU part: what CAN be pinned without the packages -- the parameter census of the published architecture, the state-dict
+naming contract between oracle and product, the transposed-convolution identity the product relies on."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+
+def test_architecture_census():
+    """EfficientNet-B4 has 19 341 616 parameters, 1 793 000 of them in the classifier smp drops (1792 x 1000 + 1000): the encoder
+    as restated must hold the remaining 17 548 616; 32 blocks; smp's feature channels (3, 48, 32, 56, 160, 448)."""
+    from oracle import linknet_ref as R
+    t = R.template()
+    n_enc = sum(int(torch.tensor(s).prod()) if len(s) else 1 for k, s in t.items()
+                if k.startswith('encoder.') and not k.endswith(('running_mean', 'running_var', 'num_batches_tracked')))
+    assert n_enc == 19341616 - (1792 * 1000 + 1000)
+    assert len(R.blocks()) == 32 and R.ENC_CHANNELS == (3, 48, 32, 56, 160, 448)
+    # static "same" padding of efficientnet-pytorch 0.6.3 (native 380-pixel input at every layer)
+    assert [R.same_pad(k, s) for k, s in ((3, 1), (5, 1), (3, 2), (5, 2))] == [(1, 1), (2, 2), (0, 1), (1, 2)]
+
+
+def test_product_container_has_the_oracles_state_dict_names():
+    from oracle import linknet_ref as R
+    from vfloodnet_amd.linknet import LinknetB4
+    sd = LinknetB4().state_dict()
+    t = R.template()
+    assert set(sd) == set(t)
+    for k, shp in t.items():
+        assert tuple(sd[k].shape) == tuple(shp), k
+
+
+def test_oracle_forward_shapes_and_determinism():
+    from oracle import linknet_ref as R
+    from tools import synth_linknet as S
+    sd = S.make_state_dict(H=96, W=128)
+    x = S.frame(5, 64, 96)
+    with torch.no_grad():
+        feats = R.encoder(sd, x)
+        y = R.forward(sd, x)
+    assert [tuple(f.shape[1:]) for f in feats] == [(3, 64, 96), (48, 32, 48), (32, 16, 24), (56, 8, 12), (160, 4, 6), (448, 2, 3)]
+    assert y.shape == (1, 1, 64, 96) and float(y.min()) >= 0 and float(y.max()) <= 1
+    sd2 = S.make_state_dict(H=96, W=128)
+    assert all(torch.equal(sd[k], sd2[k]) for k in sd)
+    with pytest.raises(RuntimeError):
+        R.forward(sd, torch.zeros(1, 3, 60, 96))
+
+
+def test_transposed_conv_as_conv_of_zero_inserted_input():
+    """ConvTranspose2d(k=4, s=2, p=1)(x) == conv2d(zero-inserted x, flipped / transposed filters, padding (2 before, 1 after)):
+    the form the product runs through its implicit-GEMM kernel."""
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(1, 6, 5, 7, generator=g, dtype=torch.float64)
+    wt = torch.randn(6, 4, 4, 4, generator=g, dtype=torch.float64)
+    ref = F.conv_transpose2d(x, wt, stride=2, padding=1)
+    z = torch.zeros(1, 6, 10, 14, dtype=torch.float64)
+    z[:, :, ::2, ::2] = x
+    wc = wt.flip(2, 3).transpose(0, 1)
+    got = F.conv2d(F.pad(z, (2, 1, 2, 1)), wc)
+    assert got.shape == ref.shape and (got - ref).abs().max() < 1e-12
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('H,W', [(416, 416), (96, 160)])
+def test_linknet_hip_vs_oracle(gpu, H, W):
+    """predict() on the HIP path against the torch restatement, synthetic weights: every encoder feature smp would hand the
+    decoder (through the product's logits) -- logits within 2e-3 absolute of the float64 oracle, probabilities within 5e-4, labels
+    equal away from |logit| < 5e-3."""
+    from oracle import linknet_ref as R
+    from tools import synth_linknet as S
+    from vfloodnet_amd.linknet import LinknetB4
+    sd = S.make_state_dict()
+    x = S.frame(3, H, W)
+    with torch.no_grad():
+        z_ref = R.logits({k: (v.double() if v.is_floating_point() else v) for k, v in sd.items()}, x.double())
+        p_ref = torch.sigmoid(z_ref)
+    model = LinknetB4.from_checkpoint(sd, gpu)
+    z = model.predict(x.to(gpu), logits=True).cpu().double()
+    p = model.predict(x.to(gpu)).cpu().double()
+    assert z.shape == z_ref.shape == (1, 1, H, W)
+    err = (z - z_ref).abs().max().item()
+    print(f'linknet {H}x{W}: max |dlogit| {err:.2e} (logit std {z_ref.std().item():.2f}), max |dprob| {(p - p_ref).abs().max().item():.2e}')
+    assert err < 2e-3 and (p - p_ref).abs().max() < 5e-4
+    sure = z_ref.abs() > 5e-3
+    assert torch.equal((p > 0.5)[sure], (p_ref > 0.5)[sure])
+    with pytest.raises(RuntimeError):
+        model.predict(torch.zeros(1, 3, 100, 96, device=gpu))
+
+
+@pytest.mark.gpu
+def test_bootstrap_through_test_waterseg(gpu, tmp_path):
+    """test_image_seg.test_waterseg with the HIP model behind ``.predict``: a first-frame mask + overlay appear where
+    test_video_seg.py:64-69 looks for them, and the mask equals the plumbing run on the oracle's probabilities."""
+    import numpy as np
+    from PIL import Image
+    from oracle import linknet_ref as R
+    from tools import synth, synth_linknet as S
+    from vfloodnet_amd import image_seg
+    from vfloodnet_amd.linknet import LinknetB4
+    sd = S.make_state_dict()
+    f0, _ = synth.frame0(9, 240, 432)
+    img = Image.fromarray((f0.permute(1, 2, 0).numpy() * 255).astype(np.uint8))
+    path = tmp_path / '00000.jpg'
+    img.save(path, quality=95)
+    ck = tmp_path / 'link.pth'
+    torch.save(sd, ck)
+    image_seg.test_waterseg(str(ck), str(path), 'clip', str(tmp_path / 'segs'), gpu)
+    mask = np.array(Image.open(tmp_path / 'segs' / 'clip' / 'mask' / '00000.png'))
+    assert mask.shape == (240, 432) and set(np.unique(mask)) <= {0, 1}
+    assert (tmp_path / 'segs' / 'clip' / 'overlay' / '00000.png').exists()
+
+    class Ref:
+        def predict(self, x):
+            with torch.no_grad():
+                return R.forward(sd, x.cpu().float())
+    want = np.array(image_seg.predict_pil(Ref(), image_seg.load_image_in_PIL(str(path)), (416, 416), torch.device('cpu')))
+    assert (mask != want).mean() < 2e-3
+
+
+@pytest.mark.gpu
+def test_video_seg_main_bootstraps_a_clip_without_first_mask(gpu, tmp_path, monkeypatch):
+    """test_video_seg.py:64-69: no ``output/segs/<name>/mask/<first frame>.png`` -> the image model writes it, then the clip runs.
+    ``./records/link_efficientb4_model.pth`` relative to the working directory, as in the reference."""
+    import argparse
+    import numpy as np
+    from PIL import Image
+    from vfloodnet_amd import video_seg
+    from tools import synth, synth_linknet as S
+    from golden_util import state_dict
+    T, H, W = 3, 120, 200
+    frames, _ = synth.clip(4, T, H, W)
+    fdir = tmp_path / 'frames'
+    fdir.mkdir()
+    for i in range(T):
+        Image.fromarray((frames[i].permute(1, 2, 0).numpy() * 255).astype(np.uint8)).save(str(fdir / f'{i:05d}.jpg'), quality=92)
+    ckpt = str(tmp_path / 'ckpt.pth')
+    torch.save({'epoch': 0, 'model': state_dict(), 'loss': 0.0, 'seed': 20200212}, ckpt)
+    (tmp_path / 'records').mkdir()
+    torch.save(S.make_state_dict(), str(tmp_path / 'records' / 'link_efficientb4_model.pth'))
+    monkeypatch.chdir(tmp_path)
+    args = argparse.Namespace(gpu=0, budget=250000, viz=True, model_path=ckpt, update_rate=0.1, merge_thres=0.95,
+                              test_path=str(fdir), test_name='noclipmask', decode='device')
+    video_seg.main(args, gpu)
+    masks = [np.array(Image.open(str(tmp_path / 'output' / 'segs' / 'noclipmask' / 'mask' / f'{i:05d}.png'))) for i in range(T)]
+    assert all(m.shape == (H, W) and set(np.unique(m)) <= {0, 1} for m in masks)
+    assert 0 < masks[0].mean() < 1                       # the bootstrap found water and background on the synthetic frame

@@ -169,6 +169,12 @@ SIGNATURES = {
     'vfn_png_unfilter_sizes': [_i, _i, _i, C.POINTER(_i), C.POINTER(_ll)],
     'vfn_png_unfilter_u8': [_p, _i, _i, _i, _p, _p, _p, _p],
     'vfn_png_to_tensor_f32': [_p, _i, _i, _i, _i, _p, _p, _p, _p],
+    'vfn_ln_stem_f32': [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p],
+    'vfn_ln_dwconv_f32': [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p],
+    'vfn_ln_se_gate_f32': [_p, _f, _p, _p, _p, _p, _p, _i, _i, _i, _p],
+    'vfn_ln_scale_cols_f32': [_p, _p, _p, _i, _i, _p],
+    'vfn_ln_add_f32': [_p, _p, _p, _ll, _p],
+    'vfn_ln_head_f32': [_p, _p, _f, _p, _ll, _i, _i, _i, _p],
 }
 # every symbol include/vfn_hip.h declares (checked by tests/test_abi.py)
 ALL_SYMBOLS = sorted(list(SIGNATURES) + [

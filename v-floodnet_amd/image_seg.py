@@ -69,7 +69,11 @@ def test_waterseg(model_path, test_path, test_name, out_path, device, model=None
     """test_image_seg.py:127-151.  ``model`` overrides ``torch.load(model_path)`` (the pickled smp module
     needs its package to unpickle; a stand-in with ``.predict`` is enough for the plumbing)."""
     if model is None:
-        model = torch.load(model_path, weights_only=False)
+        # the reference unpickles a whole smp module and calls its predict (:133); here the parameters are read by name out of
+        # whatever the file holds (the pickled module, if its package is importable, or a state dict) and predict runs on the
+        # HIP path (linknet.LinknetB4)
+        from .linknet import LinknetB4
+        model = LinknetB4.from_checkpoint(model_path, device)
     out_path = os.path.join(out_path, test_name)
     mask_out = os.path.join(out_path, 'mask')
     overlay_out = os.path.join(out_path, 'overlay')

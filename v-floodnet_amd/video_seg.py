@@ -270,9 +270,9 @@ def main(args, device):
     mask_dir = os.path.join(out_dir, args.test_name, 'mask')
     mask_path = os.path.join(mask_dir, first_name + '.png')
     if not os.path.exists(mask_path):
-        # test_video_seg.py:67-69: bootstrap the first mask with the image model (plumbing in image_seg.py;
-        # the pickled LinkNet itself is outside this path)
-        image_model_path = './records/link_efficientb4_model.pth'
+        # test_video_seg.py:67-69: bootstrap the first mask with the image model -- LinkNet over EfficientNet-B4 on the HIP
+        # path (linknet.LinknetB4 behind image_seg.test_waterseg; its parameters are read by name out of the reference's file)
+        image_model_path = getattr(args, 'image_model_path', None) or './records/link_efficientb4_model.pth'
         if not os.path.isfile(image_model_path):
             raise IOError(f'first-frame mask {mask_path} not found and no image model at {image_model_path}')
         from .image_seg import test_waterseg
