@@ -1,21 +1,24 @@
-"""Backward pass, first slice: the decoder's global branch.
+"""Backward pass of the training step: ``loss.backward()`` of ``train_video_seg.py:65-74`` on the HIP path.
 
-``train_video_seg.py:65-74`` calls ``loss.backward()`` through ``AFB_URR.segment``; this module is the first piece of that
-on the HIP path: given dL/dp for ``p = pred2(relu(RF2(r2, RF3(r3, ResMM(convFM(patch_match))))))`` (``AFB_URR.py:209-212``,
-the decoder before the local refinement), it returns dL/d(weights and biases) of ``convFM, ResMM, RF3.*, RF2.*, pred2`` and
-dL/d(``patch_match, r3, r2``) -- the gradients that flow on into the encoders and the memory read.
+``DecoderBackward``: from dL/dscores through the decoder (logit / clamp tail, both interpolations, the two softmaxes, the top-2
+uncertainty, the 7x7 local windows, local head, global branch: ``AFB_URR.py:185-240``) to every ``decoder.*`` parameter and to the
+decoder's inputs.  ``ModelBackward``: the memory read (``Matcher.forward``, bank = one frame), ``KeyValue``, both ResNet trunks
+with BatchNorm frozen (``train_video_seg.py:103-106``) and the 7x7 stems -- the gradient of EVERY parameter; ``train.py`` drives
+it (one sample after the other, the gradients that reach the bank go through ``memorize`` once).
 
 How (all f32, exact MFMA; csrc/backward_ops.hip has the details):
   * data gradients run the forward implicit-GEMM kernel over flipped, transposed filters; the ReLU in front of the forward
-    convolution and the ResBlock's skip connection are undone in its epilogue (``vfn_conv_desc.mask`` / ``res``);
+    convolution and the skip connection are undone in its epilogue (``vfn_conv_desc.mask`` / ``res`` / ``mask_after``); a stride-2
+    convolution differentiates as the stride-1 data gradient of the zero-inserted gradient (``vfn_dilate2_f32``);
   * weight gradients are GEMMs over the pixels: both operands are transposed (``vfn_transpose_taps_f32``: dY^T and the
     transposed im2col image of the layer's input) and the same kernel runs a 1x1 problem cut along K over the whole chip;
-  * bias gradients are column sums; ``Refine``'s interpolate-and-add has its adjoint kernel.
+  * bias and frozen-BatchNorm (gamma, beta) gradients are two-stage column sums; ``Refine``'s interpolate-and-add, the max-pool
+    and the window statistics have adjoint kernels.
 The forward's economies are mirrored: branches the objects share (``RF*.convFS / ResFS``, the query half of ``convFM``) are
 differentiated once on the gradient summed over the objects -- what autograd does to the reference's ``expand``.
 
-Activations come from the forward's own buffers (``FramePlan`` / ``QuerySet``): call it right after ``segment``.
-Not yet covered: the local refinement head, the softmax-of-softmax tail, the memory read and the encoders."""
+Activations come from the forward's own buffers (the training ``FramePlan`` / ``QuerySet`` keep them): call it right after
+``segment``.  Checked against float64 autograd through the oracle (tests/test_backward_gpu.py)."""
 import torch
 
 from . import _lib, ops, weights as W
