@@ -149,7 +149,18 @@ class LinknetB4(nn.Module):
     def from_checkpoint(cls, path_or_obj, device):
         """The reference's ``torch.load(model_path)`` (test_image_seg.py:133) returns the pickled smp module (its package must be
         importable to unpickle it); a saved state dict works as well.  Either way the parameters are read by name."""
-        obj = torch.load(path_or_obj, map_location='cpu', weights_only=False) if isinstance(path_or_obj, (str, bytes)) or hasattr(path_or_obj, 'read') else path_or_obj
+        obj = path_or_obj
+        if isinstance(path_or_obj, (str, bytes)) or hasattr(path_or_obj, 'read'):
+            try:                                   # a plain state dict loads without executing anything from the file
+                obj = torch.load(path_or_obj, map_location='cpu', weights_only=True)
+            except Exception:
+                if hasattr(path_or_obj, 'seek'):
+                    path_or_obj.seek(0)
+                try:                               # the reference's file: a whole pickled module (test_image_seg.py:133) -- as unsafe
+                    obj = torch.load(path_or_obj, map_location='cpu', weights_only=False)        # on untrusted files as it is there
+                except ModuleNotFoundError as e:
+                    raise RuntimeError(f'{path_or_obj}: the file is a pickled module of a package that is not installed ({e.name}); '
+                                       'install it to unpickle, or save model.state_dict() and pass that file') from e
         sd = obj.state_dict() if hasattr(obj, 'state_dict') else obj
         if isinstance(sd, dict) and 'model' in sd and 'encoder._conv_stem.weight' not in sd:
             sd = sd['model']
