@@ -67,8 +67,8 @@ def test_decoder_global_branch_backward_vs_autograd(gpu, H, W):
     assert set(grads) == want, want ^ set(grads)
 
 
-@pytest.mark.parametrize('H,W', [(96, 160), (90, 150)])
-def test_whole_decoder_backward_vs_autograd(gpu, H, W):
+@pytest.mark.parametrize('H,W,K', [(96, 160, 2), (90, 150, 2), (96, 160, 3)])
+def test_whole_decoder_backward_vs_autograd(gpu, H, W, K):
     """dL/dscore -> every ``decoder.*`` parameter and (mem, q_out, r3, r2, r1): the tail (interpolations, clamp / logit, the
     two softmaxes, top-2 uncertainty, 7x7 average / max windows), the local refinement head and the global branch, against
     float64 autograd through the oracle's ``decoder`` + the logit tail of ``segment`` (AFB_URR.py:208-239,300,309-316).
@@ -82,14 +82,16 @@ def test_whole_decoder_backward_vs_autograd(gpu, H, W):
     model = AFB_URR(gpu, update_bank=False).to(gpu).eval()
     model.load_state_dict(sd, strict=True)
     frames, m0 = synth.clip(4, 2, H, W)
-    oh = synth.onehot(m0).unsqueeze(0)
+    if K == 3:                                           # a third object: the water right of the middle column
+        m0 = m0.clone()
+        m0[:, W // 2:][m0[:, W // 2:] == 1] = 2
+    oh = synth.onehot(m0, K).unsqueeze(0)
     k, v = model.memorize(frames[0:1].to(gpu), oh.to(gpu))
-    fb = FeatureBank(2, 250000, gpu)
+    fb = FeatureBank(K, 250000, gpu)
     fb.init_bank(k, v)
     score, _ = model.segment(frames[1:2].to(gpu), fb)
     eng = model.engine()
     plan, qs, slot = eng.last_query
-    K = 2
     g = torch.Generator().manual_seed(H + W)
     G = torch.randn(K, H, W, generator=g).to(gpu)
     grads, gin = DecoderBackward(eng).run_tail(plan, G, qs, slot)
@@ -237,20 +239,47 @@ def _sd64(sd):
                 else (t.double() if t.is_floating_point() else t)) for n, t in sd.items()}
 
 
-def _oracle_sample(sd64, frame0, oh, frame_i, label_i, K, lu, masks):
+def _hip_top2(eng, scores, query=None):
+    """Which two objects the HIP forward ranked highest per pixel at the oracle's two calc_uncertainty calls (the decoder's
+    rough segmentation, AFB_URR.py:222, and the training uncertainty, :302): [1,2,h,w] index tensors, first maximum wins ties."""
+    plan = (query if query is not None else eng.last_query)[0]
+
+    def top2(v):                                       # v [K,h,w]
+        i1 = v.argmax(0)
+        v2 = v.clone()
+        v2.scatter_(0, i1.unsqueeze(0), float('-inf'))
+        return torch.stack([i1, v2.argmax(0)], 0).unsqueeze(0).cpu()
+    return [top2(plan.rough), top2(torch.softmax(torch.sigmoid(scores[0]), 0))]
+
+
+def _oracle_sample(sd64, frame0, oh, frame_i, label_i, K, lu, masks, top2=None):
     """float64 autograd through the oracle's memorize / segment / loss for one sample, its ReLUs at the HIP pattern ``masks``
-    (a list in call order).  Returns (scores, loss); gradients accumulate in sd64's leaves after ``loss.backward()``."""
+    (a list in call order) and -- ``top2``, needed from three objects on -- its two top-2 selections (calc_uncertainty,
+    myutils/data.py:40-46) those of the HIP forward: like ReLU at 0, the choice of the second-largest object is a
+    non-differentiable point (two pixels of 15 360 whose second and third object differ by < 1e-6 moved the bias gradients by
+    3e-3).  Returns (scores, loss); gradients accumulate in sd64's leaves after ``loss.backward()``."""
     import torch.nn.functional as F
     from oracle import afb_urr_ref as O
     it = iter(masks)
     flips = []
     real_relu = F.relu
+    real_unc = O.calc_uncertainty
+    it2 = iter(top2) if top2 is not None else None
+    swaps = []
+
+    def unc_at_hip_choice(score):
+        idx = next(it2)
+        top = score.gather(1, idx)
+        swaps.append(int((idx != score.detach().topk(2, dim=1).indices).any(1).sum()))
+        return torch.exp(1 - top[:, 0] / (top[:, 1] + 1e-8)).unsqueeze(1)
 
     def relu_at_hip_pattern(x, *a_, **k_):
         mk = next(it)
         flips.append(int(((x.detach() > 0) != mk).sum()))
         return x * mk.to(x.dtype)
     O.F.relu = relu_at_hip_pattern
+    if it2 is not None:
+        O.calc_uncertainty = unc_at_hip_choice
     try:
         k_ref, v_ref = O.memorize(sd64, frame0.double(), oh)
         fbr = O.FeatureBankRef(K, 250000)
@@ -258,12 +287,15 @@ def _oracle_sample(sd64, frame0, oh, frame_i, label_i, K, lu, masks):
         sc, un = O.segment(sd64, frame_i.double(), fbr, update_bank=False, training=True)
     finally:
         O.F.relu = real_relu
+        O.calc_uncertainty = real_unc
     assert next(it, None) is None and sum(flips) <= 40, (sum(flips), len(flips))
+    assert sum(swaps) <= 40, swaps                       # pixels where the float64 ranking differs from the HIP one
     loss = F.cross_entropy(sc, label_i) + lu * un
     return sc, un, loss
 
 
-def test_whole_model_backward_vs_autograd(gpu):
+@pytest.mark.parametrize('K', [2, 3])
+def test_whole_model_backward_vs_autograd(gpu, K):
     """One training sample end to end (train_video_seg.py:65-74): memorize -> bank -> segment (training branch) -> loss on the HIP
     path, then ``ModelBackward``: decoder, memory read, KeyValue, query encoder, and -- through the bank's keys / values --
     KeyValue and the memory encoder again.  EVERY trainable parameter's gradient (convolutions, frozen-BatchNorm weights and
@@ -272,13 +304,16 @@ def test_whole_model_backward_vs_autograd(gpu):
     from tools import synth
     from vfloodnet_amd import AFB_URR, FeatureBank, ops
     from vfloodnet_amd.backward import ModelBackward
-    H, W, K, lu = 96, 160, 2, 0.5
+    H, W, lu = 96, 160, 0.5
     sd = synth.make_state_dict(SEED)
     model = AFB_URR(gpu, update_bank=False).to(gpu)
     model.load_state_dict(sd, strict=True)
     model.train()
     frames, m0 = synth.clip(6, 2, H, W)
-    oh = synth.onehot(m0).unsqueeze(0)
+    if K == 3:                                           # a third object: the water right of the middle column
+        m0 = m0.clone()
+        m0[:, W // 2:][m0[:, W // 2:] == 1] = 2
+    oh = synth.onehot(m0, K).unsqueeze(0)
     k, v = model.memorize(frames[0:1].to(gpu), oh.to(gpu))
     fb = FeatureBank(K, 250000, gpu)
     fb.init_bank(k, v)
@@ -294,7 +329,8 @@ def test_whole_model_backward_vs_autograd(gpu):
     # ---- the oracle, float64, its ReLUs at the HIP pattern
     mem_masks, q_masks = _hip_relu_masks(eng, K)
     sd64 = _sd64(sd)
-    sc, un, loss = _oracle_sample(sd64, frames[0:1], oh, frames[1:2], label, K, lu, mem_masks + q_masks)
+    sc, un, loss = _oracle_sample(sd64, frames[0:1], oh, frames[1:2], label, K, lu, mem_masks + q_masks,
+                                  top2=_hip_top2(eng, scores) if K > 2 else None)
     assert (sc.detach() - scores.cpu().double()).abs().max() < 5e-3
     assert abs(loss.item() - stats[0].item()) < 1e-4 * abs(loss.item())
     loss.backward()
