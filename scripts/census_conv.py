@@ -1,6 +1,6 @@
 """Debug: where a small conv layer's microseconds go (needs the census build: make -C v-floodnet_amd/csrc census; VFN_LIB_PATH=.../libvfn_census.so).
 Per workgroup, 100 MHz timestamps at kernel entry, after the first K tile is staged, after the K loop, after the last
-store has left.  usage: census_conv.py N,H,W,Cin,Cout,k cfg [ksplit]"""
+store has left.  usage: census_conv.py N,H,W,Cin,Cout,k cfg [ksplit [mode]]"""
 import sys, os, ctypes
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch, vfloodnet_amd
@@ -8,6 +8,7 @@ from vfloodnet_amd import ops, _lib
 dev = torch.device('cuda', 0)
 N, H, W, Cin, Cout, k = (int(x) for x in sys.argv[1].split(','))
 cfg = int(sys.argv[2]); ks = int(sys.argv[3]) if len(sys.argv) > 3 else 1
+mode = int(sys.argv[4]) if len(sys.argv) > 4 else 0          # 0 f32, 1 bf16, 2 bf16x3 (packed filters, f32 activations)
 x = torch.randn(N, H, W, Cin, device=dev)
 wp = ops.pad_rows(torch.randn(Cout, k * k * Cin, device=dev) * 0.05)
 sc = torch.ones(Cout, device=dev); sh = torch.zeros(Cout, device=dev)
@@ -15,11 +16,14 @@ out = torch.empty(N, H, W, Cout, device=dev)
 d = ops.make_conv_desc(x, wp, Cout, k, k, 1, k // 2, out, sc, sh, None, True, False)
 ws = torch.empty(32 * 1024 * 1024, device=dev)
 ops.set_splitk(d, ks, ws if ks > 1 else None)
-for _ in range(5): ops.conv2d_launch(d, cfg)
+if mode:
+    w_lp = ops.pack_weights_lp(wp, mode)
+    ops.use_packed_weights(d, w_lp)
+for _ in range(5): ops.conv2d_launch(d, cfg, mode)
 torch.cuda.synchronize()
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 e0.record()
-for _ in range(20): ops.conv2d_launch(d, cfg)
+for _ in range(20): ops.conv2d_launch(d, cfg, mode)
 e1.record(); torch.cuda.synchronize()
 L = _lib.lib()
 buf = np.zeros(4096 * 8, np.uint64)
