@@ -371,10 +371,26 @@ def test_adamw_kernel_vs_torch_optim(gpu):
             for n in shapes:
                 assert (mine[n].detach().cpu() - ref[n].detach()).abs().max() <= 4e-7 * max(1.0, lr / 1e-5) * max(1.0, ref[n].abs().max().item()), (n, step)
                 st = o_ref.state[ref[n]]
-                sd_ = o.state_dict()
-                assert _rel(sd_['exp_avg'][n].cpu(), st['exp_avg']) < 1e-6 and _rel(sd_['exp_avg_sq'][n].cpu(), st['exp_avg_sq']) < 1e-6
+                sd_ = o.state_dict()['state'][list(shapes).index(n)]
+                assert _rel(sd_['exp_avg'].cpu(), st['exp_avg']) < 1e-6 and _rel(sd_['exp_avg_sq'].cpu(), st['exp_avg_sq']) < 1e-6
     with pytest.raises(KeyError):
         o.set_grads({'a.weight': torch.zeros(shapes['a.weight'], device=gpu)})
+
+    # the state dictionary is torch.optim.AdamW's: load the reference optimiser's into ours and ours into a fresh torch one,
+    # then one more step on both sides stays equal (train_video_seg.py:129,186-193)
+    o.load_state_dict(o_ref.state_dict())
+    o_new = torch.optim.AdamW(list(ref.values()), lr=1.0)
+    mine_sd = o.state_dict()
+    o_new.load_state_dict({'state': {i: {k_: (v_.cpu() if torch.is_tensor(v_) else v_) for k_, v_ in st.items()} for i, st in mine_sd['state'].items()},
+                           'param_groups': mine_sd['param_groups']})
+    assert o_new.param_groups[0]['lr'] == o_ref.param_groups[0]['lr'] and o.step_count == 3
+    grads = {n: torch.randn(*s, generator=g) for n, s in shapes.items()}
+    for n, p in ref.items():
+        p.grad = grads[n].clone()
+    o_new.step()
+    o.zero_grad(); o.set_grads({n: t.to(gpu) for n, t in grads.items()}); o.step()
+    for n in shapes:
+        assert (mine[n].detach().cpu() - ref[n].detach()).abs().max() <= 4e-7 * 300 * max(1.0, ref[n].abs().max().item()), n
 
 
 def test_train_step_vs_reference_loop(gpu):
@@ -462,4 +478,4 @@ def test_train_step_vs_reference_loop(gpu):
     sched.step()
     assert sched.get_last_lr() == [lr * 0.5] and opt.lr == lr * 0.5
     sdo = opt.state_dict()
-    assert sdo['step'] == 4 and set(sdo['exp_avg']) == set(opt.names)
+    assert int(sdo['state'][0]['step']) == 4 and len(sdo['state']) == len(opt.names) == len(sdo['param_groups'][0]['params'])

@@ -88,18 +88,43 @@ class AdamW:
                                        self.betas[0], self.betas[1], self.eps, self.weight_decay, self.step_count, stream()),
               'vfn_adamw_f32')
 
-    # checkpoint pieces of train_video_seg.py:186-193 ('optimizer': optimizer.state_dict())
+    # checkpoint pieces of train_video_seg.py:186-193 ('optimizer': optimizer.state_dict()) and :129 (optimizer.load_state_dict): the
+    # dictionary has torch.optim.AdamW's own layout -- parameters numbered in model.parameters() order -- so a checkpoint written by
+    # the reference resumes here and the other way round
     def state_dict(self):
-        return {'step': self.step_count, 'lr': self.lr, 'betas': self.betas, 'eps': self.eps, 'weight_decay': self.weight_decay,
-                'exp_avg': {n: self.exp_avg[o:o + k].view(s).clone() for n, (o, k, s) in self.offsets.items()},
-                'exp_avg_sq': {n: self.exp_avg_sq[o:o + k].view(s).clone() for n, (o, k, s) in self.offsets.items()}}
+        state = {}
+        for i, n in enumerate(self.names):
+            o, k, shp = self.offsets[n]
+            state[i] = {'step': torch.tensor(float(self.step_count)), 'exp_avg': self.exp_avg[o:o + k].view(shp).clone(),
+                        'exp_avg_sq': self.exp_avg_sq[o:o + k].view(shp).clone()}
+        group = {'lr': self.lr, 'betas': self.betas, 'eps': self.eps, 'weight_decay': self.weight_decay, 'amsgrad': False,
+                 'maximize': False, 'foreach': None, 'capturable': False, 'differentiable': False, 'fused': None,
+                 'params': list(range(len(self.names)))}
+        return {'state': state if self.step_count else {}, 'param_groups': [group]}
 
     def load_state_dict(self, sd):
-        self.step_count = int(sd['step'])
-        self.lr, self.betas, self.eps, self.weight_decay = float(sd['lr']), tuple(sd['betas']), float(sd['eps']), float(sd['weight_decay'])
-        for n, (o, k, s) in self.offsets.items():
-            self.exp_avg[o:o + k].view(s).copy_(sd['exp_avg'][n])
-            self.exp_avg_sq[o:o + k].view(s).copy_(sd['exp_avg_sq'][n])
+        groups = sd['param_groups']
+        if len(groups) != 1 or len(groups[0]['params']) != len(self.names):
+            raise ValueError(f"loaded state dict has {sum(len(g['params']) for g in groups)} parameters in {len(groups)} group(s), "
+                             f'this optimizer has {len(self.names)} in one')
+        g = groups[0]
+        if g.get('amsgrad') or g.get('maximize'):
+            raise ValueError('amsgrad / maximize are not implemented (train_video_seg.py:109 uses neither)')
+        self.lr, self.betas, self.eps, self.weight_decay = float(g['lr']), (float(g['betas'][0]), float(g['betas'][1])), float(g['eps']), float(g['weight_decay'])
+        steps = set()
+        self.exp_avg.zero_()
+        self.exp_avg_sq.zero_()
+        for i, n in enumerate(self.names):
+            st = sd['state'].get(g['params'][i])
+            if st is None:
+                continue
+            o, k, shp = self.offsets[n]
+            self.exp_avg[o:o + k].view(shp).copy_(st['exp_avg'])
+            self.exp_avg_sq[o:o + k].view(shp).copy_(st['exp_avg_sq'])
+            steps.add(int(st['step']))                      # (an int before torch 1.12, a tensor since)
+        if len(steps) > 1:
+            raise ValueError(f'parameters with different step counts {sorted(steps)}: one flat buffer steps them together')
+        self.step_count = steps.pop() if steps else 0
 
 
 @torch.no_grad()
