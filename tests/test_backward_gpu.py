@@ -467,6 +467,11 @@ def test_train_step_vs_reference_loop(gpu):
         assert (p.detach().cpu() - ref_p[n].detach()).abs().max() <= 4e-7 * max(1.0, ref_p[n].abs().max().item()), n
     print('train step: losses over three steps on one sample', [f'{x:.6f}' for x in losses])
     assert losses[2] < losses[1] < losses[0]
+    # every sum in the step runs in a fixed order: a second model taken through the same three steps ends bit-identical
+    for _ in range(2):
+        T.train_step(model2, opt2, frames, masks, lu)
+    for (n, p), (_, q) in zip(model.named_parameters(), model2.named_parameters()):
+        assert torch.equal(p, q), n
 
     # the epoch loop (train_video_seg.py:51-89) and the scheduler (:146-147): a single-object sample is skipped
     sched = T.StepLR(opt, step_size=1, gamma=0.5)
