@@ -7,7 +7,8 @@ from vfloodnet_amd import ops
 
 dev = torch.device('cuda', 0)
 MODE = int(os.environ.get('MODE', '1'))
-SHAPES = [(2, 120, 216, 256, 256, 3, 1), (1, 120, 216, 256, 256, 3, 1), (2, 60, 108, 256, 256, 3, 1),
+SHAPES = [(2, 120, 216, 64, 64, 3, 1), (2, 120, 216, 256, 64, 1, 1), (2, 120, 216, 64, 64, 1, 1), (1, 120, 216, 64, 64, 3, 1), (4, 120, 216, 64, 64, 3, 1),
+          (2, 120, 216, 256, 256, 3, 1), (1, 120, 216, 256, 256, 3, 1), (2, 60, 108, 256, 256, 3, 1),
           (1, 60, 108, 128, 128, 3, 1), (1, 30, 54, 256, 256, 3, 1), (2, 30, 54, 1024, 256, 3, 1), (1, 30, 54, 1024, 640, 3, 1),
           (1, 30, 54, 256, 1024, 1, 1), (1, 30, 54, 1024, 256, 1, 1), (1, 120, 216, 64, 256, 1, 1), (1, 120, 216, 256, 64, 1, 1),
           (2, 240, 432, 128, 32, 3, 1)]

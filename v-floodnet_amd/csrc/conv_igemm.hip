@@ -1068,6 +1068,8 @@ extern "C" int vfn_conv2d_nhwc_bf16(const vfn_conv_desc* d, int cfg, void* strea
         case 10: return launch_cfg<64, 128, 2, 4, 0, 1>(*d, s);
         case 17: return launch_cfg<128, 256, 2, 4, 0, 1>(*d, s);
         case 19: return launch_cfg<64, 256, 2, 4, 0, 1>(*d, s);
+        case 22: return launch_cfg<128, 64, 4, 2, 0, 1>(*d, s);
+        case 23: return launch_cfg<256, 64, 4, 2, 0, 1>(*d, s);
         default: if (cfg >= 26 && cfg <= 37) return launch_wk_cfg<1>(*d, cfg, s);
     }
     return VFN_ERR_ARG;
@@ -1106,6 +1108,8 @@ extern "C" int vfn_conv2d_nhwc_bf16x3(const vfn_conv_desc* d, int cfg, void* str
         case 10: return launch_cfg<64, 128, 2, 4, 0, 2>(*d, s);
         case 17: return launch_cfg<128, 256, 2, 4, 0, 2>(*d, s);
         case 19: return launch_cfg<64, 256, 2, 4, 0, 2>(*d, s);
+        case 22: return launch_cfg<128, 64, 4, 2, 0, 2>(*d, s);      // tall tiles for the 64-filter layers: fewer operand bytes per
+        case 23: return launch_cfg<256, 64, 4, 2, 0, 2>(*d, s);      // FLOP from L2 (the reduced-precision K loop is L2 -> LDS bound)
         default: if (cfg >= 26 && cfg <= 37) return launch_wk_cfg<2>(*d, cfg, s);
     }
     return VFN_ERR_ARG;

@@ -46,6 +46,9 @@ def _load_tuned():
     if os.environ.get('VFN_IGNORE_TUNED') == '1':
         return
     for path, table in zip(_TABLE_PATHS, _TABLES):
+        alt = os.environ.get('VFN_TUNED_DIR')                     # (A/B of two sets of tables: same file names in another directory)
+        if alt and os.path.isfile(os.path.join(alt, os.path.basename(path))):
+            path = os.path.join(alt, os.path.basename(path))
         if os.path.isfile(path):
             for k, v in json.load(open(path)).items():
                 table[tuple(int(x) for x in k.split(','))] = (int(v[0]), int(v[1]), int(v[2]) if len(v) > 2 else 0)
@@ -802,7 +805,7 @@ class Engine:
         check(L.vfn_memread_finish(_lib.C.byref(m), s), 'vfn_memread_finish')
 
     # ------------------------------------------------------------------ tuning
-    def autotune(self, H0, W0, obj_n, iters=3, only_missing=False):
+    def autotune(self, H0, W0, obj_n, iters=3, only_missing=False, shape_filter=None, cfg_filter=None):
         """Time every tile config for every distinct conv shape of this frame size; keep the fastest.
         ``only_missing``: leave shapes that the measured table already covers alone (a frame size the shipped
         tables were not tuned for costs a few seconds once, e.g. at the start of ``video_seg.main``)."""
@@ -816,6 +819,8 @@ class Engine:
                     d = l.args[0]
                     key = (d.M, d.Cout, d.KH * d.KW * d.Cin, int(l.args[2]))
                     if only_missing and key[:3] in _TABLES[key[3]]:
+                        continue
+                    if shape_filter is not None and not shape_filter(key[:3]):      # (re-tune a subset, e.g. after a new tile shape)
                         continue
                     seen.setdefault(key, []).append((l, l_side))
         tiles = ops.conv_cfg_tiles()
@@ -841,6 +846,8 @@ class Engine:
             best, best_t = None, None
             for c, (bm, bn) in enumerate(tiles):
                 if bf and c not in ops.BF16_CFGS:              # no LDS-DMA variants (the DMA cannot convert)
+                    continue
+                if cfg_filter is not None and not cfg_filter(key[:3], c):
                     continue
                 if d.cout_pad < ((d.Cout + bn - 1) // bn) * bn:
                     continue

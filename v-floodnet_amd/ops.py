@@ -169,7 +169,7 @@ def conv2d_launch(desc, cfg, mode=0):
     check(getattr(_lib.lib(), name)(C.byref(desc), int(cfg), stream()), name)
 
 
-BF16_CFGS = (0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 17, 19) + tuple(range(26, 38))     # (no LDS-DMA variants: the DMA cannot convert)
+BF16_CFGS = (0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 17, 19, 22, 23) + tuple(range(26, 38))     # (no LDS-DMA variants: the DMA cannot convert)
 
 
 def conv2d_nhwc(x, wp, cout, kh, kw, stride, pad, scale=None, shift=None, res=None,
