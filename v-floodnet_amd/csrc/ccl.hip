@@ -83,9 +83,15 @@ __global__ void ccl_merge_kernel(const unsigned char* __restrict__ pred, int* __
     }
 }
 
-// parent[i] = root(i); count[root] += 1, aggregated per wave (most waves sit inside one component: one atomic)
-__global__ void ccl_flatten_kernel(int* __restrict__ parent, int* __restrict__ count, int n) {
-    const int lane = threadIdx.x & 63;
+// parent[i] = root(i); count[root] += 1.  A frame's water is mostly ONE component, so nearly every count lands on the same address:
+// aggregated per wave that was one atomic per 64 pixels -- 14 400 adds to one counter at 720p, which the memory side serialises
+// (74 us of a 2.6 ms C3 frame).  Now the 16 waves of a workgroup first pool their (root, count) pairs in LDS and one wave issues
+// one atomic per DISTINCT root of the workgroup (900 adds at 720p); a wave with more than 4 distinct roots (component borders)
+// sends the rest directly.
+__global__ __launch_bounds__(1024)
+void ccl_flatten_kernel(int* __restrict__ parent, int* __restrict__ count, int n) {
+    __shared__ int s_root[16 * 4], s_cnt[16 * 4], s_n[16];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
     const int nround = (n + (int)(gridDim.x * blockDim.x) - 1) / (int)(gridDim.x * blockDim.x);
     for (int k = 0; k < nround; ++k) {
         const int i = (k * gridDim.x + blockIdx.x) * blockDim.x + threadIdx.x;
@@ -95,13 +101,33 @@ __global__ void ccl_flatten_kernel(int* __restrict__ parent, int* __restrict__ c
             parent[i] = r;                               // safe: r is a root, roots never change after the merge pass
         }
         unsigned long long todo = __ballot(r >= 0);
-        while (todo) {                                   // one atomic per distinct root in the wave
+        int slots = 0;
+        while (todo) {                                   // one entry per distinct root in the wave
             const int leader = __ffsll((long long)todo) - 1;
             const int rl = __shfl(r, leader, 64);
             const unsigned long long same = __ballot(r == rl);
-            if (lane == leader) atomicAdd(&count[rl], __popcll(same));
+            if (lane == leader) {
+                if (slots < 4) { s_root[wave * 4 + slots] = rl; s_cnt[wave * 4 + slots] = __popcll(same); }
+                else atomicAdd(&count[rl], __popcll(same));
+            }
+            ++slots;                                     // (wave-uniform)
             todo &= ~same;
         }
+        if (lane == 0) s_n[wave] = slots < 4 ? slots : 4;
+        __syncthreads();
+        if (wave == 0) {                                 // lane e = entry e of the pool; equal roots are summed by their first holder
+            const int w = lane >> 2, e = lane & 3;
+            const bool live = w < nw && e < s_n[w];
+            const int my_r = live ? s_root[lane] : -1, my_c = live ? s_cnt[lane] : 0;
+            int total = 0;
+            bool first = live;
+            for (int j = 0; j < 64; ++j) {
+                const int rj = __shfl(my_r, j, 64), cj = __shfl(my_c, j, 64);
+                if (live && rj == my_r) { total += cj; if (j < lane) first = false; }
+            }
+            if (first) atomicAdd(&count[my_r], total);
+        }
+        __syncthreads();
     }
 }
 
@@ -167,7 +193,7 @@ extern "C" int vfn_postprocess_pred_device_u8(const unsigned char* pred, unsigne
     const int rblocks = cdiv(H * segs, 4);                         // 4 waves per workgroup
     hipLaunchKernelGGL(ccl_init_kernel, dim3(rblocks), dim3(256), 0, s, pred, parent, count, H, W, segs);
     hipLaunchKernelGGL(ccl_merge_kernel, dim3(rblocks), dim3(256), 0, s, pred, parent, H, W, segs);
-    hipLaunchKernelGGL(ccl_flatten_kernel, dim3(blocks), dim3(256), 0, s, parent, count, n);
+    hipLaunchKernelGGL(ccl_flatten_kernel, dim3(cdiv(n, 1024) < 1024 ? cdiv(n, 1024) : 1024), dim3(1024), 0, s, parent, count, n);
     hipLaunchKernelGGL(ccl_pick_kernel, dim3(blocks < 128 ? blocks : 128), dim3(1024), 0, s, parent, count, result, n);
     hipLaunchKernelGGL(ccl_write_kernel, dim3(blocks), dim3(256), 0, s, pred, parent, result, out, n);
     return vfn_check_launch();
