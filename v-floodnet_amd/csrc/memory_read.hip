@@ -426,17 +426,19 @@ void bank_scan_kernel(const vfn_bankscan_desc p) {
 }
 
 // combine bank-split partials.  MODE 0 -> ml[obj][q] = (m, l); MODE 1 -> idx[obj][q], corr[obj][q]
+// Eight lanes per query column: lane j folds the slices j, j + 8, ... (a fixed order), then the eight partial results are folded
+// in lane order -- 8 + 7 steps instead of a 59-long chain on one thread (the kernel sits between the scan and the apply kernel of
+// every frame: 18-22 us -> a few).  Deterministic: the order of the folds does not depend on the schedule.
 template <int MODE>
 __global__ void bank_scan_finish_kernel(const float* __restrict__ part, int nsplit, int HW, int obj_n,
                                         float* __restrict__ ml, int* __restrict__ idx, float* __restrict__ corr,
                                         const float* __restrict__ colscale) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= obj_n * HW) return;
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    const int i = min(t >> 3, obj_n * HW - 1), j = t & 7;          // (surplus groups repeat the last column: whole waves shuffle)
+    const bool live = (t >> 3) < obj_n * HW;
     const int obj = i / HW, q = i - obj * HW;
     float m = -INFINITY, x = (MODE == 0) ? 0.f : __int_as_float(0x7fffffff);
-    for (int s = 0; s < nsplit; ++s) {
-        const float* src = part + (((size_t)obj * nsplit + s) * HW + q) * 2;
-        const float om = src[0], ox = src[1];
+    auto fold = [&](float om, float ox) {
         if (MODE == 0) {
             const float mn = fmaxf(m, om);
             if (mn > -INFINITY) x = x * expf(m - mn) + ox * expf(om - mn);
@@ -445,7 +447,18 @@ __global__ void bank_scan_finish_kernel(const float* __restrict__ part, int nspl
             const int i0 = __float_as_int(x), i1 = __float_as_int(ox);
             if (om > m || (om == m && i1 < i0)) { m = om; x = ox; }
         }
+    };
+    for (int s = j; s < nsplit; s += 8) {
+        const float* src = part + (((size_t)obj * nsplit + s) * HW + q) * 2;
+        fold(src[0], src[1]);
     }
+    const int base = (threadIdx.x & 63) & ~7;
+#pragma unroll
+    for (int o = 1; o < 8; ++o) {
+        const float om = __shfl(m, base + o, 64), ox = __shfl(x, base + o, 64);
+        if (j == 0) fold(om, ox);
+    }
+    if (j != 0 || !live) return;
     if (MODE == 0) { ml[(size_t)i * 2] = m; ml[(size_t)i * 2 + 1] = x; }
     else { idx[i] = __float_as_int(x); corr[i] = m * colscale[i]; }
 }
@@ -1251,11 +1264,11 @@ extern "C" int vfn_bank_scan_finish(const float* part, int nsplit, int HW, int o
     const int total = obj_n * HW;
     if (mode == 0) {
         if (!ml) return VFN_ERR_ARG;
-        hipLaunchKernelGGL(bank_scan_finish_kernel<0>, dim3(cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream,
+        hipLaunchKernelGGL(bank_scan_finish_kernel<0>, dim3(cdiv(total * 8, 256)), dim3(256), 0, (hipStream_t)stream,
                            part, nsplit, HW, obj_n, ml, idx, corr, colscale);
     } else {
         if (!idx || !corr || !colscale) return VFN_ERR_ARG;
-        hipLaunchKernelGGL(bank_scan_finish_kernel<1>, dim3(cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream,
+        hipLaunchKernelGGL(bank_scan_finish_kernel<1>, dim3(cdiv(total * 8, 256)), dim3(256), 0, (hipStream_t)stream,
                            part, nsplit, HW, obj_n, ml, idx, corr, colscale);
     }
     return vfn_check_launch();
