@@ -1331,7 +1331,7 @@ extern "C" int vfn_memread_finish(const vfn_memread_desc* d, void* stream) {
     if (!d || !d->o_part || !d->out || !d->bank_len) return VFN_ERR_ARG;
     if (d->cnt && !d->info) return VFN_ERR_ARG;
     if (d->ld_out % 4 || d->ldqv % 4) return VFN_ERR_ARG;
-    const dim3 grid(256, d->obj_n);
+    const dim3 grid(1024, d->obj_n);
     hipLaunchKernelGGL(memread_finish_kernel, grid, dim3(256), 0, (hipStream_t)stream, *d);
     return vfn_check_launch();
 }
