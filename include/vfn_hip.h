@@ -27,7 +27,7 @@ extern "C" {
 /* ------------------------------------------------------------------ version
  * vfn_abi_version() == VFN_ABI_VERSION of the header the binding was written against, and
  * vfn_sizeof_desc(which) == sizeof of the binding's own struct: checked when the library is loaded. */
-#define VFN_ABI_VERSION 9
+#define VFN_ABI_VERSION 10
 enum { VFN_DESC_CONV = 0, VFN_DESC_STEM = 1, VFN_DESC_BANKSCAN = 2, VFN_DESC_MEMREAD = 3, VFN_DESC_BANK = 4 };
 int vfn_abi_version(void);
 int vfn_sizeof_desc(int which);
@@ -380,6 +380,14 @@ int vfn_bank_remove(const vfn_bank_desc* d, void* stream);
 int vfn_bank_refresh_norms(const vfn_bank_desc* d, float* bank_knorm, float* bank_kinv, float* bank_vnorm, void* stream);
 int vfn_scatter_mean_f32(const float* src, long long src_s0, long long src_s1, const long long* index,
                          int S, float* out, long long out_s0, long long out_s1, int D, void* stream);
+/* The same with the argument validation torch_scatter performs (a device-side assert there) done on the device, so that the
+ * operator never synchronises the host (ABI 10): index row 0 is used; a target outside [0, B) is skipped and sets bit 0 of
+ * *status (an int in device memory, sticky, zero at rest); index_s0 != 0 declares a materialised [D][S] index with that row
+ * stride (elements), whose rows must all equal row 0 -- a differing element sets bit 1.  The caller reads *status whenever
+ * it synchronises anyway (v-floodnet_amd/scatter.py: check_status). */
+int vfn_scatter_mean_checked_f32(const float* src, long long src_s0, long long src_s1, const long long* index,
+                                 long long index_s0, int S, float* out, long long out_s0, long long out_s1, int D,
+                                 long long B, int* status, void* stream);
 
 /* ------------------------------------------------------------------ per-frame loop operators (planar NCHW)
  * vfn_resize_bicubic_f32    TF.resize(frame, 480, BICUBIC)                       test_video_seg.py:88,107

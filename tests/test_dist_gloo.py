@@ -62,3 +62,23 @@ def test_single_process_is_identity():
     from vfloodnet_amd import dist as vdist
     out = vdist.run_sharded(_fake_clip, 3, 0, 1, torch.device('cpu'))
     assert all(torch.equal(out[c], _fake_clip(c)) for c in range(3))
+
+
+def test_no_clips_reports_instead_of_crashing(tmp_path):
+    """Empty inputs: zero clips enter no collective and return empty results; an empty benchmark directory is a
+    clear error raised before any collective."""
+    import argparse
+    import vfloodnet_amd  # noqa: F401
+    from vfloodnet_amd import dist as vdist, batch_video_seg
+    out = vdist.run_sharded(_fake_clip, 0, 0, 1, torch.device('cpu'))
+    assert out.numel() == 0 and out.dtype == torch.uint8
+    assert vdist.gather_ragged([], 0, 0, 1, torch.device('cpu')) == []
+    empty = tmp_path / 'bench'
+    empty.mkdir()
+    args = argparse.Namespace(benchmark_path=str(empty), gpu=0, save_gathered=None)
+    env = {k: os.environ.pop(k) for k in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE') if k in os.environ}
+    try:
+        with pytest.raises(ValueError, match='no clip sub-folders'):
+            batch_video_seg.run(args, run_clip=lambda a, d: None, device=torch.device('cpu'), backend='gloo')
+    finally:
+        os.environ.update(env)

@@ -344,14 +344,28 @@ def test_overlay_device_on_reference_loop_output(gpu):
 
 
 def test_scatter_mean_rejects_out_of_range_index(gpu):
-    from vfloodnet_amd import scatter_mean
+    """Validation happens on the device (no host synchronisation inside the operator, as torch_scatter's device-side
+    assert): the offending element is skipped, the others are scattered, and ``scatter.check_status`` raises."""
+    from vfloodnet_amd import scatter_mean, scatter
     src = torch.ones(4, 6, device=gpu)
-    out = torch.zeros(4, 5, device=gpu)
     for bad in (5, -1):
+        out = torch.zeros(4, 5, device=gpu)
         idx = torch.tensor([0, 1, 2, bad, 3, 4], device=gpu).unsqueeze(0).expand(4, 6)
-        with pytest.raises(RuntimeError):
-            scatter_mean(src, idx, dim=1, out=out)
-    assert float(out.abs().sum()) == 0.0
+        scatter_mean(src, idx, dim=1, out=out)
+        with pytest.raises(RuntimeError, match='outside'):
+            scatter.check_status(gpu)
+        scatter.check_status(gpu)                                   # the flag is cleared by the report
+        assert torch.equal(out.cpu(), torch.ones(4, 5))             # the five valid targets got their element
+    # a materialised [D,S] index whose rows differ is reported the same way; a row-constant one is accepted
+    out = torch.zeros(4, 5, device=gpu)
+    idx = torch.tensor([0, 1, 2, 2, 3, 4], device=gpu).unsqueeze(0).repeat(4, 1)
+    scatter_mean(src, idx, dim=1, out=out)
+    scatter.check_status(gpu)
+    assert torch.equal(out.cpu(), torch.ones(4, 5))
+    idx[2, 1] = 4
+    scatter_mean(src, idx, dim=1, out=torch.zeros(4, 5, device=gpu))
+    with pytest.raises(RuntimeError, match='row-broadcast'):
+        scatter.check_status(gpu)
 
 
 @pytest.mark.parametrize('K,h,w', [(2, 240, 432), (3, 37, 53), (1, 9, 70), (4, 50, 16), (2, 24, 17)])

@@ -17,10 +17,27 @@ def test_step_lr_matches_torch():
     for epoch in range(80):
         assert s.get_last_lr()[0] == pytest.approx(ref.get_last_lr()[0], rel=1e-12), epoch
         ref_opt.step(); ref.step(); s.step()
-    # resume (train_video_seg.py:146-147: last_epoch = start_epoch - 1)
-    o2 = _Opt()
-    s2 = StepLR(o2, step_size=25, gamma=0.5, last_epoch=59)
-    assert s2.get_last_lr()[0] == pytest.approx(1e-5 * 0.5 ** 2)
+    # resume (train_video_seg.py:129,146-147: optimizer.load_state_dict restores the DECAYED rate, then
+    # StepLR(last_epoch = start_epoch - 1)): the schedule continues, it does not decay a second time
+    for saved_epoch in (30, 49, 50, 74):
+        o1, r1_p = _Opt(), torch.nn.Parameter(torch.zeros(1))
+        r1 = torch.optim.SGD([r1_p], lr=1e-5)
+        s1, rs1 = StepLR(o1, 25, 0.5), torch.optim.lr_scheduler.StepLR(r1, 25, 0.5)
+        for _ in range(saved_epoch):
+            r1.step(); rs1.step(); s1.step()
+        ref_sd = r1.state_dict()                              # what the checkpoint of epoch `saved_epoch` holds
+        assert ref_sd['param_groups'][0]['initial_lr'] == o1.initial_lr == 1e-5
+        o2 = _Opt()
+        o2.lr, o2.initial_lr = o1.lr, o1.initial_lr          # AdamW.load_state_dict
+        r2 = torch.optim.SGD([torch.nn.Parameter(torch.zeros(1))], lr=1e-5)
+        r2.load_state_dict(ref_sd)
+        s2, rs2 = StepLR(o2, 25, 0.5, last_epoch=saved_epoch), torch.optim.lr_scheduler.StepLR(r2, 25, 0.5, last_epoch=saved_epoch)
+        for epoch in range(saved_epoch + 1, 110):
+            assert s2.get_last_lr()[0] == pytest.approx(rs2.get_last_lr()[0], rel=1e-12), (saved_epoch, epoch)
+            assert s2.get_last_lr()[0] == pytest.approx(1e-5 * 0.5 ** (epoch // 25), rel=1e-12)
+            r2.step(); rs2.step(); s2.step()
+    with pytest.raises(KeyError):                             # torch refuses a resumed optimizer without 'initial_lr'
+        StepLR(_Opt(), 25, 0.5, last_epoch=10)
 
 
 def test_no_cpu_fallback_in_training():

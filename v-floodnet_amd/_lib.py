@@ -67,7 +67,7 @@ class BankDesc(C.Structure):
                 ('obj_n', C.c_int), ('cap', C.c_int), ('rm_class', C.c_int), ('rm_request', C.c_int)]
 
 
-ABI_VERSION = 9          # include/vfn_hip.h VFN_ABI_VERSION; csrc/abi.hip
+ABI_VERSION = 10         # include/vfn_hip.h VFN_ABI_VERSION; csrc/abi.hip
 DESC_IDS = {0: ConvDesc, 1: StemDesc, 2: BankScanDesc, 3: MemReadDesc, 4: BankDesc}     # vfn_sizeof_desc(which)
 
 
@@ -152,6 +152,7 @@ SIGNATURES = {
     'vfn_bank_scan_finish': [_p, _i, _i, _i, _i, _p, _p, _p, _p, _p],
     'vfn_row_norms': [_p, _ll, _i, _i, _p, _i, _i, _p, _p, _ll, _p],
     'vfn_scatter_mean_f32': [_p, _ll, _ll, _p, _i, _p, _ll, _ll, _i, _p],
+    'vfn_scatter_mean_checked_f32': [_p, _ll, _ll, _p, _ll, _i, _p, _ll, _ll, _i, _ll, _p, _p],
     'vfn_resize_bicubic_f32': [_p, _p, _i, _i, _i, _i, _i, _p],
     'vfn_resize_nearest_f32': [_p, _p, _i, _i, _i, _i, _i, _p],
     'vfn_softmax_objects_f32': [_p, _p, _i, _i, _p],

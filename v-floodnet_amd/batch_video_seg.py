@@ -77,6 +77,11 @@ def run(args, run_clip=run_clip_on_gpu, device=None, backend=None):
         torch.cuda.set_device(device)
     assert os.path.isdir(args.benchmark_path)
     clips = list_clips(args.benchmark_path)
+    if not clips:                         # every rank sees the same (empty) directory: leave before any collective
+        if world > 1:
+            import torch.distributed as dist
+            dist.destroy_process_group()
+        raise ValueError(f'no clip sub-folders in {args.benchmark_path}')
     mine = vdist.clips_of_rank(len(clips), rank, world)
     local = []
     for c in mine:

@@ -439,13 +439,27 @@ __global__ void bank_refresh_lp_kernel(const vfn_bank_desc p, char* __restrict__
 
 // ---------------------------------------------------------------- scatter_mean operator
 // out[d][t] = (out[d][t] + sum_{s: index[s]==t} src[d][s]) / max(count_t, 1), dim = 1, index row-broadcast
+// B > 0 (vfn_scatter_mean_checked_f32): the validation torch_scatter does with a device-side assert happens here, without
+// a host round trip -- a target outside [0, B) is skipped and sets bit 0 of *status; a materialised [D][S] index
+// (index_s0 != 0) whose rows differ sets bit 1.
 __global__ __launch_bounds__(256)
 void scatter_mean_kernel(const float* __restrict__ src, long long src_s0, long long src_s1,
-                         const long long* __restrict__ index, int S, float* __restrict__ out,
-                         long long out_s0, long long out_s1, int D) {
+                         const long long* __restrict__ index, long long index_s0, int S, float* __restrict__ out,
+                         long long out_s0, long long out_s1, int D, long long B, int* __restrict__ status) {
     __shared__ int s_any;
     const int s = blockIdx.x, tid = threadIdx.x;
     const long long tgt = index[s];
+    if (status) {
+        if (index_s0 != 0) {
+            int bad = 0;
+            for (int d = tid; d < D; d += 256) bad |= (index[d * index_s0 + s] != tgt);
+            if (bad) atomicOr(status, 2);
+        }
+        if (tgt < 0 || tgt >= B) {                       // (uniform over the block)
+            if (tid == 0) atomicOr(status, 1);
+            return;
+        }
+    }
     if (tid == 0) s_any = 0;
     __syncthreads();
     int found = 0;
@@ -519,7 +533,17 @@ extern "C" int vfn_scatter_mean_f32(const float* src, long long src_s0, long lon
     if (!src || !index || !out || S < 0 || D < 1) return VFN_ERR_ARG;
     if (S == 0) return VFN_OK;
     hipLaunchKernelGGL(scatter_mean_kernel, dim3(S), dim3(256), 0, (hipStream_t)stream,
-                       src, src_s0, src_s1, index, S, out, out_s0, out_s1, D);
+                       src, src_s0, src_s1, index, 0LL, S, out, out_s0, out_s1, D, 0LL, (int*)nullptr);
+    return vfn_check_launch();
+}
+
+extern "C" int vfn_scatter_mean_checked_f32(const float* src, long long src_s0, long long src_s1, const long long* index,
+                                            long long index_s0, int S, float* out, long long out_s0, long long out_s1, int D,
+                                            long long B, int* status, void* stream) {
+    if (!src || !index || !out || !status || S < 0 || D < 1 || B < 1) return VFN_ERR_ARG;
+    if (S == 0) return VFN_OK;
+    hipLaunchKernelGGL(scatter_mean_kernel, dim3(S), dim3(256), 0, (hipStream_t)stream,
+                       src, src_s0, src_s1, index, index_s0, S, out, out_s0, out_s1, D, B, status);
     return vfn_check_launch();
 }
 

@@ -22,6 +22,7 @@
 //
 // Exact f32: the MFMA is a k-ordered fmaf chain, no reduced precision anywhere.
 #include "common.h"
+#include "conv_internal.h"
 #include "../../include/vfn_hip.h"
 
 namespace {
@@ -899,10 +900,7 @@ int launch_cfg(const vfn_conv_desc& p, hipStream_t s) {
     if constexpr (DMA != 0) hipLaunchKernelGGL((conv_igemm_dma_kernel<BM, BN, WM, WN, DMA>), dim3(grid), dim3(NT), lds, s, p);
     else hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN, MODE>), dim3(grid), dim3(NT), lds, s, p);
     if (ks > 1 && p.split_from < tiles && !p.tile_counters) {
-        const int m_start = (p.split_from / n_tiles) * BM;
-        const size_t total = (size_t)(p.M - m_start) * (p.Cout / 4);
-        const int blocks = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
-        hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, s, p, m_start);
+        vfn_conv_splitk_reduce(p, (p.split_from / n_tiles) * BM, s);
     }
     return vfn_check_launch();
 }
@@ -927,19 +925,27 @@ int launch_wk(const vfn_conv_desc& p, hipStream_t s) {
 
 }  // namespace
 
-extern "C" int vfn_conv_cfg_count(void) { return 38; }
+void vfn_conv_splitk_reduce(const vfn_conv_desc& p, int m_start, hipStream_t s) {
+    const size_t total = (size_t)(p.M - m_start) * (p.Cout / 4);
+    const int blocks = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, s, p, m_start);
+}
+
+constexpr int kCfgCount = VFN_DIRECT_CFG0 + VFN_DIRECT_CFGS;
+extern "C" int vfn_conv_cfg_count(void) { return kCfgCount; }
 
 // K groups per workgroup of a tile configuration (1 = none): configurations 26.. split K inside the workgroup
 extern "C" int vfn_conv_cfg_wk(int cfg) {
     static const int wk[12] = {4, 2, 2, 4, 4, 2, 2, 2, 1, 1, 1, 1};
-    if (cfg < 0 || cfg >= 38) return 0;
+    if (cfg < 0 || cfg >= kCfgCount) return 0;
+    if (cfg >= VFN_DIRECT_CFG0) { int w = 0; vfn_conv_direct_info(cfg - VFN_DIRECT_CFG0, nullptr, nullptr, &w); return w; }
     return cfg < 26 ? 1 : wk[cfg - 26];
 }
 
 // K tiles between two workgroup barriers (1 for all but configurations 32..37, which run 2 with a 4-tile register prefetch)
 extern "C" int vfn_conv_cfg_tpb(int cfg) {
-    if (cfg < 0 || cfg >= 38) return 0;
-    return cfg < 32 ? 1 : 2;
+    if (cfg < 0 || cfg >= kCfgCount) return 0;
+    return (cfg < 32 || cfg >= VFN_DIRECT_CFG0) ? 1 : 2;
 }
 
 extern "C" int vfn_conv_cfg_info(int cfg, int* bm, int* bn, int* wm, int* wn, int* dma) {
@@ -963,6 +969,13 @@ extern "C" int vfn_conv_cfg_info(int cfg, int* bm, int* bn, int* wm, int* wn, in
                                  {32, 128, 1, 4, 0},
                                  {32, 64, 1, 2, 0}, {64, 64, 2, 2, 0}, {32, 64, 1, 2, 0}, {64, 64, 2, 2, 0}, {64, 128, 2, 4, 0},
                                  {32, 128, 1, 4, 0}};
+    if (cfg >= VFN_DIRECT_CFG0 && cfg < kCfgCount) {
+        // wave-autonomous kernels (conv_direct.hip): 4 waves; reported as wm = wn = 0, dma = 9
+        if (wm) *wm = 0;
+        if (wn) *wn = 0;
+        if (dma) *dma = 9;
+        return vfn_conv_direct_info(cfg - VFN_DIRECT_CFG0, bm, bn, nullptr);
+    }
     if (cfg < 0 || cfg >= 38) return VFN_ERR_ARG;
     if (bm) *bm = t[cfg][0];
     if (bn) *bn = t[cfg][1];
@@ -1034,7 +1047,9 @@ extern "C" int vfn_conv2d_nhwc_f32(const vfn_conv_desc* d, int cfg, void* stream
         case 23: return launch_cfg<256, 64, 4, 2>(*d, s);
         case 24: return launch_cfg<32, 64, 1, 1>(*d, s);
         case 25: return launch_cfg<64, 64, 1, 2>(*d, s);
-        default: if (cfg >= 26 && cfg <= 37) return launch_wk_cfg<0>(*d, cfg, s);
+        default:
+            if (cfg >= 26 && cfg <= 37) return launch_wk_cfg<0>(*d, cfg, s);
+            if (cfg >= VFN_DIRECT_CFG0 && cfg < kCfgCount) return vfn_conv_direct_launch(*d, cfg - VFN_DIRECT_CFG0, s);
     }
     return VFN_ERR_ARG;
 }

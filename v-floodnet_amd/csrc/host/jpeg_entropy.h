@@ -225,7 +225,11 @@ inline int jpeg_entropy_decode(const unsigned char* data, long long size, short*
         off[c] = total;
         total += (long long)bpr[c] * brows[c] * 64;
     }
-    if (total > 0x7fffffffLL) return -2;                           // (info[23] is an int; 65535 x 65535 files are not frames)
+    // A frame, not a decompression bomb: a ~200-byte forged header may declare 65535 x 16000 and have the caller allocate and
+    // clear gigabytes of coefficients before the entropy data turns out truncated.  64 Mpx is well past any video frame and
+    // in line with PIL's MAX_IMAGE_PIXELS guard (89 Mpx); larger files fall through to PIL (-2 = outside the subset).
+    if ((long long)width * height > 64LL * 1024 * 1024) return -2;
+    if (total > 0x7fffffffLL) return -2;                           // (info[23] is an int)
     info[0] = width; info[1] = height; info[2] = ncomp; info[3] = hmax; info[4] = vmax; info[5] = mcu_cols; info[6] = mcu_rows;
     for (int c = 0; c < 3; ++c) {
         const bool ok = c < ncomp;

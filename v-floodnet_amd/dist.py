@@ -157,13 +157,16 @@ def gather_masks(local_labels, n_clips, rank, world):
 
 def run_sharded(run_one_clip, n_clips, rank, world, device):
     """``run_one_clip(c) -> uint8 [T,H,W]`` (host or device) for every clip of this rank; gather all."""
+    if n_clips <= 0:                      # nothing to run: no collective is entered (every rank sees the same n_clips)
+        return torch.zeros(0, 0, 0, 0, dtype=torch.uint8, device=device)
     mine = clips_of_rank(n_clips, rank, world)
     labels = [run_one_clip(c).to(device) for c in mine]
     if labels:
         local = torch.stack(labels, 0)
     else:
         local = None
-    # ranks without a clip still take part in the collective; learn the shape from rank 0
+    # ranks without a clip still take part in the collective; learn the shape from rank 0 (clip 0 -> rank 0: with at
+    # least one clip rank 0 always has one)
     shape = torch.zeros(3, dtype=torch.int64, device=device)
     if rank == 0:
         shape = torch.tensor(local.shape[1:], dtype=torch.int64, device=device)
@@ -178,6 +181,8 @@ def gather_ragged(local_labels, n_clips, rank, world, device):
     """Clips of different length / frame size (a benchmark directory): ``local_labels`` = list of uint8 [T_c,H_c,W_c] for
     ``clips_of_rank``.  The shapes travel first (3 integers per clip), every block is padded to the largest clip and the
     masks then cross in the ONE all-gather of ``gather_masks``.  Returns the list of uint8 [T_c,H_c,W_c] in clip order."""
+    if n_clips <= 0:                      # an empty benchmark directory: nothing to gather, no collective
+        return []
     per = clips_per_rank(n_clips, world)
     # (gloo gathers host tensors only; RCCL device tensors only)
     shp = torch.zeros(per, 3, dtype=torch.int64, device=device if (world > 1 and dist.get_backend() == 'nccl') else 'cpu')

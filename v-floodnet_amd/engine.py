@@ -454,6 +454,8 @@ class QuerySet:
         self.split = {1: 0, 2: 0}                           # pre[n][:split[n]] = the first half (by estimated time)
         # bookkeeping of Engine.prefetch_*: which frames the slots hold
         self.keys = [None, None]
+        self.held = [None, None]                            # the frames behind ``keys``: a key is an allocator address, so
+                                                            # the set keeps its frames alive until they are consumed
         self.consumed = [True, True]
         self.stage = 0                                      # 0 idle, 1 first half enqueued, 2 complete
         self.n = 0
@@ -653,7 +655,7 @@ class Engine:
                 if self._side_busy is not None:             # (that set's last prefetch, if any, has finished with it)
                     torch.cuda.current_stream().wait_event(self._side_busy)
                 qs.frames[0].copy_(fr[0])
-                qs.keys, qs.consumed, qs.stage, qs.n = [None, None], [True, True], 0, 0
+                qs.keys, qs.held, qs.consumed, qs.stage, qs.n = [None, None], [None, None], [True, True], 0, 0
                 for l in qs.pre[1]:
                     l()
                 slot = 0
@@ -681,6 +683,7 @@ class Engine:
                         self.prefetch_finish(p)
                     torch.cuda.current_stream().wait_event(qs.done)
                     qs.consumed[slot] = True
+                    qs.held[slot] = None
                     return qs, slot
         return None, 0
 
@@ -731,6 +734,7 @@ class Engine:
             qs.done.record()
         self._side_busy = qs.done
         qs.keys = [self._key(fr) for fr in frames] + [None] * (2 - n)
+        qs.held = list(frames) + [None] * (2 - n)
         qs.consumed = [False] * n + [True] * (2 - n)
         qs.n = n
         qs.stage = 2 if full else 1

@@ -403,6 +403,16 @@ def row_norms(x, stride_obj, ld, dim, len_dev, rows, obj_n, nrm, inv, stride_n):
                                    int(stride_n), stream()), 'vfn_row_norms')
 
 
+def scatter_mean_checked_launch(src, index, index_s0, out, status):
+    """src [D,S] (any strides), index int64 (row 0 contiguous; ``index_s0`` = row stride of a materialised [D,S] index, 0 for
+    a broadcast / 1-D one), out [D,B] (any strides), status int32[1] on the device (sticky: bit 0 = a target outside
+    [0, B), bit 1 = index rows differ).  No host synchronisation."""
+    D, S = src.shape
+    check(_lib.lib().vfn_scatter_mean_checked_f32(ptr(src), src.stride(0), src.stride(1), ptr(index), int(index_s0), S, ptr(out),
+                                                  out.stride(0), out.stride(1), D, out.shape[1], ptr(status), stream()),
+          'vfn_scatter_mean_checked_f32')
+
+
 def scatter_mean_launch(src, index_row, out):
     """src [D,S] (any strides), index_row int64 [S] contiguous, out [D,B] (any strides)."""
     D, S = src.shape

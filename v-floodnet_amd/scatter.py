@@ -5,12 +5,42 @@
 with torch-scatter 2.0.8 semantics for ``out=``: ``out += scatter_add(src)``, ``count =
 scatter_add(ones)``, ``count.clamp_(min=1)``, ``out /= count``.  The reference always passes a
 row-broadcast index (``idx.unsqueeze(0).expand(D, -1)``), which is the only form the HIP kernel
-implements; anything else raises.  Sums run in ascending source order (deterministic, unlike the
-float-atomic CUDA kernel of torch_scatter).
+implements.  Sums run in ascending source order (deterministic, unlike the float-atomic CUDA kernel of
+torch_scatter).  The call never synchronises the host: an out-of-range index or an index that is not
+row-broadcast is detected BY THE KERNEL (the element is skipped, a sticky device flag is set) and raised by
+``check_status()`` -- torch_scatter's CUDA kernel reports them through a device-side assert, i.e. asynchronously too.
 """
 import torch
 
 from . import ops
+
+_status = {}          # device -> int32[1], sticky flags written by the kernel (zero at rest)
+
+
+def _status_word(device):
+    key = str(device)
+    if key not in _status:
+        _status[key] = torch.zeros(1, dtype=torch.int32, device=device)
+    return _status[key]
+
+
+def check_status(device=None):
+    """Raise if a ``scatter_mean`` call since the last check met an index outside ``out.shape[1]`` (that element was
+    skipped) or a materialised index whose rows differ.  The operator itself never synchronises the host: torch_scatter's
+    CUDA kernel reports the same conditions through a device-side assert, i.e. also at the next synchronisation.  Call this
+    wherever the host synchronises anyway (it reads one int: one synchronisation per call)."""
+    for key, word in _status.items():
+        if device is not None and key != str(device):
+            continue
+        flags = int(word.item())
+        if flags:
+            word.zero_()
+            what = []
+            if flags & 1:
+                what.append('an index outside [0, out.shape[1])')
+            if flags & 2:
+                what.append('an index that is not row-broadcast')
+            raise RuntimeError('scatter_mean: ' + ' and '.join(what) + ' (reported by the device; the offending elements were skipped)')
 
 
 def scatter_mean(src, index, dim=-1, out=None, dim_size=None):
@@ -22,21 +52,19 @@ def scatter_mean(src, index, dim=-1, out=None, dim_size=None):
         raise RuntimeError('scatter_mean: tensors must live on the GPU (HIP kernel, no CPU fallback)')
     if src.dtype != torch.float32 or out.dtype != torch.float32:
         raise RuntimeError('scatter_mean: float32 only')
-    if index.dim() == 2:
-        if index.shape[0] > 1 and index.stride(0) != 0:
-            # a materialised [D,S] index must still be row-constant
-            if not bool((index == index[0:1]).all()):
-                raise RuntimeError('scatter_mean: only a row-broadcast index is supported')
-        index_row = index[0]
-    else:
-        index_row = index
-    if index_row.shape[0] != src.shape[1]:
+    if index.dim() not in (1, 2) or index.shape[-1] != src.shape[1] or (index.dim() == 2 and index.shape[0] not in (1, src.shape[0])):
         raise RuntimeError('scatter_mean: index / src size mismatch')
     if src.shape[1] == 0:
         return out            # nothing selected (an all-append frame): out/1 is out
-    index_row = index_row.to(torch.int64).contiguous()
-    lo, hi = int(index_row.min()), int(index_row.max())       # (torch_scatter raises on an out-of-range index too)
-    if lo < 0 or hi >= out.shape[1]:
-        raise RuntimeError(f'scatter_mean: index range [{lo}, {hi}] outside out.shape[1] = {out.shape[1]}')
-    ops.scatter_mean_launch(src, index_row, out)
+    index = index.to(torch.int64)
+    index_s0 = 0
+    if index.dim() == 2 and index.shape[0] > 1 and index.stride(0) != 0:
+        # a materialised [D,S] index must still be row-constant: the kernel compares every row with row 0
+        if index.stride(1) != 1:
+            index = index.contiguous()
+        index_s0 = index.stride(0)
+    else:
+        index = (index[0] if index.dim() == 2 else index).contiguous()
+    # range and row-constancy are checked by the kernel (sticky device flags, read by check_status): no host round trip
+    ops.scatter_mean_checked_launch(src, index, index_s0, out, _status_word(src.device))
     return out

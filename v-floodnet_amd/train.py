@@ -62,6 +62,10 @@ class AdamW:
         self.exp_avg = torch.zeros_like(self.flat)
         self.exp_avg_sq = torch.zeros_like(self.flat)
         self.step_count = 0
+        # torch's schedulers keep the un-decayed rate in the param group ('initial_lr'); StepLR below sets it, state_dict()
+        # carries it, so that a resumed run decays from the right base and a checkpoint written here resumes in the reference
+        # (torch's StepLR(last_epoch != -1) raises KeyError without it)
+        self.initial_lr = None
 
     def zero_grad(self):
         self.grad.zero_()
@@ -100,6 +104,8 @@ class AdamW:
         group = {'lr': self.lr, 'betas': self.betas, 'eps': self.eps, 'weight_decay': self.weight_decay, 'amsgrad': False,
                  'maximize': False, 'foreach': None, 'capturable': False, 'differentiable': False, 'fused': None,
                  'params': list(range(len(self.names)))}
+        if self.initial_lr is not None:
+            group['initial_lr'] = self.initial_lr
         return {'state': state if self.step_count else {}, 'param_groups': [group]}
 
     def load_state_dict(self, sd):
@@ -111,6 +117,7 @@ class AdamW:
         if g.get('amsgrad') or g.get('maximize'):
             raise ValueError('amsgrad / maximize are not implemented (train_video_seg.py:109 uses neither)')
         self.lr, self.betas, self.eps, self.weight_decay = float(g['lr']), (float(g['betas'][0]), float(g['betas'][1])), float(g['eps']), float(g['weight_decay'])
+        self.initial_lr = float(g.get('initial_lr', g['lr']))       # (a group written without a scheduler: the loaded rate is the base)
         steps = set()
         self.exp_avg.zero_()
         self.exp_avg_sq.zero_()
@@ -209,23 +216,34 @@ def train_step(model, optimizer, frames, masks, lu=0.5, budget=300000):
 
 class StepLR:
     """``torch.optim.lr_scheduler.StepLR(optimizer, step_size, gamma, last_epoch)`` for ``AdamW`` above
-    (train_video_seg.py:146-147,181): lr = initial_lr * gamma ** (epoch // step_size)."""
+    (train_video_seg.py:146-147,181), in torch's own (chainable) form: the constructor records the optimizer's
+    ``initial_lr`` (a fresh run) or requires it (``last_epoch != -1``: a resumed optimizer, whose ``lr`` is the already
+    decayed rate ``load_state_dict`` restored) and takes one step; a step multiplies the CURRENT rate by gamma whenever the new
+    epoch is a positive multiple of step_size.  So ``optimizer.load_state_dict(ckpt['optimizer'])`` followed by
+    ``StepLR(..., last_epoch=start_epoch - 1)`` (train_video_seg.py:129,146) continues the schedule instead of decaying twice."""
 
     def __init__(self, optimizer, step_size, gamma=0.1, last_epoch=-1):
         self.opt, self.step_size, self.gamma = optimizer, int(step_size), float(gamma)
-        self.base_lr = optimizer.lr
-        self.epoch = last_epoch + 1
-        self._set()
+        if last_epoch == -1:
+            if getattr(optimizer, 'initial_lr', None) is None:
+                optimizer.initial_lr = optimizer.lr
+        elif getattr(optimizer, 'initial_lr', None) is None:
+            raise KeyError("param 'initial_lr' is not specified in param_groups[0] when resuming an optimizer")
+        self.base_lr = optimizer.initial_lr
+        self.last_epoch = last_epoch
+        self.step()
 
-    def _set(self):
-        self.opt.lr = self.base_lr * self.gamma ** (self.epoch // self.step_size)
+    @property
+    def epoch(self):
+        return self.last_epoch
 
     def get_last_lr(self):
         return [self.opt.lr]
 
     def step(self):
-        self.epoch += 1
-        self._set()
+        self.last_epoch += 1
+        if self.last_epoch != 0 and self.last_epoch % self.step_size == 0:
+            self.opt.lr = self.opt.lr * self.gamma
 
 
 def train_model(model, dataloader, optimizer, lu=0.5, budget=300000, progress=None):

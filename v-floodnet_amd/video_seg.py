@@ -84,7 +84,7 @@ class ClipRunner:
         self.t = 0
         self._pinned = None
         self._stats_pinned = None
-        self._net_cache = {}                 # source frame (data_ptr, version) -> its network-resolution tensor
+        self._net_cache = {}                 # source frame (data_ptr, version, shape) -> (the source frame, its network-resolution tensor)
         self.lookahead = int(os.environ.get('VFN_LOOKAHEAD', 3))    # frames of look-ahead the query side may use (0..3)
 
     def _net_frame(self, frame):
@@ -123,14 +123,18 @@ class ClipRunner:
         self._pending = []
 
     def _net_cached(self, frame):
+        """The network-resolution tensor of ``frame``, resized once however often the look-ahead sees it.  The key is an
+        allocator address, so an entry OWNS its source tensor: while the key is live the block cannot be handed out again
+        for a later frame (video_seg.main decodes every frame into a fresh ``torch.empty`` with ``_version`` 0; without
+        the reference a block recycled 6-7 frames later hit the stale entry of an older frame)."""
         key = (frame.data_ptr(), frame._version, tuple(frame.shape))
-        f = self._net_cache.get(key)
-        if f is None:
-            f = self._net_frame(frame)
+        hit = self._net_cache.get(key)
+        if hit is None:
+            hit = (frame, self._net_frame(frame))
             if len(self._net_cache) >= 8:
                 self._net_cache.pop(next(iter(self._net_cache)))
-            self._net_cache[key] = f
-        return f
+            self._net_cache[key] = hit
+        return hit[1]
 
     def _look_ahead(self, nxt):
         """The query side of the coming frames (``nxt``: network-resolution tensors of frames t+1, t+2, ...), which depends
