@@ -47,7 +47,7 @@ PEAKS = {'fp32': PEAK_F32_MATRIX_TFLOPS, 'bf16': PEAK_BF16_MATRIX_TFLOPS, 'bf16x
 DTYPES = {'fp32': 'f32', 'bf16': 'bf16 operands, f32 accumulate/storage', 'bf16x3': 'bf16x3 (split-bf16 operands, 3 MFMAs per product), f32 accumulate/storage'}
 WORKLOADS = {'C2': (480, 854, 1), 'C3': (720, 1280, 5), 'C5': (1080, 1920, 1)}      # H0, W0, memorize every n-th frame
 CLIP_FRAMES = 100                     # BASELINE.json configs[1]: "100-frame 480p synthetic clip"
-PROFILE_ROUND = 'r03'
+PROFILE_ROUND = 'r04'
 
 
 def miou(a, b):
@@ -371,8 +371,13 @@ def main(argv=None):
     run_iters(1, s_first - 1, False)                                       # untimed pre-roll
     t0 = bracket()
     run_iters(s_first, s_first + K - 1, True)                              # ---- exactly K timed steps
+    gather_s = 0.0
+    torch.cuda.synchronize()
+    g0 = time.perf_counter()                                               # (this rank's K frames are done: compute time = g0 - t0)
     if world > 1:
         vdist.gather_masks(labels[s_first:s_first + K].unsqueeze(0), world, rank, world)   # one RCCL all-gather
+        torch.cuda.synchronize()
+        gather_s = time.perf_counter() - g0
     t1 = bracket()
     run_iters(s_first + K, last_iter, False)                               # rest of the clip, untimed
     if world > 1:
@@ -403,6 +408,20 @@ def main(argv=None):
         return float(v.item())
     elapsed = max_over_ranks(t1 - t0)
     clip_elapsed = max_over_ranks(clip1 - clip0)
+
+    def all_ranks(vals):
+        """[world][len(vals)] on every rank: one small all-gather (outside every timed region)."""
+        on_dev = (world == 1 or dist.get_backend() == 'nccl')
+        v = torch.tensor(vals, dtype=torch.float64, device=dev if on_dev else 'cpu')
+        if world == 1:
+            return [v.tolist()]
+        parts = [torch.empty_like(v) for _ in range(world)]
+        dist.all_gather(parts, v)
+        return [p_.tolist() for p_ in parts]
+    per_rank = all_ranks([g0 - t0, gather_s, float(torch.cuda.max_memory_allocated(dev))])
+    dist_info = {'backend': (dist.get_backend() if world > 1 else None),
+                 'world_size': (dist.get_world_size() if world > 1 else 1),
+                 'device_of_rank0': torch.cuda.get_device_name(dev)}
 
     if rank != 0:
         if world > 1:
@@ -548,6 +567,42 @@ def main(argv=None):
            'full_clip_frame_mfma_frac_Fmin': round((full_clip_fps / world) * f_min_clip / (peak * 1e12), 4) if mem_every == 1 else None,
            'frame_ms': frame_stats, 'sustained': sustained,
            'roofline': roof, 'memory_read': memread, 'cpu_baseline': cpu, 'parity': parity}
+    # ---- what a multi-GPU record needs to show that N ranks met over RCCL, and where the time went
+    rates = [K / r_[0] for r_ in per_rank]
+    out['distributed'] = dict(dist_info, **{
+        'collective': 'one all_gather_into_tensor of the uint8 label blocks [K, H0, W0] per rank inside the timed bracket' if world > 1 else None,
+        'all_gather_ms_max': round(1e3 * max(r_[1] for r_ in per_rank), 3) if world > 1 else None,
+        'all_gather_ms_per_rank': [round(1e3 * r_[1], 3) for r_ in per_rank] if world > 1 else None,
+        'all_gather_bytes_per_rank': int(K * H0 * W0) if world > 1 else None,
+        'frames_per_s_per_rank': [round(x, 3) for x in rates],
+        'frames_per_s_per_rank_min': round(min(rates), 3), 'frames_per_s_per_rank_max': round(max(rates), 3),
+        'per_rank_note': 'K timed frames / (time until this rank\'s last frame has left the GPU); `value` = world * K / (max over ranks of the '
+                         'whole bracket incl. the all-gather and both barriers)'})
+    # ---- memory: peak HBM of the run ("peak HBM bytes")
+    fb_ = runner.fb
+    bank_bytes = 0
+    for nm_ in ('_kbuf', '_vbuf', '_ibuf'):
+        t_ = getattr(fb_, nm_, None)
+        if t_ is not None:
+            bank_bytes += t_.numel() * t_.element_size()
+    out['hbm'] = {'peak_bytes_allocated': int(max(r_[2] for r_ in per_rank)), 'peak_bytes_reserved': int(torch.cuda.max_memory_reserved(dev)),
+                  'resident_frames_bytes': int(frames.numel() * frames.element_size()),
+                  'bank_slab_bytes_f32': int(bank_bytes), 'bank_capacity_entries_per_object': int(getattr(fb_, '_cap', 0)),
+                  'final_bank_entries_per_object': [int(x) for x in bank_sizes[-1]] if bank_sizes else None,
+                  'capacity': '288 GB HBM3E per MI355X'}
+    # ---- frames/s against the bank size: blocks of the timed frames
+    blk = 100 if K >= 400 else (10 if K >= 40 else 0)
+    if blk:
+        curve = []
+        by_t = {t_: ms_ for t_, ms_ in frame_ms}
+        for a in range(s_first, s_first + K - blk + 1, blk):
+            ms_blk = [by_t[t_] for t_ in range(a, a + blk) if t_ in by_t]
+            sz = bank_sizes[a - 1:a - 1 + blk]
+            if len(ms_blk) == blk and sz:
+                curve.append({'frames': [a, a + blk - 1], 'mean_bank_entries_per_object': round(sum(sum(x) for x in sz) / (2.0 * len(sz)), 1),
+                              'frames_per_s': round(1e3 * blk / sum(ms_blk), 2)})
+        out['bank_curve'] = {'block_frames': blk, 'points': curve,
+                             'note': 'host wall between step completions, this rank; sampled frames (events around every launch) included'}
     print(json.dumps(out))
     if os.environ.get('VFN_BENCH_DUMP'):            # per-step host times of the whole run (diagnostics)
         with open(os.environ['VFN_BENCH_DUMP'], 'w') as f:

@@ -98,6 +98,18 @@ int vfn_conv_cfg_wk(int cfg);
 /* K tiles a workgroup multiplies between two barriers: 1, or 2 (configurations with a 4-tile register prefetch and four
  * LDS buffers, conv_igemm_wk_kernel<bm, bn, wm, wn, wk, 4, 2, mode>; ksplit <= 1).  0: no such cfg */
 int vfn_conv_cfg_tpb(int cfg);
+/* Kind of tile configuration cfg (ABI 10): 0 = LDS-tiled (conv_igemm_kernel / _wk_kernel / _dma_kernel), 1 = wave-autonomous
+ * (conv_direct_kernel: operands straight into the MFMA registers, no LDS staging; f32 only; ksplit / split_from as for kind 0,
+ * tile_counters must be NULL), 2 = stream-K (conv_streamk_kernel: a persistent launch in which every wave takes an equal share
+ * of the layer's (output tile, K tile) pairs and cut tiles are finished inside the launch in K order; f32 only; ksplit <= 1;
+ * `partial` must point at VFN_CONV_SK_WS_FLOATS floats and `tile_counters` at VFN_CONV_SK_MAX_TILES ints that are zero at rest,
+ * neither shared with a launch that may run concurrently).  -1: no such cfg */
+#define VFN_CONV_SK_WS_FLOATS (16 * 1024 * 1024)
+#define VFN_CONV_SK_MAX_TILES 16384
+int vfn_conv_cfg_kind(int cfg);
+/* kernel instantiation behind a configuration of kind 1 / 2 as rocprofv3 prints it, e.g. "conv_direct_kernel<2, 2, 1, 1, 4, 2>"
+ * (kind 0: bench.py derives it from vfn_conv_cfg_info); NUL-terminated into buf[0 .. n).  0 ok */
+int vfn_conv_cfg_name(int cfg, char* buf, int n);
 int vfn_conv2d_nhwc_f32(const vfn_conv_desc* d, int cfg, void* stream);
 /* Same convolution with both operands rounded to bf16 (nearest-even) as they are staged into LDS and multiplied
  * on v_mfma_f32_32x32x16_bf16 with f32 accumulation; tensors stay f32 in HBM.  Cin must be a multiple of 64;

@@ -24,6 +24,7 @@ if len(sys.argv) > 1 and sys.argv[1] != 'all':
 tiles = ops.conv_cfg_tiles()
 D0 = 38
 ws = torch.empty(engine.WS_FLOATS, device=dev)
+cnt = torch.zeros(ops.SK_MAX_TILES, dtype=torch.int32, device=dev)
 
 
 def timeit(d, c, iters=10):
@@ -54,7 +55,7 @@ for (N, H, W, Cin, Cout, k, s, relu_in, use_res) in SHAPES:
     K = k * k * Cin
     fl = 2.0 * d.M * Cout * K
     choice = engine.choose_cfg(d.M, Cout, K, 0)
-    cfg = engine.apply_choice(d, choice, ws, None)
+    cfg = engine.apply_choice(d, choice, ws, cnt)
     t_old = timeit(d, cfg)
     ref = out.clone()
     results = []
@@ -64,13 +65,15 @@ for (N, H, W, Cin, Cout, k, s, relu_in, use_res) in SHAPES:
             continue
         blocks = ((d.M + bm - 1) // bm) * ((Cout + bn - 1) // bn)
         options = [(c, 1, 0)]
-        if blocks < 256:
+        if ops.conv_cfg_kind(c) == 2:
+            pass
+        elif blocks < 256:
             options += [(c, k_, 0) for k_ in ops.valid_splits(d, 16)[1:] if k_ * d.M * Cout <= engine.WS_FLOATS]
         else:
             options += [(c, k_, full) for (full, k_, rows) in ops.tail_split_options(d, bm, bn, 8)
                         if k_ * rows * Cout <= engine.WS_FLOATS and k_ in (2, 3, 4, 5, 6, 8)]
         for opt in options:
-            engine.apply_choice(d, opt, ws, None)
+            engine.apply_choice(d, opt, ws, cnt)
             out.zero_()
             t = timeit(d, c)
             err = (out - ref).abs().max().item() / max(1e-6, ref.abs().max().item())
@@ -79,7 +82,7 @@ for (N, H, W, Cin, Cout, k, s, relu_in, use_res) in SHAPES:
     t_new, opt, err = results[0]
     tot_old += t_old; tot_new += min(t_old, t_new)
     def nm(ch):
-        return '%dx%d' % tiles[ch[0]] + (f'/wk{ops.conv_cfg_wk(ch[0])}' if ops.conv_cfg_wk(ch[0]) > 1 else '') + (f'/k{ch[1]}@{ch[2]}' if ch[1] > 1 else '')
+        return '%dx%d' % tiles[ch[0]] + (f'/wk{ops.conv_cfg_wk(ch[0])}' if ops.conv_cfg_wk(ch[0]) > 1 else '') + ('/sk' if ops.conv_cfg_kind(ch[0]) == 2 else '') + (f'/k{ch[1]}@{ch[2]}' if ch[1] > 1 else '')
     print(f'M={d.M:6d} Cout={Cout:4d} K={K:5d} r{relu_in}{use_res} | tuned cfg{choice[0]:2d} {nm(choice):16s} {t_old:7.1f} us {fl / t_old / 1e6:6.1f} TF | '
           f'direct cfg{opt[0]:2d} {nm(opt):16s} {t_new:7.1f} us {fl / t_new / 1e6:6.1f} TF  relerr {err:.1e} | '
           + '  '.join(f'{nm(o)}:{t:.1f}' for t, o, _ in results[1:4]), flush=True)

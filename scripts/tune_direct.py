@@ -1,0 +1,90 @@
+"""Add the wave-autonomous / stream-K configurations (conv_direct.hip) to the f32 table where they beat the shipped
+choice by a margin: every conv shape of the C2 / C3 / C5 plans is timed with its current choice and with every
+configuration of kind 1 / 2 (+ split options); a shape changes hands only when the new time is below MARGIN x the old one
+(timing noise between boxes is 1-3 %).  Writes gpurun_out/tuned_gfx950.json + a report."""
+import sys, os, json
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch, vfloodnet_amd
+from vfloodnet_amd import AFB_URR, engine, ops
+MARGIN = float(os.environ.get('VFN_TUNE_MARGIN', 0.97))
+dev = torch.device('cuda', 0)
+model = AFB_URR(dev, update_bank=True).to(dev).eval()
+eng = model.engine()
+tiles = ops.conv_cfg_tiles()
+table = engine._TABLES[0]
+report = []
+
+
+def timeit(d, c, iters=12):
+    for _ in range(2):
+        ops.conv2d_launch(d, c, 0)
+    torch.cuda.synchronize()
+    best = None
+    for _ in range(4):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(iters):
+            ops.conv2d_launch(d, c, 0)
+        e1.record(); torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / iters
+        best = ms if best is None else min(best, ms)
+    return best * 1e3
+
+
+for (h, w) in [(480, 854), (480, 853), (480, 800)]:
+    p = eng.plan(h, w, 2)
+    seen = {}
+    side_lists = [id(qs.pre[n]) for qs in p.qsets for n in (1, 2)]
+    for lst in p.all_lists():
+        for l in lst:
+            if l.fn is ops.conv2d_launch and int(l.args[2]) == 0:
+                d = l.args[0]
+                key = (d.M, d.Cout, d.KH * d.KW * d.Cin)
+                seen.setdefault(key, []).append((l, id(lst) in side_lists))
+    for key, launches in seen.items():
+        if any(r[0] == key for r in report):
+            continue
+        d = launches[0][0].args[0]
+        old = engine.choose_cfg(*key, 0)
+        c_old = engine.apply_choice(d, old, p.ws, p.cnt)
+        t_old = timeit(d, c_old)
+        best, t_best = old, t_old
+        for c in range(38, len(tiles)):
+            bm, bn = tiles[c]
+            if d.cout_pad < ((d.Cout + bn - 1) // bn) * bn or (bn > 64 and d.Cout <= 32) or (bn > 128 and d.Cout < 256):
+                continue
+            blocks = ((d.M + bm - 1) // bm) * ((d.Cout + bn - 1) // bn)
+            options = [(c, 1, 0)]
+            kind, wk = ops.conv_cfg_kind(c), ops.conv_cfg_wk(c)
+            if kind == 2:
+                if blocks > ops.SK_MAX_TILES:
+                    continue
+            elif d.Cout % 4 == 0 and d.out_ld % 4 == 0 and (not d.res or d.res_ld % 4 == 0):
+                if blocks < 256:
+                    options += [(c, k_, 0) for k_ in ops.valid_splits(d, 8 if wk > 1 else 16, 0)[1:] if k_ * d.M * d.Cout <= engine.WS_FLOATS]
+                elif wk == 1:
+                    options += [(c, k_, full) for (full, k_, rows) in ops.tail_split_options(d, bm, bn, 8, 0)
+                                if k_ * rows * d.Cout <= engine.WS_FLOATS and k_ in (2, 3, 4, 5, 6, 8)]
+            for opt in options:
+                engine.apply_choice(d, opt, p.ws, p.cnt)
+                t = timeit(d, c, iters=6)
+                if t < t_best:
+                    best, t_best = opt, t
+        if best != old:                                      # confirm with the long timing, alternating
+            engine.apply_choice(d, best, p.ws, p.cnt); t_new = timeit(d, best[0])
+            engine.apply_choice(d, old, p.ws, p.cnt); t_old2 = timeit(d, c_old)
+            t_old = min(t_old, t_old2)
+            if t_new < MARGIN * t_old:
+                table[key] = best
+            else:
+                best = old
+            t_best = t_new
+        report.append((key, list(old), round(t_old, 1), list(best), round(t_best, 1), len(launches)))
+        print(report[-1], flush=True)
+        for l, in_q in launches:
+            l.args = (l.args[0], engine.apply_choice(l.args[0], table.get(key, old), p.ws_q if in_q else p.ws, p.cnt_q if in_q else p.cnt), 0)
+os.makedirs('gpurun_out', exist_ok=True)
+engine.save_tuned('gpurun_out/tuned_gfx950.json', 0)
+json.dump(report, open('gpurun_out/r04_tune_direct_report.json', 'w'))
+changed = [r for r in report if r[1] != r[3]]
+print(len(changed), 'of', len(report), 'shapes changed; saved us per launch-instance:', round(sum((r[2] - r[4]) * r[5] for r in changed), 1))

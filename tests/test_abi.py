@@ -30,7 +30,7 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(L, s), s
     hdr = open(os.path.join(ROOT, 'include', 'vfn_hip.h')).read()
     assert L.vfn_abi_version() == _lib.ABI_VERSION == int(re.search(r'#define VFN_ABI_VERSION (\d+)', hdr).group(1))
-    assert L.vfn_conv_cfg_count() == 56
+    assert L.vfn_conv_cfg_count() == 62
 
 
 def test_descriptor_sizes_match_the_library():

@@ -41,6 +41,14 @@ def test_self_launch_two_ranks_on_one_device(gpu):
     d = _run(['--gpus', '2', '--steps', '6', '--warmup', '1', '--min-warm-s', '0', '--no-cpu-baseline'],
              {'VFN_DIST_BACKEND': 'gloo', 'VFN_SINGLE_DEVICE': '1'})
     assert d['n_gpus'] == 2 and d['scaling'] == 'weak' and d['value'] > 0
+    # what a SCALE record needs to show that N ranks met over the collective backend, and where the time went
+    x = d['distributed']
+    assert x['backend'] == 'gloo' and x['world_size'] == 2                   # ('nccl' = RCCL on a multi-GPU node)
+    assert len(x['frames_per_s_per_rank']) == 2 and x['frames_per_s_per_rank_min'] <= x['frames_per_s_per_rank_max']
+    assert len(x['all_gather_ms_per_rank']) == 2 and x['all_gather_ms_max'] > 0 and x['all_gather_bytes_per_rank'] == 6 * 480 * 854
+    # the whole-job value is bounded by the per-rank rates (the bracket also holds the gather and two barriers)
+    assert d['value'] <= sum(x['frames_per_s_per_rank']) * 1.001
+    assert d['hbm']['peak_bytes_allocated'] > d['hbm']['bank_slab_bytes_f32'] > 0
 
 
 @pytest.mark.parametrize('workload,steps', [('C3', 12), ('C5', 12)])
@@ -50,3 +58,16 @@ def test_reduced_precision_lines_carry_parity(gpu, workload, steps):
     assert d['dtype'].startswith('bf16x3') and d['parity'] is not None
     assert d['parity']['miou_vs_oracle'] >= 0.99 and d['parity']['bank_sizes_equal']
     assert d['config']['network_resolution'].startswith('480x853')
+    assert d['distributed']['world_size'] == 1 and d['distributed']['backend'] is None
+    assert d['hbm']['peak_bytes_allocated'] >= d['hbm']['resident_frames_bytes'] > 0
+
+
+def test_c5_line_carries_bank_curve_and_peak_hbm(gpu):
+    """frames/s against the bank size and the peak HBM bytes are part of the line."""
+    d = _run(['--workload', 'C5', '--precision', 'bf16x3', '--steps', '60', '--warmup', '1', '--min-warm-s', '0', '--no-cpu-baseline'])
+    pts = d['bank_curve']['points']
+    assert d['bank_curve']['block_frames'] == 10 and len(pts) == 6
+    sizes = [p_['mean_bank_entries_per_object'] for p_ in pts]
+    assert sizes == sorted(sizes) and sizes[-1] > sizes[0] > 1620          # the bank only grows in C5
+    assert all(p_['frames_per_s'] > 0 for p_ in pts)
+    assert d['hbm']['final_bank_entries_per_object'][0] <= d['hbm']['bank_capacity_entries_per_object']

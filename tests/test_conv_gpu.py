@@ -246,3 +246,38 @@ def test_split_bf16_activation_image_round_trip(gpu, shape, relu):
     dbad.relu_in = 0
     with pytest.raises(RuntimeError):
         ops.conv2d_launch(dbad, 3, 0)
+
+
+def test_streamk_hand_off_is_reproducible_under_load(gpu):
+    """conv_streamk_kernel finishes cut tiles inside the launch (write-through partials, arrival counter, the last arriver adds
+    the segments in K order).  Repeated launches next to a second stream that keeps the chip busy must give the SAME bits every
+    time (whichever wave arrives last), agree with the LDS-tiled kernel, and leave the counters at rest."""
+    from vfloodnet_amd import ops
+    g = torch.Generator().manual_seed(5)
+    cases = [(2, 30, 54, 256, 256, 3, 1), (1, 60, 108, 128, 128, 3, 1), (2, 30, 54, 1024, 256, 1, 1), (1, 33, 47, 64, 96, 3, 1)]
+    sk_cfgs = [c for c in range(len(ops.conv_cfg_tiles())) if ops.conv_cfg_kind(c) == 2]
+    assert len(sk_cfgs) >= 4
+    side = torch.cuda.Stream(device=gpu)
+    big_x = torch.randn(2, 120, 216, 256, generator=g).to(gpu)
+    big_w = ops.pad_rows(torch.randn(256, 9 * 256, generator=g) * 0.02).to(gpu)
+    for (N, H, W, Cin, Cout, k, s) in cases:
+        x = torch.randn(N, H, W, Cin, generator=g).to(gpu)
+        wp = ops.pad_rows(torch.randn(Cout, k * k * Cin, generator=g) / (Cin * k * k) ** 0.5).to(gpu)
+        res = torch.randn(N, (H + 2 * (k // 2) - k) // s + 1, (W + 2 * (k // 2) - k) // s + 1, Cout, generator=g).to(gpu)
+        ref = ops.conv2d_nhwc(x, wp, Cout, k, k, s, k // 2, None, None, res, True, True, cfg=3)
+        ws, cnt = ops.streamk_scratch(gpu)
+        for cfg in sk_cfgs:
+            first = None
+            for it in range(12):
+                if it % 3 == 0:
+                    with torch.cuda.stream(side):                      # uneven load beside the hand-offs
+                        ops.conv2d_nhwc(big_x, big_w, 256, 3, 3, 1, 1, cfg=9)
+                y = ops.conv2d_nhwc(x, wp, Cout, k, k, s, k // 2, None, None, res, True, True, cfg=cfg)
+                if first is None:
+                    first = y.clone()
+                    err = (y - ref).abs().max().item()
+                    assert err < 2e-4 * max(1.0, ref.abs().max().item()), (cfg, err)
+                else:
+                    assert torch.equal(y, first), f'cfg {cfg}: launch {it} differs from launch 0'
+            torch.cuda.synchronize()
+            assert int(cnt.abs().sum()) == 0, 'arrival counters must return to rest'

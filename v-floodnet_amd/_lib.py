@@ -104,6 +104,10 @@ def _declare(L):
     L.vfn_conv_cfg_wk.restype = i
     L.vfn_conv_cfg_tpb.argtypes = [i]
     L.vfn_conv_cfg_tpb.restype = i
+    L.vfn_conv_cfg_kind.argtypes = [i]
+    L.vfn_conv_cfg_name.argtypes = [i, C.c_char_p, i]
+    L.vfn_conv_cfg_name.restype = i
+    L.vfn_conv_cfg_kind.restype = i
     L.vfn_sizeof_desc.argtypes = [i]
     L.vfn_conv2d_nhwc_f32.argtypes = [C.POINTER(ConvDesc), i, p]
     L.vfn_conv2d_nhwc_bf16.argtypes = [C.POINTER(ConvDesc), i, p]
@@ -179,7 +183,7 @@ SIGNATURES = {
 }
 # every symbol include/vfn_hip.h declares (checked by tests/test_abi.py)
 ALL_SYMBOLS = sorted(list(SIGNATURES) + [
-    'vfn_abi_version', 'vfn_sizeof_desc', 'vfn_conv_cfg_count', 'vfn_conv_cfg_tile', 'vfn_conv_cfg_info', 'vfn_conv_cfg_wk', 'vfn_conv_cfg_tpb', 'vfn_conv2d_nhwc_f32', 'vfn_conv2d_nhwc_bf16', 'vfn_conv2d_nhwc_bf16x3',
+    'vfn_abi_version', 'vfn_sizeof_desc', 'vfn_conv_cfg_count', 'vfn_conv_cfg_tile', 'vfn_conv_cfg_info', 'vfn_conv_cfg_wk', 'vfn_conv_cfg_tpb', 'vfn_conv_cfg_kind', 'vfn_conv_cfg_name', 'vfn_conv2d_nhwc_f32', 'vfn_conv2d_nhwc_bf16', 'vfn_conv2d_nhwc_bf16x3',
     'vfn_stem_conv7x7_f32',
     'vfn_bank_scan', 'vfn_memread_apply', 'vfn_memread_finish', 'vfn_bank_merge', 'vfn_bank_append', 'vfn_bank_remove', 'vfn_bank_refresh_norms', 'vfn_bank_refresh_lp'])
 

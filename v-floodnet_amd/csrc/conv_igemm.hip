@@ -985,6 +985,17 @@ extern "C" int vfn_conv_cfg_info(int cfg, int* bm, int* bn, int* wm, int* wn, in
     return VFN_OK;
 }
 
+extern "C" int vfn_conv_cfg_kind(int cfg) {
+    if (cfg < 0 || cfg >= kCfgCount) return -1;
+    if (cfg < VFN_DIRECT_CFG0) return 0;
+    return vfn_conv_direct_is_streamk(cfg - VFN_DIRECT_CFG0) ? 2 : 1;
+}
+
+extern "C" int vfn_conv_cfg_name(int cfg, char* buf, int n) {
+    if (cfg < VFN_DIRECT_CFG0 || cfg >= kCfgCount) return VFN_ERR_ARG;
+    return vfn_conv_direct_name(cfg - VFN_DIRECT_CFG0, buf, n);
+}
+
 extern "C" int vfn_conv_cfg_tile(int cfg, int* bm, int* bn) { return vfn_conv_cfg_info(cfg, bm, bn, nullptr, nullptr, nullptr); }
 
 // configurations 26..37 (in-workgroup split-K / deep prefetch / two tiles per barrier) in any arithmetic mode

@@ -89,6 +89,12 @@ def _tiles():
 def apply_choice(desc, choice, ws, counters=None):
     """Configure a conv descriptor for a (cfg, ksplit, split_from) choice; returns the cfg index."""
     cfg, ks, split_from = choice
+    if ops.conv_cfg_kind(cfg) == 2:                       # stream-K: its own workspace + counters, never a K split on top
+        if counters is None or ws is None or ws.numel() < ops.SK_WS_FLOATS:
+            # (callers with no counters of their own -- the backward pass, LinkNet: main-stream launches, one after the other)
+            ws, counters = ops.streamk_scratch(ws.device if ws is not None else torch.device('cuda', torch.cuda.current_device()))
+        ops.set_streamk(desc, ws, counters)
+        return cfg
     if ks > 1:
         bm, bn = _tiles()[cfg]
         n_tiles = (desc.Cout + bn - 1) // bn
@@ -96,7 +102,7 @@ def apply_choice(desc, choice, ws, counters=None):
         # In-launch finish (last-arriving slice reduces the tile) is built and bit-identical, but measured SLOWER
         # on MI355X (C2: 93 vs 100 frames/s): every slice workgroup pays an agent-scope release (L2 write-back),
         # more than the ~2 us kernel boundary it removes.  Off unless VFN_INLAUNCH_SPLITK=1.
-        if desc.Cout % bn or not _INLAUNCH_SPLITK:
+        if desc.Cout % bn or not _INLAUNCH_SPLITK or ops.conv_cfg_kind(cfg) != 0:
             counters = None
         ops.set_splitk(desc, ks, ws, split_from, rows, counters)
     else:
@@ -270,8 +276,8 @@ class FramePlan:
         self._lp_state = {}                   # (ptr, shape) of an f32 view -> its twin holds the image of relu(x)? (True / False)
         self.ws = f(WS_FLOATS)
         self.ws_q = f(WS_FLOATS)              # split-K workspace of the query-encoder list (side stream)
-        self.cnt = torch.zeros(4096, dtype=torch.int32, device=dev)      # split-tile arrival counters (zero at rest)
-        self.cnt_q = torch.zeros(4096, dtype=torch.int32, device=dev)
+        self.cnt = torch.zeros(ops.SK_MAX_TILES, dtype=torch.int32, device=dev)      # split-tile arrival counters (zero at rest)
+        self.cnt_q = torch.zeros(ops.SK_MAX_TILES, dtype=torch.int32, device=dev)
         self._ws_cur, self._cnt_cur = self.ws, self.cnt
 
         self.mem = []         # memorize
@@ -860,7 +866,14 @@ class Engine:
                 blocks = ((d.M + bm - 1) // bm) * ((d.Cout + bn - 1) // bn)
                 options = [(c, 1, 0)]
                 wk = ops.conv_cfg_wk(c)
-                if wk > 1 or ops.conv_cfg_tpb(c) > 1:          # split-K inside the workgroup / two tiles per barrier:
+                kind = ops.conv_cfg_kind(c)
+                if kind == 2:                                  # stream-K balances by itself
+                    if blocks > ops.SK_MAX_TILES:
+                        continue
+                elif kind == 1 and wk > 1:                     # wave-autonomous with K groups: a second split only when tiles are scarce
+                    if blocks < 256:
+                        options += [(c, k_, 0) for k_ in ops.valid_splits(d, 8, bf)[1:] if k_ * d.M * d.Cout <= WS_FLOATS]
+                elif wk > 1 or ops.conv_cfg_tpb(c) > 1:          # split-K inside the workgroup / two tiles per barrier:
                     if blocks > 1024 or d.KH * d.KW * d.Cin // (64 if bf == 1 else 32) < 2 * wk:   # no second split, scarce tiles
                         continue
                 elif blocks < 256:

@@ -38,6 +38,34 @@ def conv_cfg_tpb(cfg):
     return _lib.lib().vfn_conv_cfg_tpb(int(cfg))
 
 
+def conv_cfg_kind(cfg):
+    """0 = LDS-tiled, 1 = wave-autonomous (conv_direct_kernel), 2 = stream-K (conv_streamk_kernel) -- vfn_conv_cfg_kind."""
+    return _lib.lib().vfn_conv_cfg_kind(int(cfg))
+
+
+SK_WS_FLOATS = 16 * 1024 * 1024       # include/vfn_hip.h VFN_CONV_SK_WS_FLOATS / VFN_CONV_SK_MAX_TILES
+SK_MAX_TILES = 16384
+_sk_scratch = {}
+
+
+def streamk_scratch(device):
+    """(workspace, counters) for stream-K launches made through the convenience wrappers (one pair per device; launches on
+    one stream run one after the other, so they may share it)."""
+    key = str(device)
+    if key not in _sk_scratch:
+        _sk_scratch[key] = (torch.empty(SK_WS_FLOATS, dtype=torch.float32, device=device),
+                            torch.zeros(SK_MAX_TILES, dtype=torch.int32, device=device))
+    return _sk_scratch[key]
+
+
+def set_streamk(desc, workspace, counters):
+    """A stream-K configuration (conv_cfg_kind == 2) needs its partial-tile workspace and zeroed tile counters."""
+    assert workspace.numel() >= SK_WS_FLOATS and counters.numel() >= SK_MAX_TILES
+    desc.ksplit, desc.split_from = 1, 0
+    desc.partial, desc.tile_counters = ptr(workspace), ptr(counters)
+    return desc
+
+
 def conv_cfg_names(mode=0):
     """Kernel instantiation behind every tile configuration, as rocprofv3 prints it."""
     L = _lib.lib()
@@ -47,6 +75,11 @@ def conv_cfg_names(mode=0):
         L.vfn_conv_cfg_info(c, *[C.byref(x) for x in v])
         bm, bn, wm, wn, dma = [x.value for x in v]
         wk, tpb = L.vfn_conv_cfg_wk(c), L.vfn_conv_cfg_tpb(c)
+        if L.vfn_conv_cfg_kind(c) > 0:
+            buf = C.create_string_buffer(96)
+            L.vfn_conv_cfg_name(c, buf, 96)
+            out.append(buf.value.decode())
+            continue
         out.append(f'conv_igemm_dma_kernel<{bm}, {bn}, {wm}, {wn}, {dma}>' if dma else
                    f'conv_igemm_wk_kernel<{bm}, {bn}, {wm}, {wn}, {wk}, {4 if tpb > 1 else 3}, {tpb}, {int(mode)}>' if (wk > 1 or tpb > 1) else
                    f'conv_igemm_kernel<{bm}, {bn}, {wm}, {wn}, {int(mode)}>')
@@ -181,6 +214,8 @@ def conv2d_nhwc(x, wp, cout, kh, kw, stride, pad, scale=None, shift=None, res=No
     if out is None:
         out = torch.empty(N, Ho, Wo, cout, device=x.device, dtype=torch.float32)
     d = make_conv_desc(x, wp, cout, kh, kw, stride, pad, out, scale, shift, res, relu_in, relu_out)
+    if mode == 0 and conv_cfg_kind(cfg) == 2:
+        set_streamk(d, *streamk_scratch(x.device))
     conv2d_launch(d, cfg, mode)
     return out
 
