@@ -244,6 +244,13 @@ int vfn_upsample2x_add_backward_f32(const float* gm, float* gs, float* gpm, int 
  *     stats: 3 + bs floats = (loss, cross entropy, uncertainty, ||u|| per sample).  Deterministic two-stage sums. */
 int vfn_segment_loss_f32(const float* logit, const int* label, int bs, int obj_n, int n, float lu, float* partial, float* stats,
                          float* grad, void* stream);
+/* vfn_segment_uncertainty_backward_f32   the adjoint of the uncertainty alone (ABI 10), for an autograd boundary where the
+ *     criterion is the caller's (``scores, uncertainty = model.segment(frames, fb); loss = criterion(scores, label) + lu *
+ *     uncertainty; loss.backward()``, train_video_seg.py:69-74): grad [bs][obj][n] = g_scores (optional: dL/dscores from the
+ *     caller's criterion) + *g_unc_dev * d uncertainty / d scores; g_unc_dev = dL/duncertainty as a float IN DEVICE MEMORY (what
+ *     autograd hands over: no host round trip).  partial / stats as vfn_segment_loss_f32. */
+int vfn_segment_uncertainty_backward_f32(const float* logit, int bs, int obj_n, int n, const float* g_unc_dev,
+                                         const float* g_scores, float* partial, float* stats, float* grad, void* stream);
 int vfn_tail_grad_o_f32(const float* G, const float* p_up, const float* unc, const float* conf, const float* q, float* g_o,
                         int obj_n, int h, int w, int pad_top, int pad_left, int H0, int W0, void* stream);
 int vfn_tail_split_f32(const float* g_p2, const float* unc, const float* conf, const float* q, float* g_q, float* g_cf, float* g_u,

@@ -55,3 +55,49 @@ def miou(a, b):
         union = ((a == c) | (b == c)).sum().item()
         v.append(1.0 if union == 0 else inter / union)
     return sum(v) / 2
+
+
+# ---- the reference's own training step (oracle/gen_train_golden.py -> tests/golden/train_step_96x160.npz)
+TRAIN_H, TRAIN_W, TRAIN_K, TRAIN_LU, TRAIN_LR, TRAIN_NS = 96, 160, 2, 0.5, 1e-5, 16
+
+
+def train_sample():
+    """The 3-frame sample the fixture was generated on (clip seed 6, 5 % label noise): frames [3,3,H,W], masks [3,K,H,W], lab."""
+    import vfloodnet_amd  # noqa: F401
+    from tools import synth
+    frames, m0 = synth.clip(6, 3, TRAIN_H, TRAIN_W)
+    gen = torch.Generator().manual_seed(11)
+    lab = torch.stack([m0.long()] + [torch.roll(m0.long(), (2 * k_, 5 * k_), (0, 1)) for k_ in (1, 2)], 0)
+    flip = torch.rand(3, TRAIN_H, TRAIN_W, generator=gen) < 0.05
+    lab = torch.where(flip, 1 - lab, lab)
+    masks = torch.nn.functional.one_hot(lab, TRAIN_K).permute(0, 3, 1, 2).float()
+    return frames, masks, lab
+
+
+def train_positions(numel, name):
+    import zlib
+    g = np.random.default_rng(zlib.crc32(name.encode()))
+    return np.sort(g.integers(0, numel, size=TRAIN_NS)).astype(np.int64)
+
+
+def train_names():
+    return open(os.path.join(GOLDEN, 'train_step_names.txt')).read().split()
+
+
+def compare_grads_with_reference(grads, g, names=None):
+    """``grads``: state-dict name -> gradient tensor (any device / dtype).  Per tensor, against the reference's own backward:
+    relative error of the L2 norm, of the 16 sampled elements and (for the 24 tensors stored whole) of every element, each
+    relative to the tensor's largest gradient magnitude.  Returns name -> worst of them."""
+    names = names or train_names()
+    worst = {}
+    for i, n in enumerate(names):
+        x = grads[n].detach().double().cpu().flatten()
+        nrm, _sum, amax = g['grad_stats'][i]
+        scale = max(amax, 1e-30)
+        e = abs(float(x.norm()) - nrm) / max(nrm, 1e-30)
+        idx = torch.from_numpy(train_positions(x.numel(), n))
+        e = max(e, float((x[idx] - torch.from_numpy(g['grad_samples'][i]).double()).abs().max()) / scale)
+        if 'full_grad.' + n in g:
+            e = max(e, float((x - torch.from_numpy(g['full_grad.' + n]).double().flatten()).abs().max()) / scale)
+        worst[n] = e
+    return worst

@@ -134,3 +134,47 @@ def test_segment_batch_and_training_branch_vs_reference():
             assert abs(float(unc) - float(g[f'{tag}_uncertainty'])) < 1e-6
         else:
             assert unc is None
+
+
+def test_oracle_training_step_vs_reference(sd):
+    """One training step of THE REFERENCE (train_video_seg.py:56-74 on its own AFB_URR / FeatureBank, loss.backward(),
+    AdamW.step(); oracle/gen_train_golden.py) against autograd through the oracle's memorize / segment / loss in the same
+    float32 arithmetic, with NOTHING adapted to a device under test: loss, uncertainty, logits, the gradient of all 300
+    parameters and the parameters after the optimiser step.  This pins the oracle's backward; tests/test_backward_gpu.py then
+    holds the HIP path against the same fixture."""
+    import torch.nn.functional as F
+    from golden_util import train_sample, train_names, train_positions, compare_grads_with_reference, TRAIN_K, TRAIN_LU, TRAIN_LR
+    g = load('train_step_96x160.npz')
+    frames, masks, lab = train_sample()
+    names = train_names()
+    assert len(names) == 300
+    leaf = {n: (v.clone().requires_grad_() if n in set(names) else v) for n, v in sd.items()}
+    k_ref, v_ref = O.memorize(leaf, frames[0:1], masks[0:1])
+    fb = O.FeatureBankRef(TRAIN_K, 300000)
+    fb.init_bank(k_ref, v_ref)
+    loss, unc, scs = 0.0, 0.0, []
+    for i in range(2):                      # (the batch's samples are independent given the bank: batch means = means of the samples')
+        sc, un = O.segment(leaf, frames[1 + i:2 + i], fb, update_bank=False, training=True)
+        loss = loss + (F.cross_entropy(sc, lab[1 + i:2 + i]) + TRAIN_LU * un) / 2
+        unc += un.item() / 2
+        scs.append(sc.detach())
+    loss.backward()
+    tot = loss.item()
+    scores = torch.cat(scs, 0)
+    assert abs(tot - float(g['loss'])) < 2e-6 * abs(float(g['loss'])), (tot, float(g['loss']))
+    assert abs(unc - float(g['uncertainty'])) < 2e-6
+    pos = torch.from_numpy(train_positions(scores.numel(), 'scores'))
+    assert (scores.flatten()[pos] - t(g['scores_sample'])).abs().max() < 1e-3
+    assert abs(float(scores.double().abs().sum()) - float(g['scores_abs_sum'])) < 1e-5 * float(g['scores_abs_sum'])
+    worst = compare_grads_with_reference({n: leaf[n].grad for n in names}, g, names)
+    top = sorted(worst.items(), key=lambda kv: -kv[1])[:5]
+    print('oracle backward vs the reference\'s, worst relative errors:', {n: f'{e:.1e}' for n, e in top})
+    assert max(worst.values()) < 1e-3, top
+    # the optimiser step: torch.optim.AdamW on the oracle's gradients against the reference's parameters after ITS step
+    params = [torch.nn.Parameter(sd[n].clone()) for n in names]
+    for p_, n in zip(params, names):
+        p_.grad = leaf[n].grad.clone()
+    torch.optim.AdamW(params, TRAIN_LR).step()
+    for i, (p_, n) in enumerate(zip(params, names)):
+        d = p_.detach().double() - sd[n].double()
+        assert abs(float(d.norm()) - g['step_stats'][i][0]) <= 2e-3 * g['step_stats'][i][0] + 1e-12, n

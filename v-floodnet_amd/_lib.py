@@ -146,6 +146,7 @@ SIGNATURES = {
     'vfn_upsample2x_add_backward_f32': [_p, _p, _p, _i, _i, _i, _i, _i, _p],
     'vfn_tail_grad_o_f32': [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p],
     'vfn_segment_loss_f32': [_p, _p, _i, _i, _i, _f, _p, _p, _p, _p],
+    'vfn_segment_uncertainty_backward_f32': [_p, _i, _i, _i, _p, _p, _p, _p, _p, _p],
     'vfn_tail_split_f32': [_p, _p, _p, _p, _p, _p, _p, _i, _i, _p],
     'vfn_local_stats_backward_f32': [_p] * 13 + [_i, _i, _i, _i, _p],
     'vfn_local_hpass_f32': [_p, _p, _p, _p, _p, _i, _i, _i, _i, _p],

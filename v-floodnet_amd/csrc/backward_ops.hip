@@ -360,8 +360,10 @@ void loss_partial_kernel(const float* __restrict__ logit, const int* __restrict_
         }
         float zden = 0.f, sden = 0.f;
         for (int k = 0; k < obj_n; ++k) { zden += expf(z[k] - zmax); s[k] = expf(s[k] - smax); sden += s[k]; }
-        const int lab = label[(size_t)b * n + i];
-        ce += logf(zden) + zmax - z[lab];
+        if (label) {
+            const int lab = label[(size_t)b * n + i];
+            ce += logf(zden) + zmax - z[lab];
+        }
         float t1 = -1.f, t2 = -1.f;
         for (int k = 0; k < obj_n; ++k) {
             const float pk = s[k] / sden;
@@ -401,9 +403,15 @@ __global__ void loss_finish_kernel(const float* __restrict__ part_ce, const floa
 
 // dloss/dlogit.  The uncertainty term reaches the logit through s = sigmoid(logit) (ds/dlogit = s (1 - s); where the clamp of
 // AFB_URR.py:309 is active that factor is below 1e-7 and the term is dropped with the rest of that pixel's gradient).
+// label == NULL: no cross-entropy term (vfn_segment_uncertainty_backward_f32: the uncertainty's adjoint alone, for an autograd
+// boundary where the criterion is the caller's); lu_dev != NULL: the factor in front of the uncertainty is read from device
+// memory (dL/duncertainty as autograd hands it over: no host round trip); add != NULL: added to the result (dL/dscores arriving
+// from the caller's criterion).
 __global__ void loss_grad_kernel(const float* __restrict__ logit, const int* __restrict__ label, const float* __restrict__ stats,
-                                 int bs, int obj_n, int n, float lu, float* __restrict__ grad) {
+                                 int bs, int obj_n, int n, float lu, float* __restrict__ grad,
+                                 const float* __restrict__ lu_dev = nullptr, const float* __restrict__ add = nullptr) {
     const int b = blockIdx.y;
+    if (lu_dev) lu = *lu_dev;
     const float* src = logit + (size_t)b * obj_n * n;
     float* dst = grad + (size_t)b * obj_n * n;
     const float norm = stats[3 + b];
@@ -432,11 +440,12 @@ __global__ void loss_grad_kernel(const float* __restrict__ logit, const int* __r
         if (k2 >= 0) gP[k2] = cu * u * (u * t1 / ((t2 + 1e-8f) * (t2 + 1e-8f)));
         float dot = 0.f;
         for (int k = 0; k < obj_n; ++k) dot += gP[k] * (e[k] / sden);
-        const int lab = label[(size_t)b * n + i];
+        const int lab = label ? label[(size_t)b * n + i] : -1;
         for (int k = 0; k < obj_n; ++k) {
             const float P = e[k] / sden;
             const float g_s = P * (gP[k] - dot);
-            const float ce_g = (expf(z[k] - zmax) / zden - (k == lab ? 1.f : 0.f)) * cce;
+            float ce_g = label ? (expf(z[k] - zmax) / zden - (k == lab ? 1.f : 0.f)) * cce : 0.f;
+            if (add) ce_g += add[(size_t)b * obj_n * n + (size_t)k * n + i];
             dst[(size_t)k * n + i] = ce_g + g_s * s[k] * (1.f - s[k]);
         }
     }
@@ -639,6 +648,21 @@ extern "C" int vfn_segment_loss_f32(const float* logit, const int* label, int bs
     hipLaunchKernelGGL(loss_partial_kernel, dim3(LOSS_BLOCKS, bs), dim3(256), 0, s, logit, label, obj_n, n, pce, pu2);
     hipLaunchKernelGGL(loss_finish_kernel, dim3(1), dim3(64), 0, s, pce, pu2, bs, n, lu, stats);
     if (grad) hipLaunchKernelGGL(loss_grad_kernel, dim3(256, bs), dim3(256), 0, s, logit, label, stats, bs, obj_n, n, lu, grad);
+    return vfn_check_launch();
+}
+
+// The uncertainty's adjoint on its own (an autograd boundary: ``scores, uncertainty = model.segment(...)``, the criterion is the
+// caller's): grad = g_scores (optional, [bs][obj][n]) + *g_unc_dev * d uncertainty / d logit.  partial / stats as above.
+extern "C" int vfn_segment_uncertainty_backward_f32(const float* logit, int bs, int obj_n, int n, const float* g_unc_dev,
+                                                    const float* g_scores, float* partial, float* stats, float* grad, void* stream) {
+    if (!logit || !g_unc_dev || !partial || !stats || !grad || bs < 1 || obj_n < 2 || obj_n > MAX_OBJ || n < 1) return VFN_ERR_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    float* pce = partial;
+    float* pu2 = partial + (size_t)bs * LOSS_BLOCKS;
+    hipLaunchKernelGGL(loss_partial_kernel, dim3(LOSS_BLOCKS, bs), dim3(256), 0, s, logit, (const int*)nullptr, obj_n, n, pce, pu2);
+    hipLaunchKernelGGL(loss_finish_kernel, dim3(1), dim3(64), 0, s, pce, pu2, bs, n, 0.f, stats);
+    hipLaunchKernelGGL(loss_grad_kernel, dim3(256, bs), dim3(256), 0, s, logit, (const int*)nullptr, stats, bs, obj_n, n, 0.f, grad,
+                       g_unc_dev, g_scores);
     return vfn_check_launch();
 }
 

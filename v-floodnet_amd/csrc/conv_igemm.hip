@@ -40,44 +40,47 @@ __device__ __forceinline__ void split_bf16(const f32x4& v, bf16x4& h, bf16x4& l)
     }
 }
 
-// In-launch finish of a K-split tile (replaces the separate reduce launch): every slice workgroup stores its
-// raw partial tile, then takes a ticket on the tile's arrival counter; the workgroup that draws the last
-// ticket sums the slices IN SLICE ORDER (bit-reproducible whichever workgroup arrives last) and applies the
-// epilogue.  Hand-off = agent-scope release by the producers / acquire by the last arriver
-// (cdna_hip_programming.md guideline 16, counter form): results do not depend on dispatch order or XCD
-// placement.  `flag` is one int of the (now idle) dynamic LDS; counters are zero at rest.
+// In-launch finish of a K-split tile (replaces the separate reduce launch): every slice workgroup stores its raw partial tile
+// WRITE-THROUGH (sc0 sc1: the bytes leave the XCD's L2 with the store -- no release fence, whose L2 write-back made the
+// round-1 form of this slower than the second launch), every storing wave drains its stores, and behind a workgroup barrier one
+// lane takes a ticket on the tile's arrival counter; the workgroup that draws the last ticket loads all slices (sc0 sc1 loads:
+// served past the non-coherent L1 / L2) and sums them IN SLICE ORDER -- bit-identical to the reduce launch whichever workgroup
+// arrives last -- then applies the epilogue.  (MI355X_MICROARCH.md "Valid forms": sc1 stores + per-wave vmcnt(0) + workgroup
+// barrier + agent-scope counter add; the last adder's workgroup loads with sc1 loads behind a barrier that lane joins.)
+// `flag` is one int of the (now idle) dynamic LDS; counters are zero at rest.
+constexpr int CP_WT = 17;                          // buffer cache policy: sc0 | sc1
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t partial_rsrc(const vfn_conv_desc& p) {
+    return __builtin_amdgcn_make_buffer_rsrc(p.partial, 0, 0x7ffffff0, 0x00020000);
+}
+
 template <int BM, int BN, int NT>
 __device__ __forceinline__ void splitk_finish(const vfn_conv_desc& p, int* flag, int tile, int m0, int n0, int n_tiles) {
     const int tid = threadIdx.x;
     const int ksplit = p.ksplit;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // this wave's partial stores have left
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // this wave's write-through partial stores have left
     __syncthreads();
     if (tid == 0) {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         int* cnt = p.tile_counters + (tile - p.split_from);
         const int prev = __hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const int last = (prev == ksplit - 1);
-        if (last) {
-            __hip_atomic_store(cnt, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // at rest again for the next launch
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        }
+        if (last) __hip_atomic_store(cnt, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // at rest again for the next launch
         *flag = last;
     }
     __syncthreads();
     if (!*flag) return;
 
+    const __amdgpu_buffer_rsrc_t rp = partial_rsrc(p);
     const int m_start = (p.split_from / n_tiles) * BM;
-    const size_t slab = (size_t)(p.M - m_start) * p.Cout;
+    const int slab = (p.M - m_start) * p.Cout * (int)sizeof(float);      // bytes of one slice's slab
     constexpr int C4 = BN / 4;
     for (int i = tid; i < BM * C4; i += NT) {
         const int row = m0 + i / C4;
         const int col = n0 + (i % C4) * 4;
         if (row >= p.M || col >= p.Cout) continue;
-        const float* src = p.partial + (size_t)(row - m_start) * p.Cout + col;
-        f32x4 a = *reinterpret_cast<const f32x4*>(src);
-        for (int sp = 1; sp < ksplit; ++sp) a += *reinterpret_cast<const f32x4*>(src + sp * slab);
+        const int off = ((row - m_start) * p.Cout + col) * (int)sizeof(float);
+        f32x4 a = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rp, off, 0, CP_WT));
+        for (int sp = 1; sp < ksplit; ++sp) a += __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rp, off + sp * slab, 0, CP_WT));
         f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
         if (p.scale) sc = *reinterpret_cast<const f32x4*>(p.scale + col);
         if (p.shift) sh = *reinterpret_cast<const f32x4*>(p.shift + col);
@@ -120,8 +123,7 @@ __device__ __forceinline__ bool wide_epilogue(const vfn_conv_desc& p, char* smem
     constexpr int ROWS = WM * 32;                                   // tile rows handled per round
     constexpr int PITCH = (ROWS * (BN + 4) <= LDS_FLOATS) ? BN + 4 : BN;
     static_assert(ROWS * PITCH <= LDS_FLOATS, "C tile does not fit the staging LDS");
-    const bool wide = (p.Cout % 4 == 0) && (p.out_ld % 4 == 0) && (!p.res || p.res_ld % 4 == 0) && (!p.mask || p.mask_ld % 4 == 0) &&
-                      !(split_tile && p.tile_counters);
+    const bool wide = (p.Cout % 4 == 0) && (p.out_ld % 4 == 0) && (!p.res || p.res_ld % 4 == 0) && (!p.mask || p.mask_ld % 4 == 0);
     if (!wide) return false;
     // (tid_in / active: the in-workgroup split-K variant runs this with its K group 0 only; the other groups keep the
     // barriers company and touch nothing)
@@ -136,6 +138,8 @@ __device__ __forceinline__ bool wide_epilogue(const vfn_conv_desc& p, char* smem
     const bool col_ok = col < p.Cout;
     f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
     float* part = nullptr;
+    const bool wt = split_tile && p.tile_counters;                  // in-launch finish: the partial goes out write-through
+    const __amdgpu_buffer_rsrc_t rp = partial_rsrc(p);
     if (split_tile) {
         const int m_start = (p.split_from / n_tiles) * BM;
         part = p.partial + ((long long)kz * (p.M - m_start) - m_start) * (long long)p.Cout;
@@ -160,7 +164,12 @@ __device__ __forceinline__ bool wide_epilogue(const vfn_conv_desc& p, char* smem
             if (row >= p.M || !col_ok) continue;
             f32x4 v = *reinterpret_cast<const f32x4*>(sC + rr * PITCH + c4 * 4);
             if (split_tile) {
-                *reinterpret_cast<f32x4*>(part + (size_t)row * p.Cout + col) = v;
+                if (wt) {
+                    const int off = (int)((part + (size_t)row * p.Cout + col) - p.partial) * (int)sizeof(float);
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((ext_vector_type(4))) unsigned, v), rp, off, 0, CP_WT);
+                } else {
+                    *reinterpret_cast<f32x4*>(part + (size_t)row * p.Cout + col) = v;
+                }
                 continue;
             }
 #pragma unroll
@@ -559,7 +568,10 @@ __device__ __forceinline__ void conv_igemm_body(const vfn_conv_desc& p) {
         if (wide_epilogue<BM, BN, WM, WN>(p, smem_all, acc, false, 0, m0, n0, n_tiles, tid, grp == 0)) return;
         if (grp > 0) return;
     } else {
-        if (wide_epilogue<BM, BN, WM, WN>(p, smem, acc, split_tile, kz, m0, n0, n_tiles)) return;
+        if (wide_epilogue<BM, BN, WM, WN>(p, smem, acc, split_tile, kz, m0, n0, n_tiles)) {
+            if (split_tile && p.tile_counters) splitk_finish<BM, BN, WM * WN * 64>(p, reinterpret_cast<int*>(smem), tile, m0, n0, n_tiles);
+            return;
+        }
     }
 
     // split-K: raw partial sums to the workspace slab of this split; vfn_conv_splitk_reduce finishes
@@ -580,8 +592,7 @@ __device__ __forceinline__ void conv_igemm_body(const vfn_conv_desc& p) {
                 }
             }
         }
-        if (p.tile_counters) splitk_finish<BM, BN, WM * WN * 64>(p, reinterpret_cast<int*>(smem), tile, m0, n0, n_tiles);
-        return;
+        return;                                    // (split tiles always take the 16-byte epilogue above: the launcher checks)
     }
 
     // epilogue: lane holds filter column (lane&31) for rows (reg&3)+8*(reg>>2)+4*(lane>>5)
@@ -790,7 +801,10 @@ void conv_igemm_dma_kernel(const vfn_conv_desc p) {
         __syncthreads();                               // next tile landed; this buffer may be refilled
     }
 
-    if (wide_epilogue<BM, BN, WM, WN>(p, smem, acc, split_tile, kz, m0, n0, n_tiles)) return;
+    if (wide_epilogue<BM, BN, WM, WN>(p, smem, acc, split_tile, kz, m0, n0, n_tiles)) {
+        if (split_tile && p.tile_counters) splitk_finish<BM, BN, WM * WN * 64>(p, reinterpret_cast<int*>(smem), tile, m0, n0, n_tiles);
+        return;
+    }
 
     if (split_tile) {
         const int m_start = (p.split_from / n_tiles) * BM;
@@ -809,7 +823,6 @@ void conv_igemm_dma_kernel(const vfn_conv_desc p) {
                 }
             }
         }
-        if (p.tile_counters) splitk_finish<BM, BN, WM * WN * 64>(p, reinterpret_cast<int*>(smem), tile, m0, n0, n_tiles);
         return;
     }
 #pragma unroll

@@ -76,7 +76,7 @@ def pad_divide_by(h, w, d=16):
 
 
 WS_FLOATS = 16 * 1024 * 1024        # split-K workspace (64 MB), shared by all launches of a plan
-_INLAUNCH_SPLITK = __import__('os').environ.get('VFN_INLAUNCH_SPLITK') == '1'
+_INLAUNCH_SPLITK = __import__('os').environ.get('VFN_INLAUNCH_SPLITK', '1') == '1'
 
 
 def _tiles():
@@ -99,10 +99,12 @@ def apply_choice(desc, choice, ws, counters=None):
         bm, bn = _tiles()[cfg]
         n_tiles = (desc.Cout + bn - 1) // bn
         rows = desc.M - (split_from // n_tiles) * bm
-        # In-launch finish (last-arriving slice reduces the tile) is built and bit-identical, but measured SLOWER
-        # on MI355X (C2: 93 vs 100 frames/s): every slice workgroup pays an agent-scope release (L2 write-back),
-        # more than the ~2 us kernel boundary it removes.  Off unless VFN_INLAUNCH_SPLITK=1.
-        if desc.Cout % bn or not _INLAUNCH_SPLITK or ops.conv_cfg_kind(cfg) != 0:
+        # In-launch finish (the slice that arrives last reduces the tile; bit-identical to the reduce launch).  Round 1 published
+        # the partials with an agent-scope release fence (an L2 write-back per slice workgroup) and measured slower than the
+        # second launch; round 4 publishes them with write-through stores instead (no fence).  VFN_INLAUNCH_SPLITK=0 restores
+        # the separate reduce launch.  f32 LDS-tiled configurations only.
+        if (desc.Cout % bn or not _INLAUNCH_SPLITK or ops.conv_cfg_kind(cfg) != 0 or desc.w_packed or desc.in_lp or desc.out_lp
+                or desc.mask):
             counters = None
         ops.set_splitk(desc, ks, ws, split_from, rows, counters)
     else:
@@ -321,7 +323,7 @@ class FramePlan:
     # ------------------------------------------------------------------ builders
     def _lp_args(self, out):
         """Extra arguments of ops.upsample2x_add in bf16x3 mode: the image of relu(out) for the ResBlock behind it."""
-        if self.eng.mode != 2 or out.shape[-1] % 32:
+        if not self.eng.any_x3 or out.shape[-1] % 32:
             return ()
         self._lp_state[(out.data_ptr(), tuple(out.shape))] = True
         return (self.lp_twin(out), True)
@@ -344,7 +346,10 @@ class FramePlan:
         """``lp_out`` ('plain' / 'relu', bf16x3 mode only): the epilogue also writes the split-bf16 image of the result (of
         its ReLU) into the twin of ``out``; ``f32_out=False`` then drops the f32 tensor when only convolutions consume
         it.  An input whose twin holds the image this layer needs (has_lp) is staged from the twin without conversion."""
-        lp = self.eng.mode == 2
+        bf = self.eng.layer_mode(name)
+        lp = bf == 2
+        if self.eng.mixed:
+            f32_out = True                                    # (a consumer in another mode reads the f32 tensor)
         d = ops.make_conv_desc(x, layer.w, layer.cout, layer.k, layer.k, layer.stride, layer.pad, out,
                                layer.scale, layer.shift, res, relu_in, relu_out,
                                cin=layer.cin, in_ld=in_ld if in_ld is not None else x.shape[-1],
@@ -360,7 +365,6 @@ class FramePlan:
         else:
             self._lp_state.pop((out.data_ptr(), tuple(out.shape)), None)      # (an f32-only producer: the twin is stale)
         K = layer.k * layer.k * layer.cin
-        bf = self.eng.mode
         if bf == 1 and layer.cin % 64:                     # (the 32-channel local head: no 64-channel K tile)
             bf = 2
         if bf:
@@ -546,9 +550,33 @@ class Engine:
         if self.precision not in ops.MODES:
             raise ValueError(f"precision must be one of {sorted(ops.MODES)}, got {self.precision!r}")
         self.mode = ops.MODES[self.precision]
+        # per-layer arithmetic (round 4, the precision sweep of scripts/precision_sweep.py): "prefix=mode,prefix=mode" in
+        # VFN_PRECISION_MAP or a dict in model.precision_map; a layer takes the mode of the longest matching prefix of its name
+        # ('encoder_q', 'encoder_m.res4', 'keyval', 'decoder.RF2', 'decoder.local', 'memread', 'bank_update' ...), else the model's
+        pm = dict(getattr(model, 'precision_map', None) or {})
+        for item in filter(None, os.environ.get('VFN_PRECISION_MAP', '').split(',')):
+            k_, v_ = item.split('=')
+            pm.setdefault(k_.strip(), v_.strip())
+        for v_ in pm.values():
+            if v_ not in ops.MODES:
+                raise ValueError(f'precision map: unknown mode {v_!r}')
+        self.pmap = sorted(((k_, ops.MODES[v_]) for k_, v_ in pm.items()), key=lambda kv: -len(kv[0]))
+        self.mixed = bool(self.pmap)
+        self.any_x3 = self.mode == 2 or any(m_ == 2 for _, m_ in self.pmap)
+        self.fwd_count = 0           # segment samples / memorize calls run so far: vfloodnet_amd.autograd checks with them
+        self.mem_count = 0           # whether the activations a backward pass needs are still the ones its forward wrote
         self._side = None            # side stream for the query side of the next frames
         self._side_busy = None       # event behind the last work enqueued on it
         self._pack(model)
+
+    def layer_mode(self, name):
+        for prefix, m_ in self.pmap:
+            if name.startswith(prefix):
+                return m_
+        return self.mode
+
+    def layer_precision(self, name):
+        return {v: k for k, v in ops.MODES.items()}[self.layer_mode(name)]
 
     # ------------------------------------------------------------------ weights
     def _pack_trunk(self, enc):
@@ -624,6 +652,7 @@ class Engine:
         _, K, H, Wd = mask.shape
         p = self.plan(frame.shape[2], frame.shape[3], K, keep_acts=training)
         self.last_memorize = p
+        self.mem_count += 1
         p.frame_in.copy_(frame[0])
         p.mask_in.copy_(mask[0])                       # uint8 / float -> float32 (mask.float(), AFB_URR.py:262)
         for l in p.mem:
@@ -669,6 +698,7 @@ class Engine:
             for l in qs.post[slot]:
                 l()
             self.last_query = (p, qs, slot)                 # (where the backward slice finds this frame's activations)
+            self.fwd_count += 1
             if bs > 1:
                 out[b].copy_(p.score[0])
         return out
@@ -782,14 +812,15 @@ class Engine:
         d.stride_q, d.stride_k, d.stride_rs = 0, cap * DK, 0
         d.scale = scale
         d.ldq, d.q_per_obj, d.HW, d.obj_n, d.nsplit, d.mode = DK + DV, 0, HW, K, nsplit_scan, 0
-        d.precision = self.mode
+        mr_mode = self.layer_mode('memread')
+        d.precision = mr_mode
         d.work_counter = ptr(p.work)
-        klp, vlp = fb.lp_image() if self.mode else (None, None)      # the bank's kept split-bf16 image (reduced precision)
+        klp, vlp = fb.lp_image() if mr_mode else (None, None)      # the bank's kept split-bf16 image (reduced precision)
         d.bank_k_lp = ptr(klp) if klp is not None else None
         # f32: the scan stores the scores it forms and the apply kernel reads them back instead of repeating the
         # keys x queries GEMM (bit-identical; HW x capacity floats per object, VFN_STORE_SCORES=0 or more than
         # VFN_SCORES_MAX_GB switch it off)
-        scores = _scores_buffer(p, fb) if self.mode == 0 else None
+        scores = _scores_buffer(p, fb) if mr_mode == 0 else None
         if scores is not None:
             d.scores, d.stride_scores = ptr(scores), scores.shape[1]
         check(L.vfn_bank_scan(_lib.C.byref(d), s), 'vfn_bank_scan')
@@ -804,7 +835,7 @@ class Engine:
         m.stride_k, m.stride_v, m.stride_cnt, m.stride_info = cap * DK, cap * DV, cap, cap * 2
         m.scale, m.thres = scale, 1e-3
         m.ldq, m.ldqv, m.ld_out, m.HW, m.obj_n = DK + DV, DK + DV, p.dec_in.shape[-1], HW, K
-        m.precision = self.mode
+        m.precision = mr_mode
         # 128 query columns per workgroup (8 waves)
         m.nsplit = pick_nsplit(HW, K, fb.len_upper(), QT_SCAN, MAX_SPLIT)
         if klp is not None:

@@ -71,6 +71,7 @@ class FeatureBank:
         if self.precision not in ops.MODES:
             raise ValueError(f'precision must be one of {sorted(ops.MODES)}, got {self.precision!r}')
 
+        self._graph_kv = None
         self.peak_n = np.zeros(obj_n)
         self.replace_n = np.zeros(obj_n)
 
@@ -254,6 +255,7 @@ class FeatureBank:
         return [self._ibuf[i, :n[i]] for i in range(self.obj_n)]
 
     # ------------------------------------------------------------------ API
+    @torch.no_grad()
     def _write_columns(self, keys, values, start, frame_idx, hit_init):
         """Copy per-object [128,n] / [512,n] columns into the slabs at row ``start[i]`` (plumbing copies)."""
         for i in range(self.obj_n):
@@ -273,6 +275,10 @@ class FeatureBank:
         self._write_columns(keys, values, [0] * self.obj_n, frame_idx, 0.0)
         lens = [int(k.shape[1]) for k in keys]
         self._set_lengths(lens)
+        # training (train_video_seg.py:66-69): the keys / values memorize returned are nodes of an autograd graph; the slabs hold
+        # their values, these references carry the gradient that segment's backward sends to the bank back into memorize
+        # (vfloodnet_amd.autograd).  Any later change of the bank drops them.
+        self._graph_kv = (list(keys), list(values)) if any(getattr(t_, 'requires_grad', False) for t_ in list(keys) + list(values)) else None
 
     def _set_lengths(self, lens):
         self._len_host = list(lens)
@@ -299,6 +305,7 @@ class FeatureBank:
         if need > self._cap:
             self._grow(need)
         self._write_columns(keys, values, lens, frame_idx, 20.0)
+        self._graph_kv = None
         self._norms_valid = self._lp_valid = False
         self._set_lengths([lens[i] + int(keys[i].shape[1]) for i in range(self.obj_n)])
 
@@ -340,6 +347,7 @@ class FeatureBank:
     def update(self, prev_key, prev_value, frame_idx, update_rate=-1):
         """FeatureBank.py:53-115: cosine match -> merge (scatter_mean + blend) / append / LFU evict."""
         self._require_gpu()
+        self._graph_kv = None
         if update_rate == -1:
             update_rate = self.update_rate
         hw = prev_key[0].shape[1]
@@ -414,6 +422,7 @@ class FeatureBank:
         returns that balance.  (``update`` runs the same plan fused with the append; this entry point is the
         reference's public method.)"""
         self._require_gpu()
+        self._graph_kv = None
         L = _lib.lib()
         o, cap, hw = self.obj_n, self._cap, self._hw
         self._sync_len()

@@ -41,6 +41,7 @@ class AFB_URR(nn.Module):
         self.keyval_r4 = W.make_keyval(1024, 128, 512)
         self.decoder = W.make_decoder()
         self._engine = None
+        self._engine_version = -1
         self._allow_cpu_container = _allow_cpu_container
 
     # -- weight lifecycle ---------------------------------------------------
@@ -61,28 +62,48 @@ class AFB_URR(nn.Module):
             pass
         return out
 
+    def _param_version(self):
+        return sum(p._version for p in self.parameters())
+
     def engine(self):
+        # training: an optimizer that steps the nn.Parameters in place (torch.optim.AdamW, train_video_seg.py:109) leaves the
+        # engine's packed filters / folded BatchNorm constants stale -- every in-place update bumps the tensors' version counters
+        if self._engine is not None and self.training and self._engine_version != self._param_version():
+            self._engine = None
         if self._engine is None:
             from .engine import Engine
             self._engine = Engine(self)
+            self._engine_version = self._param_version()
         return self._engine
 
     # -- reference API ------------------------------------------------------
-    @torch.no_grad()
     def memorize(self, frame, mask):
         """AFB_URR.py:255-272.  frame f32[1,3,h,w] in [0,1]; mask [1,K,h,w] (u8 or float).  Identical in eval and in
         training mode (the reference pads here in both, :259); BatchNorm always uses its running statistics -- in
-        training mode that is the frozen-BN setting of train_video_seg.py:103-106."""
-        return self.engine().memorize(frame, mask, training=self.training)
+        training mode that is the frozen-BN setting of train_video_seg.py:103-106.  In training mode with autograd on the
+        returned keys / values are nodes of an autograd graph (vfloodnet_amd.autograd), as train_video_seg.py:66-74 expects."""
+        from . import autograd as A
+        if A.wants_graph(self):
+            return A.memorize(self, frame, mask)
+        with torch.no_grad():
+            return self.engine().memorize(frame, mask, training=self.training)
+
+    def segment(self, frame, fb_global):
+        if fb_global.obj_n >= 2:
+            from . import autograd as A
+            if A.wants_graph(self):
+                # train_video_seg.py:69-74: ``scores, uncertainty`` carry the graph; ``loss.backward()`` runs the HIP backward
+                return A.segment(self, frame, fb_global)
+        return self._segment_no_grad(frame, fb_global)
 
     @torch.no_grad()
-    def segment(self, frame, fb_global):
+    def _segment_no_grad(self, frame, fb_global):
         """AFB_URR.py:274-318, forward only.  frame f32[bs,3,h,w]; returns (logits f32[bs,obj_n,h,w], uncertainty).
         eval: pads to a multiple of 16, uncertainty is None (test_video_seg.py:108).  After ``model.train()``: the
         training branch -- no padding (:278) and the scalar uncertainty of :302-305 as a 0-dim tensor
-        (train_video_seg.py:69,73-74) -- with BatchNorm frozen as train_video_seg.py:103-106 sets it.  There is no
-        autograd graph: the backward pass and the optimiser step of the training loop are ``vfloodnet_amd.train``
-        (``train_step``), which differentiates the activations this call keeps."""
+        (train_video_seg.py:69,73-74) -- with BatchNorm frozen as train_video_seg.py:103-106 sets it.  (This is the graph-free
+        form, used under ``torch.no_grad()`` and by ``vfloodnet_amd.train.train_step``, which differentiates the activations
+        this call keeps; with autograd on, ``segment`` goes through ``vfloodnet_amd.autograd``.)"""
         if fb_global.obj_n < 2:
             # the reference fails here as well: calc_uncertainty takes the top-2 over the object axis
             # (myutils/data.py:40-46, `score.topk(k=2, dim=1)` -> "selected index k out of range")

@@ -336,6 +336,22 @@ def segment_loss(score, label, lu, want_grad=True):
     return stats, grad
 
 
+def segment_uncertainty_backward(score, g_unc, g_score=None):
+    """dL/dscores [bs,obj,H,W] = g_score (optional, from the caller's criterion) + g_unc * d uncertainty / d scores, where
+    ``g_unc`` is dL/duncertainty as a 0-dim DEVICE tensor (autograd's hand-over; no host synchronisation)."""
+    bs, obj_n, H, W = score.shape
+    assert score.is_contiguous() and g_unc.is_cuda and g_unc.numel() == 1 and g_unc.dtype == torch.float32
+    if g_score is not None:
+        g_score = g_score.to(torch.float32).contiguous()
+        assert g_score.shape == score.shape
+    partial = torch.empty(2 * bs * 64, device=score.device, dtype=torch.float32)
+    stats = torch.empty(3 + bs, device=score.device, dtype=torch.float32)
+    grad = torch.empty_like(score)
+    check(_lib.lib().vfn_segment_uncertainty_backward_f32(ptr(score), bs, obj_n, H * W, ptr(g_unc), ptr(g_score), ptr(partial),
+                                                          ptr(stats), ptr(grad), stream()), 'vfn_segment_uncertainty_backward_f32')
+    return grad
+
+
 # --------------------------------------------------------------------------- loop operators
 def resize_bicubic(x, Ho, Wo, out=None):
     """x [C,Hi,Wi] (or [1,C,Hi,Wi]) float32 -> [.., Ho, Wo]."""

@@ -79,8 +79,10 @@ class ClipRunner:
         self.obj_n = obj_n
         self.size = size
         self.mem_every = mem_every
-        self.fb = FeatureBank(obj_n, budget, self.device, update_rate=update_rate, thres_close=thres_close,
-                              precision=getattr(model, 'precision', None))
+        prec = getattr(model, 'precision', None)
+        if getattr(model, 'precision_map', None) or os.environ.get('VFN_PRECISION_MAP'):
+            prec = model.engine().layer_precision('bank_update')      # (per-layer arithmetic: engine.Engine.layer_mode)
+        self.fb = FeatureBank(obj_n, budget, self.device, update_rate=update_rate, thres_close=thres_close, precision=prec)
         self.t = 0
         self._pinned = None
         self._stats_pinned = None
