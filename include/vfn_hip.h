@@ -28,7 +28,7 @@ extern "C" {
  * vfn_abi_version() == VFN_ABI_VERSION of the header the binding was written against, and
  * vfn_sizeof_desc(which) == sizeof of the binding's own struct: checked when the library is loaded. */
 #define VFN_ABI_VERSION 10
-enum { VFN_DESC_CONV = 0, VFN_DESC_STEM = 1, VFN_DESC_BANKSCAN = 2, VFN_DESC_MEMREAD = 3, VFN_DESC_BANK = 4 };
+enum { VFN_DESC_CONV = 0, VFN_DESC_STEM = 1, VFN_DESC_BANKSCAN = 2, VFN_DESC_MEMREAD = 3, VFN_DESC_BANK = 4, VFN_DESC_WGRAD = 5 };
 int vfn_abi_version(void);
 int vfn_sizeof_desc(int which);
 
@@ -204,6 +204,26 @@ int vfn_segment_uncertainty_f32(const float* logit, int bs, int obj_n, int n, fl
  *     gpm [N][h/2][w/2][C] = interpolate^T(gm). */
 int vfn_transpose_taps_f32(const float* x, int N, int H, int W, int C, int ld_x, int relu, int k, int stride, int pad, int Ho, int Wo,
                            const float* colscale, float* out, int Mpad, void* stream);
+
+/* vfn_conv_wgrad_f32 (ABI 10)   the weight gradient of y = conv_{k x k, stride, pad}(act(x)) as an implicit GEMM over the pixels,
+ *     straight from the NHWC tensors (no transposed copies): dw[co][(kh*k + kw)*Cin + ci] (the packed filter layout) =
+ *     (accumulate ? dw : 0) + rowscale[co] * sum_m gy[m][co] * act(x)[pixel(m) + (kh, kw)][ci].  loss.backward() of
+ *     train_video_seg.py:73 for every nn.Conv2d of AFB_URR.py / the torchvision bottlenecks.  ksplit > 1 cuts the pixels into
+ *     4 * ksplit slices (4 per workgroup, summed through LDS; the rest through `partial` and a reduce launch, fixed order). */
+typedef struct vfn_wgrad_desc {
+    const float* x;          /* NHWC [N,H,W,ld_x]: the convolution's input (before act) */
+    const float* gy;         /* [N,Ho,Wo,ld_g]: dL/dy */
+    const float* rowscale;   /* optional [Cout]: the frozen BatchNorm scale behind the convolution */
+    float* dw;               /* [Cout][k*k*Cin] */
+    float* partial;          /* ksplit > 1: [ksplit][Cout][k*k*Cin] floats of workspace */
+    int N, H, W, Cin, ld_x;
+    int Ho, Wo, Cout, ld_g;
+    int k, stride, pad;
+    int relu;                /* act = max(., 0) */
+    int accumulate;          /* add to dw instead of overwriting it */
+    int ksplit;
+} vfn_wgrad_desc;
+int vfn_conv_wgrad_f32(const vfn_wgrad_desc* d, void* stream);
 /* Encoder pieces (ResNet trunks, BatchNorm frozen as train_video_seg.py:103-106 sets it), memory read, optimiser:
  * vfn_dilate2_f32          out[n][2y][2x][c] = g[n][y][x][c], 0 elsewhere ([N][H][W][C] from [N][Ho][Wo][C]): the data gradient of a
  *     stride-2 convolution is the stride-1 data-gradient convolution of this.
@@ -219,6 +239,9 @@ int vfn_transpose_taps_f32(const float* x, int N, int H, int W, int C, int ld_x,
 int vfn_dilate2_f32(const float* g, float* out, int N, int Ho, int Wo, int H, int W, int C, void* stream);
 int vfn_bn_param_grads_f32(const float* g, const float* y, const float* idn, const float* beta, const float* gamma, int M, int C,
                            float* partial, int nb, float* dgamma, float* dbeta, void* stream);
+int vfn_bn_param_grads_acc_f32(const float* g, const float* y, const float* idn, const float* beta, const float* gamma, int M, int C,
+                               float* partial, int nb, float* dgamma, float* dbeta, int accumulate, int* counter,
+                               void* stream);   /* (ABI 10; accumulate / counter as vfn_colsum_acc_f32) */
 int vfn_maxpool3x3s2_backward_f32(const float* x, const float* g, float* gx, int N, int H, int W, int C, const float* add, int relu_mask,
                                   void* stream);
 int vfn_softmax_cols_f32(const float* S, int B, int Q, int ld, float scale, float* P, void* stream);
@@ -226,6 +249,11 @@ int vfn_softmax_cols_backward_f32(const float* P, const float* dP, int B, int Q,
 int vfn_adamw_f32(float* p, const float* g, float* m, float* v, long long n, double lr, double beta1, double beta2, double eps,
                   double weight_decay, int step, void* stream);
 int vfn_colsum_f32(const float* x, int M, int C, int ld, float* partial, int nb, float* out, void* stream);
+/* the same with the result ADDED to `out` when accumulate != 0 (ABI 10: a running gradient over the samples of a batch);
+ * counter != NULL (one int in device memory, zero at rest): ONE launch -- the blocks publish their partial rows write-through and
+ * the block that arrives last adds them in block order (the same sums, no second launch) */
+int vfn_colsum_acc_f32(const float* x, int M, int C, int ld, float* partial, int nb, float* out, int accumulate, int* counter,
+                       void* stream);
 int vfn_upsample2x_add_backward_f32(const float* gm, float* gs, float* gpm, int N, int h, int w, int C, int s_bcast,
                                     void* stream);
 /* The decoder's tail backwards (AFB_URR.py:214-237,300,309-316), in the stages the host threads the local head's convolution

@@ -414,3 +414,39 @@ def test_pred2_tap_gemm_matches_conv(gpu, N, h, w, cin):
     out = torch.empty(N, h, w, 2, device=gpu)
     ops.pred2_gather(z, layer.bias, out)
     assert (nchw(out.cpu()) - ref).abs().max() < 2e-5 * max(1.0, float(ref.abs().max()))
+
+
+@pytest.mark.parametrize('case', [(2, 12, 20, 64, 64, 3, 1, True), (1, 13, 19, 128, 96, 3, 2, False), (2, 9, 14, 256, 256, 1, 1, False),
+                                  (1, 16, 24, 256, 512, 1, 2, False), (2, 30, 40, 32, 32, 3, 1, True), (1, 25, 40, 1024, 640, 3, 1, False),
+                                  (3, 50, 50, 64, 256, 1, 1, False)])
+def test_conv_wgrad_implicit_gemm_vs_autograd(gpu, case):
+    """vfn_conv_wgrad_f32 (weight gradient straight from the NHWC tensors, reduction over the pixels) against torch.autograd of
+    F.conv2d in float64: with / without ReLU on the input, strides 1 / 2, a frozen-BatchNorm row scale, accumulation into an
+    existing gradient, forced split factors (the fixed-order reduce) and run-to-run bit-reproducibility."""
+    import torch.nn.functional as F
+    from vfloodnet_amd import ops
+    N, H, W, Cin, Cout, k, s, relu = case
+    g = torch.Generator().manual_seed(hash(case) & 0xFFFF)
+    x = torch.randn(N, Cin, H, W, generator=g)
+    w = (torch.randn(Cout, Cin, k, k, generator=g) / (Cin * k * k) ** 0.5).double().requires_grad_()
+    scale = 1 + 0.1 * torch.randn(Cout, generator=g)
+    y = F.conv2d(F.relu(x.double()) if relu else x.double(), w, stride=s, padding=k // 2) * scale.double().view(1, -1, 1, 1)
+    gy = torch.randn(y.shape, generator=g)
+    (y * gy.double()).sum().backward()
+    ref = w.grad.permute(0, 2, 3, 1).reshape(Cout, -1)                       # packed (kh, kw, cin)
+    xd = x.permute(0, 2, 3, 1).contiguous().to(gpu)
+    gd = gy.permute(0, 2, 3, 1).contiguous().to(gpu)
+    sc = scale.to(gpu)
+    tol = 2e-4 * ref.abs().max().item()
+    first = None
+    for ks in (None, 1, 3):
+        got = ops.conv_wgrad(xd, gd, k, s, k // 2, relu=relu, rowscale=sc, ksplit=ks)
+        torch.cuda.synchronize()
+        assert (got.cpu().double() - ref).abs().max().item() < tol, (ks, (got.cpu().double() - ref).abs().max().item(), tol)
+        again = ops.conv_wgrad(xd, gd, k, s, k // 2, relu=relu, rowscale=sc, ksplit=ks)
+        assert torch.equal(got, again)
+        if first is None:
+            first = got
+    acc = first.clone()
+    ops.conv_wgrad(xd, gd, k, s, k // 2, relu=relu, rowscale=sc, out=acc, accumulate=True)
+    assert (acc.cpu().double() - 2 * ref).abs().max().item() < 2 * tol

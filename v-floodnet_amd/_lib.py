@@ -27,6 +27,13 @@ class ConvDesc(C.Structure):
                 ('w_packed', C.c_int), ('in_lp', C.c_int), ('out_lp_relu', C.c_int), ('out_lp', c_fp), ('mask', c_fp), ('mask_ld', C.c_int), ('mask_after', C.c_int)]
 
 
+class WgradDesc(C.Structure):
+    _fields_ = [('x', c_fp), ('gy', c_fp), ('rowscale', c_fp), ('dw', c_fp), ('partial', c_fp),
+                ('N', C.c_int), ('H', C.c_int), ('W', C.c_int), ('Cin', C.c_int), ('ld_x', C.c_int),
+                ('Ho', C.c_int), ('Wo', C.c_int), ('Cout', C.c_int), ('ld_g', C.c_int),
+                ('k', C.c_int), ('stride', C.c_int), ('pad', C.c_int), ('relu', C.c_int), ('accumulate', C.c_int), ('ksplit', C.c_int)]
+
+
 class StemDesc(C.Structure):
     _fields_ = [('frame', c_fp), ('mask', c_fp), ('w', c_fp), ('scale', c_fp), ('shift', c_fp), ('out', c_fp),
                 ('mean', C.c_float * 3), ('std', C.c_float * 3),
@@ -68,7 +75,7 @@ class BankDesc(C.Structure):
 
 
 ABI_VERSION = 10         # include/vfn_hip.h VFN_ABI_VERSION; csrc/abi.hip
-DESC_IDS = {0: ConvDesc, 1: StemDesc, 2: BankScanDesc, 3: MemReadDesc, 4: BankDesc}     # vfn_sizeof_desc(which)
+DESC_IDS = {0: ConvDesc, 1: StemDesc, 2: BankScanDesc, 3: MemReadDesc, 4: BankDesc, 5: WgradDesc}     # vfn_sizeof_desc(which)
 
 
 def lib():
@@ -120,6 +127,7 @@ def _declare(L):
     L.vfn_bank_append.argtypes = [C.POINTER(BankDesc), p]
     L.vfn_bank_remove.argtypes = [C.POINTER(BankDesc), p]
     L.vfn_bank_refresh_norms.argtypes = [C.POINTER(BankDesc), p, p, p, p]
+    L.vfn_conv_wgrad_f32.argtypes = [C.POINTER(WgradDesc), p]
     L.vfn_bank_refresh_lp.argtypes = [C.POINTER(BankDesc), p, p, i, p]
     for name, args in SIGNATURES.items():
         fn = getattr(L, name)
@@ -138,11 +146,13 @@ SIGNATURES = {
     'vfn_transpose_taps_f32': [_p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p, _p, _i, _p],
     'vfn_dilate2_f32': [_p, _p, _i, _i, _i, _i, _i, _i, _p],
     'vfn_bn_param_grads_f32': [_p, _p, _p, _p, _p, _i, _i, _p, _i, _p, _p, _p],
+    'vfn_bn_param_grads_acc_f32': [_p, _p, _p, _p, _p, _i, _i, _p, _i, _p, _p, _i, _p, _p],
     'vfn_maxpool3x3s2_backward_f32': [_p, _p, _p, _i, _i, _i, _i, _p, _i, _p],
     'vfn_softmax_cols_f32': [_p, _i, _i, _i, _f, _p, _p],
     'vfn_softmax_cols_backward_f32': [_p, _p, _i, _i, _i, _f, _p, _p],
     'vfn_adamw_f32': [_p, _p, _p, _p, _ll, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, _i, _p],
     'vfn_colsum_f32': [_p, _i, _i, _i, _p, _i, _p, _p],
+    'vfn_colsum_acc_f32': [_p, _i, _i, _i, _p, _i, _p, _i, _p, _p],
     'vfn_upsample2x_add_backward_f32': [_p, _p, _p, _i, _i, _i, _i, _i, _p],
     'vfn_tail_grad_o_f32': [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p],
     'vfn_segment_loss_f32': [_p, _p, _i, _i, _i, _f, _p, _p, _p, _p],
@@ -186,7 +196,7 @@ SIGNATURES = {
 ALL_SYMBOLS = sorted(list(SIGNATURES) + [
     'vfn_abi_version', 'vfn_sizeof_desc', 'vfn_conv_cfg_count', 'vfn_conv_cfg_tile', 'vfn_conv_cfg_info', 'vfn_conv_cfg_wk', 'vfn_conv_cfg_tpb', 'vfn_conv_cfg_kind', 'vfn_conv_cfg_name', 'vfn_conv2d_nhwc_f32', 'vfn_conv2d_nhwc_bf16', 'vfn_conv2d_nhwc_bf16x3',
     'vfn_stem_conv7x7_f32',
-    'vfn_bank_scan', 'vfn_memread_apply', 'vfn_memread_finish', 'vfn_bank_merge', 'vfn_bank_append', 'vfn_bank_remove', 'vfn_bank_refresh_norms', 'vfn_bank_refresh_lp'])
+    'vfn_bank_scan', 'vfn_memread_apply', 'vfn_memread_finish', 'vfn_bank_merge', 'vfn_bank_append', 'vfn_bank_remove', 'vfn_bank_refresh_norms', 'vfn_bank_refresh_lp', 'vfn_conv_wgrad_f32'])
 
 
 def check(status, what):

@@ -26,6 +26,9 @@ from ._lib import ptr, stream, check
 from .engine import choose_cfg, apply_choice, DK, DV
 
 
+_IMPLICIT_WGRAD = __import__('os').environ.get('VFN_IMPLICIT_WGRAD', '1') == '1'      # 0: the round-3 path (transposed operands)
+
+
 def _dgrad_filters(w):
     """Forward filters [Cout,Cin,3,3] -> packed filters of the data-gradient convolution (Cin 'filters' over Cout channels)."""
     wt = w.detach().float().flip(2, 3).transpose(0, 1).contiguous()          # [Cin, Cout, 3, 3]
@@ -34,6 +37,7 @@ def _dgrad_filters(w):
 
 class DecoderBackward:
     NB = 256          # blocks of the column-sum's first stage
+    NB1 = 128         # ... of the one-launch form (vfn_colsum_acc_f32 with a counter)
 
     def __init__(self, engine):
         self.eng = engine
@@ -65,6 +69,8 @@ class DecoderBackward:
         wp[:2] = d.local_pred2.weight.detach().float()
         self.f['local_pred2'] = (_dgrad_filters(wp).to(dev), d.local_pred2.weight.shape[1])
         self._scratch = {}
+        self._ticket = torch.zeros(1, dtype=torch.int32, device=dev)       # arrival counter of the one-launch column sums (zero at rest)
+        self.sink = None                                   # ModelBackward: weight gradients accumulate there, in the kernel
 
     # ------------------------------------------------------------------ pieces
     def _buf(self, key, numel):
@@ -78,7 +84,7 @@ class DecoderBackward:
         choice = choose_cfg(d.M, d.Cout, d.KH * d.KW * d.Cin, 0)
         if choice[1] > 1 and (d.out_ld % 4 or (d.res and d.res_ld % 4) or (d.mask and d.mask_ld % 4)):
             choice = (choice[0], 1, 0)
-        cfg = apply_choice(d, choice, plan.ws, None)
+        cfg = apply_choice(d, choice, plan.ws, plan.cnt)          # (split tiles are finished inside the launch)
         ops.conv2d_launch(d, cfg, 0)
 
     def dgrad(self, plan, name, gy, N, H, Wd, mask=None, res=None):
@@ -92,15 +98,28 @@ class DecoderBackward:
         self._launch(d, plan)
         return out
 
-    def wgrad(self, plan, x, gy, relu, x_ld=None, x_c=None, gy_c=None):
+    def wgrad(self, plan, x, gy, relu, x_ld=None, x_c=None, gy_c=None, name=None):
         """(dL/dW [Cout,Cin,3,3], dL/db [Cout]) of y = conv3x3(act(x)) + b given gy [N,H,W,Cout] (``gy_c``: the first gy_c
-        channels of a wider gradient tensor)."""
+        channels of a wider gradient tensor).  ``name`` (with a ``sink``): the weight gradient is accumulated into the sink's
+        buffer of that parameter by the kernel and None is returned in its place."""
         L = _lib.lib()
         N, H, Wd = gy.shape[0], gy.shape[1], gy.shape[2]
         cout = gy_c if gy_c is not None else gy.shape[-1]
         cin = x_c if x_c is not None else x.shape[-1]
         ld_x = x_ld if x_ld is not None else x.shape[-1]
         M = N * H * Wd
+        if name is not None and self.sink is not None and self.sink.wgrad_into(name, x, gy, 3, 1, 1, cin, cout, ld_x, relu, None, N, H, Wd):
+            db = torch.empty(cout, device=self.dev)
+            part = self._buf('colsum', self.NB * cout)
+            check(L.vfn_colsum_acc_f32(ptr(gy), M, cout, gy.shape[-1], ptr(part), self.NB1, ptr(db), 0, ptr(self._ticket), stream()), 'vfn_colsum_acc_f32')
+            return None, db
+        if _IMPLICIT_WGRAD and cin % 32 == 0 and cout >= 32:
+            # round 4: the reduction over the pixels straight from the NHWC tensors (vfn_conv_wgrad_f32), nothing transposed
+            dw = ops.conv_wgrad(x, gy, 3, 1, 1, cin=cin, cout=cout, ld_x=ld_x, relu=relu, N=N, H=H, W=Wd)
+            db = torch.empty(cout, device=self.dev)
+            part = self._buf('colsum', self.NB * cout)
+            check(L.vfn_colsum_acc_f32(ptr(gy), M, cout, gy.shape[-1], ptr(part), self.NB1, ptr(db), 0, ptr(self._ticket), stream()), 'vfn_colsum_acc_f32')
+            return dw.view(cout, 3, 3, cin).permute(0, 3, 1, 2), db
         Mpad = (M + 31) // 32 * 32
         rows = (9 * cin + 255) // 256 * 256                                  # filter rows padded to the widest tile
         xt = self._buf('xt', rows * Mpad).view(rows, Mpad)
@@ -125,15 +144,15 @@ class DecoderBackward:
         ops.conv2d_launch(d, cfg, 0)
         db = torch.empty(cout, device=self.dev)
         part = self._buf('colsum', self.NB * cout)
-        check(L.vfn_colsum_f32(ptr(gy), M, cout, gy.shape[-1], ptr(part), self.NB, ptr(db), stream()), 'vfn_colsum_f32')
+        check(L.vfn_colsum_acc_f32(ptr(gy), M, cout, gy.shape[-1], ptr(part), self.NB1, ptr(db), 0, ptr(self._ticket), stream()), 'vfn_colsum_acc_f32')
         return dw.view(cout, 3, 3, cin).permute(0, 3, 1, 2), db              # packed (kh,kw,cin) -> torch's [Cout,Cin,kh,kw]
 
     def resblock(self, plan, grads, name, x, r, gy, N, H, Wd):
         """ResBlock y = x + conv2(relu(conv1(relu(x)))) (AFB_URR.py:23-30): returns dL/dx; weight gradients into ``grads``."""
         g_r = self.dgrad(plan, name + '.conv2', gy, N, H, Wd, mask=r)
-        grads[f'decoder.{name}.conv2.weight'], grads[f'decoder.{name}.conv2.bias'] = self.wgrad(plan, r, gy, True)
+        grads[f'decoder.{name}.conv2.weight'], grads[f'decoder.{name}.conv2.bias'] = self.wgrad(plan, r, gy, True, name=f'decoder.{name}.conv2.weight')
         g_x = self.dgrad(plan, name + '.conv1', g_r, N, H, Wd, mask=x, res=gy)
-        grads[f'decoder.{name}.conv1.weight'], grads[f'decoder.{name}.conv1.bias'] = self.wgrad(plan, x, g_r, True)
+        grads[f'decoder.{name}.conv1.weight'], grads[f'decoder.{name}.conv1.bias'] = self.wgrad(plan, x, g_r, True, name=f'decoder.{name}.conv1.weight')
         return g_x
 
     def refine(self, plan, grads, name, f, s, dm, g_out, N, H, Wd):
@@ -146,7 +165,7 @@ class DecoderBackward:
         g_pm = torch.empty(N, H // 2, Wd // 2, C, device=self.dev)
         check(L.vfn_upsample2x_add_backward_f32(ptr(g_m), ptr(g_s), ptr(g_pm), N, H, Wd, C, 1, stream()), 'vfn_upsample2x_add_backward_f32')
         g_s0 = self.resblock(plan, grads, name + '.ResFS', s[0], s[1], g_s, 1, H, Wd)
-        grads[f'decoder.{name}.convFS.weight'], grads[f'decoder.{name}.convFS.bias'] = self.wgrad(plan, f, g_s0, False)
+        grads[f'decoder.{name}.convFS.weight'], grads[f'decoder.{name}.convFS.bias'] = self.wgrad(plan, f, g_s0, False, name=f'decoder.{name}.convFS.weight')
         g_f = self.dgrad(plan, name + '.convFS', g_s0, 1, H, Wd)
         return g_f, g_pm
 
@@ -165,7 +184,7 @@ class DecoderBackward:
         # pred2(relu(x)), x = RF2's output (AFB_URR.py:212)
         x = p.d4[2]
         g = self.dgrad(p, 'pred2', g32, K, p.h4, p.w4, mask=x)
-        grads['decoder.pred2.weight'], grads['decoder.pred2.bias'] = self.wgrad(p, x, grad_p.contiguous(), True)
+        grads['decoder.pred2.weight'], grads['decoder.pred2.bias'] = self.wgrad(p, x, grad_p.contiguous(), True, name='decoder.pred2.weight')
         # RF2, RF3 (AFB_URR.py:210-211)
         g_r2, g = self.refine(p, grads, 'RF2', o(qs.q['res2']['out']), [o(t) for t in qs.s4], p.d4, g, K, p.h4, p.w4)
         g_r3, g = self.refine(p, grads, 'RF3', o(qs.q['res3']['out']), [o(t) for t in qs.s8], p.d8, g, K, p.h8, p.w8)
@@ -211,7 +230,7 @@ class DecoderBackward:
         # q = conf * local_pred2(relu(local_ResMM(local_convFM(cat([r1, r1_local])))))   (AFB_URR.py:231-234)
         l2 = p.l2
         g = self.dgrad(p, 'local_pred2', g_q, K, h2, w2, mask=l2[2])
-        grads['decoder.local_pred2.weight'], grads['decoder.local_pred2.bias'] = self.wgrad(p, l2[2], g_q, True, gy_c=2)
+        grads['decoder.local_pred2.weight'], grads['decoder.local_pred2.bias'] = self.wgrad(p, l2[2], g_q, True, gy_c=2, name='decoder.local_pred2.weight')
         g = self.resblock(p, grads, 'local_ResMM', l2[0], l2[1], g, K, h2, w2)
         g_lm = self.dgrad(p, 'local_convFM.loc', g, K, h2, w2)
         dw_loc, _ = self.wgrad(p, p.lm, g, False)
@@ -264,11 +283,13 @@ def _bn_scale(bn):
 
 
 class ModelBackward:
+
     """dL/dscores -> the gradient of EVERY parameter of AFB_URR for one training sample (train_video_seg.py:65-74):
     decoder (DecoderBackward), memory read, KeyValue, query encoder; ``finish_memorize`` then carries the gradients that
     arrived at the bank's keys / values back through KeyValue and the memory encoder.  Gradients accumulate in ``self.grads``
     (state-dict name -> tensor)."""
     NB = 256
+    NB1 = 128         # blocks of the one-launch column sums (the last block adds NB1 partial rows)
 
     def __init__(self, engine):
         self.eng = engine
@@ -290,15 +311,53 @@ class ModelBackward:
         kv = m.keyval_r4
         wkv = torch.cat([kv.Key.weight.detach().float(), kv.Value.weight.detach().float()], 0)      # one 640-filter conv
         self.cb['keyval'] = _ConvBwd(wkv, 1, 1, dev)
-        self.grads = {}
+        self._grads = {}
+        self._ticket = torch.zeros(1, dtype=torch.int32, device=dev)       # arrival counter of the one-launch column sums (zero at rest)
+        # convolution weight gradients accumulate IN THE KERNEL (vfn_conv_wgrad_f32, accumulate = 1) in the packed filter layout
+        # [Cout][kh][kw][Cin]; ``grads`` hands them out as [Cout,Cin,kh,kw] views -- no torch add / copy per sample and layer
+        self._packed = {}            # name -> (buffer [cout, k*k*cin], cout, k, cin)
+        self.dec.sink = self         # the decoder's weight gradients go the same way
+
+    @property
+    def grads(self):
+        """state-dict name -> gradient, everything accumulated so far."""
+        for name, (buf, cout, k, cin) in list(self._packed.items()):
+            g = buf.view(cout, k, k, cin).permute(0, 3, 1, 2)
+            if name in self._grads:
+                self._grads[name] += g
+            else:
+                self._grads[name] = g
+            del self._packed[name]
+        return self._grads
+
+    def wgrad_into(self, name, x, gy, k, stride, pad, cin, cout, ld_x, relu, rowscale, N, H, Wd):
+        """Accumulate dL/dW of one convolution for parameter ``name`` (see vfn_conv_wgrad_f32); False if the shapes need the
+        round-3 path (channel counts that are not multiples of 32, two-filter heads)."""
+        if not (_IMPLICIT_WGRAD and cout >= 32 and (cin % 32 == 0 or cin < 32)) or name in self._grads:
+            return False
+        have = self._packed.get(name)
+        if have is None:
+            buf = torch.empty(cout, k * k * cin, device=self.dev)
+            self._packed[name] = (buf, cout, k, cin)
+        else:
+            buf = have[0]
+        ops.conv_wgrad(x, gy, k, stride, pad, cin=cin, cout=cout, ld_x=ld_x, relu=relu, rowscale=rowscale, out=buf,
+                       accumulate=have is not None, N=N, H=H, W=Wd)
+        return True
 
     # ------------------------------------------------------------------ generic pieces
     def _acc(self, name, g):
+        grads = self.grads if name in self._packed else self._grads
         g = g.contiguous()
-        if name in self.grads:
-            self.grads[name] += g
+        if name in grads:
+            grads[name] += g
         else:
-            self.grads[name] = g.clone()
+            grads[name] = g.clone()
+
+    def _wacc(self, name, plan, x, gy, cb, N, H, Wd, relu=False):
+        """dL/dW of the convolution ``cb`` into parameter ``name``."""
+        if not self.wgrad_into(name, x, gy, cb.k, cb.stride, cb.pad, cb.cin, gy.shape[-1], x.shape[-1], relu, cb.scale, N, H, Wd):
+            self._acc(name, self._wgrad(plan, x, gy, cb, N, H, Wd, relu=relu))
 
     def _dgrad(self, plan, cb, gy, N, H, Wd, mask=None, res=None, mask_after=False):
         """Data gradient of a k x k convolution at input resolution H x W (``gy`` already zero-inserted for stride 2)."""
@@ -324,6 +383,9 @@ class ModelBackward:
         cout = gy.shape[-1]
         Ho, Wo = gy.shape[1], gy.shape[2]
         M = N * Ho * Wo
+        if _IMPLICIT_WGRAD and cout >= 32 and (cin % 32 == 0 or cin < 32):        # (cin < 32: the stems' 3 / 5 planes)
+            dw = ops.conv_wgrad(x, gy, k, s, pad, cin=cin, cout=cout, ld_x=ld_x, relu=relu, rowscale=cb.scale, N=N, H=H, W=Wd)
+            return dw.view(cout, k, k, cin).permute(0, 3, 1, 2)
         Mpad = (M + 31) // 32 * 32
         kk = k * k * cin
         rows = (kk + 255) // 256 * 256
@@ -351,25 +413,32 @@ class ModelBackward:
         ops.conv2d_launch(d, cfg, 0)
         return dw.view(cout, k, k, cin).permute(0, 3, 1, 2)
 
+    def _small(self, name, C):
+        """(running-gradient buffer of a bias / BatchNorm parameter, does it hold a value already)"""
+        have = name in self._grads
+        if not have:
+            self._grads[name] = torch.empty(C, device=self.dev)
+        return self._grads[name], int(have)
+
     def _colsum(self, g, C=None):
         C = C if C is not None else g.shape[-1]
         M = g.numel() // g.shape[-1]
         out = torch.empty(C, device=self.dev)
         part = self.dec._buf('colsum', self.NB * C)
-        check(_lib.lib().vfn_colsum_f32(ptr(g), M, C, g.shape[-1], ptr(part), self.NB, ptr(out), stream()), 'vfn_colsum_f32')
+        check(_lib.lib().vfn_colsum_acc_f32(ptr(g), M, C, g.shape[-1], ptr(part), self.NB1, ptr(out), 0, ptr(self._ticket), stream()),
+              'vfn_colsum_acc_f32')
         return out
 
     def _bn_grads(self, name, bn, g, y, idn=None):
         """Gradients of a frozen BatchNorm's weight / bias (they stay trainable: only the statistics are frozen)."""
         C = g.shape[-1]
         M = g.numel() // C
-        dg, db = torch.empty(C, device=self.dev), torch.empty(C, device=self.dev)
-        part = self.dec._buf('bn', 2 * self.NB * C)
-        check(_lib.lib().vfn_bn_param_grads_f32(ptr(g), ptr(y), ptr(idn), ptr(bn.bias.detach().float().contiguous()),
-                                                ptr(bn.weight.detach().float().contiguous()), M, C, ptr(part), self.NB, ptr(dg), ptr(db),
-                                                stream()), 'vfn_bn_param_grads_f32')
-        self._acc(name + '.weight', dg)
-        self._acc(name + '.bias', db)
+        dg, acc_g = self._small(name + '.weight', C)                          # accumulated by the kernel: no torch add per sample
+        db, acc_b = self._small(name + '.bias', C)
+        assert acc_g == acc_b
+        part = self.dec._buf('bn', 2 * self.NB1 * C)
+        check(_lib.lib().vfn_bn_param_grads_acc_f32(ptr(g), ptr(y), ptr(idn), ptr(bn.bias.detach()), ptr(bn.weight.detach()), M, C, ptr(part),
+                                                    self.NB1, ptr(dg), ptr(db), acc_g, ptr(self._ticket), stream()), 'vfn_bn_param_grads_acc_f32')
 
     # ------------------------------------------------------------------ ResNet bottleneck / trunk
     def _bottleneck(self, plan, pre, blk, a, N, g_pre, extra, mask_x):
@@ -382,23 +451,23 @@ class ModelBackward:
         idn = a['ds'] if a['ds'] is not None else x
         # conv3 + bn3 (+ idn) + relu
         self._bn_grads(pre + '.bn3', blk.bn3, g_pre, out, idn)
-        self._acc(pre + '.conv3.weight', self._wgrad(plan, t2, g_pre, c3, N, Ho, Wo))
+        self._wacc(pre + '.conv3.weight', plan, t2, g_pre, c3, N, Ho, Wo)
         g_t2 = self._dgrad(plan, c3, g_pre, N, Ho, Wo, mask=t2)
         # conv2 + bn2 + relu
         self._bn_grads(pre + '.bn2', blk.bn2, g_t2, t2)
-        self._acc(pre + '.conv2.weight', self._wgrad(plan, t1, g_t2, c2, N, H, Wd))
+        self._wacc(pre + '.conv2.weight', plan, t1, g_t2, c2, N, H, Wd)
         g_t1 = self._dgrad(plan, c2, self._dilate(g_t2, H, Wd) if s == 2 else g_t2, N, H, Wd, mask=t1)
         # identity branch
         if a['ds'] is not None:
             cd = self.cb[pre + '.downsample.0']
             self._bn_grads(pre + '.downsample.1', blk.downsample[1], g_pre, a['ds'])
-            self._acc(pre + '.downsample.0.weight', self._wgrad(plan, x, g_pre, cd, N, H, Wd))
+            self._wacc(pre + '.downsample.0.weight', plan, x, g_pre, cd, N, H, Wd)
             side = self._dgrad(plan, cd, self._dilate(g_pre, H, Wd) if s == 2 else g_pre, N, H, Wd, res=extra)
         else:
             side = g_pre if extra is None else g_pre + extra
         # conv1 + bn1 + relu, joined with the identity branch; then the ReLU that produced x
         self._bn_grads(pre + '.bn1', blk.bn1, g_t1, t1)
-        self._acc(pre + '.conv1.weight', self._wgrad(plan, x, g_t1, c1, N, H, Wd))
+        self._wacc(pre + '.conv1.weight', plan, x, g_t1, c1, N, H, Wd)
         return self._dgrad(plan, c1, g_t1, N, H, Wd, mask=x if mask_x else None, res=side, mask_after=True)
 
     def _trunk(self, plan, enc_name, enc, acts, bufs, N, g_r4, extras):
@@ -504,7 +573,8 @@ class ModelBackward:
         K = plan.obj_n
         g_dec, gin = self.dec.run_tail(plan, grad_score, qs, slot)
         for n_, g_ in g_dec.items():
-            self._acc(n_, g_)
+            if g_ is not None:                                                # (None: accumulated by the kernel, wgrad_into)
+                self._acc(n_, g_)
         kvq = qs.kv_q[slot]                                                   # [HW,640]
         g_qk, g_bk, g_bv = self.memory_read(plan, fb, kvq[:, :DK].contiguous(), gin['mem'].reshape(K, plan.HW, DV))
         # KeyValue on the query side: dL/d[key | value]
@@ -523,10 +593,14 @@ class ModelBackward:
 
     def _keyval(self, plan, r4, g_kv, N):
         m = self.eng.model
-        dw = self._wgrad(plan, r4, g_kv, self.cb['keyval'], N, plan.h16, plan.w16)            # [640,1024,3,3]
         db = self._colsum(g_kv)
-        self._acc('keyval_r4.Key.weight', dw[:DK])
-        self._acc('keyval_r4.Value.weight', dw[DK:])
+        ok_k = self.wgrad_into('keyval_r4.Key.weight', r4, g_kv[..., :DK], 3, 1, 1, r4.shape[-1], DK, r4.shape[-1], False, None, N, plan.h16, plan.w16)
+        ok_v = self.wgrad_into('keyval_r4.Value.weight', r4, g_kv[..., DK:], 3, 1, 1, r4.shape[-1], DV, r4.shape[-1], False, None, N, plan.h16, plan.w16)
+        if not (ok_k and ok_v):
+            assert not ok_k and not ok_v
+            dw = self._wgrad(plan, r4, g_kv, self.cb['keyval'], N, plan.h16, plan.w16)            # [640,1024,3,3]
+            self._acc('keyval_r4.Key.weight', dw[:DK])
+            self._acc('keyval_r4.Value.weight', dw[DK:])
         self._acc('keyval_r4.Key.bias', db[:DK])
         self._acc('keyval_r4.Value.bias', db[DK:])
 

@@ -14,6 +14,7 @@ extern "C" int vfn_sizeof_desc(int which) {
         case VFN_DESC_BANKSCAN: return (int)sizeof(vfn_bankscan_desc);
         case VFN_DESC_MEMREAD: return (int)sizeof(vfn_memread_desc);
         case VFN_DESC_BANK: return (int)sizeof(vfn_bank_desc);
+        case VFN_DESC_WGRAD: return (int)sizeof(vfn_wgrad_desc);
     }
     return -1;
 }

@@ -99,11 +99,11 @@ __device__ __forceinline__ float final_sum(const float* __restrict__ partial, in
     __syncthreads();
     return t;
 }
-__global__ void colsum_final_kernel(const float* __restrict__ partial, int nb, int C, float* __restrict__ out) {
+__global__ void colsum_final_kernel(const float* __restrict__ partial, int nb, int C, float* __restrict__ out, int accumulate = 0) {
     __shared__ float red[256];
     const int c = blockIdx.x * 32 + (threadIdx.x & 31);
     const float s = final_sum(partial, nb, C, c, C, red);
-    if (threadIdx.x < 32 && c < C) out[c] = s;
+    if (threadIdx.x < 32 && c < C) out[c] = accumulate ? out[c] + s : s;
 }
 
 // gs[p][c] = sum_n gm[n][p][c]  (the objects share s)
@@ -336,6 +336,88 @@ __global__ void local_stats_bwd_kernel(const float* __restrict__ dA, const float
     }
 }
 
+// The same for C = 64 with the channels across lanes (round 4): 16 lanes per pixel, one float4 of channels each, so the window
+// reads of dA are coalesced 256-byte rows (the kernel above walks 64 channels x 49 taps per THREAD with a 256-byte stride between
+// neighbouring threads: 2.0 ms per sample at 200 x 200); the 49 scalar taps of dBv / the max-pool routing are dealt to the 16
+// lanes as well, and the per-pixel sums meet in a 16-lane butterfly (fixed order).
+__global__ __launch_bounds__(256)
+void local_stats_bwd64_kernel(const float* __restrict__ dA, const float* __restrict__ dBv, const float* __restrict__ g_cf,
+                              const int* __restrict__ amax, const float* __restrict__ g_u, const float* __restrict__ g_p2,
+                              const float* __restrict__ r1, const float* __restrict__ rough, const float* __restrict__ p_up,
+                              float* __restrict__ g_r1, float* __restrict__ g_pup, int obj_n, int h, int w) {
+    constexpr int C = 64;
+    const int npix = h * w;
+    const int l16 = threadIdx.x & 15;
+    const int i = blockIdx.x * 16 + (threadIdx.x >> 4);
+    const bool live = i < npix;
+    const int ii = live ? i : npix - 1;
+    const int x = ii % w, y = ii / w;
+    float g_rough[MAX_OBJ], rg[MAX_OBJ];
+    for (int n = 0; n < obj_n; ++n) { g_rough[n] = 0.f; rg[n] = rough[(size_t)n * npix + ii]; }
+    // the scalar taps: lane l takes window positions l, l + 16, l + 32, l + 48
+    for (int n = 0; n < obj_n; ++n) {
+        float part = 0.f;
+        for (int t = l16; t < 49; t += 16) {
+            const int yy = y + t / 7 - 3, xx = x + t % 7 - 3;
+            if ((unsigned)yy >= (unsigned)h || (unsigned)xx >= (unsigned)w) continue;
+            const size_t pn = (size_t)n * npix + yy * w + xx;
+            part += dBv[pn] * (1.f / 49.f);
+            if (amax[pn] == ii) part += g_cf[pn];
+        }
+        g_rough[n] = part;
+    }
+    // the channel taps: this lane's four channels
+    const f32x4 rv = *reinterpret_cast<const f32x4*>(r1 + (size_t)ii * C + l16 * 4);
+    f32x4 gr1 = {0.f, 0.f, 0.f, 0.f};
+    for (int n = 0; n < obj_n; ++n) {
+        f32x4 sa = {0.f, 0.f, 0.f, 0.f};
+        for (int dy = -3; dy <= 3; ++dy) {
+            const int yy = y + dy;
+            if ((unsigned)yy >= (unsigned)h) continue;
+            for (int dx = -3; dx <= 3; ++dx) {
+                const int xx = x + dx;
+                if ((unsigned)xx < (unsigned)w) sa += *reinterpret_cast<const f32x4*>(dA + ((size_t)n * npix + yy * w + xx) * C + l16 * 4);
+            }
+        }
+        sa *= (1.f / 49.f);
+        gr1 += rg[n] * sa;
+        g_rough[n] += (rv[0] * sa[0] + rv[1] * sa[1]) + (rv[2] * sa[2] + rv[3] * sa[3]);
+    }
+    if (live) {
+        f32x4* dst = reinterpret_cast<f32x4*>(g_r1 + (size_t)ii * C + l16 * 4);
+        *dst = *dst + gr1;
+    }
+    for (int n = 0; n < obj_n; ++n)
+#pragma unroll
+        for (int o = 1; o < 16; o <<= 1) g_rough[n] += __shfl_xor(g_rough[n], o, 64);
+    if (!live || l16 != 0) return;
+    int k1 = 0, k2 = -1;
+    float t1 = -INFINITY, t2 = -INFINITY;
+    for (int n = 0; n < obj_n; ++n) {
+        if (rg[n] > t1) { t2 = t1; k2 = k1; t1 = rg[n]; k1 = n; }
+        else if (rg[n] > t2) { t2 = rg[n]; k2 = n; }
+    }
+    const float u = expf(1.f - t1 / (t2 + 1e-8f));
+    const float gu = g_u[ii];
+    g_rough[k1] += gu * (-u / (t2 + 1e-8f));
+    if (k2 >= 0) g_rough[k2] += gu * (u * t1 / ((t2 + 1e-8f) * (t2 + 1e-8f)));
+    float dot = 0.f;
+    for (int n = 0; n < obj_n; ++n) dot += g_rough[n] * rg[n];
+    for (int n = 0; n < obj_n; ++n) {
+        const size_t pn = (size_t)n * npix + ii;
+        const float g_rp = rg[n] * (g_rough[n] - dot);
+        const float v0 = p_up[pn * 2], v1 = p_up[pn * 2 + 1];
+        const float m = fmaxf(v0, v1);
+        const float e0 = expf(v0 - m), e1 = expf(v1 - m);
+        const float rp = e1 / (e0 + e1);
+        const float d = g_rp * rp * (1.f - rp);
+        g_pup[pn * 4] = g_p2[pn * 4] - d;
+        g_pup[pn * 4 + 1] = g_p2[pn * 4 + 1] + d;
+        g_pup[pn * 4 + 2] = 0.f;
+        g_pup[pn * 4 + 3] = 0.f;
+    }
+}
+
 // ------------------------------------------------------------------ the training loss and its gradient
 // train_video_seg.py:72-74: loss = CrossEntropyLoss(scores, label) + lu * uncertainty, scores = the logits segment returns
 // [bs][obj][n], label [bs][n], uncertainty = AFB_URR.py:302-305 (vfn_segment_uncertainty_f32: mean over the batch of
@@ -489,12 +571,113 @@ __global__ void bn_grads_partial_kernel(const float* __restrict__ g, const float
         partial[((size_t)blockIdx.x * 2 + 1) * C + c] = sx;
     }
 }
-__global__ void bn_grads_final_kernel(const float* __restrict__ partial, int nb, int C, float* __restrict__ dgamma, float* __restrict__ dbeta) {
+__global__ void bn_grads_final_kernel(const float* __restrict__ partial, int nb, int C, float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                      int accumulate = 0) {
     __shared__ float red[256];
     const int c = blockIdx.x * 32 + (threadIdx.x & 31);
     const float sg = final_sum(partial, nb, (size_t)2 * C, c, C, red);
     const float sx = final_sum(partial + C, nb, (size_t)2 * C, c, C, red);
-    if (threadIdx.x < 32 && c < C) { dbeta[c] = sg; dgamma[c] = sx; }
+    if (threadIdx.x < 32 && c < C) {
+        dbeta[c] = accumulate ? dbeta[c] + sg : sg;
+        dgamma[c] = accumulate ? dgamma[c] + sx : sx;
+    }
+}
+
+// ---- one-launch forms of the two-stage column sums (round 4): every block publishes its partial row write-through (sc1 stores),
+// drains, and one lane takes a ticket; the block that draws the last ticket adds the rows IN BLOCK ORDER (sc1 loads) -- the same
+// sums in the same order as the two-launch form, without the second launch.  *counter is zero at rest.
+__device__ __forceinline__ bool last_block_arrives(int* counter, int* flag) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const int prev = __hip_atomic_fetch_add(counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int last = prev == (int)gridDim.x - 1;
+        if (last) __hip_atomic_store(counter, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        *flag = last;
+    }
+    __syncthreads();
+    return *flag != 0;
+}
+__device__ __forceinline__ void wt_store(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ float wt_load(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+// Thread layout of the fused column sums: for C < 256 the 256 threads of a block are C channels x (256 / C) row groups (a thread
+// per channel alone left 3/4 of the block idle at C = 64); the row groups meet through LDS in group order.
+__global__ __launch_bounds__(256)
+void colsum_fused_kernel(const float* __restrict__ x, int M, int C, int ld, float* __restrict__ partial, int* counter,
+                         float* __restrict__ out, int accumulate) {
+    __shared__ int flag;
+    __shared__ float red[256];
+    const int cw = C < 256 ? C : 256, rg = 256 / cw;                  // C is a power of two or a multiple of 256 here; else rg = 1
+    const int tx = threadIdx.x % cw, ty = threadIdx.x / cw;
+    const bool shaped = (256 % cw) == 0;
+    for (int c0 = 0; c0 < C; c0 += 256) {
+        const int c = c0 + (shaped ? tx : (int)threadIdx.x);
+        float s = 0.f;
+        if (c < C) {
+            if (shaped) { for (int m = blockIdx.x * rg + ty; m < M; m += gridDim.x * rg) s += x[(size_t)m * ld + c]; }
+            else { for (int m = blockIdx.x; m < M; m += gridDim.x) s += x[(size_t)m * ld + c]; }
+        }
+        if (shaped && rg > 1) {
+            red[threadIdx.x] = s;
+            __syncthreads();
+            if (ty == 0) { for (int g = 1; g < rg; ++g) s += red[g * cw + tx]; }
+            __syncthreads();
+        }
+        if (c < C && (!shaped || ty == 0)) wt_store(partial + (size_t)blockIdx.x * C + c, s);
+    }
+    if (!last_block_arrives(counter, &flag)) return;
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+        float s = 0.f;
+        for (int b = 0; b < (int)gridDim.x; ++b) s += wt_load(partial + (size_t)b * C + c);
+        out[c] = accumulate ? out[c] + s : s;
+    }
+}
+__global__ __launch_bounds__(256)
+void bn_grads_fused_kernel(const float* __restrict__ g, const float* __restrict__ y, const float* __restrict__ idn,
+                           const float* __restrict__ beta, const float* __restrict__ gamma, int M, int C,
+                           float* __restrict__ partial, int* counter, float* __restrict__ dgamma, float* __restrict__ dbeta,
+                           int accumulate) {
+    __shared__ int flag;
+    __shared__ float red[2][256];
+    const int cw = C < 256 ? C : 256, rg = 256 / cw;
+    const int tx = threadIdx.x % cw, ty = threadIdx.x / cw;
+    const bool shaped = (256 % cw) == 0;
+    for (int c0 = 0; c0 < C; c0 += 256) {
+        const int c = c0 + (shaped ? tx : (int)threadIdx.x);
+        float sg = 0.f, sx = 0.f;
+        if (c < C) {
+            const float b = beta[c], ig = 1.f / gamma[c];
+            const int m0 = shaped ? blockIdx.x * rg + ty : blockIdx.x, dm = shaped ? gridDim.x * rg : gridDim.x;
+            for (int m = m0; m < M; m += dm) {
+                const float gv = g[(size_t)m * C + c];
+                const float yv = y[(size_t)m * C + c] - (idn ? idn[(size_t)m * C + c] : 0.f);
+                sg += gv;
+                sx += gv * (yv - b) * ig;
+            }
+        }
+        if (shaped && rg > 1) {
+            red[0][threadIdx.x] = sg;
+            red[1][threadIdx.x] = sx;
+            __syncthreads();
+            if (ty == 0) { for (int q = 1; q < rg; ++q) { sg += red[0][q * cw + tx]; sx += red[1][q * cw + tx]; } }
+            __syncthreads();
+        }
+        if (c < C && (!shaped || ty == 0)) {
+            wt_store(partial + ((size_t)blockIdx.x * 2) * C + c, sg);
+            wt_store(partial + ((size_t)blockIdx.x * 2 + 1) * C + c, sx);
+        }
+    }
+    if (!last_block_arrives(counter, &flag)) return;
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+        float sg = 0.f, sx = 0.f;
+        for (int q = 0; q < (int)gridDim.x; ++q) {
+            sg += wt_load(partial + ((size_t)q * 2) * C + c);
+            sx += wt_load(partial + ((size_t)q * 2 + 1) * C + c);
+        }
+        dbeta[c] = accumulate ? dbeta[c] + sg : sg;
+        dgamma[c] = accumulate ? dgamma[c] + sx : sx;
+    }
 }
 
 // MaxPool2d(3, 2, 1) backwards: gx[n][y][x][c] = sum of g[n][yo][xo][c] over the output windows whose FIRST maximum (row-major, as
@@ -533,24 +716,54 @@ __global__ void maxpool3x3s2_bwd_kernel(const float* __restrict__ x, const float
 }
 
 // ------------------------------------------------------------------ memory read, backwards (training: the bank is one frame)
-// P[b][q] = softmax over b of scale * S[b][q] (AFB_URR.py:144-145); one thread per query column, rows strided by ld
-__global__ void softmax_cols_kernel(const float* __restrict__ S, int B, int Q, int ld, float scale, float* __restrict__ P) {
-    const int q = blockIdx.x * blockDim.x + threadIdx.x;
-    if (q >= Q) return;
+// P[b][q] = softmax over b of scale * S[b][q] (AFB_URR.py:144-145).  64 query columns per workgroup, the bank rows dealt to
+// SM_R row groups (round 3 walked all B rows three times on ONE thread per column: 340 us at B = Q = 625); the groups' maxima
+// and sums meet through LDS in group order (deterministic).
+constexpr int SM_R = 16;
+__global__ __launch_bounds__(64 * SM_R)
+void softmax_cols_kernel(const float* __restrict__ S, int B, int Q, int ld, float scale, float* __restrict__ P) {
+    __shared__ float red[SM_R][64];
+    const int cx = threadIdx.x & 63, rgp = threadIdx.x >> 6;
+    const int q = blockIdx.x * 64 + cx;
+    const bool ok = q < Q;
     float m = -INFINITY;
-    for (int b = 0; b < B; ++b) m = fmaxf(m, S[(size_t)b * ld + q] * scale);
+    if (ok)
+        for (int b = rgp; b < B; b += SM_R) m = fmaxf(m, S[(size_t)b * ld + q] * scale);
+    red[rgp][cx] = m;
+    __syncthreads();
+    m = red[0][cx];
+#pragma unroll
+    for (int g = 1; g < SM_R; ++g) m = fmaxf(m, red[g][cx]);
+    __syncthreads();
     float l = 0.f;
-    for (int b = 0; b < B; ++b) l += expf(S[(size_t)b * ld + q] * scale - m);
-    for (int b = 0; b < B; ++b) P[(size_t)b * ld + q] = expf(S[(size_t)b * ld + q] * scale - m) / l;
+    if (ok)
+        for (int b = rgp; b < B; b += SM_R) l += expf(S[(size_t)b * ld + q] * scale - m);
+    red[rgp][cx] = l;
+    __syncthreads();
+    l = 0.f;
+#pragma unroll
+    for (int g = 0; g < SM_R; ++g) l += red[g][cx];
+    if (ok)
+        for (int b = rgp; b < B; b += SM_R) P[(size_t)b * ld + q] = expf(S[(size_t)b * ld + q] * scale - m) / l;
 }
 // dS[b][q] = scale * P (dP - sum_b' P dP)
-__global__ void softmax_cols_bwd_kernel(const float* __restrict__ P, const float* __restrict__ dP, int B, int Q, int ld, float scale,
-                                        float* __restrict__ dS) {
-    const int q = blockIdx.x * blockDim.x + threadIdx.x;
-    if (q >= Q) return;
+__global__ __launch_bounds__(64 * SM_R)
+void softmax_cols_bwd_kernel(const float* __restrict__ P, const float* __restrict__ dP, int B, int Q, int ld, float scale,
+                             float* __restrict__ dS) {
+    __shared__ float red[SM_R][64];
+    const int cx = threadIdx.x & 63, rgp = threadIdx.x >> 6;
+    const int q = blockIdx.x * 64 + cx;
+    const bool ok = q < Q;
     float dot = 0.f;
-    for (int b = 0; b < B; ++b) dot += P[(size_t)b * ld + q] * dP[(size_t)b * ld + q];
-    for (int b = 0; b < B; ++b) dS[(size_t)b * ld + q] = scale * P[(size_t)b * ld + q] * (dP[(size_t)b * ld + q] - dot);
+    if (ok)
+        for (int b = rgp; b < B; b += SM_R) dot += P[(size_t)b * ld + q] * dP[(size_t)b * ld + q];
+    red[rgp][cx] = dot;
+    __syncthreads();
+    dot = 0.f;
+#pragma unroll
+    for (int g = 0; g < SM_R; ++g) dot += red[g][cx];
+    if (ok)
+        for (int b = rgp; b < B; b += SM_R) dS[(size_t)b * ld + q] = scale * P[(size_t)b * ld + q] * (dP[(size_t)b * ld + q] - dot);
 }
 
 // ------------------------------------------------------------------ AdamW (torch.optim.AdamW defaults' arithmetic)
@@ -585,6 +798,19 @@ extern "C" int vfn_colsum_f32(const float* x, int M, int C, int ld, float* parti
     if (!x || !partial || !out || M < 1 || C < 1 || ld < C || nb < 1 || nb > 1024) return VFN_ERR_ARG;
     hipLaunchKernelGGL(colsum_partial_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, x, M, C, ld, partial);
     hipLaunchKernelGGL(colsum_final_kernel, dim3(cdiv(C, 32)), dim3(256), 0, (hipStream_t)stream, partial, nb, C, out);
+    return vfn_check_launch();
+}
+
+// ... accumulating into `out` (a running gradient over the samples of a batch: no separate add launch)
+extern "C" int vfn_colsum_acc_f32(const float* x, int M, int C, int ld, float* partial, int nb, float* out, int accumulate, int* counter,
+                                  void* stream) {
+    if (!x || !partial || !out || M < 1 || C < 1 || ld < C || nb < 1 || nb > 1024) return VFN_ERR_ARG;
+    if (counter) {                             // one launch: the last block to arrive adds the partial rows
+        hipLaunchKernelGGL(colsum_fused_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, x, M, C, ld, partial, counter, out, accumulate);
+        return vfn_check_launch();
+    }
+    hipLaunchKernelGGL(colsum_partial_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, x, M, C, ld, partial);
+    hipLaunchKernelGGL(colsum_final_kernel, dim3(cdiv(C, 32)), dim3(256), 0, (hipStream_t)stream, partial, nb, C, out, accumulate);
     return vfn_check_launch();
 }
 
@@ -632,8 +858,12 @@ extern "C" int vfn_local_stats_backward_f32(const float* g_lm, const float* lm, 
     const int total = obj_n * h * w;
     hipLaunchKernelGGL(window_argmax_kernel, dim3(grid_for(total)), dim3(256), 0, s, rough, amax, obj_n, h, w);
     hipLaunchKernelGGL(local_ratio_bwd_kernel, dim3(grid_for(total)), dim3(256), 0, s, g_lm, lm, rough, dA, dBv, obj_n, h, w, C);
-    hipLaunchKernelGGL(local_stats_bwd_kernel, dim3(grid_for(h * w)), dim3(256), 0, s, dA, dBv, g_cf, amax, g_u, g_p2, r1, rough, p_up,
-                       g_r1, g_pup, obj_n, h, w, C);
+    if (C == 64)
+        hipLaunchKernelGGL(local_stats_bwd64_kernel, dim3(cdiv(h * w, 16)), dim3(256), 0, s, dA, dBv, g_cf, amax, g_u, g_p2, r1, rough, p_up,
+                           g_r1, g_pup, obj_n, h, w);
+    else
+        hipLaunchKernelGGL(local_stats_bwd_kernel, dim3(grid_for(h * w)), dim3(256), 0, s, dA, dBv, g_cf, amax, g_u, g_p2, r1, rough, p_up,
+                           g_r1, g_pup, obj_n, h, w, C);
     return vfn_check_launch();
 }
 
@@ -680,6 +910,20 @@ extern "C" int vfn_bn_param_grads_f32(const float* g, const float* y, const floa
     return vfn_check_launch();
 }
 
+extern "C" int vfn_bn_param_grads_acc_f32(const float* g, const float* y, const float* idn, const float* beta, const float* gamma, int M,
+                                          int C, float* partial, int nb, float* dgamma, float* dbeta, int accumulate, int* counter,
+                                          void* stream) {
+    if (!g || !y || !beta || !gamma || !partial || !dgamma || !dbeta || M < 1 || C < 1 || nb < 1 || nb > 1024) return VFN_ERR_ARG;
+    if (counter) {
+        hipLaunchKernelGGL(bn_grads_fused_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, g, y, idn, beta, gamma, M, C, partial, counter,
+                           dgamma, dbeta, accumulate);
+        return vfn_check_launch();
+    }
+    hipLaunchKernelGGL(bn_grads_partial_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, g, y, idn, beta, gamma, M, C, partial);
+    hipLaunchKernelGGL(bn_grads_final_kernel, dim3(cdiv(C, 32)), dim3(256), 0, (hipStream_t)stream, partial, nb, C, dgamma, dbeta, accumulate);
+    return vfn_check_launch();
+}
+
 extern "C" int vfn_maxpool3x3s2_backward_f32(const float* x, const float* g, float* gx, int N, int H, int W, int C, const float* add,
                                              int relu_mask, void* stream) {
     if (!x || !g || !gx || N < 1 || H < 1 || W < 1 || C < 1) return VFN_ERR_ARG;
@@ -691,13 +935,13 @@ extern "C" int vfn_maxpool3x3s2_backward_f32(const float* x, const float* g, flo
 
 extern "C" int vfn_softmax_cols_f32(const float* S, int B, int Q, int ld, float scale, float* P, void* stream) {
     if (!S || !P || B < 1 || Q < 1 || ld < Q) return VFN_ERR_ARG;
-    hipLaunchKernelGGL(softmax_cols_kernel, dim3(cdiv(Q, 64)), dim3(64), 0, (hipStream_t)stream, S, B, Q, ld, scale, P);
+    hipLaunchKernelGGL(softmax_cols_kernel, dim3(cdiv(Q, 64)), dim3(64 * SM_R), 0, (hipStream_t)stream, S, B, Q, ld, scale, P);
     return vfn_check_launch();
 }
 
 extern "C" int vfn_softmax_cols_backward_f32(const float* P, const float* dP, int B, int Q, int ld, float scale, float* dS, void* stream) {
     if (!P || !dP || !dS || B < 1 || Q < 1 || ld < Q) return VFN_ERR_ARG;
-    hipLaunchKernelGGL(softmax_cols_bwd_kernel, dim3(cdiv(Q, 64)), dim3(64), 0, (hipStream_t)stream, P, dP, B, Q, ld, scale, dS);
+    hipLaunchKernelGGL(softmax_cols_bwd_kernel, dim3(cdiv(Q, 64)), dim3(64 * SM_R), 0, (hipStream_t)stream, P, dP, B, Q, ld, scale, dS);
     return vfn_check_launch();
 }
 

@@ -1,0 +1,268 @@
+// Weight gradient of a convolution as an IMPLICIT GEMM over the pixels (round 4; train_video_seg.py:73 loss.backward()):
+//
+//     dW[co][kh][kw][ci] = rowscale[co] * sum_m  gy[m][co] * act(x)[pix(m) + (kh, kw)][ci]          (m = output pixel)
+//
+// The reduction index is the pixel, and both operands are pixel-major in HBM (NHWC): round 3 materialised dY^T and the
+// transposed im2col image of every layer input (vfn_transpose_taps_f32: 10 % of the step's device time, 728 launches per
+// step) to feed the forward kernel.  Here nothing is transposed: in the f32 MFMA a lane supplies ONE operand element per
+// instruction -- lane (l & 31, l >> 5) holds row l & 31 at k = l >> 5 -- so with lane = channel and k = pixel a wave's operand
+// load is `buffer_load_dword` over 32 consecutive channels of one pixel (128 contiguous bytes per half wave): the NHWC tensors
+// ARE the operand layout.  As in conv_direct.hip there is no LDS staging and no barrier in the loop; a wave owns a
+// (32 TM output channels) x (32 TN input channels of one filter tap) tile of dW over a slice of the pixels, 32 pixels of
+// operands in flight behind the 32 being multiplied, out-of-image taps and pixels past the slice load zeros (raw buffer loads
+// with an out-of-range offset).
+//
+//   workgroup   4 waves = 4 consecutive pixel slices of one dW tile, summed through LDS in slice order
+//   grid        dW tiles x ksplit; ksplit > 1: partial tiles to `partial` [ksplit][Cout][k*k*Cin], wgrad_reduce_kernel adds them
+//               in slice order (deterministic), applies rowscale and (accumulate) adds the running gradient
+//   rowscale    the frozen BatchNorm scale behind the convolution (train_video_seg.py:103-106): applied to the sum instead of to
+//               every gy element
+//   ReLU        act = max(., 0) on x for the decoder's pre-activation ResBlocks (AFB_URR.py:24-25)
+#include "common.h"
+#include "../../include/vfn_hip.h"
+
+namespace {
+
+template <int TM, int TN, bool RELU>
+__global__ __launch_bounds__(256, 2)
+void conv_wgrad_kernel(const vfn_wgrad_desc p) {
+    constexpr int CH = 8;                        // k-steps (pixel pairs) per chunk (16: the loads' 64 offsets spill)
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 31, lh = lane >> 5;
+
+    const int kk = p.k * p.k;
+    const int ci_tiles = (p.Cin + 32 * TN - 1) / (32 * TN);
+    const int col_tiles = kk * ci_tiles;
+    const int tiles = ((p.Cout + 32 * TM - 1) / (32 * TM)) * col_tiles;
+    const int tile = blockIdx.x % tiles, kz = blockIdx.x / tiles;
+    const int ct = tile % col_tiles, rt = tile / col_tiles;
+    const int tap = ct / ci_tiles, cit = ct - tap * ci_tiles;
+    const int kh = tap / p.k, kw = tap - kh * p.k;
+    const int co0 = rt * 32 * TM, ci0 = cit * 32 * TN;
+
+    // pixel slice of this wave: slices of equal, even length
+    const int M = p.N * p.Ho * p.Wo;
+    const int S = p.ksplit * 4;
+    int per = (M + S - 1) / S;
+    per += per & 1;
+    const int m_begin = (kz * 4 + wave) * per;
+    const int m_end = min(M, m_begin + per);
+
+    const __amdgpu_buffer_rsrc_t rg = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(p.gy), 0, (int)((size_t)M * p.ld_g * sizeof(float)), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(p.x), 0, (int)((size_t)p.N * p.H * p.W * p.ld_x * sizeof(float)), 0x00020000);
+    constexpr int OOB = 0x7fffff00;
+
+    // this lane's pixel: m = m_begin + 2 * step + lh, tracked incrementally (no multiply or divide in the loop): output
+    // coordinates (ho, wo) for the wrap, input coordinates (hi, wi) of the tap for the range check, byte offsets into gy / x
+    int m = m_begin + lh;
+    int ho, wo, hi, wi, g_off, x_off;
+    {
+        const int HoWo = p.Ho * p.Wo;
+        const int mm = min(m, M - 1);
+        const int n = mm / HoWo;
+        const int rem = mm - n * HoWo;
+        ho = rem / p.Wo;
+        wo = rem - ho * p.Wo;
+        hi = ho * p.stride - p.pad + kh;
+        wi = wo * p.stride - p.pad + kw;
+        g_off = (mm * p.ld_g + co0 + li) * (int)sizeof(float);
+        x_off = (((n * p.H + hi) * p.W + wi) * p.ld_x + ci0 + li) * (int)sizeof(float);
+    }
+    // per step (two pixels on): uniform increments; a row / image wrap adds the rest of the way
+    const int px = p.ld_x * (int)sizeof(float);
+    const int x_step = 2 * p.stride * px;
+    const int x_wrap_row = (p.stride * p.W - p.Wo * p.stride) * px;               // column wo - Wo of the next output row
+    const int x_wrap_img = (p.H - p.Ho * p.stride) * p.W * px;                    // row 0 of the next image
+    const int g_step = 2 * p.ld_g * (int)sizeof(float);
+    int a_ok[TM], b_ok[TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) a_ok[i] = co0 + i * 32 + li < p.Cout;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) b_ok[j] = ci0 + j * 32 + li < p.Cin;
+
+    float ga[2][TM][CH], xb[2][TN][CH];
+    auto load = [&](int slot) {
+#pragma unroll
+        for (int s = 0; s < CH; ++s) {
+            // (bitwise, not short-circuit: hipcc turned `a && b ? load(x) : load(OOB)` into exec-masked branches with a
+            // full wait inside; offsets are selected first, the loads are unconditional)
+            const int in_slice = m < m_end;
+            const int in_img = in_slice & ((unsigned)hi < (unsigned)p.H) & ((unsigned)wi < (unsigned)p.W);
+            int og[TM], ox[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) og[i] = (in_slice & a_ok[i]) ? g_off + i * 128 : OOB;
+#pragma unroll
+            for (int j = 0; j < TN; ++j) ox[j] = (in_img & b_ok[j]) ? x_off + j * 128 : OOB;
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+                ga[slot][i][s] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rg, og[i], 0, 0));
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+                xb[slot][j][s] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rx, ox[j], 0, 0));
+            m += 2;
+            g_off += g_step;
+            wo += 2;
+            wi += 2 * p.stride;
+            x_off += x_step;
+            const int wr = -(int)(wo >= p.Wo);                                 // all ones on a row wrap (Wo >= 2: launcher)
+            wo -= wr & p.Wo;
+            wi -= wr & (p.Wo * p.stride);
+            ho -= wr;
+            hi += wr & p.stride;
+            x_off += wr & x_wrap_row;
+            const int wi2 = -(int)(ho >= p.Ho);                                // ... on an image wrap
+            ho -= wi2 & p.Ho;
+            hi -= wi2 & (p.Ho * p.stride);
+            x_off += wi2 & x_wrap_img;
+        }
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    auto compute = [&](int slot) {
+        if constexpr (RELU) {
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int s = 0; s < CH; ++s) xb[slot][j][s] = fmaxf(xb[slot][j][s], 0.f);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int s = 0; s < CH; ++s)
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(ga[slot][i][s], xb[slot][j][s], acc[i][j], 0, 0, 0);
+    };
+
+    const int nch = (max(0, m_end - m_begin) + 2 * CH - 1) / (2 * CH);
+    if (nch > 0) load(0);
+    int c = 0;
+    for (; c + 2 < nch; c += 2) {
+        load(1);
+        compute(0);
+        load(0);
+        compute(1);
+    }
+    if (c + 1 < nch) {
+        load(1);
+        compute(0);
+        compute(1);
+    } else if (c < nch) {
+        compute(0);
+    }
+
+    // ---- the four pixel slices of the workgroup: slices 1.. -> LDS (lane-major), summed by wave 0 in slice order
+    float* red = reinterpret_cast<float*>(smem);
+    if (wave > 0) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    red[(((wave - 1) * (TM * TN) + i * TN + j) * 16 + r) * 64 + lane] = acc[i][j][r];
+    }
+    __syncthreads();
+    if (wave > 0) return;
+#pragma unroll
+    for (int g = 1; g < 4; ++g)
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    acc[i][j][r] += red[(((g - 1) * (TM * TN) + i * TN + j) * 16 + r) * 64 + lane];
+
+    // ---- store: a result register is 32 consecutive input channels (lane l & 31) of one output channel (row); buffer
+    // stores with 32-bit offsets (64 flat addresses at once spilled registers)
+    const int Kc = kk * p.Cin;
+    const bool direct = p.ksplit <= 1;
+    float* dst = direct ? p.dw : p.partial + (size_t)kz * p.Cout * Kc;
+    const __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc(dst, 0, (int)((size_t)p.Cout * Kc * sizeof(float)), 0x00020000);
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int ci = ci0 + j * 32 + li;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int co = co0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                const int off = (ci < p.Cin && co < p.Cout) ? (co * Kc + tap * p.Cin + ci) * (int)sizeof(float) : OOB;
+                float v = acc[i][j][r];
+                if (direct) {
+                    if (p.rowscale) v *= p.rowscale[min(co, p.Cout - 1)];
+                    if (p.accumulate) v += __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rd, off, 0, 0));
+                }
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rd, off, 0, 0);
+            }
+    }
+}
+
+// dw[co][c] = (accumulate ? dw[co][c] : 0) + rowscale[co] * (partial[0][co][c] + partial[1][co][c] + ...), slice order
+__global__ void wgrad_reduce_kernel(const vfn_wgrad_desc p) {
+    const int Kc = p.k * p.k * p.Cin;
+    const size_t slab = (size_t)p.Cout * Kc;
+    if (Kc % 4 == 0) {
+        const size_t total = slab / 4;
+        for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+            f32x4 a = *reinterpret_cast<const f32x4*>(p.partial + i * 4);
+            for (int s = 1; s < p.ksplit; ++s) a += *reinterpret_cast<const f32x4*>(p.partial + s * slab + i * 4);
+            const int co = (int)((i * 4) / Kc);
+            const float sc = p.rowscale ? p.rowscale[co] : 1.f;
+            f32x4 v;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = a[e] * sc;
+            if (p.accumulate) v += *reinterpret_cast<const f32x4*>(p.dw + i * 4);
+            *reinterpret_cast<f32x4*>(p.dw + i * 4) = v;
+        }
+    } else {                                   // (the 7 x 7 stems: 3 / 5 input planes)
+        for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < slab; i += (size_t)gridDim.x * blockDim.x) {
+            float a = p.partial[i];
+            for (int s = 1; s < p.ksplit; ++s) a += p.partial[s * slab + i];
+            float v = a * (p.rowscale ? p.rowscale[i / Kc] : 1.f);
+            if (p.accumulate) v += p.dw[i];
+            p.dw[i] = v;
+        }
+    }
+}
+
+template <int TM, int TN>
+int launch_wgrad(const vfn_wgrad_desc& p, hipStream_t s) {
+    const int tiles = cdiv(p.Cout, 32 * TM) * p.k * p.k * cdiv(p.Cin, 32 * TN);
+    const int ks = p.ksplit > 1 ? p.ksplit : 1;
+    constexpr size_t lds = (size_t)3 * TM * TN * 16 * 64 * sizeof(float);
+    if (p.relu) hipLaunchKernelGGL((conv_wgrad_kernel<TM, TN, true>), dim3(tiles * ks), dim3(256), lds, s, p);
+    else hipLaunchKernelGGL((conv_wgrad_kernel<TM, TN, false>), dim3(tiles * ks), dim3(256), lds, s, p);
+    if (ks > 1) {
+        const size_t total = (size_t)p.Cout * p.k * p.k * p.Cin / ((p.k * p.k * p.Cin) % 4 ? 1 : 4);
+        const int blocks = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
+        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, s, p);
+    }
+    return vfn_check_launch();
+}
+
+}  // namespace
+
+extern "C" int vfn_conv_wgrad_f32(const vfn_wgrad_desc* d, void* stream) {
+    if (!d || !d->x || !d->gy || !d->dw) return VFN_ERR_ARG;
+    if (d->Cin < 1 || d->Cout < 1 || d->k < 1 || d->stride < 1 || d->N < 1 || d->ld_x < d->Cin || d->ld_g < d->Cout) return VFN_ERR_ARG;
+    if (d->ksplit > 1 && !d->partial) return VFN_ERR_ARG;
+    if (d->Wo < 2) return VFN_ERR_ARG;                     // (the pixel walk wraps at most one row per two pixels)
+    if ((long long)d->N * d->H * d->W * d->ld_x * 4 >= 0x7fffff00LL || (long long)d->N * d->Ho * d->Wo * d->ld_g * 4 >= 0x7fffff00LL) return VFN_ERR_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    if (d->Cin <= 32) return launch_wgrad<2, 1>(*d, s);
+    return launch_wgrad<2, 2>(*d, s);
+}

@@ -103,8 +103,7 @@ def apply_choice(desc, choice, ws, counters=None):
         # the partials with an agent-scope release fence (an L2 write-back per slice workgroup) and measured slower than the
         # second launch; round 4 publishes them with write-through stores instead (no fence).  VFN_INLAUNCH_SPLITK=0 restores
         # the separate reduce launch.  f32 LDS-tiled configurations only.
-        if (desc.Cout % bn or not _INLAUNCH_SPLITK or ops.conv_cfg_kind(cfg) != 0 or desc.w_packed or desc.in_lp or desc.out_lp
-                or desc.mask):
+        if desc.Cout % bn or not _INLAUNCH_SPLITK or ops.conv_cfg_kind(cfg) != 0 or desc.w_packed or desc.in_lp or desc.out_lp:
             counters = None
         ops.set_splitk(desc, ks, ws, split_from, rows, counters)
     else:
@@ -812,7 +811,7 @@ class Engine:
         d.stride_q, d.stride_k, d.stride_rs = 0, cap * DK, 0
         d.scale = scale
         d.ldq, d.q_per_obj, d.HW, d.obj_n, d.nsplit, d.mode = DK + DV, 0, HW, K, nsplit_scan, 0
-        mr_mode = self.layer_mode('memread')
+        mr_mode = self.layer_mode('memread') if hasattr(self, 'layer_mode') else self.mode     # (tests drive this with a stand-in engine)
         d.precision = mr_mode
         d.work_counter = ptr(p.work)
         klp, vlp = fb.lp_image() if mr_mode else (None, None)      # the bank's kept split-bf16 image (reduced precision)

@@ -336,6 +336,50 @@ def segment_loss(score, label, lu, want_grad=True):
     return stats, grad
 
 
+_wgrad_ws = {}
+
+
+def conv_wgrad(x, gy, k, stride, pad, cin=None, cout=None, ld_x=None, relu=False, rowscale=None, out=None, accumulate=False,
+               N=None, H=None, W=None, ksplit=None):
+    """dL/dW of y = conv_{k x k, stride, pad}(act(x)) as an implicit GEMM over the pixels (vfn_conv_wgrad_f32): x NHWC
+    [N,H,W,ld_x] (``cin`` channels used), gy [N,Ho,Wo,ld_g] (``cout`` used) -> out [cout, k*k*cin] in the packed filter layout
+    (kh, kw, cin); ``rowscale`` [cout]: the frozen BatchNorm scale; ``accumulate``: add to ``out``."""
+    from ._lib import WgradDesc
+    if N is None:
+        N, H, W = x.shape[0], x.shape[1], x.shape[2]
+    Ho, Wo = gy.shape[1], gy.shape[2]
+    ld_x = ld_x if ld_x is not None else (x.stride(-2) if x.dim() >= 2 else x.shape[-1])     # (channel-sliced views keep their pixel stride)
+    cin = cin if cin is not None else x.shape[-1]
+    cout = cout if cout is not None else gy.shape[-1]
+    ld_g = gy.stride(-2)
+    assert x.stride(-1) == 1 and gy.stride(-1) == 1
+    Kc = k * k * cin
+    if out is None:
+        assert not accumulate
+        out = torch.empty(cout, Kc, device=x.device, dtype=torch.float32)
+    assert out.is_contiguous() and out.numel() == cout * Kc
+    M = N * Ho * Wo
+    if ksplit is None:
+        tiles = ((cout + 63) // 64) * k * k * ((cin + (31 if cin <= 32 else 63)) // (32 if cin <= 32 else 64))
+        ksplit = max(1, min(64, -(-2048 // (4 * tiles)), M // 256))         # ~2 waves per SIMD, at least 64 pixels per slice
+    d = WgradDesc()
+    d.x, d.gy, d.rowscale, d.dw = ptr(x), ptr(gy), ptr(rowscale), ptr(out)
+    d.N, d.H, d.W, d.Cin, d.ld_x = N, H, W, cin, ld_x
+    d.Ho, d.Wo, d.Cout, d.ld_g = Ho, Wo, cout, ld_g
+    d.k, d.stride, d.pad, d.relu, d.accumulate, d.ksplit = k, stride, pad, int(relu), int(accumulate), int(ksplit)
+    part = None
+    if ksplit > 1:
+        key = str(x.device)
+        need = ksplit * cout * Kc
+        part = _wgrad_ws.get(key)
+        if part is None or part.numel() < need:
+            part = torch.empty(max(need, 8 * 1024 * 1024), device=x.device, dtype=torch.float32)
+            _wgrad_ws[key] = part
+    d.partial = ptr(part)
+    check(_lib.lib().vfn_conv_wgrad_f32(C.byref(d), stream()), 'vfn_conv_wgrad_f32')
+    return out
+
+
 def segment_uncertainty_backward(score, g_unc, g_score=None):
     """dL/dscores [bs,obj,H,W] = g_score (optional, from the caller's criterion) + g_unc * d uncertainty / d scores, where
     ``g_unc`` is dL/duncertainty as a 0-dim DEVICE tensor (autograd's hand-over; no host synchronisation)."""

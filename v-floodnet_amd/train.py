@@ -84,7 +84,10 @@ class AdamW:
         if missing:
             raise KeyError(f'no gradient for {missing[:4]} ({len(missing)} parameters)')
         for n in self.names:
-            self.grad_view(n).copy_(grads[n].reshape(self.offsets[n][2]))
+            g = grads[n]
+            shp = self.offsets[n][2]
+            # (a weight gradient arrives as a strided [Cout,Cin,kh,kw] view of its packed buffer: one strided copy, no reshape)
+            self.grad_view(n).copy_(g if tuple(g.shape) == tuple(shp) else g.reshape(shp))
 
     def step(self):
         self.step_count += 1
