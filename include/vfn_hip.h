@@ -84,6 +84,10 @@ typedef struct vfn_conv_desc {
     int mask_ld;
     int mask_after;       /* 1: the mask is applied AFTER the residual add: y = mask > 0 ? acc * scale + shift + res : 0 (a block's
                              input gradient = its two branches summed, then the ReLU that produced that input) */
+    /* --- batched filters (f32; ABI 10): the Winograd-domain GEMMs of vfn_conv_winograd_* multiply every transform component
+     * with its own filter matrix in ONE launch ---------------------------------------------------------------------------- */
+    int w_batch_rows;     /* > 0: output rows [b * w_batch_rows, (b + 1) * w_batch_rows) use filter bank b = w + b * cout_pad * K
+                             floats; a multiple of the tile height of the configuration used; 1x1 problems; 0: one filter bank */
 } vfn_conv_desc;
 
 int vfn_conv_cfg_count(void);
@@ -120,6 +124,19 @@ int vfn_conv2d_nhwc_bf16(const vfn_conv_desc* d, int cfg, void* stream);
  * is hi*hi + hi*lo + lo*hi on the bf16 matrix cores, f32 accumulation: relative error ~2^-16 per product (bf16: 2^-9,
  * f32: 2^-24).  Cin multiple of 32, split-K slices are 32-channel tiles (as the f32 kernel); cfg as for _bf16. */
 int vfn_conv2d_nhwc_bf16x3(const vfn_conv_desc* d, int cfg, void* stream);
+
+/* ------------------------------------------------------------------ Winograd F(4x4, 3x3) around the matrix kernels (ABI 10)
+ * A 3x3 / stride-1 / pad-1 nn.Conv2d (the decoder's, AFB_URR.py:20-30,114-127,191-195) as 36 GEMMs in the transform domain:
+ *   vfn_winograd_input_f32    V [36][rows_pad][C] = B^T d B per 4x4 output tile (6x6 input patch, zeros outside the image;
+ *                             relu: max(d, 0) first); tiles in (n, ty, tx) order, vfn_winograd_tiles of them, rows_pad >= that
+ *   the GEMMs                 vfn_conv2d_nhwc_f32 on in = V (one "image" of 36 * rows_pad pixels), w = U [36][cout_pad][C] with
+ *                             U[6i+j] = (G g G^T)[i][j], w_batch_rows = rows_pad, out = M [36][rows_pad][Cout], no epilogue
+ *   vfn_winograd_output_f32   out[n][y][x][co] = act((A^T M A) * scale + shift + res) -- the convolution's own epilogue
+ * (Lavin & Gray's matrices; the same identity cuDNN uses for the reference's convolutions.) */
+int vfn_winograd_tiles(int N, int H, int W);
+int vfn_winograd_input_f32(const float* x, int N, int H, int W, int C, int ld_x, int relu, float* V, int rows_pad, void* stream);
+int vfn_winograd_output_f32(const float* Mb, int rows_pad, int N, int H, int W, int Cout, const float* scale, const float* shift,
+                            const float* res, int res_ld, int res_mod, int relu_out, float* out, int out_ld, void* stream);
 
 /* ------------------------------------------------------------------ encoder stems
  * vfn_stem_conv7x7_f32: pad_divide_by (myutils/data.py:132-149) + (x-mean)/std + conv1

@@ -48,7 +48,7 @@ for (h, w) in [(480, 854), (480, 853), (480, 800)]:
         old = engine.choose_cfg(*key, 0)
         c_old = engine.apply_choice(d, old, p.ws, p.cnt)
         t_old = timeit(d, c_old)
-        best, t_best = old, t_old
+        best, t_best = None, None                            # best of the NEW configurations, whatever the old one does
         for c in range(38, len(tiles)):
             bm, bn = tiles[c]
             if d.cout_pad < ((d.Cout + bn - 1) // bn) * bn or (bn > 64 and d.Cout <= 32) or (bn > 128 and d.Cout < 256):
@@ -68,9 +68,11 @@ for (h, w) in [(480, 854), (480, 853), (480, 800)]:
             for opt in options:
                 engine.apply_choice(d, opt, p.ws, p.cnt)
                 t = timeit(d, c, iters=6)
-                if t < t_best:
+                if t_best is None or t < t_best:
                     best, t_best = opt, t
-        if best != old:                                      # confirm with the long timing, alternating
+        if best is None:
+            best, t_best = old, t_old
+        if best != old and t_best < 1.15 * MARGIN * t_old:   # confirm with the long timing, alternating
             engine.apply_choice(d, best, p.ws, p.cnt); t_new = timeit(d, best[0])
             engine.apply_choice(d, old, p.ws, p.cnt); t_old2 = timeit(d, c_old)
             t_old = min(t_old, t_old2)
@@ -79,12 +81,16 @@ for (h, w) in [(480, 854), (480, 853), (480, 800)]:
             else:
                 best = old
             t_best = t_new
+        elif best != old:
+            best, t_best = old, t_old
         report.append((key, list(old), round(t_old, 1), list(best), round(t_best, 1), len(launches)))
         print(report[-1], flush=True)
         for l, in_q in launches:
             l.args = (l.args[0], engine.apply_choice(l.args[0], table.get(key, old), p.ws_q if in_q else p.ws, p.cnt_q if in_q else p.cnt), 0)
 os.makedirs('gpurun_out', exist_ok=True)
-engine.save_tuned('gpurun_out/tuned_gfx950.json', 0)
+out_name = os.environ.get('VFN_TUNE_OUT', 'gpurun_out/tuned_gfx950.json')
+os.makedirs(os.path.dirname(out_name), exist_ok=True)
+engine.save_tuned(out_name, 0)
 json.dump(report, open('gpurun_out/r04_tune_direct_report.json', 'w'))
 changed = [r for r in report if r[1] != r[3]]
 print(len(changed), 'of', len(report), 'shapes changed; saved us per launch-instance:', round(sum((r[2] - r[4]) * r[5] for r in changed), 1))

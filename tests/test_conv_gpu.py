@@ -281,3 +281,34 @@ def test_streamk_hand_off_is_reproducible_under_load(gpu):
                     assert torch.equal(y, first), f'cfg {cfg}: launch {it} differs from launch 0'
             torch.cuda.synchronize()
             assert int(cnt.abs().sum()) == 0, 'arrival counters must return to rest'
+
+
+@pytest.mark.parametrize('case', [(2, 12, 20, 64, 64, True, True, True), (1, 13, 19, 128, 96, False, False, True), (2, 30, 54, 256, 256, True, False, True),
+                                  (1, 33, 47, 64, 256, False, True, False), (2, 9, 14, 32, 32, True, False, True)])
+def test_winograd_f4x4_matches_torch_cpu(gpu, case):
+    """Winograd F(4x4, 3x3) around the matrix kernels (input transform -> 36 batched-filter GEMMs -> output transform + epilogue)
+    against F.conv2d on the CPU, at the tolerance of every other configuration of the convolution; image sizes that are not
+    multiples of 4, every epilogue piece, and three kernel families for the GEMMs (LDS-tiled, wave-autonomous, stream-K)."""
+    from vfloodnet_amd import ops
+    N, H, W, Cin, Cout, relu_in, relu_out, use_res = case
+    g = torch.Generator().manual_seed(hash(case) & 0xFFFF)
+    x = torch.randn(N, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) / (Cin * 9) ** 0.5
+    scale = 1 + 0.1 * torch.randn(Cout, generator=g)
+    shift = 0.1 * torch.randn(Cout, generator=g)
+    xin = F.relu(x) if relu_in else x
+    ref = F.conv2d(xin.double(), w.double(), padding=1) * scale.double().view(1, -1, 1, 1) + shift.double().view(1, -1, 1, 1)
+    res = torch.randn(ref.shape, generator=g) if use_res else None
+    if use_res:
+        ref = ref + res.double()
+    if relu_out:
+        ref = F.relu(ref)
+    xd = x.permute(0, 2, 3, 1).contiguous().to(gpu)
+    resd = res.permute(0, 2, 3, 1).contiguous().to(gpu) if use_res else None
+    sc, sh = scale.to(gpu), shift.to(gpu)
+    tol = 2e-4 * max(1.0, ref.abs().max().item())
+    for cfg in (2, 3, 42, 56):
+        y = ops.conv2d_winograd(xd, w, sc, sh, resd, relu_in, relu_out, cfg=cfg)
+        torch.cuda.synchronize()
+        err = (y.permute(0, 3, 1, 2).cpu().double() - ref).abs().max().item()
+        assert err < tol, (cfg, err, tol)

@@ -200,7 +200,7 @@ def test_segment_batch_and_training_branch(gpu, tag, H, W, training):
     fb.init_bank(k, v)
     score, unc = model.segment(frames[1:3].to(gpu), fb)
     assert tuple(score.shape) == (2, 2, H, W)
-    ok, dl, dp = close_logits(score.cpu(), t(g[f'{tag}_score']), 1e-3)
+    ok, dl, dp = close_logits(score.detach().cpu(), t(g[f'{tag}_score']), 1e-3)      # (training mode with autograd on: a graph node)
     assert ok, (dl, dp)
     for i in range(2):
         assert (fb.info[i][:, 1].cpu() - t(g[f'{tag}_info1'][i])).abs().max() < 1e-3      # hit counts: sample 0 only

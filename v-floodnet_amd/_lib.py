@@ -24,7 +24,7 @@ class ConvDesc(C.Structure):
                 ('KH', C.c_int), ('KW', C.c_int), ('stride', C.c_int), ('pad', C.c_int),
                 ('relu_in', C.c_int), ('relu_out', C.c_int), ('M', C.c_int), ('ksplit', C.c_int),
                 ('split_from', C.c_int), ('res_mod', C.c_int), ('partial', c_fp), ('tile_counters', c_fp),
-                ('w_packed', C.c_int), ('in_lp', C.c_int), ('out_lp_relu', C.c_int), ('out_lp', c_fp), ('mask', c_fp), ('mask_ld', C.c_int), ('mask_after', C.c_int)]
+                ('w_packed', C.c_int), ('in_lp', C.c_int), ('out_lp_relu', C.c_int), ('out_lp', c_fp), ('mask', c_fp), ('mask_ld', C.c_int), ('mask_after', C.c_int), ('w_batch_rows', C.c_int)]
 
 
 class WgradDesc(C.Structure):
@@ -167,6 +167,9 @@ SIGNATURES = {
     'vfn_bank_scan_finish': [_p, _i, _i, _i, _i, _p, _p, _p, _p, _p],
     'vfn_row_norms': [_p, _ll, _i, _i, _p, _i, _i, _p, _p, _ll, _p],
     'vfn_scatter_mean_f32': [_p, _ll, _ll, _p, _i, _p, _ll, _ll, _i, _p],
+    'vfn_winograd_tiles': [_i, _i, _i],
+    'vfn_winograd_input_f32': [_p, _i, _i, _i, _i, _i, _i, _p, _i, _p],
+    'vfn_winograd_output_f32': [_p, _i, _i, _i, _i, _i, _p, _p, _p, _i, _i, _i, _p, _i, _p],
     'vfn_scatter_mean_checked_f32': [_p, _ll, _ll, _p, _ll, _i, _p, _ll, _ll, _i, _ll, _p, _p],
     'vfn_resize_bicubic_f32': [_p, _p, _i, _i, _i, _i, _i, _p],
     'vfn_resize_nearest_f32': [_p, _p, _i, _i, _i, _i, _i, _p],

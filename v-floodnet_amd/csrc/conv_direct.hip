@@ -67,8 +67,9 @@ __device__ __forceinline__ void wave_gemm(const vfn_conv_desc& p, const __amdgpu
         }
     }
     int w_off[TN];
+    const int wb_rows = p.w_batch_rows > 0 ? (m0 / p.w_batch_rows) * p.cout_pad : 0;       // filter bank of this tile (batched filters)
 #pragma unroll
-    for (int j = 0; j < TN; ++j) w_off[j] = ((n0 + j * 32 + li) * Ktot + lh * 16) * (int)sizeof(float);
+    for (int j = 0; j < TN; ++j) w_off[j] = ((wb_rows + n0 + j * 32 + li) * Ktot + lh * 16) * (int)sizeof(float);
 
     int kh, kw, cb;                              // tap / channel block of the K tile being loaded
     {
@@ -162,7 +163,8 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t conv_rsrc_in(const vfn_conv_de
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.in), 0, (int)((size_t)p.N * p.H * p.W * p.in_ld * sizeof(float)), 0x00020000);
 }
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t conv_rsrc_w(const vfn_conv_desc& p) {
-    return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.w), 0, (int)((size_t)p.cout_pad * p.KH * p.KW * p.Cin * sizeof(float)), 0x00020000);
+    const int banks = p.w_batch_rows > 0 ? (p.M + p.w_batch_rows - 1) / p.w_batch_rows : 1;
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.w), 0, (int)((size_t)banks * p.cout_pad * p.KH * p.KW * p.Cin * sizeof(float)), 0x00020000);
 }
 
 template <int TM, int TN, int GM, int GN, int WK, int OCC, bool RELU>

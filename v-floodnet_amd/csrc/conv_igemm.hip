@@ -315,8 +315,11 @@ __device__ __forceinline__ void conv_igemm_body(const vfn_conv_desc& p) {
     // w_packed (MODE >= 1): the filters were converted on the host (ops.pack_weights_lp) into the LDS row image,
     // 128 bytes per filter and K tile (bf16: 64 bf16; bf16x3: 32 hi then 32 lo) -- staged with no VALU work
     const bool wpk = (MODE != 0) && p.w_packed;
+    // (batched filters, vfn_conv_desc.w_batch_rows: output rows of bank b multiply filter matrix b; f32 only)
+    const int w_banks = p.w_batch_rows > 0 ? (p.M + p.w_batch_rows - 1) / p.w_batch_rows : 1;
+    const int wb_rows = p.w_batch_rows > 0 ? (m0 / p.w_batch_rows) * p.cout_pad : 0;
     const __amdgpu_buffer_rsrc_t rsrc_w = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<float*>(p.w), 0, wpk ? (int)((size_t)p.cout_pad * nk_all * 128) : (int)((size_t)p.cout_pad * Ktot * sizeof(float)),
+        const_cast<float*>(p.w), 0, wpk ? (int)((size_t)p.cout_pad * nk_all * 128) : (int)((size_t)w_banks * p.cout_pad * Ktot * sizeof(float)),
         0x00020000);
     constexpr int BCP = BN * 8 / NT;       // 16-byte chunks of a packed B tile per thread
     const int pc = tid & 7, pr0 = tid >> 3;
@@ -330,7 +333,7 @@ __device__ __forceinline__ void conv_igemm_body(const vfn_conv_desc& p) {
     int w_off[BC];
 #pragma unroll
     for (int j = 0; j < BC; ++j)
-        w_off[j] = ((n0 + r0 + j * RSTEP) * Ktot + c16 * 4) * (int)sizeof(float);
+        w_off[j] = ((wb_rows + n0 + r0 + j * RSTEP) * Ktot + c16 * 4) * (int)sizeof(float);
 
     f32x4 ra[PD][AC], rb[PD][BC];
     int kh, kw, cb;                        // tap / channel block of the tile being *loaded*
@@ -724,7 +727,7 @@ void conv_igemm_dma_kernel(const vfn_conv_desc p) {
 #pragma unroll
     for (int j = 0; j < BPW; ++j) {
         const int r = (wave * BPW + j) * 8 + lr;
-        wsrc[j] = p.w + (size_t)(n0 + r) * Ktot + ((pc ^ ((r >> 1) & 7)) << 2);
+        wsrc[j] = p.w + (size_t)((p.w_batch_rows > 0 ? (m0 / p.w_batch_rows) * p.cout_pad : 0) + n0 + r) * Ktot + ((pc ^ ((r >> 1) & 7)) << 2);
     }
 
     int kh, kw, cb;
@@ -1037,6 +1040,7 @@ extern "C" int vfn_conv2d_nhwc_f32(const vfn_conv_desc* d, int cfg, void* stream
     int bm, bn;
     if (vfn_conv_cfg_tile(cfg, &bm, &bn) != VFN_OK) return VFN_ERR_ARG;
     if (d->cout_pad < cdiv(d->Cout, bn) * bn) return VFN_ERR_ARG;
+    if (d->w_batch_rows < 0 || (d->w_batch_rows > 0 && (d->w_batch_rows % bm || d->KH != 1 || d->KW != 1))) return VFN_ERR_ARG;
     if (d->ksplit > 1) {
         const int nk_all = d->KH * d->KW * (d->Cin / BK);
         if (!d->partial || d->Cout % 4 || d->out_ld % 4 || (d->res && d->res_ld % 4) || (d->mask && d->mask_ld % 4)) return VFN_ERR_ARG;
@@ -1081,7 +1085,7 @@ extern "C" int vfn_conv2d_nhwc_f32(const vfn_conv_desc* d, int cfg, void* stream
 // Same convolution with bf16 operands (rounded to nearest-even as they are staged; f32 accumulate, f32
 // tensors in HBM): BASELINE configs C3 / C5.  Register-staged tile configurations only (LDS-DMA cannot convert).
 extern "C" int vfn_conv2d_nhwc_bf16(const vfn_conv_desc* d, int cfg, void* stream) {
-    if (!d || !d->in || !d->w || !d->out || d->in_lp || d->out_lp) return VFN_ERR_ARG;
+    if (!d || !d->in || !d->w || !d->out || d->in_lp || d->out_lp || d->w_batch_rows) return VFN_ERR_ARG;
     if (d->Cin % 64 != 0 || d->in_ld % 4 != 0 || d->M <= 0) return VFN_ERR_ARG;
     int bm, bn;
     if (vfn_conv_cfg_tile(cfg, &bm, &bn) != VFN_OK) return VFN_ERR_ARG;
@@ -1118,7 +1122,7 @@ extern "C" int vfn_conv2d_nhwc_bf16(const vfn_conv_desc* d, int cfg, void* strea
 // product (hi*hi + hi*lo + lo*hi), f32 accumulate: relative error ~2^-16 per product, against 2^-9 for plain bf16
 // and 2^-24 for f32.  Same tile configurations and K tiling (32 channels) as the f32 kernel's register-staged ones.
 extern "C" int vfn_conv2d_nhwc_bf16x3(const vfn_conv_desc* d, int cfg, void* stream) {
-    if (!d || !d->in || !d->w || (!d->out && !d->out_lp)) return VFN_ERR_ARG;
+    if (!d || !d->in || !d->w || (!d->out && !d->out_lp) || d->w_batch_rows) return VFN_ERR_ARG;
     if (d->in_lp && (d->relu_in || d->in_ld % 32)) return VFN_ERR_ARG;            // ReLU belongs to the image's producer
     // the image is written by the 16-byte epilogue only (4 channels per lane): shapes that fall back to the dword form are refused
     if (d->out_lp && (d->Cout % 32 || d->out_ld % 32 || (d->res && d->res_ld % 4) || d->tile_counters)) return VFN_ERR_ARG;

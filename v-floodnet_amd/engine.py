@@ -76,6 +76,8 @@ def pad_divide_by(h, w, d=16):
 
 
 WS_FLOATS = 16 * 1024 * 1024        # split-K workspace (64 MB), shared by all launches of a plan
+_WINOGRAD = os.environ.get('VFN_WINOGRAD', '0')
+_WINOGRAD_MIN_M = int(os.environ.get('VFN_WINOGRAD_MIN_M', 10000))
 _INLAUNCH_SPLITK = __import__('os').environ.get('VFN_INLAUNCH_SPLITK', '1') == '1'
 
 
@@ -183,6 +185,14 @@ class ConvLayer:
             self._w_lp[mode] = ops.pack_weights_lp(self.w, mode)
         return self._w_lp[mode]
 
+    def w_wino(self):
+        """The 36 transform-domain filter banks U = G g G^T of a 3x3 layer (Winograd F(4x4, 3x3), built once)."""
+        if 'wino' not in self._w_lp:
+            assert self.k == 3
+            w = self.w[:self.cout].view(self.cout, 3, 3, self.cin).permute(0, 3, 1, 2)       # packed (kh,kw,cin) -> [Cout,Cin,3,3]
+            self._w_lp['wino'] = ops.pack_winograd_weight(w).to(self.w.device)
+        return self._w_lp['wino']
+
 
 class Pred2Layer:
     """A 3x3 convolution with two filters (pred2 / local_pred2, AFB_URR.py:195,202) as a tap GEMM: the 9 taps x 2 filters
@@ -280,6 +290,7 @@ class FramePlan:
         self.cnt = torch.zeros(ops.SK_MAX_TILES, dtype=torch.int32, device=dev)      # split-tile arrival counters (zero at rest)
         self.cnt_q = torch.zeros(ops.SK_MAX_TILES, dtype=torch.int32, device=dev)
         self._ws_cur, self._cnt_cur = self.ws, self.cnt
+        self._wino = {}                       # id(workspace of the launch list's stream) -> (V, M) scratch of the Winograd layers
 
         self.mem = []         # memorize
         self._build()
@@ -349,6 +360,9 @@ class FramePlan:
         lp = bf == 2
         if self.eng.mixed:
             f32_out = True                                    # (a consumer in another mode reads the f32 tensor)
+        if (bf == 0 and in_ld is None and not self.keep_acts and x.shape[-1] == layer.cin and
+                self.eng.use_winograd(layer, N * H * Wd)):
+            return self._conv_winograd(lst, layer, x, out, N, H, Wd, res, relu_in, relu_out, name, out_ld, res_mod)
         d = ops.make_conv_desc(x, layer.w, layer.cout, layer.k, layer.k, layer.stride, layer.pad, out,
                                layer.scale, layer.shift, res, relu_in, relu_out,
                                cin=layer.cin, in_ld=in_ld if in_ld is not None else x.shape[-1],
@@ -373,6 +387,31 @@ class FramePlan:
             choice = (choice[0], 1, 0)
         cfg = apply_choice(d, choice, self._ws_cur, self._cnt_cur)
         lst.append(Launch(ops.conv2d_launch, (d, cfg, bf), f'{name}[{d.M}x{layer.cout}x{K}]', 2.0 * d.M * layer.cout * K))
+        return out
+
+    def _conv_winograd(self, lst, layer, x, out, N, H, Wd, res, relu_in, relu_out, name, out_ld, res_mod):
+        """A 3x3 / stride-1 layer as Winograd F(4x4, 3x3): input transform, the 36 transform-domain GEMMs as ONE batched-filter
+        launch of the convolution kernels (tile choice from the same tables / tuner, keyed by the GEMM's shape), output transform
+        with the layer's epilogue (csrc/conv_winograd.hip)."""
+        rows = ops.winograd_rows(N, H, Wd)
+        key = id(self._ws_cur)
+        need_v, need_m = 36 * rows * layer.cin, 36 * rows * layer.cout
+        V, Mb = self._wino.get(key, (None, None))
+        if V is None or V.numel() < need_v or Mb.numel() < need_m:
+            dev = self.eng.device
+            V = torch.zeros(max(need_v, V.numel() if V is not None else 0), device=dev)
+            Mb = torch.empty(max(need_m, Mb.numel() if Mb is not None else 0), device=dev)
+            self._wino[key] = (V, Mb)                      # (launches built earlier keep their own, smaller buffers alive)
+        V, Mb = V[:need_v].view(36 * rows, layer.cin), Mb[:need_m].view(36 * rows, layer.cout)
+        lst.append(Launch(ops.winograd_input, (x, V, rows, relu_in, N, H, Wd, layer.cin, x.shape[-1]), name + '.wino_in'))
+        dg = ops.make_winograd_gemm_desc(V, layer.w_wino(), Mb, rows, layer.cin, layer.cout)
+        choice = choose_cfg(dg.M, layer.cout, layer.cin, 0)
+        cfg = apply_choice(dg, choice, self._ws_cur, self._cnt_cur)
+        lst.append(Launch(ops.conv2d_launch, (dg, cfg, 0), f'{name}.wino_gemm[{dg.M}x{layer.cout}x{layer.cin}]', 2.0 * dg.M * layer.cout * layer.cin))
+        self._lp_state.pop((out.data_ptr(), tuple(out.shape)), None)
+        lst.append(Launch(ops.winograd_output, (Mb, rows, out, N, H, Wd, layer.cout, layer.scale, layer.shift, res,
+                                                res.shape[-1] if res is not None else 0, res_mod, relu_out,
+                                                out_ld if out_ld is not None else out.shape[-1]), name + '.wino_out'))
         return out
 
     def _trunk(self, lst, enc, bufs, N, prefix, acts=None):
@@ -567,6 +606,13 @@ class Engine:
         self._side = None            # side stream for the query side of the next frames
         self._side_busy = None       # event behind the last work enqueued on it
         self._pack(model)
+
+    def use_winograd(self, layer, M):
+        """Winograd F(4x4, 3x3) for this layer?  VFN_WINOGRAD = 0 (off) | 1 (3x3 / stride-1 layers with >= 128 input and output
+        channels and at least VFN_WINOGRAD_MIN_M output pixels: the decoder's 256 -> 256 layers at 1/4 and 1/8 resolution)."""
+        if _WINOGRAD == '0' or getattr(layer, 'k', 0) != 3 or layer.stride != 1 or layer.pad != 1:
+            return False
+        return layer.cin % 32 == 0 and layer.cout % 4 == 0 and layer.cin >= 128 and layer.cout >= 128 and M >= _WINOGRAD_MIN_M
 
     def layer_mode(self, name):
         for prefix, m_ in self.pmap:

@@ -136,6 +136,7 @@ def make_conv_desc(x, wp, cout, kh, kw, stride, pad, out, scale=None, shift=None
     d.w_packed = 0
     d.in_lp, d.out_lp_relu, d.out_lp = 0, 0, None
     d.mask, d.mask_ld, d.mask_after = None, 0, 0
+    d.w_batch_rows = 0
     assert wp.shape[1] == kh * kw * cin
     return d
 
@@ -218,6 +219,76 @@ def conv2d_nhwc(x, wp, cout, kh, kw, stride, pad, scale=None, shift=None, res=No
         set_streamk(d, *streamk_scratch(x.device))
     conv2d_launch(d, cfg, mode)
     return out
+
+
+# --------------------------------------------------------------------------- Winograd F(4x4, 3x3)
+_WINO_G = torch.tensor([[1 / 4, 0, 0], [-1 / 6, -1 / 6, -1 / 6], [-1 / 6, 1 / 6, -1 / 6], [1 / 24, 1 / 12, 1 / 6], [1 / 24, -1 / 12, 1 / 6], [0, 0, 1]],
+                       dtype=torch.float64)
+WINO_ROW_MULT = 256                   # rows per transform component are padded to a multiple of the tallest tile
+
+
+def pack_winograd_weight(w):
+    """[Cout, Cin, 3, 3] conv filters -> U [36 * cout_pad, Cin] f32: U[6i+j] = (G g G^T)[i][j] for every filter pair, computed
+    in float64 (the 36 filter banks of the transform-domain GEMMs; cout_pad = Cout rounded up to 256 like pad_rows)."""
+    cout, cin = w.shape[0], w.shape[1]
+    assert tuple(w.shape[2:]) == (3, 3)
+    g = w.detach().double().cpu()
+    U = torch.einsum('ia,ocab,jb->ijoc', _WINO_G, g, _WINO_G)                 # [6,6,Cout,Cin]
+    cp = (cout + 255) // 256 * 256
+    out = torch.zeros(36, cp, cin, dtype=torch.float32)
+    out[:, :cout] = U.reshape(36, cout, cin).float()
+    return out.reshape(36 * cp, cin).contiguous()
+
+
+def winograd_rows(N, H, W):
+    t = N * ((H + 3) // 4) * ((W + 3) // 4)
+    return (t + WINO_ROW_MULT - 1) // WINO_ROW_MULT * WINO_ROW_MULT
+
+
+def winograd_input(x, V, rows_pad, relu, N=None, H=None, W=None, cin=None, ld_x=None):
+    if N is None:
+        N, H, W = x.shape[0], x.shape[1], x.shape[2]
+    cin = cin if cin is not None else x.shape[-1]
+    ld_x = ld_x if ld_x is not None else x.shape[-1]
+    check(_lib.lib().vfn_winograd_input_f32(ptr(x), N, H, W, cin, ld_x, int(relu), ptr(V), rows_pad, stream()), 'vfn_winograd_input_f32')
+
+
+def winograd_output(Mb, rows_pad, out, N, H, W, cout, scale, shift, res, res_ld, res_mod, relu_out, out_ld=None):
+    check(_lib.lib().vfn_winograd_output_f32(ptr(Mb), rows_pad, N, H, W, cout, ptr(scale), ptr(shift), ptr(res), int(res_ld), int(res_mod),
+                                             int(relu_out), ptr(out), out_ld if out_ld is not None else out.shape[-1], stream()),
+          'vfn_winograd_output_f32')
+
+
+def make_winograd_gemm_desc(V, U, Mb, rows_pad, cin, cout):
+    """The 36 transform-domain GEMMs as one batched-filter launch of the convolution kernels."""
+    d = make_conv_desc(V, U, cout, 1, 1, 1, 0, Mb, None, None, None, False, False, cin=cin, in_ld=cin, out_ld=cout, N=1, H=1, W=36 * rows_pad)
+    d.cout_pad = U.shape[0] // 36
+    d.w_batch_rows = rows_pad
+    return d
+
+
+def conv2d_winograd(x, w, scale=None, shift=None, res=None, relu_in=False, relu_out=False, cfg=2, res_mod=0):
+    """Convenience form for tests: x NHWC, w [Cout,Cin,3,3] (torch layout) -> NHWC output of the 3x3 / stride-1 / pad-1 convolution."""
+    N, H, W, cin = x.shape
+    cout = w.shape[0]
+    rows = winograd_rows(N, H, W)
+    U = pack_winograd_weight(w).to(x.device)
+    V = torch.empty(36 * rows, cin, device=x.device, dtype=torch.float32)
+    Mb = torch.empty(36 * rows, cout, device=x.device, dtype=torch.float32)
+    out = torch.empty(N, H, W, cout, device=x.device, dtype=torch.float32)
+    if rows > vfn_winograd_tiles(N, H, W):
+        V.view(36, rows, cin)[:, vfn_winograd_tiles(N, H, W):].zero_()
+    winograd_input(x, V, rows, relu_in)
+    d = make_winograd_gemm_desc(V, U, Mb, rows, cin, cout)
+    if conv_cfg_kind(cfg) == 2:
+        set_streamk(d, *streamk_scratch(x.device))
+    conv2d_launch(d, cfg, 0)
+    winograd_output(Mb, rows, out, N, H, W, cout, scale, shift, res, res.shape[-1] if res is not None else 0, res_mod, relu_out)
+    return out
+
+
+def vfn_winograd_tiles(N, H, W):
+    return N * ((H + 3) // 4) * ((W + 3) // 4)
 
 
 # --------------------------------------------------------------------------- stems / pooling
