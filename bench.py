@@ -469,7 +469,8 @@ def main(argv=None):
                                   f'FETCH doubled per MI355X_MICROARCH.md; not re-measured in this run)',
                 'launches_timed': n, 'avg_launch_us': round(ms * 1e3 / n, 2),
                 'share_of_instrumented_time': round(ms / all_ms, 4),
-                'algorithmic_flop': '2*M*Cout*K per conv launch; memory-read apply launch: 1024 * bank entries * HW (P^T V; the scores come from the '
+                'algorithmic_flop': '2*M*Cout*K per conv launch (a Winograd-domain GEMM launch: the FLOP it executes, 2*36*tiles*Cin*Cout); '
+                                    'memory-read apply launch: 1024 * bank entries * HW (P^T V; the scores come from the '
                                     'statistics scan, memread_apply_ss_kernel) or 1280 * entries * HW where it recomputes them',
                 'timing': 'HIP events around every launch of frames that take no part in the side-stream overlap (kernel alone '
                           f'on the device); rocprofv3 counterpart: profiles/{PROFILE_ROUND}_kernel_stats_no_overlap.csv (--no-overlap run); '
@@ -506,6 +507,15 @@ def main(argv=None):
     f_ref = 666.56e9 + 3072.0 * b_mean * 1620          # op-for-op reference FLOPs (per-object duplicate convs counted)
     frame_frac_ref = (fps / world) * f_ref / (peak * 1e12)
     f_min_clip = 538.48e9 + 3072.0 * b_mean_clip * 1620
+    # what the matrix pipe EXECUTES per frame: the plan's launch lists carry every launch's own FLOP (a Winograd-domain GEMM
+    # 2 * 36 * tiles * Cin * Cout = 1/4 of the direct convolution it replaces); one memorize + one decoder pass + half a two-frame
+    # query pass per frame, + the memory read / update contractions
+    qs0 = plan.qsets[0]
+    lsum = lambda lst: sum(l.flops for l in lst)
+    conv_exec = lsum(plan.mem) + lsum(qs0.post[0]) + lsum(qs0.pre[2]) / 2.0
+    wino_names = [l.name.split('.wino_gemm')[0] for lst in (plan.mem, qs0.post[0], qs0.pre[2]) for l in lst if '.wino_gemm' in l.name]
+    f_exec = conv_exec + 3072.0 * b_mean * 1620
+    frame_frac_exec = (fps / world) * f_exec / (peak * 1e12)
     tms = sorted(ms_ for t_, ms_ in frame_ms if s_first <= t_ < s_first + K)
     frame_stats = {'p50': round(tms[len(tms) // 2], 3), 'p90': round(tms[min(len(tms) - 1, int(0.9 * len(tms)))], 3),
                    'max': round(tms[-1], 3), 'min': round(tms[0], 3),
@@ -562,6 +572,12 @@ def main(argv=None):
                       'full_clip_mean_bank_entries_per_object': round(b_mean_clip, 1),
                       'network_resolution': f'{Hn}x{Wn} ' + ('(native)' if args.native and (Hn, Wn) == (H0, W0) else '(reference semantics: 480-pixel short edge)'),
                       'frame_mfma_frac_Fmin': round(frame_frac, 4) if mem_every == 1 else None,
+                      'frame_mfma_frac_executed': round(frame_frac_exec, 4) if mem_every == 1 else None,
+                      'conv_gflop_per_frame': {'algorithmic_Fmin': 538.48, 'executed': round(conv_exec / 1e9, 2),
+                                               'note': 'Winograd F(4x4,3x3) layers execute 1/4 of their direct-convolution FLOP (csrc/conv_winograd.hip; '
+                                                       'frame_mfma_frac_Fmin prices the frame at the ALGORITHMIC FLOP of SURVEY.md 8(d), '
+                                                       'frame_mfma_frac_executed at what the matrix pipe runs)'},
+                      'winograd_layers': sorted(set(wino_names)),
                       'frame_mfma_frac_Fref_reference_equivalent': round(frame_frac_ref, 4) if mem_every == 1 else None},
            'full_clip_fps': round(full_clip_fps, 3),
            'full_clip_frame_mfma_frac_Fmin': round((full_clip_fps / world) * f_min_clip / (peak * 1e12), 4) if mem_every == 1 else None,

@@ -76,8 +76,15 @@ def pad_divide_by(h, w, d=16):
 
 
 WS_FLOATS = 16 * 1024 * 1024        # split-K workspace (64 MB), shared by all launches of a plan
-_WINOGRAD = os.environ.get('VFN_WINOGRAD', '0')
+# Winograd F(4x4, 3x3) for the 3x3 / stride-1 layers (csrc/conv_winograd.hip): 1 (default) = where the measured table says so
+# (wino_gfx950.json: "M,cin,cout" -> 0 / 1, scripts/tune_winograd.py; shapes it lacks: >= 128 channels either side and at least
+# VFN_WINOGRAD_MIN_M output pixels), 2 = every eligible layer, 0 = off (the direct implicit GEMM everywhere)
+_WINOGRAD = os.environ.get('VFN_WINOGRAD', '1')
 _WINOGRAD_MIN_M = int(os.environ.get('VFN_WINOGRAD_MIN_M', 10000))
+_WINO_TABLE = {}
+_WINO_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'wino_gfx950.json')
+if os.path.isfile(_WINO_PATH) and os.environ.get('VFN_IGNORE_TUNED') != '1':
+    _WINO_TABLE = {tuple(int(x) for x in k.split(',')): int(v) for k, v in __import__('json').load(open(_WINO_PATH)).items()}
 _INLAUNCH_SPLITK = __import__('os').environ.get('VFN_INLAUNCH_SPLITK', '1') == '1'
 
 
@@ -608,11 +615,17 @@ class Engine:
         self._pack(model)
 
     def use_winograd(self, layer, M):
-        """Winograd F(4x4, 3x3) for this layer?  VFN_WINOGRAD = 0 (off) | 1 (3x3 / stride-1 layers with >= 128 input and output
-        channels and at least VFN_WINOGRAD_MIN_M output pixels: the decoder's 256 -> 256 layers at 1/4 and 1/8 resolution)."""
+        """Winograd F(4x4, 3x3) for this layer (M = N * H * W output pixels)?  See _WINOGRAD above."""
         if _WINOGRAD == '0' or getattr(layer, 'k', 0) != 3 or layer.stride != 1 or layer.pad != 1:
             return False
-        return layer.cin % 32 == 0 and layer.cout % 4 == 0 and layer.cin >= 128 and layer.cout >= 128 and M >= _WINOGRAD_MIN_M
+        if layer.cin % 32 or layer.cout % 4 or layer.cout < 32:
+            return False
+        if _WINOGRAD == '2':
+            return True
+        hit = _WINO_TABLE.get((M, layer.cin, layer.cout))
+        if hit is not None:
+            return bool(hit)
+        return layer.cin >= 128 and layer.cout >= 128 and M >= _WINOGRAD_MIN_M
 
     def layer_mode(self, name):
         for prefix, m_ in self.pmap:
