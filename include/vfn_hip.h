@@ -267,8 +267,10 @@ int vfn_adamw_f32(float* p, const float* g, float* m, float* v, long long n, dou
                   double weight_decay, int step, void* stream);
 int vfn_colsum_f32(const float* x, int M, int C, int ld, float* partial, int nb, float* out, void* stream);
 /* the same with the result ADDED to `out` when accumulate != 0 (ABI 10: a running gradient over the samples of a batch);
- * counter != NULL (one int in device memory, zero at rest): ONE launch -- the blocks publish their partial rows write-through and
- * the block that arrives last adds them in block order (the same sums, no second launch) */
+ * counter != NULL (VFN_COLSUM_COUNTERS ints in device memory, zero at rest): ONE launch -- the blocks publish their partial rows
+ * write-through and the block that arrives last (of a 64-channel slab, when C % 64 == 0 and everything is 16-byte aligned) adds them
+ * in a fixed order (no second launch) */
+#define VFN_COLSUM_COUNTERS 64
 int vfn_colsum_acc_f32(const float* x, int M, int C, int ld, float* partial, int nb, float* out, int accumulate, int* counter,
                        void* stream);
 int vfn_upsample2x_add_backward_f32(const float* gm, float* gs, float* gpm, int N, int h, int w, int C, int s_bcast,

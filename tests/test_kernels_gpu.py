@@ -450,3 +450,51 @@ def test_conv_wgrad_implicit_gemm_vs_autograd(gpu, case):
     acc = first.clone()
     ops.conv_wgrad(xd, gd, k, s, k // 2, relu=relu, rowscale=sc, out=acc, accumulate=True)
     assert (acc.cpu().double() - 2 * ref).abs().max().item() < 2 * tol
+
+
+@pytest.mark.parametrize('M,C,ld,idn', [(10000, 256, 256, True), (625, 1024, 1024, False), (2500, 64, 64, True), (40000, 64, 256, False),
+                                        (157, 2048, 2048, True), (7, 128, 128, False), (3000, 2, 4, False), (1234, 96, 96, True)])
+def test_one_launch_column_sums_vs_float64(gpu, M, C, ld, idn):
+    """vfn_colsum_acc_f32 / vfn_bn_param_grads_acc_f32 with an arrival counter (one launch; the 64-channel slab form when C % 64 == 0,
+    the block-row form otherwise) against float64 sums: strided rows, accumulation into an existing value, the counters back at
+    zero, run-to-run bit-reproducibility."""
+    from vfloodnet_amd import _lib
+    L = _lib.lib()
+    ptr, check, stream = _lib.ptr, _lib.check, _lib.stream
+    gen = torch.Generator().manual_seed(M * 7 + C)
+    x = torch.randn(M, ld, generator=gen).to(gpu)
+    nb = 128
+    part = torch.empty(2 * nb * C, device=gpu)
+    cnt = torch.zeros(64, dtype=torch.int32, device=gpu)
+    ref = x[:, :C].double().sum(0).cpu()
+    tol = 1e-5 * float(x[:, :C].abs().double().sum(0).max())
+    out = torch.full((C,), float('nan'), device=gpu)
+    check(L.vfn_colsum_acc_f32(ptr(x), M, C, ld, ptr(part), nb, ptr(out), 0, ptr(cnt), stream()), 'colsum')
+    assert (out.cpu().double() - ref).abs().max().item() < tol
+    again = torch.empty(C, device=gpu)
+    check(L.vfn_colsum_acc_f32(ptr(x), M, C, ld, ptr(part), nb, ptr(again), 0, ptr(cnt), stream()), 'colsum')
+    assert torch.equal(out, again)
+    check(L.vfn_colsum_acc_f32(ptr(x), M, C, ld, ptr(part), nb, ptr(again), 1, ptr(cnt), stream()), 'colsum')
+    assert (again.cpu().double() - 2 * ref).abs().max().item() < 2 * tol
+    assert int(cnt.abs().sum()) == 0
+    if ld != C:
+        return
+    # frozen-BatchNorm parameter gradients: dbeta = sum g, dgamma = sum g * ((y - idn) - beta) / gamma
+    g = torch.randn(M, C, generator=gen).to(gpu)
+    y = x
+    i = torch.randn(M, C, generator=gen).to(gpu) if idn else None
+    beta = torch.randn(C, generator=gen).to(gpu)
+    gamma = (1 + 0.2 * torch.rand(C, generator=gen)).to(gpu)
+    yy = (y.double() - (i.double() if idn else 0) - beta.double()) / gamma.double()
+    ref_b, ref_g = g.double().sum(0).cpu(), (g.double() * yy).sum(0).cpu()
+    tol_g = 1e-5 * float((g.double() * yy).abs().sum(0).max())
+    dg, db = torch.empty(C, device=gpu), torch.empty(C, device=gpu)
+    check(L.vfn_bn_param_grads_acc_f32(ptr(g), ptr(y), ptr(i), ptr(beta), ptr(gamma), M, C, ptr(part), nb, ptr(dg), ptr(db), 0, ptr(cnt),
+                                       stream()), 'bn')
+    assert (db.cpu().double() - ref_b).abs().max().item() < 1e-5 * float(g.abs().double().sum(0).max())
+    assert (dg.cpu().double() - ref_g).abs().max().item() < tol_g
+    dg2, db2 = dg.clone(), db.clone()
+    check(L.vfn_bn_param_grads_acc_f32(ptr(g), ptr(y), ptr(i), ptr(beta), ptr(gamma), M, C, ptr(part), nb, ptr(dg2), ptr(db2), 1, ptr(cnt),
+                                       stream()), 'bn')
+    assert (dg2.cpu().double() - 2 * ref_g).abs().max().item() < 2 * tol_g
+    assert torch.equal(db2, 2 * db) and int(cnt.abs().sum()) == 0

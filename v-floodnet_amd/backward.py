@@ -69,7 +69,7 @@ class DecoderBackward:
         wp[:2] = d.local_pred2.weight.detach().float()
         self.f['local_pred2'] = (_dgrad_filters(wp).to(dev), d.local_pred2.weight.shape[1])
         self._scratch = {}
-        self._ticket = torch.zeros(1, dtype=torch.int32, device=dev)       # arrival counter of the one-launch column sums (zero at rest)
+        self._ticket = torch.zeros(64, dtype=torch.int32, device=dev)      # arrival counters (VFN_COLSUM_COUNTERS) of the one-launch column sums, zero at rest
         self.sink = None                                   # ModelBackward: weight gradients accumulate there, in the kernel
 
     # ------------------------------------------------------------------ pieces
@@ -312,7 +312,7 @@ class ModelBackward:
         wkv = torch.cat([kv.Key.weight.detach().float(), kv.Value.weight.detach().float()], 0)      # one 640-filter conv
         self.cb['keyval'] = _ConvBwd(wkv, 1, 1, dev)
         self._grads = {}
-        self._ticket = torch.zeros(1, dtype=torch.int32, device=dev)       # arrival counter of the one-launch column sums (zero at rest)
+        self._ticket = torch.zeros(64, dtype=torch.int32, device=dev)      # arrival counters (VFN_COLSUM_COUNTERS) of the one-launch column sums, zero at rest
         # convolution weight gradients accumulate IN THE KERNEL (vfn_conv_wgrad_f32, accumulate = 1) in the packed filter layout
         # [Cout][kh][kw][Cin]; ``grads`` hands them out as [Cout,Cin,kh,kw] views -- no torch add / copy per sample and layer
         self._packed = {}            # name -> (buffer [cout, k*k*cin], cout, k, cin)

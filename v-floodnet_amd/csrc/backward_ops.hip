@@ -717,6 +717,126 @@ void bn_grads_fused_kernel(const float* __restrict__ g, const float* __restrict_
     }
 }
 
+// ---- the slab form of the one-launch column sums (round 4, second pass).  The block-row form above leaves the tail to ONE block
+// that walks nb partial rows of all C channels (the more blocks, the longer the tail: 128 blocks were faster than 256), and reads a
+// dword per lane.  Here a block owns a 64-channel slab x a row block: 16 float4 columns x 16 row groups, four independent row loads
+// in flight per lane; every slab has its own arrival counter, and the last block OF A SLAB adds that slab's <= 64 partial rows, 16
+// row groups x <= 4 rows: one round trip.  Sums in a fixed order (rows of a group ascending, groups ascending, row blocks ascending).
+// MODE 0: out[c] = sum_m x[m][c];   MODE 1: dbeta[c] = sum g, dgamma[c] = sum g * ((y - idn) - beta) / gamma
+typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+struct WtBuf4 {
+    __amdgpu_buffer_rsrc_t r;
+    const float* base;
+    __device__ __forceinline__ WtBuf4(float* p) : r(__builtin_amdgcn_make_buffer_rsrc(p, 0, 0x7ffffff0, 0x00020000)), base(p) {}
+    __device__ __forceinline__ void store(const float* q, f32x4 v) const {
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, v), r, (int)((q - base) * sizeof(float)), 0, 17);
+    }
+    __device__ __forceinline__ f32x4 load(const float* q) const {
+        return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)((q - base) * sizeof(float)), 0, 17));
+    }
+};
+__device__ __forceinline__ bool last_of_slab(int* counter, int n, int* flag) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const int prev = __hip_atomic_fetch_add(counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int last = prev == n - 1;
+        if (last) __hip_atomic_store(counter, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        *flag = last;
+    }
+    __syncthreads();
+    return *flag != 0;
+}
+template <int MODE>
+__global__ __launch_bounds__(256)
+void slab_sums_kernel(const float* __restrict__ g, const float* __restrict__ y, const float* __restrict__ idn,
+                      const float* __restrict__ beta, const float* __restrict__ gamma, int M, int C, int ld,
+                      float* __restrict__ partial, int* counters, float* __restrict__ out0, float* __restrict__ out1, int accumulate) {
+    constexpr int NS = MODE ? 2 : 1;
+    __shared__ int flag;
+    __shared__ f32x4 red[NS][256];
+    const WtBuf4 wt(partial);
+    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+    const int c = blockIdx.x * 64 + tx * 4;
+    const int nbr = gridDim.y;
+    f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = {0.f, 0.f, 0.f, 0.f};
+    f32x4 b = {0.f, 0.f, 0.f, 0.f}, ig = {1.f, 1.f, 1.f, 1.f};
+    if (MODE) {
+        b = *reinterpret_cast<const f32x4*>(beta + c);
+        const f32x4 gm = *reinterpret_cast<const f32x4*>(gamma + c);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) ig[e] = 1.f / gm[e];
+    }
+    const int dm = nbr * 16;
+    int m = blockIdx.y * 16 + ty;
+    auto term = [&](const f32x4& gv, const f32x4& yv, const f32x4& iv) {
+        s0 += gv;
+        if (MODE) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) s1[e] += gv[e] * ((yv[e] - iv[e]) - b[e]) * ig[e];
+        }
+    };
+    const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+    for (; m + 3 * dm < M; m += 4 * dm) {
+        f32x4 gv[4], yv[4], iv[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const size_t o = (size_t)(m + u * dm) * ld + c;
+            gv[u] = *reinterpret_cast<const f32x4*>(g + o);
+            yv[u] = MODE ? *reinterpret_cast<const f32x4*>(y + o) : z;
+            iv[u] = (MODE && idn) ? *reinterpret_cast<const f32x4*>(idn + o) : z;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) term(gv[u], yv[u], iv[u]);
+    }
+    for (; m < M; m += dm) {
+        const size_t o = (size_t)m * ld + c;
+        const f32x4 gv = *reinterpret_cast<const f32x4*>(g + o);
+        const f32x4 yv = MODE ? *reinterpret_cast<const f32x4*>(y + o) : z;
+        const f32x4 iv = (MODE && idn) ? *reinterpret_cast<const f32x4*>(idn + o) : z;
+        term(gv, yv, iv);
+    }
+    red[0][threadIdx.x] = s0;
+    if (MODE) red[NS - 1][threadIdx.x] = s1;
+    __syncthreads();
+    if (ty == 0) {
+        for (int q = 1; q < 16; ++q) { s0 += red[0][q * 16 + tx]; if (MODE) s1 += red[NS - 1][q * 16 + tx]; }
+        wt.store(partial + ((size_t)blockIdx.y * NS) * C + c, s0);
+        if (MODE) wt.store(partial + ((size_t)blockIdx.y * NS + 1) * C + c, s1);
+    }
+    if (!last_of_slab(counters + blockIdx.x, nbr, &flag)) return;
+    s0 = z; s1 = z;
+    for (int q = ty; q < nbr; q += 16) {
+        s0 += wt.load(partial + ((size_t)q * NS) * C + c);
+        if (MODE) s1 += wt.load(partial + ((size_t)q * NS + 1) * C + c);
+    }
+    red[0][threadIdx.x] = s0;
+    if (MODE) red[NS - 1][threadIdx.x] = s1;
+    __syncthreads();
+    if (ty == 0) {
+        for (int q = 1; q < 16; ++q) { s0 += red[0][q * 16 + tx]; if (MODE) s1 += red[NS - 1][q * 16 + tx]; }
+        f32x4* o0 = reinterpret_cast<f32x4*>(out0 + c);
+        *o0 = accumulate ? *o0 + s0 : s0;
+        if (MODE) {
+            f32x4* o1 = reinterpret_cast<f32x4*>(out1 + c);
+            *o1 = accumulate ? *o1 + s1 : s1;
+        }
+    }
+}
+// row blocks of the slab form: ~512 blocks in all, <= nb (the caller's partial buffer holds nb rows), <= 64 (one-round tail)
+inline int slab_row_blocks(int M, int C, int nb) {
+    int r = 512 / (C / 64);
+    if (r > nb) r = nb;
+    if (r > 64) r = 64;
+    const int by_rows = (M + 15) / 16;
+    if (r > by_rows) r = by_rows;
+    return r < 1 ? 1 : r;
+}
+inline bool slab_ok(const void* a, const void* b, const void* c, const void* d, const void* e, int C, int ld) {
+    auto al = [](const void* p) { return ((size_t)p & 15) == 0; };
+    return C % 64 == 0 && C <= 64 * VFN_COLSUM_COUNTERS && ld % 4 == 0 && al(a) && al(b) && al(c) && al(d) && al(e);
+}
+
 // MaxPool2d(3, 2, 1) backwards: gx[n][y][x][c] = sum of g[n][yo][xo][c] over the output windows whose FIRST maximum (row-major, as
 // PyTorch) is (y, x).  A gather: the <= 2 x 2 windows that contain the input pixel are re-evaluated.
 // add (optional): a second gradient arriving at x (the decoder reads r1 too); relu_mask: x is a ReLU's output, the sum is masked
@@ -842,6 +962,12 @@ extern "C" int vfn_colsum_f32(const float* x, int M, int C, int ld, float* parti
 extern "C" int vfn_colsum_acc_f32(const float* x, int M, int C, int ld, float* partial, int nb, float* out, int accumulate, int* counter,
                                   void* stream) {
     if (!x || !partial || !out || M < 1 || C < 1 || ld < C || nb < 1 || nb > 1024) return VFN_ERR_ARG;
+    if (counter && slab_ok(x, partial, out, nullptr, nullptr, C, ld)) {
+        hipLaunchKernelGGL(slab_sums_kernel<0>, dim3(C / 64, slab_row_blocks(M, C, nb)), dim3(256), 0, (hipStream_t)stream, x, (const float*)nullptr,
+                           (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, M, C, ld, partial, counter, out, (float*)nullptr,
+                           accumulate);
+        return vfn_check_launch();
+    }
     if (counter) {                             // one launch: the last block to arrive adds the partial rows
         hipLaunchKernelGGL(colsum_fused_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, x, M, C, ld, partial, counter, out, accumulate);
         return vfn_check_launch();
@@ -951,6 +1077,11 @@ extern "C" int vfn_bn_param_grads_acc_f32(const float* g, const float* y, const 
                                           int C, float* partial, int nb, float* dgamma, float* dbeta, int accumulate, int* counter,
                                           void* stream) {
     if (!g || !y || !beta || !gamma || !partial || !dgamma || !dbeta || M < 1 || C < 1 || nb < 1 || nb > 1024) return VFN_ERR_ARG;
+    if (counter && slab_ok(g, y, idn, partial, dgamma, C, C) && ((size_t)dbeta & 15) == 0 && ((size_t)beta & 15) == 0 && ((size_t)gamma & 15) == 0) {
+        hipLaunchKernelGGL(slab_sums_kernel<1>, dim3(C / 64, slab_row_blocks(M, C, nb)), dim3(256), 0, (hipStream_t)stream, g, y, idn, beta, gamma,
+                           M, C, C, partial, counter, dbeta, dgamma, accumulate);
+        return vfn_check_launch();
+    }
     if (counter) {
         hipLaunchKernelGGL(bn_grads_fused_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, g, y, idn, beta, gamma, M, C, partial, counter,
                            dgamma, dbeta, accumulate);
