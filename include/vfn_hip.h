@@ -27,8 +27,9 @@ extern "C" {
 /* ------------------------------------------------------------------ version
  * vfn_abi_version() == VFN_ABI_VERSION of the header the binding was written against, and
  * vfn_sizeof_desc(which) == sizeof of the binding's own struct: checked when the library is loaded. */
-#define VFN_ABI_VERSION 10
-enum { VFN_DESC_CONV = 0, VFN_DESC_STEM = 1, VFN_DESC_BANKSCAN = 2, VFN_DESC_MEMREAD = 3, VFN_DESC_BANK = 4, VFN_DESC_WGRAD = 5 };
+#define VFN_ABI_VERSION 11
+enum { VFN_DESC_CONV = 0, VFN_DESC_STEM = 1, VFN_DESC_BANKSCAN = 2, VFN_DESC_MEMREAD = 3, VFN_DESC_BANK = 4, VFN_DESC_WGRAD = 5,
+       VFN_DESC_REFRESH_FILTER = 6, VFN_DESC_REFRESH_EPILOGUE = 7 };
 int vfn_abi_version(void);
 int vfn_sizeof_desc(int which);
 
@@ -241,6 +242,47 @@ typedef struct vfn_wgrad_desc {
     int ksplit;
 } vfn_wgrad_desc;
 int vfn_conv_wgrad_f32(const vfn_wgrad_desc* d, void* stream);
+
+/* Derived-parameter refresh (ABI 11; csrc/refresh.hip).  After ``optimizer.step()`` (train_video_seg.py:76) everything this library
+ * derives from the parameters -- packed filters in the forward layout, in the layout of the data-gradient convolution, the stems'
+ * padded taps, the tap form of the two-filter heads; folded BatchNorm scale / shift (the reference freezes the statistics only,
+ * train_video_seg.py:103-106) -- follows them in TWO launches over tables that live in device memory, instead of a handful of tensor
+ * operators per layer and layout.
+ *   src: a torch-layout filter tensor [cout][cin_total][kh][kw]; the entry covers input channels cin_off .. cin_off + cin - 1.
+ *   kind 0  dst[(dst_row0 + co) * dst_ld + (t * cin + ci)]                       = src[co][ci][t]            (t = y * kw + x)
+ *   kind 1  dst[(dst_row0 + ci) * dst_ld + (T-1-t) * cout_ld + dst_col0 + co]    = src[co][ci][t]            (flipped, transposed)
+ *   kind 2  dst[(((dst_row0 + ci) * kh + y) * 8 + x) * dst_ld + co]              = src[co][ci][y][x]         (stem: 8 taps per row)
+ *   kind 3  dst[(dst_row0 + t * cout + co) * dst_ld + ci]                        = src[co][ci][t]            (tap form)
+ *   gamma / var / eps (optional): the value is multiplied by gamma[co] / sqrt(var[co] + eps) (a frozen BatchNorm's scale).
+ *   block0: first workgroup of the entry; an entry takes ceil(cout * cin * kh * kw / vfn_refresh_elems_per_block()) workgroups and
+ *   the table is ordered by block0. */
+typedef struct vfn_refresh_filter {
+    const float* src;
+    float* dst;
+    const float* gamma;
+    const float* var;
+    float eps;
+    int kind;
+    int cout, cin, cin_off, cin_total, kh, kw;
+    int dst_ld, dst_row0, dst_col0, cout_ld;
+    int block0;
+    int reserved;
+} vfn_refresh_filter;
+/* scale[c] = gamma[c] / sqrt(var[c] + eps), shift[c] = beta[c] - mean[c] * scale[c] (gamma != NULL: a frozen BatchNorm; either
+ * destination may be NULL), or shift[c] = beta[c] (gamma == NULL: a plain bias; beta NULL: zero). */
+typedef struct vfn_refresh_epilogue {
+    const float* gamma;
+    const float* beta;
+    const float* mean;
+    const float* var;
+    float* scale;
+    float* shift;
+    float eps;
+    int C;
+} vfn_refresh_epilogue;
+int vfn_refresh_elems_per_block(void);
+int vfn_refresh_filters_f32(const vfn_refresh_filter* table_dev, int n, int total_blocks, void* stream);
+int vfn_refresh_epilogues_f32(const vfn_refresh_epilogue* table_dev, int n, void* stream);
 /* Encoder pieces (ResNet trunks, BatchNorm frozen as train_video_seg.py:103-106 sets it), memory read, optimiser:
  * vfn_dilate2_f32          out[n][2y][2x][c] = g[n][y][x][c], 0 elsewhere ([N][H][W][C] from [N][Ho][Wo][C]): the data gradient of a
  *     stride-2 convolution is the stride-1 data-gradient convolution of this.

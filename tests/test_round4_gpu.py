@@ -53,3 +53,103 @@ def test_main_on_a_resized_clip_does_not_reuse_stale_lookahead_entries(gpu, tmp_
     assert min(ious) > 0.995, [round(float(x), 4) for x in ious]
     # the clip moves: a frame segmented from an older frame's pixels would be far off its neighbour-in-time's mask as well
     assert all(o.shape == (H, W) for o in out['ahead'])
+
+
+def _derived_tensors(eng, mb):
+    """name -> every tensor the engine / the backward pass derive from the parameters."""
+    out = {'stem_q_w': eng.stem_q_w, 'stem_q_scale': eng.stem_q_scale, 'stem_q_shift': eng.stem_q_shift,
+           'stem_m_w': eng.stem_m_w, 'stem_m_scale': eng.stem_m_scale, 'stem_m_shift': eng.stem_m_shift}
+
+    def walk(prefix, o):
+        if isinstance(o, dict):
+            for k, v in o.items():
+                walk(f'{prefix}.{k}', v)
+        elif isinstance(o, (list, tuple)):
+            for i, v in enumerate(o):
+                walk(f'{prefix}.{i}', v)
+        else:
+            out[prefix + '.w'], out[prefix + '.scale'], out[prefix + '.shift'] = o.w, o.scale, o.shift
+            if hasattr(o, 'bias'):
+                out[prefix + '.bias'] = o.bias
+    walk('enc_q', eng.enc_q)
+    walk('enc_m', eng.enc_m)
+    walk('keyval', eng.keyval)
+    walk('dec', eng.dec)
+    for name, cb in mb.cb.items():
+        out['bwd.' + name + '.wp'] = cb.wp
+        if cb.scale is not None:
+            out['bwd.' + name + '.scale'] = cb.scale
+    for name, (wp, _) in mb.dec.f.items():
+        out['bwd.dec.' + name] = wp
+    return out
+
+
+def test_refresh_rewrites_every_derived_tensor_bit_exactly_and_keeps_the_step(gpu):
+    """``Engine.refresh()`` (two launches over device tables, csrc/refresh.hip) after the parameters changed in place: every
+    packed filter, data-gradient filter, stem tap and folded BatchNorm constant equals, bit for bit, what a newly built engine /
+    backward pass derives with tensor operators; the tensors stay where they are (descriptors keep pointing at them); and two
+    training steps through the refresh path give the losses of two steps that rebuild the engine each time."""
+    from tools import synth
+    from vfloodnet_amd import AFB_URR, train as T
+    from vfloodnet_amd.engine import Engine
+    from vfloodnet_amd.backward import ModelBackward
+    sd = synth.make_state_dict(SEED)
+    model = AFB_URR(gpu, update_bank=False).to(gpu)
+    model.load_state_dict(sd, strict=True)
+    model.train()
+    eng = model.engine()
+    mb = eng.backward()
+    before = {k: (v.data_ptr(), v.clone()) for k, v in _derived_tensors(eng, mb).items()}
+    gen = torch.Generator(device=gpu).manual_seed(5)
+    with torch.no_grad():
+        for p in model.parameters():
+            p.add_(0.05 * p.abs().mean() * torch.randn(p.shape, device=gpu, generator=gen))
+    runs = eng.refresher.runs
+    eng.refresh()
+    torch.cuda.synchronize()
+    assert eng.refresher.runs == runs + 1
+    fresh_eng = Engine(model)
+    fresh = _derived_tensors(fresh_eng, fresh_eng.backward())
+    # ... and what tensor operators alone derive (the constructors, with the settling pass switched off): pure data movement is
+    # identical, anything that went through the folded scale gamma / sqrt(var + eps) agrees to the device division's 1-2 ulp
+    settle = Engine._settle
+    Engine._settle = lambda self: None
+    try:
+        plain_eng = Engine(model)
+        plain = _derived_tensors(plain_eng, ModelBackward(plain_eng))
+    finally:
+        Engine._settle = settle
+    got = _derived_tensors(eng, mb)
+    assert set(got) == set(fresh) == set(plain) and len(got) > 500
+    changed = exact = 0
+    for k, t in got.items():
+        assert t.data_ptr() == before[k][0], k
+        assert torch.equal(t, fresh[k]), (k, (t - fresh[k]).abs().max().item())
+        err = (t - plain[k]).abs().max().item()
+        assert err <= 4e-7 * max(1e-30, plain[k].abs().max().item()), (k, err)
+        exact += int(err == 0.0)
+        changed += int(not torch.equal(t, before[k][1]))
+    assert changed > 0.9 * len(got), changed                      # (zero shifts of the bias-free halves do not change)
+    assert exact > 0.3 * len(got), exact                          # (every forward filter pack, the decoder's data-gradient filters)
+
+    # two optimizer steps: refresh path vs a rebuild per step
+    H, W, K = 96, 160, 2
+    frames, m0 = synth.clip(6, 3, H, W)
+    lab = torch.stack([torch.roll(m0.long(), (2 * t, 5 * t), (0, 1)) for t in range(3)], 0)
+    masks = torch.nn.functional.one_hot(lab, K).permute(0, 3, 1, 2).float()
+    losses = {}
+    for mode in ('refresh', 'rebuild'):
+        m = AFB_URR(gpu, update_bank=False).to(gpu)
+        m.load_state_dict(sd, strict=True)
+        m.train()
+        opt = T.AdamW(m.named_parameters(), lr=1e-4)
+        out = []
+        for _ in range(3):
+            if mode == 'rebuild':
+                m._invalidate()
+            out.append(T.train_step(m, opt, frames, masks, 0.5))
+        losses[mode] = out
+        if mode == 'refresh':
+            assert m.engine().refresher.runs == 2 + 3             # (engine built, backward pass built, three steps)
+    assert losses['refresh'] == losses['rebuild'], losses
+    assert losses['refresh'][2][0] < losses['refresh'][0][0]

@@ -34,6 +34,18 @@ class WgradDesc(C.Structure):
                 ('k', C.c_int), ('stride', C.c_int), ('pad', C.c_int), ('relu', C.c_int), ('accumulate', C.c_int), ('ksplit', C.c_int)]
 
 
+class RefreshFilter(C.Structure):
+    _fields_ = [('src', c_fp), ('dst', c_fp), ('gamma', c_fp), ('var', c_fp), ('eps', C.c_float), ('kind', C.c_int),
+                ('cout', C.c_int), ('cin', C.c_int), ('cin_off', C.c_int), ('cin_total', C.c_int), ('kh', C.c_int), ('kw', C.c_int),
+                ('dst_ld', C.c_int), ('dst_row0', C.c_int), ('dst_col0', C.c_int), ('cout_ld', C.c_int), ('block0', C.c_int),
+                ('reserved', C.c_int)]
+
+
+class RefreshEpilogue(C.Structure):
+    _fields_ = [('gamma', c_fp), ('beta', c_fp), ('mean', c_fp), ('var', c_fp), ('scale', c_fp), ('shift', c_fp),
+                ('eps', C.c_float), ('C', C.c_int)]
+
+
 class StemDesc(C.Structure):
     _fields_ = [('frame', c_fp), ('mask', c_fp), ('w', c_fp), ('scale', c_fp), ('shift', c_fp), ('out', c_fp),
                 ('mean', C.c_float * 3), ('std', C.c_float * 3),
@@ -74,8 +86,8 @@ class BankDesc(C.Structure):
                 ('obj_n', C.c_int), ('cap', C.c_int), ('rm_class', C.c_int), ('rm_request', C.c_int)]
 
 
-ABI_VERSION = 10         # include/vfn_hip.h VFN_ABI_VERSION; csrc/abi.hip
-DESC_IDS = {0: ConvDesc, 1: StemDesc, 2: BankScanDesc, 3: MemReadDesc, 4: BankDesc, 5: WgradDesc}     # vfn_sizeof_desc(which)
+ABI_VERSION = 11         # include/vfn_hip.h VFN_ABI_VERSION; csrc/abi.hip
+DESC_IDS = {0: ConvDesc, 1: StemDesc, 2: BankScanDesc, 3: MemReadDesc, 4: BankDesc, 5: WgradDesc, 6: RefreshFilter, 7: RefreshEpilogue}     # vfn_sizeof_desc(which)
 
 
 def lib():
@@ -188,6 +200,9 @@ SIGNATURES = {
     'vfn_png_unfilter_sizes': [_i, _i, _i, C.POINTER(_i), C.POINTER(_ll)],
     'vfn_png_unfilter_u8': [_p, _i, _i, _i, _p, _p, _p, _p],
     'vfn_png_to_tensor_f32': [_p, _i, _i, _i, _i, _p, _p, _p, _p],
+    'vfn_refresh_elems_per_block': [],
+    'vfn_refresh_filters_f32': [_p, _i, _i, _p],
+    'vfn_refresh_epilogues_f32': [_p, _i, _p],
     'vfn_ln_stem_f32': [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p],
     'vfn_ln_dwconv_f32': [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p],
     'vfn_ln_se_gate_f32': [_p, _f, _p, _p, _p, _p, _p, _i, _i, _i, _p],

@@ -69,7 +69,7 @@ class _Memorize(torch.autograd.Function):
         zv = lambda: torch.zeros(plan.HW, DV, device=eng.device)
         g_bk = [g[i].t().contiguous() if g[i] is not None else zk() for i in range(K)]             # [128,HW] -> [HW,128]
         g_bv = [g[K + i].t().contiguous() if g[K + i] is not None else zv() for i in range(K)]
-        mb = ModelBackward(eng)
+        mb = eng.backward()
         mb.finish_memorize(ctx.frame, ctx.mask, g_bk, g_bv)
         names, params = trainable(model)
         return (None, None, None) + _param_grads(names, params, mb.grads)
@@ -100,7 +100,7 @@ class _Segment(torch.autograd.Function):
             g_unc = torch.zeros((), device=eng.device)
         # dL/dscores in total: the caller's criterion (g_score) + the uncertainty's adjoint, one kernel, no host round trip
         total = ops.segment_uncertainty_backward(score.contiguous(), g_unc.reshape(1).float().contiguous(), g_score)
-        mb = ModelBackward(eng)
+        mb = eng.backward()
         g_bk = g_bv = None
         # the sample that ran last still has its activations in the plan; the others are run again (see the module docstring)
         order = [bs - 1] + list(range(bs - 1)) if eng.fwd_count == ctx.token else list(range(bs))

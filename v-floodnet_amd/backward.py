@@ -23,6 +23,7 @@ import torch
 
 from . import _lib, ops, weights as W
 from ._lib import ptr, stream, check
+from .refresh import DGRAD
 from .engine import choose_cfg, apply_choice, DK, DV
 
 
@@ -52,25 +53,35 @@ class DecoderBackward:
                            ('RF3.ResMM.conv1', d.RF3.ResMM.conv1), ('RF3.ResMM.conv2', d.RF3.ResMM.conv2),
                            ('RF2.convFS', d.RF2.convFS), ('RF2.ResFS.conv1', d.RF2.ResFS.conv1), ('RF2.ResFS.conv2', d.RF2.ResFS.conv2),
                            ('RF2.ResMM.conv1', d.RF2.ResMM.conv1), ('RF2.ResMM.conv2', d.RF2.ResMM.conv2)):
-            self.f[name] = (_dgrad_filters(conv.weight).to(dev), conv.weight.shape[1])
+            self._filters(name, conv.weight)
         wfm = d.convFM.weight
-        self.f['convFM.m'] = (_dgrad_filters(wfm[:, :DV]).to(dev), DV)
-        self.f['convFM.q'] = (_dgrad_filters(wfm[:, DV:]).to(dev), DV)
-        wp = torch.zeros(32, d.pred2.weight.shape[1], 3, 3)                 # pred2 has 2 filters: its gradient arrives in a
-        wp[:2] = d.pred2.weight.detach().float()                           # 32-channel tensor (channels 2.. are zero)
-        self.f['pred2'] = (_dgrad_filters(wp).to(dev), d.pred2.weight.shape[1])
-        # the local refinement head (AFB_URR.py:231-234)
+        self._filters('convFM.m', wfm, 0, DV)
+        self._filters('convFM.q', wfm, DV, DV)
+        self._filters('pred2', d.pred2.weight, cout_ld=32)                  # pred2 has 2 filters: its gradient arrives in a
+        # the local refinement head (AFB_URR.py:231-234)                     # 32-channel tensor (channels 2.. are zero)
         for name, conv in (('local_ResMM.conv1', d.local_ResMM.conv1), ('local_ResMM.conv2', d.local_ResMM.conv2)):
-            self.f[name] = (_dgrad_filters(conv.weight).to(dev), conv.weight.shape[1])
+            self._filters(name, conv.weight)
         wl = d.local_convFM.weight                                           # input = cat([r1, r1_local]): 64 + 64 channels
-        self.f['local_convFM.r1'] = (_dgrad_filters(wl[:, :64]).to(dev), 64)
-        self.f['local_convFM.loc'] = (_dgrad_filters(wl[:, 64:]).to(dev), 64)
-        wp = torch.zeros(32, d.local_pred2.weight.shape[1], 3, 3)
-        wp[:2] = d.local_pred2.weight.detach().float()
-        self.f['local_pred2'] = (_dgrad_filters(wp).to(dev), d.local_pred2.weight.shape[1])
+        self._filters('local_convFM.r1', wl, 0, 64)
+        self._filters('local_convFM.loc', wl, 64, 64)
+        self._filters('local_pred2', d.local_pred2.weight, cout_ld=32)
         self._scratch = {}
         self._ticket = torch.zeros(64, dtype=torch.int32, device=dev)      # arrival counters (VFN_COLSUM_COUNTERS) of the one-launch column sums, zero at rest
         self.sink = None                                   # ModelBackward: weight gradients accumulate there, in the kernel
+
+    def _filters(self, name, weight, cin_off=0, cin=None, cout_ld=0):
+        """Packed data-gradient filters of (a slice of the input channels of) a 3 x 3 convolution, ``cout_ld`` > Cout: zero
+        filters up to that width; registered with the engine's Refresher so that they follow the parameter."""
+        cout = weight.shape[0]
+        cin = weight.shape[1] if cin is None else cin
+        w = weight.detach().float()[:, cin_off:cin_off + cin]
+        if cout_ld > cout:
+            wp = torch.zeros(cout_ld, cin, 3, 3, device=w.device)
+            wp[:cout] = w
+            w = wp
+        self.f[name] = (_dgrad_filters(w).to(self.dev), cin)
+        self.eng.refresher.add_filter(weight, self.f[name][0], DGRAD, cin=cin, cin_off=cin_off, dst_ld=9 * max(cout, cout_ld),
+                                      cout_ld=max(cout, cout_ld))
 
     # ------------------------------------------------------------------ pieces
     def _buf(self, key, numel):
@@ -269,13 +280,20 @@ class _ConvBwd:
     """One forward convolution seen from the backward pass: the packed filters of its data-gradient convolution (a frozen
     BatchNorm's scale folded in: d/dx of scale * conv(x) is conv(g * scale, flipped filters)) and its geometry."""
 
-    def __init__(self, weight, stride, pad, dev, scale=None):
+    def __init__(self, weight, stride, pad, dev, bn=None, reg=None):
+        """``bn``: the frozen BatchNorm behind the convolution; ``reg`` (refresh.Refresher): filters and scale follow the
+        parameters in place after an optimizer step."""
         w = weight.detach().float()
+        scale = None if bn is None else _bn_scale(bn)
         self.cout, self.cin, self.k, _ = w.shape
         self.stride, self.pad = int(stride), int(pad)
         ws = w if scale is None else w * scale.detach().float().view(-1, 1, 1, 1).to(w.device)
         self.wp = _dgrad_filters(ws).to(dev)
         self.scale = None if scale is None else scale.detach().float().to(dev).contiguous()
+        if reg is not None and isinstance(weight, torch.nn.Parameter):
+            reg.add_filter(weight, self.wp, DGRAD, dst_ld=self.k * self.k * self.cout, bn=bn)
+            if bn is not None:
+                reg.add_epilogue(self.scale, None, bn=bn)
 
 
 def _bn_scale(bn):
@@ -297,26 +315,36 @@ class ModelBackward:
         self.dec = DecoderBackward(engine)
         m = engine.model
         dev = self.dev
+        reg = engine.refresher
         self.cb = {}
         for enc_name, enc in (('encoder_q', m.encoder_q), ('encoder_m', m.encoder_m)):
             for lname in ('res2', 'res3', 'res4'):
                 for bi, blk in enumerate(getattr(enc, lname)):
                     pre = f'{enc_name}.{lname}.{bi}'
-                    self.cb[pre + '.conv1'] = _ConvBwd(blk.conv1.weight, 1, 0, dev, _bn_scale(blk.bn1))
-                    self.cb[pre + '.conv2'] = _ConvBwd(blk.conv2.weight, blk.conv2.stride[0], 1, dev, _bn_scale(blk.bn2))
-                    self.cb[pre + '.conv3'] = _ConvBwd(blk.conv3.weight, 1, 0, dev, _bn_scale(blk.bn3))
+                    self.cb[pre + '.conv1'] = _ConvBwd(blk.conv1.weight, 1, 0, dev, blk.bn1, reg)
+                    self.cb[pre + '.conv2'] = _ConvBwd(blk.conv2.weight, blk.conv2.stride[0], 1, dev, blk.bn2, reg)
+                    self.cb[pre + '.conv3'] = _ConvBwd(blk.conv3.weight, 1, 0, dev, blk.bn3, reg)
                     if hasattr(blk, 'downsample'):
                         self.cb[pre + '.downsample.0'] = _ConvBwd(blk.downsample[0].weight, blk.downsample[0].stride[0], 0, dev,
-                                                                  _bn_scale(blk.downsample[1]))
+                                                                  blk.downsample[1], reg)
         kv = m.keyval_r4
         wkv = torch.cat([kv.Key.weight.detach().float(), kv.Value.weight.detach().float()], 0)      # one 640-filter conv
         self.cb['keyval'] = _ConvBwd(wkv, 1, 1, dev)
+        col = 0
+        for c in (kv.Key, kv.Value):
+            reg.add_filter(c.weight, self.cb['keyval'].wp, DGRAD, dst_ld=9 * wkv.shape[0], dst_col0=col, cout_ld=wkv.shape[0])
+            col += c.weight.shape[0]
         self._grads = {}
         self._ticket = torch.zeros(64, dtype=torch.int32, device=dev)      # arrival counters (VFN_COLSUM_COUNTERS) of the one-launch column sums, zero at rest
         # convolution weight gradients accumulate IN THE KERNEL (vfn_conv_wgrad_f32, accumulate = 1) in the packed filter layout
         # [Cout][kh][kw][Cin]; ``grads`` hands them out as [Cout,Cin,kh,kw] views -- no torch add / copy per sample and layer
         self._packed = {}            # name -> (buffer [cout, k*k*cin], cout, k, cin)
         self.dec.sink = self         # the decoder's weight gradients go the same way
+
+    def reset(self):
+        """Forget the gradients of the previous step (their tensors belong to whoever took them from ``grads``)."""
+        self._grads = {}
+        self._packed = {}
 
     @property
     def grads(self):
@@ -492,7 +520,7 @@ class ModelBackward:
         planes) + bn1.  xn: the padded, normalised input planes [N,Hp,Wp,C]; g_c1: dL/d(bn1 output), masked."""
         self._bn_grads(enc_name + '.bn1', enc.bn1, g_c1, r1)
         C = xn.shape[-1]
-        cb = _ConvBwd(torch.zeros(64, C, 7, 7), 2, 3, self.dev, _bn_scale(enc.bn1))
+        cb = _ConvBwd(torch.zeros(64, C, 7, 7), 2, 3, self.dev, enc.bn1)
         dw = self._wgrad(plan, xn, g_c1, cb, N, plan.Hp, plan.Wp)              # [64, C, 7, 7]
         c0 = 0
         for name, nc in names:

@@ -15,6 +15,8 @@ extern "C" int vfn_sizeof_desc(int which) {
         case VFN_DESC_MEMREAD: return (int)sizeof(vfn_memread_desc);
         case VFN_DESC_BANK: return (int)sizeof(vfn_bank_desc);
         case VFN_DESC_WGRAD: return (int)sizeof(vfn_wgrad_desc);
+        case VFN_DESC_REFRESH_FILTER: return (int)sizeof(vfn_refresh_filter);
+        case VFN_DESC_REFRESH_EPILOGUE: return (int)sizeof(vfn_refresh_epilogue);
     }
     return -1;
 }

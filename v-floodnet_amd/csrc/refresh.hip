@@ -1,0 +1,95 @@
+// Derived-parameter refresh (round 4): after an optimizer step every convolution's packed filters (forward layout, the
+// flipped / transposed layout of its data-gradient convolution, the stems' padded-tap layout, the 20-row tap form of the two-filter
+// heads) and every folded-BatchNorm epilogue (train_video_seg.py:103-109: the statistics are frozen, weight and bias train) have to
+// follow the parameters.  Rebuilding them with tensor operators costs ~1 500 tiny launches per training step (six per layer and
+// layout); here they are TWO launches over tables in device memory -- one entry per (parameter tensor, derived tensor) -- that the
+// host builds once per model (v-floodnet_amd/refresh.py) and re-uses while the tensors stay where they are.
+//
+// The results are bit-identical to the tensor-operator form (tests/test_train_gpu.py): pure data movement, one multiply for the
+// folded scale, and the scale / shift arithmetic in the same order with contraction switched off.
+#include "common.h"
+#include "../../include/vfn_hip.h"
+
+namespace {
+
+constexpr int ELEMS_PER_BLOCK = 4096;
+
+__device__ __forceinline__ float bn_scale(const float* gamma, const float* var, float eps, int c) {
+    return __fdiv_rn(gamma[c], __fsqrt_rn(__fadd_rn(var[c], eps)));
+}
+
+__global__ __launch_bounds__(256)
+void refresh_filters_kernel(const vfn_refresh_filter* __restrict__ table, int n) {
+    // the entry this block works on: the last one whose first block is <= blockIdx.x
+    int lo = 0, hi = n - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (table[mid].block0 <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
+    }
+    const vfn_refresh_filter e = table[lo];
+    const int T = e.kh * e.kw;
+    const long long total = (long long)e.cout * e.cin * T;
+    const long long base = (long long)((int)blockIdx.x - e.block0) * ELEMS_PER_BLOCK;
+    for (int i = threadIdx.x; i < ELEMS_PER_BLOCK; i += 256) {
+        const long long idx = base + i;
+        if (idx >= total) return;
+        int co, ci, t;
+        size_t dst;
+        if (e.kind == 0) {                       // forward: dst[co][(t, ci)]
+            ci = (int)(idx % e.cin);
+            t = (int)((idx / e.cin) % T);
+            co = (int)(idx / ((long long)e.cin * T));
+            dst = (size_t)(e.dst_row0 + co) * e.dst_ld + (size_t)t * e.cin + ci;
+        } else if (e.kind == 1) {                // data gradient: dst[ci][(T-1-t, co)]
+            co = (int)(idx % e.cout);
+            const int tf = (int)((idx / e.cout) % T);
+            ci = (int)(idx / ((long long)e.cout * T));
+            t = T - 1 - tf;
+            dst = (size_t)(e.dst_row0 + ci) * e.dst_ld + (size_t)tf * e.cout_ld + e.dst_col0 + co;
+        } else if (e.kind == 2) {                // stem: dst[((p0 + ci) * kh + y) * 8 + x][co], 8th tap stays zero
+            co = (int)(idx % e.cout);
+            t = (int)((idx / e.cout) % T);
+            ci = (int)(idx / ((long long)e.cout * T));
+            const int y = t / e.kw, x = t % e.kw;
+            dst = ((size_t)((e.dst_row0 + ci) * e.kh + y) * 8 + x) * e.dst_ld + co;
+        } else {                                 // tap form: dst[t * cout + co][ci]
+            ci = (int)(idx % e.cin);
+            co = (int)((idx / e.cin) % e.cout);
+            t = (int)(idx / ((long long)e.cin * e.cout));
+            dst = (size_t)(e.dst_row0 + t * e.cout + co) * e.dst_ld + ci;
+        }
+        float v = e.src[((size_t)co * e.cin_total + e.cin_off + ci) * T + t];
+        if (e.gamma) v = __fmul_rn(v, bn_scale(e.gamma, e.var, e.eps, co));
+        e.dst[dst] = v;
+    }
+}
+
+__global__ __launch_bounds__(256)
+void refresh_epilogues_kernel(const vfn_refresh_epilogue* __restrict__ table) {
+    const vfn_refresh_epilogue e = table[blockIdx.x];
+    for (int c = threadIdx.x; c < e.C; c += 256) {
+        if (e.gamma) {
+            const float s = bn_scale(e.gamma, e.var, e.eps, c);
+            if (e.scale) e.scale[c] = s;
+            if (e.shift) e.shift[c] = __fsub_rn(e.beta[c], __fmul_rn(e.mean[c], s));
+        } else if (e.shift) {
+            e.shift[c] = e.beta ? e.beta[c] : 0.f;
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int vfn_refresh_elems_per_block(void) { return ELEMS_PER_BLOCK; }
+
+extern "C" int vfn_refresh_filters_f32(const vfn_refresh_filter* table, int n, int total_blocks, void* stream) {
+    if (!table || n < 1 || total_blocks < 1) return VFN_ERR_ARG;
+    hipLaunchKernelGGL(refresh_filters_kernel, dim3(total_blocks), dim3(256), 0, (hipStream_t)stream, table, n);
+    return vfn_check_launch();
+}
+
+extern "C" int vfn_refresh_epilogues_f32(const vfn_refresh_epilogue* table, int n, void* stream) {
+    if (!table || n < 1) return VFN_ERR_ARG;
+    hipLaunchKernelGGL(refresh_epilogues_kernel, dim3(n), dim3(256), 0, (hipStream_t)stream, table);
+    return vfn_check_launch();
+}

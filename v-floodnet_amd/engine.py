@@ -167,11 +167,72 @@ def choose_cfg(M, cout, K, mode=0):
     return (best, 1, 0)
 
 
+def tune_desc(d, bf, ws, cnt, iters=3, cfg_filter=None, allow_split=True):
+    """Time every tile configuration (and its split options) on the convolution descriptor ``d`` -- launched in place, on its
+    own buffers -- and return the fastest (cfg, ksplit, split_from).  ``ws`` / ``cnt``: split-K workspace and tile counters."""
+    tiles = ops.conv_cfg_tiles()
+    key = (d.M, d.Cout, d.KH * d.KW * d.Cin)
+
+    def timeit(c):
+        ops.conv2d_launch(d, c, bf)
+        torch.cuda.synchronize()
+        best_ms = None
+        for _ in range(3):                                   # fastest of three batches: robust against a transient
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(iters):
+                ops.conv2d_launch(d, c, bf)
+            e1.record()
+            torch.cuda.synchronize()
+            ms = e0.elapsed_time(e1)
+            best_ms = ms if best_ms is None else min(best_ms, ms)
+        return best_ms
+
+    best, best_t = None, None
+    for c, (bm, bn) in enumerate(tiles):
+        if bf and c not in ops.BF16_CFGS:              # no LDS-DMA variants (the DMA cannot convert)
+            continue
+        if cfg_filter is not None and not cfg_filter(key, c):
+            continue
+        if d.cout_pad < ((d.Cout + bn - 1) // bn) * bn:
+            continue
+        if (bn > 64 and d.Cout <= 32) or (bn > 128 and d.Cout < 256):
+            continue
+        blocks = ((d.M + bm - 1) // bm) * ((d.Cout + bn - 1) // bn)
+        options = [(c, 1, 0)]
+        wk = ops.conv_cfg_wk(c)
+        kind = ops.conv_cfg_kind(c)
+        if kind == 2:                                  # stream-K balances by itself
+            if blocks > ops.SK_MAX_TILES:
+                continue
+        elif not allow_split:
+            pass
+        elif kind == 1 and wk > 1:                     # wave-autonomous with K groups: a second split only when tiles are scarce
+            if blocks < 256:
+                options += [(c, k_, 0) for k_ in ops.valid_splits(d, 8, bf)[1:] if k_ * d.M * d.Cout <= WS_FLOATS]
+        elif wk > 1 or ops.conv_cfg_tpb(c) > 1:          # split-K inside the workgroup / two tiles per barrier:
+            if blocks > 1024 or d.KH * d.KW * d.Cin // (64 if bf == 1 else 32) < 2 * wk:   # no second split, scarce tiles
+                continue
+        elif blocks < 256:
+            options += [(c, k_, 0) for k_ in ops.valid_splits(d, 16, bf)[1:] if k_ * d.M * d.Cout <= WS_FLOATS]
+        else:
+            options += [(c, k_, full) for (full, k_, rows) in ops.tail_split_options(d, bm, bn, 8, bf)
+                        if k_ * rows * d.Cout <= WS_FLOATS and k_ in (2, 3, 4, 5, 6, 8)]
+        for opt in options:
+            apply_choice(d, opt, ws, cnt)
+            t = timeit(c)
+            if best_t is None or t < best_t:
+                best, best_t = opt, t
+    return best
+
+
 class ConvLayer:
     """Packed filters + epilogue constants of one convolution (optionally of a slice of its input channels:
     a conv over torch.cat([a, b]) is conv_a(a) + conv_b(b), which lets a shared half be computed once)."""
 
-    def __init__(self, conv, bn=None, device=None, cin_range=None, with_bias=True):
+    def __init__(self, conv, bn=None, device=None, cin_range=None, with_bias=True, reg=None):
+        """``reg`` (a refresh.Refresher): the packed filters / epilogue constants are registered there, so that they follow the
+        parameters after an optimizer step without being rebuilt."""
         w = conv.weight.detach().float()
         if cin_range is not None:
             w = w[:, cin_range[0]:cin_range[1]].contiguous()
@@ -185,6 +246,23 @@ class ConvLayer:
         self.scale = sc.to(device).contiguous()
         self.shift = sh.to(device).contiguous()
         self._w_lp = {}
+        if reg is not None and isinstance(conv, torch.nn.Module):
+            from .refresh import FORWARD
+            reg.add_filter(conv.weight, self.w, FORWARD, cin=self.cin, cin_off=cin_range[0] if cin_range is not None else 0)
+            if bn is not None:
+                reg.add_epilogue(self.scale, self.shift if with_bias else None, bn=bn, eps=W.BN_EPS)
+            elif conv.bias is not None and with_bias:
+                reg.add_epilogue(None, self.shift, bias=conv.bias)
+
+    def refresh_derived(self):
+        """The images derived from ``w`` (reduced-precision operands, Winograd filter banks) again, in place."""
+        for mode, t in self._w_lp.items():
+            if mode == 'wino':
+                w = self.w[:self.cout].view(self.cout, 3, 3, self.cin).permute(0, 3, 1, 2)
+                t.copy_(ops.pack_winograd_weight(w).to(t.device))
+            else:
+                new = ops.pack_weights_lp(self.w, mode)
+                t.copy_(new)
 
     def w_lp(self, mode):
         """Filters pre-converted for the bf16 / bf16x3 kernels (built once per mode)."""
@@ -207,8 +285,8 @@ class Pred2Layer:
     the nine shifted taps and the bias."""
     TAPS = 20
 
-    def __init__(self, conv, device):
-        w = conv.weight.detach().float()                       # [2, Cin, 3, 3]
+    def __init__(self, conv, device, reg=None):
+        w = conv.weight.detach().float().cpu()                 # [2, Cin, 3, 3]
         assert w.shape[0] == 2 and w.shape[2:] == (3, 3)
         self.cin = w.shape[1]
         w18 = torch.zeros(self.TAPS, self.cin)
@@ -220,8 +298,14 @@ class Pred2Layer:
         self.w = ops.pad_rows(w18.contiguous()).to(device)
         self.scale = torch.ones(self.TAPS, device=device)
         self.shift = torch.zeros(self.TAPS, device=device)
-        self.bias = conv.bias.detach().float().to(device).contiguous()
+        self.bias = conv.bias.detach().float().to(device).contiguous().clone()
         self._w_lp = {}
+        if reg is not None:
+            from .refresh import TAPS
+            reg.add_filter(conv.weight, self.w, TAPS)
+            reg.add_epilogue(None, self.bias, bias=conv.bias)
+
+    refresh_derived = ConvLayer.refresh_derived
 
     def w_lp(self, mode):
         if mode not in self._w_lp:
@@ -612,7 +696,51 @@ class Engine:
         self.mem_count = 0           # whether the activations a backward pass needs are still the ones its forward wrote
         self._side = None            # side stream for the query side of the next frames
         self._side_busy = None       # event behind the last work enqueued on it
+        from .refresh import Refresher
+        self.refresher = Refresher(self.device)     # packed filters / folded constants follow the parameters in place (refresh())
+        self._backward = None
         self._pack(model)
+        self._settle()
+
+    def _settle(self):
+        """Run the refresh kernels once over what the constructors just derived with tensor operators: a new engine and a
+        refreshed one then hold the same bits (the kernels round the folded scale gamma / sqrt(var + eps) correctly; the
+        device's tensor-operator division is 1-2 ulp off that).  Skipped when a parameter is not a contiguous f32 device tensor."""
+        try:
+            self.refresher.run()
+        except RuntimeError:
+            pass
+
+    def refresh(self):
+        """The parameters changed in place (an optimizer step): rewrite everything derived from them -- the engine's packed
+        filters and folded BatchNorm constants, the backward pass's data-gradient filters -- where it lies (two launches,
+        csrc/refresh.hip); plans, buffers and descriptors stay.  Raises RuntimeError if a parameter is no longer a contiguous f32
+        device tensor (the caller builds a new engine then)."""
+        self.refresher.run()
+        for layer in self._layers():
+            if layer._w_lp:
+                layer.refresh_derived()
+
+    def _layers(self):
+        def walk(o):
+            if isinstance(o, (ConvLayer, Pred2Layer)):
+                yield o
+            elif isinstance(o, dict):
+                for v in o.values():
+                    yield from walk(v)
+            elif isinstance(o, (list, tuple)):
+                for v in o:
+                    yield from walk(v)
+        yield from walk([self.enc_q, self.enc_m, self.keyval, self.dec])
+
+    def backward(self):
+        """The (cached) backward pass of this engine, emptied of the previous step's gradients."""
+        from .backward import ModelBackward
+        if self._backward is None:
+            self._backward = ModelBackward(self)
+            self._settle()
+        self._backward.reset()
+        return self._backward
 
     def use_winograd(self, layer, M):
         """Winograd F(4x4, 3x3) for this layer (M = N * H * W output pixels)?  See _WINOGRAD above."""
@@ -643,10 +771,11 @@ class Engine:
         for lname in ('res2', 'res3', 'res4'):
             blocks = []
             for blk in getattr(enc, lname):
-                b = dict(conv1=ConvLayer(blk.conv1, blk.bn1, dev), conv2=ConvLayer(blk.conv2, blk.bn2, dev),
-                         conv3=ConvLayer(blk.conv3, blk.bn3, dev))
+                reg = self.refresher
+                b = dict(conv1=ConvLayer(blk.conv1, blk.bn1, dev, reg=reg), conv2=ConvLayer(blk.conv2, blk.bn2, dev, reg=reg),
+                         conv3=ConvLayer(blk.conv3, blk.bn3, dev, reg=reg))
                 if hasattr(blk, 'downsample'):
-                    b['down'] = ConvLayer(blk.downsample[0], blk.downsample[1], dev)
+                    b['down'] = ConvLayer(blk.downsample[0], blk.downsample[1], dev, reg=reg)
                 blocks.append(b)
             out[lname] = blocks
         return out
@@ -660,11 +789,20 @@ class Engine:
             ms = [float(x) for x in m.encoder_m.std.flatten().cpu()]
             if mm != self.mean or ms != self.std:
                 raise RuntimeError('encoder_m / encoder_q normalisation buffers differ; unsupported checkpoint')
+            from .refresh import FORWARD, STEM
+            reg = self.refresher
             self.stem_q_w = ops.pack_stem_weight([m.encoder_q.conv1.weight]).to(dev)
-            self.stem_q_scale, self.stem_q_shift = [t.to(dev) for t in W.bn_scale_shift(m.encoder_q.bn1)]
-            self.stem_m_w = ops.pack_stem_weight([m.encoder_m.conv1.weight, m.encoder_m.conv1_m.weight,
-                                                  m.encoder_m.conv1_o.weight]).to(dev)
-            self.stem_m_scale, self.stem_m_shift = [t.to(dev) for t in W.bn_scale_shift(m.encoder_m.bn1)]
+            self.stem_q_scale, self.stem_q_shift = [t.to(dev).clone() for t in W.bn_scale_shift(m.encoder_q.bn1)]
+            stem_m = [m.encoder_m.conv1, m.encoder_m.conv1_m, m.encoder_m.conv1_o]
+            self.stem_m_w = ops.pack_stem_weight([c.weight for c in stem_m]).to(dev)
+            self.stem_m_scale, self.stem_m_shift = [t.to(dev).clone() for t in W.bn_scale_shift(m.encoder_m.bn1)]
+            reg.add_filter(m.encoder_q.conv1.weight, self.stem_q_w, STEM)
+            reg.add_epilogue(self.stem_q_scale, self.stem_q_shift, bn=m.encoder_q.bn1, eps=W.BN_EPS)
+            plane = 0
+            for c in stem_m:
+                reg.add_filter(c.weight, self.stem_m_w, STEM, dst_row0=plane)
+                plane += c.weight.shape[1]
+            reg.add_epilogue(self.stem_m_scale, self.stem_m_shift, bn=m.encoder_m.bn1, eps=W.BN_EPS)
             self.enc_q = self._pack_trunk(m.encoder_q)
             self.enc_m = self._pack_trunk(m.encoder_m)
             # KeyValue: Key and Value share the input -> one GEMM with 640 filters (AFB_URR.py:106,109)
@@ -674,17 +812,23 @@ class Engine:
             holder = type('KV', (), {})()
             holder.weight, holder.bias, holder.stride, holder.padding = wk, bk, (1, 1), (1, 1)
             self.keyval = ConvLayer(holder, None, dev)
+            self.keyval.shift = self.keyval.shift.clone()
+            row = 0
+            for c in (kv.Key, kv.Value):                                       # the two halves of the 640-filter convolution
+                reg.add_filter(c.weight, self.keyval.w, FORWARD, dst_row0=row)
+                reg.add_epilogue(None, self.keyval.shift[row:row + c.weight.shape[0]], bias=c.bias)
+                row += c.weight.shape[0]
             d = m.decoder
-            cl = lambda c: ConvLayer(c, None, dev)
+            cl = lambda c: ConvLayer(c, None, dev, reg=reg)
             rb = lambda r: dict(conv1=cl(r.conv1), conv2=cl(r.conv2))
             rf = lambda r: dict(convFS=cl(r.convFS), ResFS=rb(r.ResFS), ResMM=rb(r.ResMM))
-            self.dec = dict(convFM_m=ConvLayer(d.convFM, None, dev, (0, DV), with_bias=False),
-                            convFM_q=ConvLayer(d.convFM, None, dev, (DV, 2 * DV)),
-                            local_convFM_r1=ConvLayer(d.local_convFM, None, dev, (0, 64)),
-                            local_convFM_loc=ConvLayer(d.local_convFM, None, dev, (64, 128), with_bias=False),
-                            ResMM=rb(d.ResMM), RF3=rf(d.RF3), RF2=rf(d.RF2), pred2=Pred2Layer(d.pred2, dev),
+            self.dec = dict(convFM_m=ConvLayer(d.convFM, None, dev, (0, DV), with_bias=False, reg=reg),
+                            convFM_q=ConvLayer(d.convFM, None, dev, (DV, 2 * DV), reg=reg),
+                            local_convFM_r1=ConvLayer(d.local_convFM, None, dev, (0, 64), reg=reg),
+                            local_convFM_loc=ConvLayer(d.local_convFM, None, dev, (64, 128), with_bias=False, reg=reg),
+                            ResMM=rb(d.ResMM), RF3=rf(d.RF3), RF2=rf(d.RF2), pred2=Pred2Layer(d.pred2, dev, reg=reg),
                             local_ResMM=rb(d.local_ResMM),
-                            local_pred2=Pred2Layer(d.local_pred2, dev))
+                            local_pred2=Pred2Layer(d.local_pred2, dev, reg=reg))
 
     # ------------------------------------------------------------------ plans
     def plan(self, H0, W0, obj_n, keep_acts=False):
@@ -922,59 +1066,10 @@ class Engine:
                     if shape_filter is not None and not shape_filter(key[:3]):      # (re-tune a subset, e.g. after a new tile shape)
                         continue
                     seen.setdefault(key, []).append((l, l_side))
-        tiles = ops.conv_cfg_tiles()
-
-        def timeit(d, c, bf):
-            ops.conv2d_launch(d, c, bf)
-            torch.cuda.synchronize()
-            best_ms = None
-            for _ in range(3):                                   # fastest of three batches: robust against a transient
-                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                e0.record()
-                for _ in range(iters):
-                    ops.conv2d_launch(d, c, bf)
-                e1.record()
-                torch.cuda.synchronize()
-                ms = e0.elapsed_time(e1)
-                best_ms = ms if best_ms is None else min(best_ms, ms)
-            return best_ms
-
         for key, launches in seen.items():
             d = launches[0][0].args[0]
             bf = key[3]
-            best, best_t = None, None
-            for c, (bm, bn) in enumerate(tiles):
-                if bf and c not in ops.BF16_CFGS:              # no LDS-DMA variants (the DMA cannot convert)
-                    continue
-                if cfg_filter is not None and not cfg_filter(key[:3], c):
-                    continue
-                if d.cout_pad < ((d.Cout + bn - 1) // bn) * bn:
-                    continue
-                if (bn > 64 and d.Cout <= 32) or (bn > 128 and d.Cout < 256):
-                    continue
-                blocks = ((d.M + bm - 1) // bm) * ((d.Cout + bn - 1) // bn)
-                options = [(c, 1, 0)]
-                wk = ops.conv_cfg_wk(c)
-                kind = ops.conv_cfg_kind(c)
-                if kind == 2:                                  # stream-K balances by itself
-                    if blocks > ops.SK_MAX_TILES:
-                        continue
-                elif kind == 1 and wk > 1:                     # wave-autonomous with K groups: a second split only when tiles are scarce
-                    if blocks < 256:
-                        options += [(c, k_, 0) for k_ in ops.valid_splits(d, 8, bf)[1:] if k_ * d.M * d.Cout <= WS_FLOATS]
-                elif wk > 1 or ops.conv_cfg_tpb(c) > 1:          # split-K inside the workgroup / two tiles per barrier:
-                    if blocks > 1024 or d.KH * d.KW * d.Cin // (64 if bf == 1 else 32) < 2 * wk:   # no second split, scarce tiles
-                        continue
-                elif blocks < 256:
-                    options += [(c, k_, 0) for k_ in ops.valid_splits(d, 16, bf)[1:] if k_ * d.M * d.Cout <= WS_FLOATS]
-                else:
-                    options += [(c, k_, full) for (full, k_, rows) in ops.tail_split_options(d, bm, bn, 8, bf)
-                                if k_ * rows * d.Cout <= WS_FLOATS and k_ in (2, 3, 4, 5, 6, 8)]
-                for opt in options:
-                    apply_choice(d, opt, p.ws, p.cnt)
-                    t = timeit(d, c, bf)
-                    if best_t is None or t < best_t:
-                        best, best_t = opt, t
+            best = tune_desc(d, bf, p.ws, p.cnt, iters=iters, cfg_filter=cfg_filter)
             _TABLES[bf][key[:3]] = best
             for l, in_q in launches:
                 l.args = (l.args[0], apply_choice(l.args[0], best, p.ws_q if in_q else p.ws, p.cnt_q if in_q else p.cnt), bf)

@@ -62,6 +62,18 @@ class AFB_URR(nn.Module):
             pass
         return out
 
+    def _refresh(self):
+        """The parameters were updated in place: the engine's derived tensors follow them where they lie (engine.Engine.refresh:
+        two kernel launches; plans, buffers and the cached backward pass stay) -- or, if a parameter moved to another dtype /
+        device / layout, the engine is dropped and rebuilt on the next call."""
+        if self._engine is None:
+            return
+        try:
+            self._engine.refresh()
+            self._engine_version = self._param_version()
+        except RuntimeError:
+            self._engine = None
+
     def _param_version(self):
         return sum(p._version for p in self.parameters())
 
@@ -69,7 +81,7 @@ class AFB_URR(nn.Module):
         # training: an optimizer that steps the nn.Parameters in place (torch.optim.AdamW, train_video_seg.py:109) leaves the
         # engine's packed filters / folded BatchNorm constants stale -- every in-place update bumps the tensors' version counters
         if self._engine is not None and self.training and self._engine_version != self._param_version():
-            self._engine = None
+            self._refresh()
         if self._engine is None:
             from .engine import Engine
             self._engine = Engine(self)

@@ -20,6 +20,8 @@ gradients that reached the bank are summed over the samples and go through ``mem
 flat ``exp_avg`` / ``exp_avg_sq`` buffers, so a step is one ``vfn_adamw_f32`` launch over 38 M floats (HBM-bound: 5 floats
 moved per parameter).  All arithmetic runs in the HIP library; there is no autograd graph and no eager fallback.
 """
+import time
+
 import torch
 
 from . import _lib, ops
@@ -158,7 +160,11 @@ def forward_backward(model, frames, masks, lu=0.5, budget=300000):
         return _forward_backward(model, frames, masks, lu, budget)
 
 
+last_enqueue_s = 0.0
+
+
 def _forward_backward(model, frames, masks, lu, budget):
+    t_start = time.perf_counter()
     T, obj_n = frames.shape[0], masks.shape[1]
     dev = model.device
     frames, masks = frames.to(dev), masks.to(dev)
@@ -167,7 +173,7 @@ def _forward_backward(model, frames, masks, lu, budget):
     k4_list, v4_list = model.memorize(frames[0:1], masks[0:1])
     fb.init_bank(k4_list, v4_list)
     label = torch.argmax(masks[1:], dim=1)
-    mb = ModelBackward(model.engine())
+    mb = model.engine().backward()
     g_bk = g_bv = None
     stats_sum = torch.zeros(3, device=dev)
     for i in range(bs):
@@ -183,6 +189,8 @@ def _forward_backward(model, frames, masks, lu, budget):
             g_bk = [a + b for a, b in zip(g_bk, bk)]
             g_bv = [a + b for a, b in zip(g_bv, bv)]
     mb.finish_memorize(frames[0:1], masks[0:1], g_bk, g_bv)
+    global last_enqueue_s
+    last_enqueue_s = time.perf_counter() - t_start                          # host time to enqueue the whole step (bench_train_step.py)
     st = (stats_sum / bs).tolist()                                          # one D2H per step, as loss.item() is
     return st[0], st[2], mb.grads
 
@@ -212,8 +220,8 @@ def train_step(model, optimizer, frames, masks, lu=0.5, budget=300000):
         loss, unc, grads = forward_backward(model, frames, masks, lu, budget)
         optimizer.set_grads(grads)
         optimizer.step()
-        model._invalidate()          # the engine's packed filters / folded BatchNorm constants are rebuilt from the new parameters
-        model.engine()               # (rebuilt here, inside the single-threaded region)
+        model._refresh()             # the engine's packed filters / folded BatchNorm constants follow the new parameters in place
+        model.engine()               # (or are rebuilt here, inside the single-threaded region, if a parameter moved)
     return loss, unc
 
 
