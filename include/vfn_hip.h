@@ -138,6 +138,11 @@ int vfn_winograd_tiles(int N, int H, int W);
 int vfn_winograd_input_f32(const float* x, int N, int H, int W, int C, int ld_x, int relu, float* V, int rows_pad, void* stream);
 int vfn_winograd_output_f32(const float* Mb, int rows_pad, int N, int H, int W, int Cout, const float* scale, const float* shift,
                             const float* res, int res_ld, int res_mod, int relu_out, float* out, int out_ld, void* stream);
+/* (ABI 11) the output transform with the epilogue of a data-gradient convolution (vfn_conv_desc.mask / mask_after): zero where
+ * mask <= 0, before (mask_after = 0) or after the residual is added -- loss.backward() through a 3x3 convolution is the same
+ * convolution over the flipped, transposed filters, so it takes the same transform-domain route (backward.py) */
+int vfn_winograd_output_masked_f32(const float* Mb, int rows_pad, int N, int H, int W, int Cout, const float* res, int res_ld,
+                                   const float* mask, int mask_ld, int mask_after, float* out, int out_ld, void* stream);
 
 /* ------------------------------------------------------------------ encoder stems
  * vfn_stem_conv7x7_f32: pad_divide_by (myutils/data.py:132-149) + (x-mean)/std + conv1
@@ -253,6 +258,11 @@ int vfn_conv_wgrad_f32(const vfn_wgrad_desc* d, void* stream);
  *   kind 1  dst[(dst_row0 + ci) * dst_ld + (T-1-t) * cout_ld + dst_col0 + co]    = src[co][ci][t]            (flipped, transposed)
  *   kind 2  dst[(((dst_row0 + ci) * kh + y) * 8 + x) * dst_ld + co]              = src[co][ci][y][x]         (stem: 8 taps per row)
  *   kind 3  dst[(dst_row0 + t * cout + co) * dst_ld + ci]                        = src[co][ci][t]            (tap form)
+ *   kind 4  dst[((xi * cout_ld + dst_row0 + co) * dst_ld + ci]                     = (G g G^T)[xi], g = src[co][ci]   (Winograd
+ *           F(4x4, 3x3) filter banks, xi = 6 i + j, computed in float64; cout_ld = rows per bank, kh = kw = 3)
+ *   kind 5  dst[((xi * cout_ld + dst_row0 + ci) * dst_ld + dst_col0 + co]          = (G g' G^T)[xi], g' = src[co][ci] flipped  (the
+ *           banks of the data-gradient convolution; cout_ld = rows per bank)
+ *           -- kinds 4 / 5 take ceil(cout * cin / vfn_refresh_elems_per_block()) workgroups --
  *   gamma / var / eps (optional): the value is multiplied by gamma[co] / sqrt(var[co] + eps) (a frozen BatchNorm's scale).
  *   block0: first workgroup of the entry; an entry takes ceil(cout * cin * kh * kw / vfn_refresh_elems_per_block()) workgroups and
  *   the table is ordered by block0. */

@@ -1,5 +1,6 @@
 """Per layer shape: the direct implicit-GEMM convolution (tuned choice) against Winograd F(4x4, 3x3) (input transform + the 36
 batched-filter GEMMs with their best tile configuration + output transform), every 3x3 / stride-1 layer of the C2 / C3 / C5 plans.
+usage: tune_winograd.py [HxW ...] (default: the bench sizes; 400x400 = the training sample).
 Writes gpurun_out/wino_gfx950.json ("M,cin,cout" -> 1 where Winograd is at least 5 % faster) and the GEMM shapes' entries
 into gpurun_out/tuned_gfx950.json."""
 import sys, os, json
@@ -28,7 +29,8 @@ def time_list(lst, iters=10):
     return best
 
 
-table, report = {}, []
+table, report = dict(engine._WINO_TABLE), []          # (shapes measured before stay as they are)
+sizes = [tuple(int(v) for v in a.split('x')) for a in sys.argv[1:]] or [(480, 854), (480, 853), (480, 800)]
 layers = []          # every ConvLayer of the engine, by identity of its packed filters
 def walk(o):
     if isinstance(o, engine.ConvLayer): layers.append(o)
@@ -38,7 +40,7 @@ def walk(o):
         for v in o: walk(v)
 for o in (eng.enc_q, eng.enc_m, eng.dec, eng.keyval): walk(o)
 by_w = {l.w.data_ptr(): l for l in layers}
-for (h, w) in [(480, 854), (480, 853), (480, 800)]:
+for (h, w) in sizes:
     p = eng.plan(h, w, 2)
     for lst in p.all_lists():
         for l in lst:

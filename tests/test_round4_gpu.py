@@ -142,7 +142,7 @@ def test_refresh_rewrites_every_derived_tensor_bit_exactly_and_keeps_the_step(gp
         m = AFB_URR(gpu, update_bank=False).to(gpu)
         m.load_state_dict(sd, strict=True)
         m.train()
-        opt = T.AdamW(m.named_parameters(), lr=1e-4)
+        opt = T.AdamW(m.named_parameters(), lr=1e-5)
         out = []
         for _ in range(3):
             if mode == 'rebuild':
@@ -153,3 +153,44 @@ def test_refresh_rewrites_every_derived_tensor_bit_exactly_and_keeps_the_step(gp
             assert m.engine().refresher.runs == 2 + 3             # (engine built, backward pass built, three steps)
     assert losses['refresh'] == losses['rebuild'], losses
     assert losses['refresh'][2][0] < losses['refresh'][0][0]
+
+
+def test_training_step_in_the_winograd_domain_matches_the_direct_step(gpu, monkeypatch):
+    """The training step with every eligible 3x3 convolution -- forward (kept activations) AND data gradient (masked output
+    transform, filter banks of the flipped / transposed filters) -- in the Winograd domain against the step with none: the same
+    loss, the same gradient for every parameter up to the transforms' f32 rounding; and the banks follow an optimizer step
+    (refresh kinds WINO / WINO_DGRAD): the second step's loss agrees too."""
+    from tools import synth
+    from vfloodnet_amd import AFB_URR, train as T, engine as E
+    H, W, K = 96, 160, 2
+    sd = synth.make_state_dict(SEED)
+    frames, m0 = synth.clip(6, 3, H, W)
+    lab = torch.stack([torch.roll(m0.long(), (2 * t, 5 * t), (0, 1)) for t in range(3)], 0)
+    masks = torch.nn.functional.one_hot(lab, K).permute(0, 3, 1, 2).float()
+    res = {}
+    for mode in ('0', '2'):
+        monkeypatch.setattr(E, '_WINOGRAD', mode)
+        m = AFB_URR(gpu, update_bank=False).to(gpu)
+        m.load_state_dict(sd, strict=True)
+        m.train()
+        loss, unc, grads = T.forward_backward(m, frames, masks, 0.5)
+        grads = {k: v.clone() for k, v in grads.items()}
+        opt = T.AdamW(m.named_parameters(), lr=1e-5)
+        l1 = T.train_step(m, opt, frames, masks, 0.5)
+        l2 = T.train_step(m, opt, frames, masks, 0.5)
+        n_wino = sum(1 for p in m.engine().plans.values() for lst in p.all_lists() for l in lst if l.name.endswith('.wino_gemm') or '.wino_gemm[' in l.name)
+        res[mode] = (loss, unc, grads, l1, l2, n_wino, len(m.engine().backward().dec.fw))
+    assert res['0'][5] == 0 and res['0'][6] == 0
+    assert res['2'][5] >= 20 and res['2'][6] >= 10, res['2'][5:]
+    a, b = res['0'], res['2']
+    assert abs(a[0] - b[0]) < 2e-5 * abs(a[0]) and abs(a[1] - b[1]) < 2e-5 * abs(a[1]), (a[:2], b[:2])
+    for i in (3, 4):
+        assert abs(a[i][0] - b[i][0]) < 5e-5 * abs(a[i][0]), (a[i], b[i])
+    assert b[4][0] < b[3][0]
+    worst = {}
+    for k in a[2]:
+        d = (a[2][k] - b[2][k]).abs().max().item() / max(1e-30, a[2][k].abs().max().item())
+        worst[k] = d
+    bad = {k: v for k, v in worst.items() if v > 2e-3}
+    assert not bad, sorted(bad.items(), key=lambda kv: -kv[1])[:8]
+    assert sorted(worst.values())[len(worst) // 2] < 1e-4

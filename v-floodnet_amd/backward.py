@@ -28,6 +28,8 @@ from .engine import choose_cfg, apply_choice, DK, DV
 
 
 _IMPLICIT_WGRAD = __import__('os').environ.get('VFN_IMPLICIT_WGRAD', '1') == '1'      # 0: the round-3 path (transposed operands)
+_SIDE_WGRAD = __import__('os').environ.get('VFN_SIDE_WGRAD', '1') == '1'              # 0: weight gradients on the main stream
+_SIDE_GROUP = int(__import__('os').environ.get('VFN_SIDE_GROUP', 8))                   # deferred launches per side-stream hand-over
 
 
 def _dgrad_filters(w):
@@ -48,6 +50,7 @@ class DecoderBackward:
         d = engine.model.decoder
         self.dev = dev
         self.f = {}                                        # name -> packed data-gradient filters
+        self.fw, self._fsrc = {}, {}                       # name -> their Winograd banks (built on first use) / the parameter behind them
         for name, conv in (('ResMM.conv1', d.ResMM.conv1), ('ResMM.conv2', d.ResMM.conv2),
                            ('RF3.convFS', d.RF3.convFS), ('RF3.ResFS.conv1', d.RF3.ResFS.conv1), ('RF3.ResFS.conv2', d.RF3.ResFS.conv2),
                            ('RF3.ResMM.conv1', d.RF3.ResMM.conv1), ('RF3.ResMM.conv2', d.RF3.ResMM.conv2),
@@ -80,6 +83,7 @@ class DecoderBackward:
             wp[:cout] = w
             w = wp
         self.f[name] = (_dgrad_filters(w).to(self.dev), cin)
+        self._fsrc[name] = (weight, cin_off, max(cout, cout_ld))
         self.eng.refresher.add_filter(weight, self.f[name][0], DGRAD, cin=cin, cin_off=cin_off, dst_ld=9 * max(cout, cout_ld),
                                       cout_ld=max(cout, cout_ld))
 
@@ -103,10 +107,55 @@ class DecoderBackward:
         (``mask`` = x) and the gradient arriving over a skip connection (``res``)."""
         wp, cin = self.f[name]
         out = torch.empty(N, H, Wd, cin, device=self.dev)
+        if self._fsrc[name][2] == self._fsrc[name][0].shape[0] and self._use_winograd(N * H * Wd, gy.shape[-1], cin):      # (not the zero-padded two-filter heads)
+            return self._dgrad_winograd(plan, name, gy, out, N, H, Wd, cin, mask, res)
         d = ops.make_conv_desc(gy, wp, cin, 3, 3, 1, 1, out, None, None, res, False, False, N=N, H=H, W=Wd)
         if mask is not None:
             d.mask, d.mask_ld = ptr(mask), mask.shape[-1]
         self._launch(d, plan)
+        return out
+
+    def _use_winograd(self, M, c_in, c_out):
+        """Winograd F(4x4, 3x3) for a data-gradient convolution with c_in gradient channels and c_out outputs (engine.Engine.
+        use_winograd's rule: the measured table, else >= 128 channels either side and enough pixels)."""
+        from . import engine as E
+        if E._WINOGRAD == '0' or not E._WINOGRAD_TRAIN or c_in % 32 or c_out % 4 or c_out < 32:
+            return False
+        if E._WINOGRAD == '2':
+            return True
+        hit = E._WINO_TABLE.get((M, c_in, c_out))
+        if hit is not None:
+            return bool(hit)
+        return c_in >= 128 and c_out >= 128 and M >= E._WINOGRAD_MIN_M
+
+    def _dgrad_winograd(self, plan, name, gy, out, N, H, Wd, cin, mask, res):
+        """The data-gradient convolution in the transform domain (csrc/conv_winograd.hip): input transform of gy, the 36 GEMMs
+        over the banks of the flipped, transposed filters, output transform with the mask / skip-connection epilogue."""
+        L = _lib.lib()
+        U = self.fw.get(name)
+        if U is None:
+            weight, cin_off, cout_ld = self._fsrc[name]
+            w = weight.detach().float()[:, cin_off:cin_off + cin].flip(2, 3).transpose(0, 1)      # [cin, Cout, 3, 3]: the dgrad's filters
+            U = ops.pack_winograd_weight(w).to(self.dev)
+            self.fw[name] = U
+            from .refresh import WINO_DGRAD
+            self.eng.refresher.add_filter(weight, U, WINO_DGRAD, cin=cin, cin_off=cin_off, dst_ld=weight.shape[0], cout_ld=U.shape[0] // 36)
+            self.eng._settle()
+        c_g = gy.shape[-1]
+        rows = ops.winograd_rows(N, H, Wd)
+        need_v, need_m = 36 * rows * c_g, 36 * rows * cin
+        V, Mb = self._scratch.get('wino_v'), self._scratch.get('wino_m')
+        if V is None or V.numel() < need_v:
+            V = self._scratch['wino_v'] = torch.zeros(need_v, device=self.dev)
+        if Mb is None or Mb.numel() < need_m:
+            Mb = self._scratch['wino_m'] = torch.empty(need_m, device=self.dev)
+        V, Mb = V[:need_v].view(36 * rows, c_g), Mb[:need_m].view(36 * rows, cin)
+        ops.winograd_input(gy, V, rows, False, N, H, Wd, c_g, c_g)
+        dg = ops.make_winograd_gemm_desc(V, U, Mb, rows, c_g, cin)
+        self._launch(dg, plan)
+        check(L.vfn_winograd_output_masked_f32(ptr(Mb), rows, N, H, Wd, cin, ptr(res), res.shape[-1] if res is not None else 0, ptr(mask),
+                                               mask.shape[-1] if mask is not None else 0, 0, ptr(out), cin, stream()),
+              'vfn_winograd_output_masked_f32')
         return out
 
     def wgrad(self, plan, x, gy, relu, x_ld=None, x_c=None, gy_c=None, name=None):
@@ -120,10 +169,13 @@ class DecoderBackward:
         ld_x = x_ld if x_ld is not None else x.shape[-1]
         M = N * H * Wd
         if name is not None and self.sink is not None and self.sink.wgrad_into(name, x, gy, 3, 1, 1, cin, cout, ld_x, relu, None, N, H, Wd):
-            db = torch.empty(cout, device=self.dev)
+            # the bias gradient accumulates in the kernel too, beside the data-gradient chain (ModelBackward's side stream)
+            db, have = self.sink._small(name[:-len('weight')] + 'bias', cout)
             part = self._buf('colsum', self.NB * cout)
-            check(L.vfn_colsum_acc_f32(ptr(gy), M, cout, gy.shape[-1], ptr(part), self.NB1, ptr(db), 0, ptr(self._ticket), stream()), 'vfn_colsum_acc_f32')
-            return None, db
+            ld_g, ticket, nb1 = gy.shape[-1], self._ticket, self.NB1
+            self.sink._side_do(lambda: check(L.vfn_colsum_acc_f32(ptr(gy), M, cout, ld_g, ptr(part), nb1, ptr(db), have, ptr(ticket), stream()),
+                                             'vfn_colsum_acc_f32'))
+            return None, None
         if _IMPLICIT_WGRAD and cin % 32 == 0 and cout >= 32:
             # round 4: the reduction over the pixels straight from the NHWC tensors (vfn_conv_wgrad_f32), nothing transposed
             dw = ops.conv_wgrad(x, gy, 3, 1, 1, cin=cin, cout=cout, ld_x=ld_x, relu=relu, N=N, H=H, W=Wd)
@@ -327,6 +379,12 @@ class ModelBackward:
                     if hasattr(blk, 'downsample'):
                         self.cb[pre + '.downsample.0'] = _ConvBwd(blk.downsample[0].weight, blk.downsample[0].stride[0], 0, dev,
                                                                   blk.downsample[1], reg)
+            # the 7x7 stem: only its weight gradient is taken (geometry + the frozen bn1 scale; no data-gradient filters needed)
+            stem = _ConvBwd(torch.zeros(64, 3 if enc_name == 'encoder_q' else 5, 7, 7), 2, 3, dev, enc.bn1)
+            reg.add_epilogue(stem.scale, None, bn=enc.bn1)
+            self.cb[enc_name + '.stem'] = stem
+        self._mean = torch.tensor(engine.mean, device=dev).view(1, 3, 1, 1)
+        self._std = torch.tensor(engine.std, device=dev).view(1, 3, 1, 1)
         kv = m.keyval_r4
         wkv = torch.cat([kv.Key.weight.detach().float(), kv.Value.weight.detach().float()], 0)      # one 640-filter conv
         self.cb['keyval'] = _ConvBwd(wkv, 1, 1, dev)
@@ -340,15 +398,67 @@ class ModelBackward:
         # [Cout][kh][kw][Cin]; ``grads`` hands them out as [Cout,Cin,kh,kw] views -- no torch add / copy per sample and layer
         self._packed = {}            # name -> (buffer [cout, k*k*cin], cout, k, cin)
         self.dec.sink = self         # the decoder's weight gradients go the same way
+        # Weight / bias / BatchNorm-parameter gradients feed nothing but the optimizer, so they run on a side stream beside the
+        # data-gradient chain (whose small layers leave most of the chip idle): launches are deferred (_side_do) and issued in
+        # groups (_flush: one event per group) after the main stream has produced their operands; the main stream joins the
+        # side stream before the next forward overwrites the activations and before the gradients are read (join).
+        self.side = torch.cuda.Stream(dev) if _SIDE_WGRAD else None
+        self._pending, self._inflight, self._by_plan = [], [], {}
+        self._ticket_main = torch.zeros(64, dtype=torch.int32, device=dev)  # (the column sums that stay on the main stream)
 
     def reset(self):
         """Forget the gradients of the previous step (their tensors belong to whoever took them from ``grads``)."""
+        self.join()
         self._grads = {}
         self._packed = {}
+
+    # ------------------------------------------------------------------ side stream
+    def _side_do(self, fn):
+        """Defer a launch whose result only the optimizer reads (the closure keeps its operand tensors alive)."""
+        if self.side is None:
+            fn()
+        else:
+            self._pending.append(fn)
+            if len(self._pending) >= _SIDE_GROUP:
+                self._flush()
+
+    def _flush(self):
+        """Issue the deferred launches on the side stream, behind everything the main stream has enqueued so far."""
+        if not self._pending:
+            return
+        self.side.wait_event(torch.cuda.current_stream().record_event())
+        with torch.cuda.stream(self.side):
+            for fn in self._pending:
+                fn()
+        self._inflight += self._pending            # (operands stay referenced until the main stream has joined the side stream)
+        self._pending = []
+
+    def join(self):
+        """The main stream waits for the side stream: before the gradients are handed out (and before a forward overwrites
+        activations whose readers are not tracked per plan)."""
+        self._flush()
+        if self._inflight or self._by_plan:
+            torch.cuda.current_stream().wait_stream(self.side)
+            self._inflight = []
+            self._by_plan = {}
+
+    def _end_sample(self, plan):
+        """Everything deferred for the sample that used ``plan`` is on the side stream now: remember where it ends."""
+        self._flush()
+        if self._inflight:
+            self._by_plan[id(plan)] = (self.side.record_event(), self._inflight)
+            self._inflight = []
+
+    def wait_plan(self, plan):
+        """The main stream is about to overwrite ``plan``'s activations: wait for the side-stream launches that read them."""
+        hit = self._by_plan.pop(id(plan), None)
+        if hit is not None:
+            torch.cuda.current_stream().wait_event(hit[0])
 
     @property
     def grads(self):
         """state-dict name -> gradient, everything accumulated so far."""
+        self.join()
         for name, (buf, cout, k, cin) in list(self._packed.items()):
             g = buf.view(cout, k, k, cin).permute(0, 3, 1, 2)
             if name in self._grads:
@@ -369,13 +479,14 @@ class ModelBackward:
             self._packed[name] = (buf, cout, k, cin)
         else:
             buf = have[0]
-        ops.conv_wgrad(x, gy, k, stride, pad, cin=cin, cout=cout, ld_x=ld_x, relu=relu, rowscale=rowscale, out=buf,
-                       accumulate=have is not None, N=N, H=H, W=Wd)
+        acc = have is not None
+        self._side_do(lambda: ops.conv_wgrad(x, gy, k, stride, pad, cin=cin, cout=cout, ld_x=ld_x, relu=relu, rowscale=rowscale, out=buf,
+                                             accumulate=acc, N=N, H=H, W=Wd))
         return True
 
     # ------------------------------------------------------------------ generic pieces
     def _acc(self, name, g):
-        grads = self.grads if name in self._packed else self._grads
+        grads = self.grads if name in self._packed else self._grads         # (``grads`` joins the side stream first)
         g = g.contiguous()
         if name in grads:
             grads[name] += g
@@ -452,8 +563,8 @@ class ModelBackward:
         C = C if C is not None else g.shape[-1]
         M = g.numel() // g.shape[-1]
         out = torch.empty(C, device=self.dev)
-        part = self.dec._buf('colsum', self.NB * C)
-        check(_lib.lib().vfn_colsum_acc_f32(ptr(g), M, C, g.shape[-1], ptr(part), self.NB1, ptr(out), 0, ptr(self._ticket), stream()),
+        part = self.dec._buf('colsum_main', self.NB * C)
+        check(_lib.lib().vfn_colsum_acc_f32(ptr(g), M, C, g.shape[-1], ptr(part), self.NB1, ptr(out), 0, ptr(self._ticket_main), stream()),
               'vfn_colsum_acc_f32')
         return out
 
@@ -465,8 +576,10 @@ class ModelBackward:
         db, acc_b = self._small(name + '.bias', C)
         assert acc_g == acc_b
         part = self.dec._buf('bn', 2 * self.NB1 * C)
-        check(_lib.lib().vfn_bn_param_grads_acc_f32(ptr(g), ptr(y), ptr(idn), ptr(bn.bias.detach()), ptr(bn.weight.detach()), M, C, ptr(part),
-                                                    self.NB1, ptr(dg), ptr(db), acc_g, ptr(self._ticket), stream()), 'vfn_bn_param_grads_acc_f32')
+        beta, gamma, ticket, nb1 = bn.bias.detach(), bn.weight.detach(), self._ticket, self.NB1
+        self._side_do(lambda: check(_lib.lib().vfn_bn_param_grads_acc_f32(ptr(g), ptr(y), ptr(idn), ptr(beta), ptr(gamma), M, C, ptr(part), nb1,
+                                                                          ptr(dg), ptr(db), acc_g, ptr(ticket), stream()),
+                                    'vfn_bn_param_grads_acc_f32'))
 
     # ------------------------------------------------------------------ ResNet bottleneck / trunk
     def _bottleneck(self, plan, pre, blk, a, N, g_pre, extra, mask_x):
@@ -520,7 +633,8 @@ class ModelBackward:
         planes) + bn1.  xn: the padded, normalised input planes [N,Hp,Wp,C]; g_c1: dL/d(bn1 output), masked."""
         self._bn_grads(enc_name + '.bn1', enc.bn1, g_c1, r1)
         C = xn.shape[-1]
-        cb = _ConvBwd(torch.zeros(64, C, 7, 7), 2, 3, self.dev, enc.bn1)
+        cb = self.cb[enc_name + '.stem']                                       # (geometry + the frozen bn1 scale; built once)
+        assert cb.cin == C
         dw = self._wgrad(plan, xn, g_c1, cb, N, plan.Hp, plan.Wp)              # [64, C, 7, 7]
         c0 = 0
         for name, nc in names:
@@ -532,8 +646,7 @@ class ModelBackward:
         for the stem's weight gradient; plain tensor ops."""
         lw, uw, lh, uh = plan.pad
         e = self.eng
-        mean = torch.tensor(e.mean, device=self.dev).view(1, 3, 1, 1)
-        std = torch.tensor(e.std, device=self.dev).view(1, 3, 1, 1)
+        mean, std = self._mean, self._std                                      # (device constants: no blocking copy per sample)
         f = torch.nn.functional.pad(frame, (lw, uw, lh, uh))
         f = (f - mean) / std
         if mask is None:
@@ -617,6 +730,7 @@ class ModelBackward:
         g_c1 = self._trunk(plan, 'encoder_q', m.encoder_q, acts, bufs, 1, g_r4, {'res3': gin['r3'], 'res2': gin['r2'], 'r1': gin['r1']})
         xn = self._normalised_input(plan, qs.frames[slot:slot + 1])
         self._stem(plan, 'encoder_q', m.encoder_q, xn, g_c1, bufs['r1'], 1, [('encoder_q.conv1.weight', 3)])
+        self._end_sample(plan)
         return g_bk, g_bv
 
     def _keyval(self, plan, r4, g_kv, N):

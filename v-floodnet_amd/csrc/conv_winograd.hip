@@ -88,7 +88,8 @@ __device__ __forceinline__ void at6(const f32x4 (&m)[6], f32x4 (&y)[4]) {
 __global__ __launch_bounds__(256)
 void winograd_output_kernel(const float* __restrict__ Mb, int rows_pad, int N, int H, int W, int Cout,
                             const float* __restrict__ scale, const float* __restrict__ shift, const float* __restrict__ res, int res_ld,
-                            int res_mod, int relu_out, float* __restrict__ out, int out_ld) {
+                            int res_mod, int relu_out, float* __restrict__ out, int out_ld, const float* __restrict__ mask, int mask_ld,
+                            int mask_after) {
     const int th = (H + 3) / 4, tw = (W + 3) / 4;
     const int c4n = Cout / 4;
     const long long total = (long long)N * th * tw * c4n;
@@ -123,7 +124,17 @@ void winograd_output_kernel(const float* __restrict__ Mb, int rows_pad, int N, i
                 f32x4 v;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[e] = y[a][e] * sc[e] + sh[e];
+                f32x4 mk = {1.f, 1.f, 1.f, 1.f};               // (the data-gradient form: the ReLU in front of the forward convolution)
+                if (mask) mk = *reinterpret_cast<const f32x4*>(mask + row * mask_ld + c4 * 4);
+                if (mask && !mask_after) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = mk[e] > 0.f ? v[e] : 0.f;
+                }
                 if (res) v += *reinterpret_cast<const f32x4*>(res + (res_mod > 0 ? row % res_mod : row) * res_ld + c4 * 4);
+                if (mask && mask_after) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = mk[e] > 0.f ? v[e] : 0.f;
+                }
                 if (relu_out) {
 #pragma unroll
                     for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
@@ -156,6 +167,18 @@ extern "C" int vfn_winograd_output_f32(const float* Mb, int rows_pad, int N, int
         rows_pad < vfn_winograd_tiles(N, H, W)) return VFN_ERR_ARG;
     const long long total = (long long)vfn_winograd_tiles(N, H, W) * (Cout / 4);
     hipLaunchKernelGGL(winograd_output_kernel, dim3(grid_of(total)), dim3(256), 0, (hipStream_t)stream, Mb, rows_pad, N, H, W, Cout, scale, shift,
-                       res, res_ld, res_mod, relu_out, out, out_ld);
+                       res, res_ld, res_mod, relu_out, out, out_ld, (const float*)nullptr, 0, 0);
+    return vfn_check_launch();
+}
+
+// ... with the epilogue of a data-gradient convolution (vfn_conv_desc.mask / mask_after): the result is zeroed where mask <= 0,
+// before (mask_after = 0) or after the residual is added
+extern "C" int vfn_winograd_output_masked_f32(const float* Mb, int rows_pad, int N, int H, int W, int Cout, const float* res, int res_ld,
+                                              const float* mask, int mask_ld, int mask_after, float* out, int out_ld, void* stream) {
+    if (!Mb || !out || N < 1 || H < 1 || W < 1 || Cout < 4 || Cout % 4 || out_ld < Cout || out_ld % 4 || (res && res_ld % 4) ||
+        (mask && mask_ld % 4) || rows_pad < vfn_winograd_tiles(N, H, W)) return VFN_ERR_ARG;
+    const long long total = (long long)vfn_winograd_tiles(N, H, W) * (Cout / 4);
+    hipLaunchKernelGGL(winograd_output_kernel, dim3(grid_of(total)), dim3(256), 0, (hipStream_t)stream, Mb, rows_pad, N, H, W, Cout,
+                       (const float*)nullptr, (const float*)nullptr, res, res_ld, 0, 0, out, out_ld, mask, mask_ld, mask_after);
     return vfn_check_launch();
 }

@@ -5,8 +5,9 @@
 // layout); here they are TWO launches over tables in device memory -- one entry per (parameter tensor, derived tensor) -- that the
 // host builds once per model (v-floodnet_amd/refresh.py) and re-uses while the tensors stay where they are.
 //
-// The results are bit-identical to the tensor-operator form (tests/test_train_gpu.py): pure data movement, one multiply for the
-// folded scale, and the scale / shift arithmetic in the same order with contraction switched off.
+// Pure data movement is bit-identical to the tensor-operator form; the folded scale gamma / sqrt(var + eps) is rounded correctly here
+// (the device's tensor-operator division is 1-2 ulp off), so a new engine settles its constants through these kernels too and a
+// refreshed engine equals a rebuilt one bit for bit (tests/test_round4_gpu.py).
 #include "common.h"
 #include "../../include/vfn_hip.h"
 
@@ -28,8 +29,44 @@ void refresh_filters_kernel(const vfn_refresh_filter* __restrict__ table, int n)
     }
     const vfn_refresh_filter e = table[lo];
     const int T = e.kh * e.kw;
-    const long long total = (long long)e.cout * e.cin * T;
     const long long base = (long long)((int)blockIdx.x - e.block0) * ELEMS_PER_BLOCK;
+    if (e.kind >= 4) {                           // Winograd F(4x4, 3x3) filter banks U = G g G^T, one (filter, channel) pair per thread
+        const long long pairs = (long long)e.cout * e.cin;
+        const double G[6][3] = {{0.25, 0.0, 0.0}, {-1.0 / 6, -1.0 / 6, -1.0 / 6}, {-1.0 / 6, 1.0 / 6, -1.0 / 6},
+                                {1.0 / 24, 1.0 / 12, 1.0 / 6}, {1.0 / 24, -1.0 / 12, 1.0 / 6}, {0.0, 0.0, 1.0}};
+        for (int i = threadIdx.x; i < ELEMS_PER_BLOCK; i += 256) {
+            const long long idx = base + i;
+            if (idx >= pairs) return;
+            int co, ci;
+            if (e.kind == 4) { ci = (int)(idx % e.cin); co = (int)(idx / e.cin); }
+            else { co = (int)(idx % e.cout); ci = (int)(idx / e.cout); }
+            const float* g = e.src + ((size_t)co * e.cin_total + e.cin_off + ci) * 9;
+            const float sc = e.gamma ? bn_scale(e.gamma, e.var, e.eps, co) : 1.f;
+            double w[3][3];
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                float v = g[e.kind == 4 ? t : 8 - t];        // (the data-gradient convolution runs over the flipped filter)
+                if (e.gamma) v = __fmul_rn(v, sc);
+                w[t / 3][t % 3] = (double)v;
+            }
+            double tmp[6][3];
+#pragma unroll
+            for (int a = 0; a < 6; ++a)
+#pragma unroll
+                for (int b = 0; b < 3; ++b) tmp[a][b] = G[a][0] * w[0][b] + G[a][1] * w[1][b] + G[a][2] * w[2][b];
+            const size_t row = e.kind == 4 ? (size_t)(e.dst_row0 + co) : (size_t)(e.dst_row0 + ci);
+            const size_t col = e.kind == 4 ? (size_t)ci : (size_t)(e.dst_col0 + co);
+#pragma unroll
+            for (int a = 0; a < 6; ++a)
+#pragma unroll
+                for (int b = 0; b < 6; ++b) {
+                    const double u = tmp[a][0] * G[b][0] + tmp[a][1] * G[b][1] + tmp[a][2] * G[b][2];
+                    e.dst[((size_t)(a * 6 + b) * e.cout_ld + row) * e.dst_ld + col] = (float)u;
+                }
+        }
+        return;
+    }
+    const long long total = (long long)e.cout * e.cin * T;
     for (int i = threadIdx.x; i < ELEMS_PER_BLOCK; i += 256) {
         const long long idx = base + i;
         if (idx >= total) return;

@@ -76,6 +76,8 @@ def pad_divide_by(h, w, d=16):
 
 
 WS_FLOATS = 16 * 1024 * 1024        # split-K workspace (64 MB), shared by all launches of a plan
+_WINOGRAD_TRAIN = os.environ.get('VFN_WINOGRAD_TRAIN', '1') == '1'     # the training plans' forward convolutions too
+_TRAIN_SLOTS = int(os.environ.get('VFN_TRAIN_SLOTS', 2))      # training plans segment() alternates between (see Engine.plan)
 # Winograd F(4x4, 3x3) for the 3x3 / stride-1 layers (csrc/conv_winograd.hip): 1 (default) = where the measured table says so
 # (wino_gfx950.json: "M,cin,cout" -> 0 / 1, scripts/tune_winograd.py; shapes it lacks: >= 128 channels either side and at least
 # VFN_WINOGRAD_MIN_M output pixels), 2 = every eligible layer, 0 = off (the direct implicit GEMM everywhere)
@@ -246,8 +248,10 @@ class ConvLayer:
         self.scale = sc.to(device).contiguous()
         self.shift = sh.to(device).contiguous()
         self._w_lp = {}
+        self._wino_src = None
         if reg is not None and isinstance(conv, torch.nn.Module):
             from .refresh import FORWARD
+            self._wino_src = (reg, conv.weight, cin_range[0] if cin_range is not None else 0)
             reg.add_filter(conv.weight, self.w, FORWARD, cin=self.cin, cin_off=cin_range[0] if cin_range is not None else 0)
             if bn is not None:
                 reg.add_epilogue(self.scale, self.shift if with_bias else None, bn=bn, eps=W.BN_EPS)
@@ -258,6 +262,8 @@ class ConvLayer:
         """The images derived from ``w`` (reduced-precision operands, Winograd filter banks) again, in place."""
         for mode, t in self._w_lp.items():
             if mode == 'wino':
+                if self._wino_src is not None:             # (registered with the Refresher: already rewritten)
+                    continue
                 w = self.w[:self.cout].view(self.cout, 3, 3, self.cin).permute(0, 3, 1, 2)
                 t.copy_(ops.pack_winograd_weight(w).to(t.device))
             else:
@@ -276,6 +282,11 @@ class ConvLayer:
             assert self.k == 3
             w = self.w[:self.cout].view(self.cout, 3, 3, self.cin).permute(0, 3, 1, 2)       # packed (kh,kw,cin) -> [Cout,Cin,3,3]
             self._w_lp['wino'] = ops.pack_winograd_weight(w).to(self.w.device)
+            if self._wino_src is not None:                 # (follows the parameter after an optimizer step: refresh kind WINO)
+                from .refresh import WINO
+                reg, weight, cin_off = self._wino_src
+                reg.add_filter(weight, self._w_lp['wino'], WINO, cin=self.cin, cin_off=cin_off, dst_ld=self.cin,
+                               cout_ld=self._w_lp['wino'].shape[0] // 36)
         return self._w_lp['wino']
 
 
@@ -300,6 +311,7 @@ class Pred2Layer:
         self.shift = torch.zeros(self.TAPS, device=device)
         self.bias = conv.bias.detach().float().to(device).contiguous().clone()
         self._w_lp = {}
+        self._wino_src = None
         if reg is not None:
             from .refresh import TAPS
             reg.add_filter(conv.weight, self.w, TAPS)
@@ -451,7 +463,7 @@ class FramePlan:
         lp = bf == 2
         if self.eng.mixed:
             f32_out = True                                    # (a consumer in another mode reads the f32 tensor)
-        if (bf == 0 and in_ld is None and not self.keep_acts and x.shape[-1] == layer.cin and
+        if (bf == 0 and in_ld is None and (_WINOGRAD_TRAIN or not self.keep_acts) and x.shape[-1] == layer.cin and
                 self.eng.use_winograd(layer, N * H * Wd)):
             return self._conv_winograd(lst, layer, x, out, N, H, Wd, res, relu_in, relu_out, name, out_ld, res_mod)
         d = ops.make_conv_desc(x, layer.w, layer.cout, layer.k, layer.k, layer.stride, layer.pad, out,
@@ -699,6 +711,7 @@ class Engine:
         from .refresh import Refresher
         self.refresher = Refresher(self.device)     # packed filters / folded constants follow the parameters in place (refresh())
         self._backward = None
+        self._train_slot = 0
         self._pack(model)
         self._settle()
 
@@ -831,15 +844,19 @@ class Engine:
                             local_pred2=Pred2Layer(d.local_pred2, dev, reg=reg))
 
     # ------------------------------------------------------------------ plans
-    def plan(self, H0, W0, obj_n, keep_acts=False):
-        """``keep_acts`` (training): a plan whose bottlenecks keep their activations for the backward pass."""
-        key = (H0, W0, obj_n, bool(keep_acts))
+    def plan(self, H0, W0, obj_n, keep_acts=False, slot=0):
+        """``keep_acts`` (training): a plan whose bottlenecks keep their activations for the backward pass; ``slot``: training
+        alternates between two such plans, so that the weight gradients of one sample (the backward pass's side stream) can
+        still read its activations while the next sample's forward runs."""
+        key = (H0, W0, obj_n, bool(keep_acts)) + ((slot,) if slot else ())
         p = self.plans.get(key)
         if p is None:
-            if len(self.plans) >= 4:
+            if len(self.plans) >= 6:
                 self.plans.pop(next(iter(self.plans)))
             p = FramePlan(self, H0, W0, obj_n, keep_acts=bool(keep_acts))
             self.plans[key] = p
+            if self.refresher._tables is None:             # (the plan registered new derived tensors: Winograd filter banks)
+                self._settle()
         return p
 
     @staticmethod
@@ -849,8 +866,18 @@ class Engine:
         _lib.require_gpu(frame, 'frame')
 
     # ------------------------------------------------------------------ API
+    def _join_backward(self, plan=None):
+        """A backward pass may still be reading activations on its side stream (backward.ModelBackward): wait for all of it, or
+        for the part that reads ``plan``'s buffers."""
+        if self._backward is not None:
+            if plan is None:
+                self._backward.join()
+            else:
+                self._backward.wait_plan(plan)
+
     def memorize(self, frame, mask, training=False):
         self._check_frame(frame)
+        self._join_backward()
         _, K, H, Wd = mask.shape
         p = self.plan(frame.shape[2], frame.shape[3], K, keep_acts=training)
         self.last_memorize = p
@@ -876,7 +903,11 @@ class Engine:
         H, Wd = frame.shape[2], frame.shape[3]
         if training and (H % 16 or Wd % 16):
             raise RuntimeError(f'training-mode segment does not pad (AFB_URR.py:278): {H}x{Wd} is not a multiple of 16')
-        p = self.plan(H, Wd, K, keep_acts=training)
+        slot = 0
+        if training and _TRAIN_SLOTS > 1:
+            slot, self._train_slot = self._train_slot, (self._train_slot + 1) % _TRAIN_SLOTS
+        p = self.plan(H, Wd, K, keep_acts=training, slot=slot)
+        self._join_backward(p)
         if fb._kbuf is None:
             raise RuntimeError('feature bank is empty: call fb.init_bank() first')
         if fb._hw != p.HW:

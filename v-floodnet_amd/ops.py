@@ -432,7 +432,9 @@ def conv_wgrad(x, gy, k, stride, pad, cin=None, cout=None, ld_x=None, relu=False
     M = N * Ho * Wo
     if ksplit is None:
         tiles = ((cout + 63) // 64) * k * k * ((cin + (31 if cin <= 32 else 63)) // (32 if cin <= 32 else 64))
-        ksplit = max(1, min(64, -(-2048 // (4 * tiles)), M // 256))         # ~2 waves per SIMD, at least 64 pixels per slice
+        # ~2 000 workgroups, at least 300 pixels per slice (swept on the training step's 51 shapes, scripts/bench_wgrad_shapes.py:
+        # 20.0 -> 17.5 ms per step against the first rule, 17.3 with the best split of every shape)
+        ksplit = max(1, min(64, 2048 // tiles, M // 300))
     d = WgradDesc()
     d.x, d.gy, d.rowscale, d.dw = ptr(x), ptr(gy), ptr(rowscale), ptr(out)
     d.N, d.H, d.W, d.Cin, d.ld_x = N, H, W, cin, ld_x
@@ -440,8 +442,8 @@ def conv_wgrad(x, gy, k, stride, pad, cin=None, cout=None, ld_x=None, relu=False
     d.k, d.stride, d.pad, d.relu, d.accumulate, d.ksplit = k, stride, pad, int(relu), int(accumulate), int(ksplit)
     part = None
     if ksplit > 1:
-        key = str(x.device)
-        need = ksplit * cout * Kc
+        key = (str(x.device), torch.cuda.current_stream(x.device).cuda_stream)     # (a workspace per stream: the backward pass
+        need = ksplit * cout * Kc                                                  #  runs weight gradients beside the data-gradient chain)
         part = _wgrad_ws.get(key)
         if part is None or part.numel() < need:
             part = torch.empty(max(need, 8 * 1024 * 1024), device=x.device, dtype=torch.float32)

@@ -14,7 +14,7 @@ import torch
 from . import _lib
 from ._lib import check, stream, RefreshFilter, RefreshEpilogue
 
-FORWARD, DGRAD, STEM, TAPS = 0, 1, 2, 3
+FORWARD, DGRAD, STEM, TAPS, WINO, WINO_DGRAD = 0, 1, 2, 3, 4, 5
 
 
 def _addr(t):
@@ -86,7 +86,8 @@ class Refresher:
             f.cout, f.cin, f.cin_off, f.cin_total, f.kh, f.kw = e['cout'], e['cin'], e['cin_off'], e['cin_total'], e['kh'], e['kw']
             f.dst_ld, f.dst_row0, f.dst_col0, f.cout_ld = e['dst_ld'], e['dst_row0'], e['dst_col0'], e['cout_ld']
             f.block0 = block
-            block += (e['cout'] * e['cin'] * e['kh'] * e['kw'] + per_block - 1) // per_block
+            elems = e['cout'] * e['cin'] * (1 if e['kind'] >= WINO else e['kh'] * e['kw'])
+            block += (elems + per_block - 1) // per_block
         et = (RefreshEpilogue * max(1, len(self._epilogues)))()
         for i, e in enumerate(self._epilogues):
             q = et[i]
