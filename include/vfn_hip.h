@@ -29,7 +29,7 @@ extern "C" {
  * vfn_sizeof_desc(which) == sizeof of the binding's own struct: checked when the library is loaded. */
 #define VFN_ABI_VERSION 11
 enum { VFN_DESC_CONV = 0, VFN_DESC_STEM = 1, VFN_DESC_BANKSCAN = 2, VFN_DESC_MEMREAD = 3, VFN_DESC_BANK = 4, VFN_DESC_WGRAD = 5,
-       VFN_DESC_REFRESH_FILTER = 6, VFN_DESC_REFRESH_EPILOGUE = 7 };
+       VFN_DESC_REFRESH_FILTER = 6, VFN_DESC_REFRESH_EPILOGUE = 7, VFN_DESC_GATHER = 8 };
 int vfn_abi_version(void);
 int vfn_sizeof_desc(int which);
 
@@ -293,6 +293,18 @@ typedef struct vfn_refresh_epilogue {
 int vfn_refresh_elems_per_block(void);
 int vfn_refresh_filters_f32(const vfn_refresh_filter* table_dev, int n, int total_blocks, void* stream);
 int vfn_refresh_epilogues_f32(const vfn_refresh_epilogue* table_dev, int n, void* stream);
+/* The way back (ABI 11): the gradients of a step -- tensors of <= 4 dimensions with arbitrary strides (the weight gradients are
+ * [Cout,Cin,kh,kw] views of packed-layout accumulators) -- copied into one flat buffer in ONE launch: dst[dst_offset + i] =
+ * src[element i in row-major order of `shape`].  block0 / workgroups per entry as vfn_refresh_filter (elements = prod(shape)). */
+typedef struct vfn_gather_entry {
+    const float* src;
+    long long dst_offset;     /* floats */
+    long long stride[4];      /* floats */
+    int shape[4];             /* leading dimensions padded with 1 */
+    int block0;
+    int reserved;
+} vfn_gather_entry;
+int vfn_gather_strided_f32(const vfn_gather_entry* table_dev, int n, int total_blocks, float* dst, void* stream);
 /* Encoder pieces (ResNet trunks, BatchNorm frozen as train_video_seg.py:103-106 sets it), memory read, optimiser:
  * vfn_dilate2_f32          out[n][2y][2x][c] = g[n][y][x][c], 0 elsewhere ([N][H][W][C] from [N][Ho][Wo][C]): the data gradient of a
  *     stride-2 convolution is the stride-1 data-gradient convolution of this.

@@ -46,6 +46,11 @@ class RefreshEpilogue(C.Structure):
                 ('eps', C.c_float), ('C', C.c_int)]
 
 
+class GatherEntry(C.Structure):
+    _fields_ = [('src', c_fp), ('dst_offset', C.c_longlong), ('stride', C.c_longlong * 4), ('shape', C.c_int * 4), ('block0', C.c_int),
+                ('reserved', C.c_int)]
+
+
 class StemDesc(C.Structure):
     _fields_ = [('frame', c_fp), ('mask', c_fp), ('w', c_fp), ('scale', c_fp), ('shift', c_fp), ('out', c_fp),
                 ('mean', C.c_float * 3), ('std', C.c_float * 3),
@@ -87,7 +92,7 @@ class BankDesc(C.Structure):
 
 
 ABI_VERSION = 11         # include/vfn_hip.h VFN_ABI_VERSION; csrc/abi.hip
-DESC_IDS = {0: ConvDesc, 1: StemDesc, 2: BankScanDesc, 3: MemReadDesc, 4: BankDesc, 5: WgradDesc, 6: RefreshFilter, 7: RefreshEpilogue}     # vfn_sizeof_desc(which)
+DESC_IDS = {0: ConvDesc, 1: StemDesc, 2: BankScanDesc, 3: MemReadDesc, 4: BankDesc, 5: WgradDesc, 6: RefreshFilter, 7: RefreshEpilogue, 8: GatherEntry}     # vfn_sizeof_desc(which)
 
 
 def lib():
@@ -204,6 +209,7 @@ SIGNATURES = {
     'vfn_refresh_elems_per_block': [],
     'vfn_refresh_filters_f32': [_p, _i, _i, _p],
     'vfn_refresh_epilogues_f32': [_p, _i, _p],
+    'vfn_gather_strided_f32': [_p, _i, _i, _p, _p],
     'vfn_ln_stem_f32': [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p],
     'vfn_ln_dwconv_f32': [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p],
     'vfn_ln_se_gate_f32': [_p, _f, _p, _p, _p, _p, _p, _i, _i, _i, _p],

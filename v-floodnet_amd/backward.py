@@ -29,6 +29,7 @@ from .engine import choose_cfg, apply_choice, DK, DV
 
 _IMPLICIT_WGRAD = __import__('os').environ.get('VFN_IMPLICIT_WGRAD', '1') == '1'      # 0: the round-3 path (transposed operands)
 _SIDE_WGRAD = __import__('os').environ.get('VFN_SIDE_WGRAD', '1') == '1'              # 0: weight gradients on the main stream
+_SIDE_PRIORITY = int(__import__('os').environ.get('VFN_SIDE_PRIORITY', 0))               # -1: the side stream's kernels are dispatched first
 _SIDE_GROUP = int(__import__('os').environ.get('VFN_SIDE_GROUP', 8))                   # deferred launches per side-stream hand-over
 
 
@@ -402,7 +403,7 @@ class ModelBackward:
         # data-gradient chain (whose small layers leave most of the chip idle): launches are deferred (_side_do) and issued in
         # groups (_flush: one event per group) after the main stream has produced their operands; the main stream joins the
         # side stream before the next forward overwrites the activations and before the gradients are read (join).
-        self.side = torch.cuda.Stream(dev) if _SIDE_WGRAD else None
+        self.side = torch.cuda.Stream(dev, priority=_SIDE_PRIORITY) if _SIDE_WGRAD else None
         self._pending, self._inflight, self._by_plan = [], [], {}
         self._ticket_main = torch.zeros(64, dtype=torch.int32, device=dev)  # (the column sums that stay on the main stream)
 

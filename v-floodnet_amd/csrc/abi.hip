@@ -17,6 +17,7 @@ extern "C" int vfn_sizeof_desc(int which) {
         case VFN_DESC_WGRAD: return (int)sizeof(vfn_wgrad_desc);
         case VFN_DESC_REFRESH_FILTER: return (int)sizeof(vfn_refresh_filter);
         case VFN_DESC_REFRESH_EPILOGUE: return (int)sizeof(vfn_refresh_epilogue);
+        case VFN_DESC_GATHER: return (int)sizeof(vfn_gather_entry);
     }
     return -1;
 }

@@ -130,3 +130,38 @@ extern "C" int vfn_refresh_epilogues_f32(const vfn_refresh_epilogue* table, int 
     hipLaunchKernelGGL(refresh_epilogues_kernel, dim3(n), dim3(256), 0, (hipStream_t)stream, table);
     return vfn_check_launch();
 }
+
+// ---- the way back: the step's gradients into the optimizer's flat gradient buffer (train.AdamW.set_grads).  The backward pass
+// hands them out as ~300 tensors -- strided [Cout,Cin,kh,kw] views of packed-layout accumulators, bias / BatchNorm vectors, a few
+// concatenations -- and a copy launch each was 550 launches at the end of every step; here one launch copies all of them: an entry
+// per tensor (<= 4 dimensions, any strides) in a device table that the host re-uses while the tensors keep their addresses.
+namespace {
+__global__ __launch_bounds__(256)
+void gather_strided_kernel(const vfn_gather_entry* __restrict__ table, int n, float* __restrict__ dst) {
+    int lo = 0, hi = n - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (table[mid].block0 <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
+    }
+    const vfn_gather_entry e = table[lo];
+    const long long total = (long long)e.shape[0] * e.shape[1] * e.shape[2] * e.shape[3];
+    const long long base = (long long)((int)blockIdx.x - e.block0) * ELEMS_PER_BLOCK;
+    float* out = dst + e.dst_offset;
+    for (int i = threadIdx.x; i < ELEMS_PER_BLOCK; i += 256) {
+        const long long idx = base + i;
+        if (idx >= total) return;
+        long long r = idx;
+        const int i3 = (int)(r % e.shape[3]); r /= e.shape[3];
+        const int i2 = (int)(r % e.shape[2]); r /= e.shape[2];
+        const int i1 = (int)(r % e.shape[1]);
+        const int i0 = (int)(r / e.shape[1]);
+        out[idx] = e.src[i0 * e.stride[0] + i1 * e.stride[1] + i2 * e.stride[2] + i3 * e.stride[3]];
+    }
+}
+}  // namespace
+
+extern "C" int vfn_gather_strided_f32(const vfn_gather_entry* table, int n, int total_blocks, float* dst, void* stream) {
+    if (!table || !dst || n < 1 || total_blocks < 1) return VFN_ERR_ARG;
+    hipLaunchKernelGGL(gather_strided_kernel, dim3(total_blocks), dim3(256), 0, (hipStream_t)stream, table, n, dst);
+    return vfn_check_launch();
+}

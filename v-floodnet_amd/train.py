@@ -64,6 +64,7 @@ class AdamW:
         self.exp_avg = torch.zeros_like(self.flat)
         self.exp_avg_sq = torch.zeros_like(self.flat)
         self.step_count = 0
+        self._gather = None            # (device table of set_grads)
         # torch's schedulers keep the un-decayed rate in the param group ('initial_lr'); StepLR below sets it, state_dict()
         # carries it, so that a resumed run decays from the right base and a checkpoint written here resumes in the reference
         # (torch's StepLR(last_epoch != -1) raises KeyError without it)
@@ -85,11 +86,35 @@ class AdamW:
         missing = [n for n in self.names if n not in grads]
         if missing:
             raise KeyError(f'no gradient for {missing[:4]} ({len(missing)} parameters)')
+        # One launch for all of them (vfn_gather_strided_f32): a weight gradient arrives as a strided [Cout,Cin,kh,kw] view of its
+        # packed accumulator, the rest as small vectors; the table of (address, strides, offset in the flat buffer) lives on the
+        # device and is re-used while the tensors keep their addresses (the caching allocator hands the same blocks out every step).
+        key, ts = [], []
         for n in self.names:
             g = grads[n]
-            shp = self.offsets[n][2]
-            # (a weight gradient arrives as a strided [Cout,Cin,kh,kw] view of its packed buffer: one strided copy, no reshape)
-            self.grad_view(n).copy_(g if tuple(g.shape) == tuple(shp) else g.reshape(shp))
+            o, k, shp = self.offsets[n]
+            if g.numel() != k or g.dim() > 4 or g.dtype != torch.float32 or not g.is_cuda:
+                raise ValueError(f'gradient of {n}: {tuple(g.shape)} {g.dtype} for a parameter of shape {shp}')
+            ts.append((g, o))
+            key.append((g.data_ptr(), tuple(g.shape), g.stride()))
+        if self._gather is None or self._gather[0] != key:
+            from ._lib import GatherEntry
+            L = _lib.lib()
+            per_block = L.vfn_refresh_elems_per_block()
+            tab = (GatherEntry * len(ts))()
+            block = 0
+            for i, (g, o) in enumerate(ts):
+                e = tab[i]
+                e.src, e.dst_offset, e.block0 = g.data_ptr(), o, block
+                pad = 4 - g.dim()
+                for d_ in range(4):
+                    e.shape[d_] = 1 if d_ < pad else g.shape[d_ - pad]
+                    e.stride[d_] = 0 if d_ < pad else g.stride(d_ - pad)
+                block += (g.numel() + per_block - 1) // per_block
+            dev_tab = torch.frombuffer(bytearray(bytes(tab)), dtype=torch.uint8).to(self.flat.device)
+            self._gather = (key, dev_tab, len(ts), block)
+        _, dev_tab, n_, blocks = self._gather
+        check(_lib.lib().vfn_gather_strided_f32(ptr(dev_tab), n_, blocks, ptr(self.grad), stream()), 'vfn_gather_strided_f32')
 
     def step(self):
         self.step_count += 1
