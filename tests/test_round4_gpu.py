@@ -235,3 +235,31 @@ def test_winograd_data_gradient_matches_the_direct_data_gradient(gpu, monkeypatc
         monkeypatch.setattr(E, '_WINOGRAD', '0')
         ref2 = dec.dgrad(plan, name, gy, N, H, W)
         assert (nomask - ref2).abs().max().item() < 2e-5 * ref2.abs().max().item()
+
+
+def test_training_steps_are_bit_reproducible_with_and_without_the_side_stream(gpu, monkeypatch):
+    """Weight / bias / BatchNorm-parameter gradients run on a side stream beside the data-gradient chain, over two alternating
+    activation plans (backward.ModelBackward, Engine.plan(slot)).  Every accumulator is touched by one stream in a fixed order, so
+    the step must not depend on the overlap: three runs of three optimizer steps give identical losses AND identical parameters,
+    and so does a run with everything on the main stream (a race between the streams shows up here as a last-bit difference)."""
+    from tools import synth
+    from vfloodnet_amd import AFB_URR, train as T, backward as Bk, engine as E
+    H, W, K = 96, 160, 2
+    sd = synth.make_state_dict(SEED)
+    frames, m0 = synth.clip(6, 4, H, W)
+    lab = torch.stack([torch.roll(m0.long(), (2 * t, 5 * t), (0, 1)) for t in range(4)], 0)
+    masks = torch.nn.functional.one_hot(lab, K).permute(0, 3, 1, 2).float()
+    runs = []
+    for side, slots in ((True, 2), (True, 2), (True, 2), (False, 1), (True, 1)):
+        monkeypatch.setattr(Bk, '_SIDE_WGRAD', side)
+        monkeypatch.setattr(E, '_TRAIN_SLOTS', slots)
+        m = AFB_URR(gpu, update_bank=False).to(gpu)
+        m.load_state_dict(sd, strict=True)
+        m.train()
+        opt = T.AdamW(m.named_parameters(), lr=1e-5)
+        losses = [T.train_step(m, opt, frames, masks, 0.5) for _ in range(3)]
+        assert (m.engine().backward().side is not None) == side
+        runs.append((losses, opt.flat.clone()))
+    for losses, flat in runs[1:]:
+        assert losses == runs[0][0], (losses, runs[0][0])
+        assert torch.equal(flat, runs[0][1])

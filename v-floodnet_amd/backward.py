@@ -30,6 +30,7 @@ from .engine import choose_cfg, apply_choice, DK, DV
 _IMPLICIT_WGRAD = __import__('os').environ.get('VFN_IMPLICIT_WGRAD', '1') == '1'      # 0: the round-3 path (transposed operands)
 _SIDE_WGRAD = __import__('os').environ.get('VFN_SIDE_WGRAD', '1') == '1'              # 0: weight gradients on the main stream
 _SIDE_PRIORITY = int(__import__('os').environ.get('VFN_SIDE_PRIORITY', 0))               # -1: the side stream's kernels are dispatched first
+_SIDE_DROP = __import__('os').environ.get('VFN_SIDE_DROP', '0') == '1'
 _SIDE_GROUP = int(__import__('os').environ.get('VFN_SIDE_GROUP', 8))                   # deferred launches per side-stream hand-over
 
 
@@ -71,6 +72,7 @@ class DecoderBackward:
         self._filters('local_pred2', d.local_pred2.weight, cout_ld=32)
         self._scratch = {}
         self._ticket = torch.zeros(64, dtype=torch.int32, device=dev)      # arrival counters (VFN_COLSUM_COUNTERS) of the one-launch column sums, zero at rest
+        self._ticket_main = torch.zeros(64, dtype=torch.int32, device=dev) # ... of the column sums that stay on the main stream (unnamed / fallback paths)
         self.sink = None                                   # ModelBackward: weight gradients accumulate there, in the kernel
 
     def _filters(self, name, weight, cin_off=0, cin=None, cout_ld=0):
@@ -181,8 +183,8 @@ class DecoderBackward:
             # round 4: the reduction over the pixels straight from the NHWC tensors (vfn_conv_wgrad_f32), nothing transposed
             dw = ops.conv_wgrad(x, gy, 3, 1, 1, cin=cin, cout=cout, ld_x=ld_x, relu=relu, N=N, H=H, W=Wd)
             db = torch.empty(cout, device=self.dev)
-            part = self._buf('colsum', self.NB * cout)
-            check(L.vfn_colsum_acc_f32(ptr(gy), M, cout, gy.shape[-1], ptr(part), self.NB1, ptr(db), 0, ptr(self._ticket), stream()), 'vfn_colsum_acc_f32')
+            part = self._buf('colsum_main', self.NB * cout)        # (main stream: not the side stream's scratch / counters)
+            check(L.vfn_colsum_acc_f32(ptr(gy), M, cout, gy.shape[-1], ptr(part), self.NB1, ptr(db), 0, ptr(self._ticket_main), stream()), 'vfn_colsum_acc_f32')
             return dw.view(cout, 3, 3, cin).permute(0, 3, 1, 2), db
         Mpad = (M + 31) // 32 * 32
         rows = (9 * cin + 255) // 256 * 256                                  # filter rows padded to the widest tile
@@ -207,8 +209,8 @@ class DecoderBackward:
         apply_choice(d, (cfg, ks, 0), plan.ws, None)
         ops.conv2d_launch(d, cfg, 0)
         db = torch.empty(cout, device=self.dev)
-        part = self._buf('colsum', self.NB * cout)
-        check(L.vfn_colsum_acc_f32(ptr(gy), M, cout, gy.shape[-1], ptr(part), self.NB1, ptr(db), 0, ptr(self._ticket), stream()), 'vfn_colsum_acc_f32')
+        part = self._buf('colsum_main', self.NB * cout)        # (main stream: not the side stream's scratch / counters)
+        check(L.vfn_colsum_acc_f32(ptr(gy), M, cout, gy.shape[-1], ptr(part), self.NB1, ptr(db), 0, ptr(self._ticket_main), stream()), 'vfn_colsum_acc_f32')
         return dw.view(cout, 3, 3, cin).permute(0, 3, 1, 2), db              # packed (kh,kw,cin) -> torch's [Cout,Cin,kh,kw]
 
     def resblock(self, plan, grads, name, x, r, gy, N, H, Wd):
@@ -416,6 +418,8 @@ class ModelBackward:
     # ------------------------------------------------------------------ side stream
     def _side_do(self, fn):
         """Defer a launch whose result only the optimizer reads (the closure keeps its operand tensors alive)."""
+        if _SIDE_DROP:                             # (measurement only: the step without its weight gradients = the main chain alone)
+            return
         if self.side is None:
             fn()
         else:
