@@ -245,6 +245,9 @@ typedef struct vfn_wgrad_desc {
     int relu;                /* act = max(., 0) */
     int accumulate;          /* add to dw instead of overwriting it */
     int ksplit;
+    int* tile_counters;      /* (ABI 11) optional, ksplit > 1: one int per dW tile (ceil(Cout / 64) * k * k * ceil(Cin / 64 or 32)), zero
+                              * at rest -- the slices are finished INSIDE the launch (write-through partial tiles, the wave that
+                              * arrives last adds them in slice order: the same sums, no reduce launch) */
 } vfn_wgrad_desc;
 int vfn_conv_wgrad_f32(const vfn_wgrad_desc* d, void* stream);
 

@@ -450,6 +450,21 @@ def test_conv_wgrad_implicit_gemm_vs_autograd(gpu, case):
     acc = first.clone()
     ops.conv_wgrad(xd, gd, k, s, k // 2, relu=relu, rowscale=sc, out=acc, accumulate=True)
     assert (acc.cpu().double() - 2 * ref).abs().max().item() < 2 * tol
+    # the slices finished inside the launch (vfn_wgrad_desc.tile_counters; off by default: measured slower on the training step):
+    # the same sums in the same order as the reduce launch, bit for bit, and the counters back at zero
+    for ks in (3, 7):
+        want = ops.conv_wgrad(xd, gd, k, s, k // 2, relu=relu, rowscale=sc, ksplit=ks)
+        ops._WGRAD_INLAUNCH = True
+        try:
+            got = ops.conv_wgrad(xd, gd, k, s, k // 2, relu=relu, rowscale=sc, ksplit=ks)
+            acc2 = want.clone()
+            ops.conv_wgrad(xd, gd, k, s, k // 2, relu=relu, rowscale=sc, ksplit=ks, out=acc2, accumulate=True)
+        finally:
+            ops._WGRAD_INLAUNCH = False
+        assert torch.equal(got, want), ks
+        assert (acc2.cpu().double() - 2 * ref).abs().max().item() < 2 * tol
+        counters = [v[1] for v in ops._wgrad_ws.values()]
+        assert counters and all(int(c.abs().sum()) == 0 for c in counters)
 
 
 @pytest.mark.parametrize('M,C,ld,idn', [(10000, 256, 256, True), (625, 1024, 1024, False), (2500, 64, 64, True), (40000, 64, 256, False),

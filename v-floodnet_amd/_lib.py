@@ -31,7 +31,8 @@ class WgradDesc(C.Structure):
     _fields_ = [('x', c_fp), ('gy', c_fp), ('rowscale', c_fp), ('dw', c_fp), ('partial', c_fp),
                 ('N', C.c_int), ('H', C.c_int), ('W', C.c_int), ('Cin', C.c_int), ('ld_x', C.c_int),
                 ('Ho', C.c_int), ('Wo', C.c_int), ('Cout', C.c_int), ('ld_g', C.c_int),
-                ('k', C.c_int), ('stride', C.c_int), ('pad', C.c_int), ('relu', C.c_int), ('accumulate', C.c_int), ('ksplit', C.c_int)]
+                ('k', C.c_int), ('stride', C.c_int), ('pad', C.c_int), ('relu', C.c_int), ('accumulate', C.c_int), ('ksplit', C.c_int),
+                ('tile_counters', c_fp)]
 
 
 class RefreshFilter(C.Structure):

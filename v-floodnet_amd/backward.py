@@ -407,6 +407,7 @@ class ModelBackward:
         # side stream before the next forward overwrites the activations and before the gradients are read (join).
         self.side = torch.cuda.Stream(dev, priority=_SIDE_PRIORITY) if _SIDE_WGRAD else None
         self._pending, self._inflight, self._by_plan = [], [], {}
+        self._pad = {}               # zero-padded operand images of the memory read's small GEMMs (_gemm_nt)
         self._ticket_main = torch.zeros(64, dtype=torch.int32, device=dev)  # (the column sums that stay on the main stream)
 
     def reset(self):
@@ -663,13 +664,26 @@ class ModelBackward:
         return torch.stack(planes, 0).permute(0, 2, 3, 1).contiguous()
 
     # ------------------------------------------------------------------ memory read (the bank = one frame, materialised P)
+    def _padded(self, key, rows, cols):
+        t = self._pad.get(key)
+        if t is None:
+            if len(self._pad) >= 32:
+                self._pad.clear()
+            t = self._pad[key] = torch.zeros(rows, cols, device=self.dev)
+        return t
+
     def _gemm_nt(self, plan, A, Bm, M, Nn, Kd):
         """C [M,Nn] = A [M,Kd] @ Bm [Nn,Kd]^T through the forward kernel (a 1x1 problem); operands zero-padded to its granules."""
         Kp = (Kd + 31) // 32 * 32
         rows = (Nn + 255) // 256 * 256
-        Ap = torch.zeros(M, Kp, device=self.dev)
-        Ap[:, :Kd] = A
-        Bp = torch.zeros(rows, Kp, device=self.dev)
+        # padded operand images live across calls (zeroed once; only the valid region is rewritten, keyed by it), and an operand
+        # that already has the kernel's layout is used where it lies: 100 fill + 50 copy launches per step less
+        if Kp == Kd and A.is_contiguous():
+            Ap = A
+        else:
+            Ap = self._padded(('A', M, Kd), M, Kp)
+            Ap[:, :Kd] = A
+        Bp = self._padded(('B', Nn, Kd), rows, Kp)
         Bp[:Nn, :Kd] = Bm
         ldo = (Nn + 3) // 4 * 4
         Cm = torch.empty(M, ldo, device=self.dev)

@@ -190,8 +190,11 @@ void conv_wgrad_kernel(const vfn_wgrad_desc p) {
     // stores with 32-bit offsets (64 flat addresses at once spilled registers)
     const int Kc = kk * p.Cin;
     const bool direct = p.ksplit <= 1;
+    const bool inlaunch = !direct && p.tile_counters != nullptr;
+    const int slab_bytes = p.Cout * Kc * (int)sizeof(float);
     float* dst = direct ? p.dw : p.partial + (size_t)kz * p.Cout * Kc;
-    const __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc(dst, 0, (int)((size_t)p.Cout * Kc * sizeof(float)), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc(dst, 0, slab_bytes, 0x00020000);
+    constexpr int WT = 17;                       // sc0 sc1: past L1 and the XCD's L2 (the slices of a tile run on any XCD)
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
         const int ci = ci0 + j * 32 + li;
@@ -206,8 +209,54 @@ void conv_wgrad_kernel(const vfn_wgrad_desc p) {
                     if (p.rowscale) v *= p.rowscale[min(co, p.Cout - 1)];
                     if (p.accumulate) v += __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rd, off, 0, 0));
                 }
-                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rd, off, 0, 0);
+                if (inlaunch) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rd, off, 0, WT);
+                else __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rd, off, 0, 0);
             }
+    }
+    if (!inlaunch) return;
+    // ---- the slices of this tile meet here (round 4): the partial tile went out write-through; once it has left the wave, one
+    // lane draws a ticket, and the wave that draws the last one adds the slices IN SLICE ORDER -- the sums of wgrad_reduce_kernel
+    // in the same order, without the second launch.  The counter is zero at rest.
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    int last = 0;
+    if (lane == 0) {
+        const int prev = __hip_atomic_fetch_add(p.tile_counters + tile, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        last = prev == p.ksplit - 1;
+        if (last) __hip_atomic_store(p.tile_counters + tile, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    last = __builtin_amdgcn_readfirstlane(last);
+    if (!last) return;
+    // (the range check covers the per-lane offset only: masked lanes carry OOB >= this size; the slice offset rides in the scalar operand)
+    const __amdgpu_buffer_rsrc_t rp = __builtin_amdgcn_make_buffer_rsrc(p.partial, 0, p.ksplit * slab_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(p.dw, 0, slab_bytes, 0x00020000);
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int ci = ci0 + j * 32 + li;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            int off[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int co = co0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                off[r] = (ci < p.Cin && co < p.Cout) ? (co * Kc + tap * p.Cin + ci) * (int)sizeof(float) : OOB;
+                acc[i][j][r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rp, off[r], 0, WT));
+            }
+            for (int sl = 1; sl < p.ksplit; ++sl) {
+                float t[16];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) t[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rp, off[r], sl * slab_bytes, WT));
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] += t[r];
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int co = co0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                float v = acc[i][j][r];
+                if (p.rowscale) v *= p.rowscale[min(co, p.Cout - 1)];
+                if (p.accumulate) v += __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rw, off[r], 0, 0));
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rw, off[r], 0, 0);
+            }
+        }
     }
 }
 
@@ -246,7 +295,7 @@ int launch_wgrad(const vfn_wgrad_desc& p, hipStream_t s) {
     constexpr size_t lds = (size_t)3 * TM * TN * 16 * 64 * sizeof(float);
     if (p.relu) hipLaunchKernelGGL((conv_wgrad_kernel<TM, TN, true>), dim3(tiles * ks), dim3(256), lds, s, p);
     else hipLaunchKernelGGL((conv_wgrad_kernel<TM, TN, false>), dim3(tiles * ks), dim3(256), lds, s, p);
-    if (ks > 1) {
+    if (ks > 1 && !p.tile_counters) {
         const size_t total = (size_t)p.Cout * p.k * p.k * p.Cin / ((p.k * p.k * p.Cin) % 4 ? 1 : 4);
         const int blocks = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
         hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, s, p);
@@ -260,6 +309,7 @@ extern "C" int vfn_conv_wgrad_f32(const vfn_wgrad_desc* d, void* stream) {
     if (!d || !d->x || !d->gy || !d->dw) return VFN_ERR_ARG;
     if (d->Cin < 1 || d->Cout < 1 || d->k < 1 || d->stride < 1 || d->N < 1 || d->ld_x < d->Cin || d->ld_g < d->Cout) return VFN_ERR_ARG;
     if (d->ksplit > 1 && !d->partial) return VFN_ERR_ARG;
+    if (d->ksplit > 1 && d->tile_counters && (long long)d->ksplit * d->Cout * d->k * d->k * d->Cin * 4 >= 0x7fffff00LL) return VFN_ERR_ARG;
     if (d->Wo < 2) return VFN_ERR_ARG;                     // (the pixel walk wraps at most one row per two pixels)
     if ((long long)d->N * d->H * d->W * d->ld_x * 4 >= 0x7fffff00LL || (long long)d->N * d->Ho * d->Wo * d->ld_g * 4 >= 0x7fffff00LL) return VFN_ERR_ARG;
     hipStream_t s = (hipStream_t)stream;

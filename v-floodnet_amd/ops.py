@@ -4,6 +4,7 @@ Used by the engine (``engine.py``), the feature bank and the parity tests.  Ever
 function enqueues on the current HIP stream and returns without synchronising.
 """
 import ctypes as C
+import os
 
 import torch
 
@@ -408,6 +409,10 @@ def segment_loss(score, label, lu, want_grad=True):
 
 
 _wgrad_ws = {}
+# 1: the pixel slices of a weight gradient are finished inside the launch (vfn_wgrad_desc.tile_counters).  Measured SLOWER on the training
+# step (49.6 against 43.1 ms: the wave that arrives last walks ksplit x 64 dwords alone, where the reduce launch spreads them over
+# the chip), so it is off; tests/test_kernels_gpu.py keeps the path correct.
+_WGRAD_INLAUNCH = os.environ.get('VFN_WGRAD_INLAUNCH', '0') == '1'
 
 
 def conv_wgrad(x, gy, k, stride, pad, cin=None, cout=None, ld_x=None, relu=False, rowscale=None, out=None, accumulate=False,
@@ -430,8 +435,8 @@ def conv_wgrad(x, gy, k, stride, pad, cin=None, cout=None, ld_x=None, relu=False
         out = torch.empty(cout, Kc, device=x.device, dtype=torch.float32)
     assert out.is_contiguous() and out.numel() == cout * Kc
     M = N * Ho * Wo
+    tiles = ((cout + 63) // 64) * k * k * ((cin + (31 if cin <= 32 else 63)) // (32 if cin <= 32 else 64))
     if ksplit is None:
-        tiles = ((cout + 63) // 64) * k * k * ((cin + (31 if cin <= 32 else 63)) // (32 if cin <= 32 else 64))
         # ~2 000 workgroups, at least 300 pixels per slice (swept on the training step's 51 shapes, scripts/bench_wgrad_shapes.py:
         # 20.0 -> 17.5 ms per step against the first rule, 17.3 with the best split of every shape)
         ksplit = max(1, min(64, 2048 // tiles, M // 300))
@@ -444,10 +449,15 @@ def conv_wgrad(x, gy, k, stride, pad, cin=None, cout=None, ld_x=None, relu=False
     if ksplit > 1:
         key = (str(x.device), torch.cuda.current_stream(x.device).cuda_stream)     # (a workspace per stream: the backward pass
         need = ksplit * cout * Kc                                                  #  runs weight gradients beside the data-gradient chain)
-        part = _wgrad_ws.get(key)
-        if part is None or part.numel() < need:
-            part = torch.empty(max(need, 8 * 1024 * 1024), device=x.device, dtype=torch.float32)
-            _wgrad_ws[key] = part
+        hit = _wgrad_ws.get(key)
+        if hit is None or hit[0].numel() < need:
+            # (+ the tiles' arrival counters of the in-launch finish, zero at rest; VFN_WGRAD_INLAUNCH=0: the separate reduce launch)
+            hit = (torch.empty(max(need, 8 * 1024 * 1024), device=x.device, dtype=torch.float32),
+                   hit[1] if hit is not None else torch.zeros(16384, dtype=torch.int32, device=x.device))
+            _wgrad_ws[key] = hit
+        part = hit[0]
+        if _WGRAD_INLAUNCH and tiles <= hit[1].numel() and need * 4 < 0x7fffff00:
+            d.tile_counters = ptr(hit[1])
     d.partial = ptr(part)
     check(_lib.lib().vfn_conv_wgrad_f32(C.byref(d), stream()), 'vfn_conv_wgrad_f32')
     return out

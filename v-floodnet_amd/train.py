@@ -29,6 +29,7 @@ the parameters -- packed filters, data-gradient filters, Winograd banks, folded 
 launches), the engine's plans and the cached backward pass (``Engine.backward()``) persist, and the step's gradients reach the
 optimizer's flat buffer in one launch (``AdamW.set_grads``).
 """
+import os
 import time
 
 import torch
