@@ -171,6 +171,17 @@ class DecoderBackward:
         cin = x_c if x_c is not None else x.shape[-1]
         ld_x = x_ld if x_ld is not None else x.shape[-1]
         M = N * H * Wd
+        if (name is not None and self.sink is not None and cout < 32 and gy.shape[-1] == 32 and
+                self.sink.wgrad_into(name, x, gy, 3, 1, 1, cin, 32, ld_x, relu, None, N, H, Wd, rows=cout)):
+            # the two-filter heads (pred2 / local_pred2): their gradient tensor is 32 channels wide with zeros beyond the second, so
+            # the implicit weight-gradient kernel takes it as it stands (30 zero rows computed, two kept) -- no transposed im2col
+            # image (184 MB per call at 1/4 resolution), no GEMM over it, and off the main stream
+            db, have = self.sink._small(name[:-len('weight')] + 'bias', cout)
+            part = self._buf('colsum', self.NB * cout)
+            ticket, nb1 = self._ticket, self.NB1
+            self.sink._side_do(lambda: check(L.vfn_colsum_acc_f32(ptr(gy), M, cout, 32, ptr(part), nb1, ptr(db), have, ptr(ticket), stream()),
+                                             'vfn_colsum_acc_f32'))
+            return None, None
         if name is not None and self.sink is not None and self.sink.wgrad_into(name, x, gy, 3, 1, 1, cin, cout, ld_x, relu, None, N, H, Wd):
             # the bias gradient accumulates in the kernel too, beside the data-gradient chain (ModelBackward's side stream)
             db, have = self.sink._small(name[:-len('weight')] + 'bias', cout)
@@ -250,7 +261,8 @@ class DecoderBackward:
         # pred2(relu(x)), x = RF2's output (AFB_URR.py:212)
         x = p.d4[2]
         g = self.dgrad(p, 'pred2', g32, K, p.h4, p.w4, mask=x)
-        grads['decoder.pred2.weight'], grads['decoder.pred2.bias'] = self.wgrad(p, x, grad_p.contiguous(), True, name='decoder.pred2.weight')
+        grads['decoder.pred2.weight'], grads['decoder.pred2.bias'] = self.wgrad(p, x, g32 if self.sink is not None else grad_p.contiguous(), True,
+                                                                                gy_c=2, name='decoder.pred2.weight')
         # RF2, RF3 (AFB_URR.py:210-211)
         g_r2, g = self.refine(p, grads, 'RF2', o(qs.q['res2']['out']), [o(t) for t in qs.s4], p.d4, g, K, p.h4, p.w4)
         g_r3, g = self.refine(p, grads, 'RF3', o(qs.q['res3']['out']), [o(t) for t in qs.s8], p.d8, g, K, p.h8, p.w8)
@@ -465,8 +477,8 @@ class ModelBackward:
     def grads(self):
         """state-dict name -> gradient, everything accumulated so far."""
         self.join()
-        for name, (buf, cout, k, cin) in list(self._packed.items()):
-            g = buf.view(cout, k, k, cin).permute(0, 3, 1, 2)
+        for name, (buf, cout, k, cin, rows) in list(self._packed.items()):
+            g = buf.view(cout, k, k, cin)[:rows].permute(0, 3, 1, 2)
             if name in self._grads:
                 self._grads[name] += g
             else:
@@ -474,15 +486,16 @@ class ModelBackward:
             del self._packed[name]
         return self._grads
 
-    def wgrad_into(self, name, x, gy, k, stride, pad, cin, cout, ld_x, relu, rowscale, N, H, Wd):
+    def wgrad_into(self, name, x, gy, k, stride, pad, cin, cout, ld_x, relu, rowscale, N, H, Wd, rows=None):
         """Accumulate dL/dW of one convolution for parameter ``name`` (see vfn_conv_wgrad_f32); False if the shapes need the
-        round-3 path (channel counts that are not multiples of 32, two-filter heads)."""
+        round-3 path (channel counts that are not multiples of 32).  ``rows``: the parameter has only that many filters (the
+        two-filter heads: their gradient arrives in a 32-channel tensor whose other channels are zero)."""
         if not (_IMPLICIT_WGRAD and cout >= 32 and (cin % 32 == 0 or cin < 32)) or name in self._grads:
             return False
         have = self._packed.get(name)
         if have is None:
             buf = torch.empty(cout, k * k * cin, device=self.dev)
-            self._packed[name] = (buf, cout, k, cin)
+            self._packed[name] = (buf, cout, k, cin, cout if rows is None else rows)
         else:
             buf = have[0]
         acc = have is not None
