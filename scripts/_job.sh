@@ -1,5 +1,3 @@
 cd $GRAFT_REPO_ROOT
-python -m pytest tests/test_backward_gpu.py tests/test_round4_gpu.py -q -m gpu --tb=short 2>&1 | tail -12 > gpurun_out/j41_tests.log
-python scripts/bench_train_step.py 6 400 400 2 8 > gpurun_out/j41_train.txt 2>&1
-python scripts/bench_train_step.py 6 400 400 2 8 >> gpurun_out/j41_train.txt 2>&1
-bash scripts/profile_train.sh j41
+python scripts/main_throughput.py 100 1 > gpurun_out/j43_main.txt 2>&1
+python scripts/main_throughput.py 100 1 >> gpurun_out/j43_main.txt 2>&1
