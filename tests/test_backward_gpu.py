@@ -223,12 +223,15 @@ def _hip_relu_masks(eng, K, memorize_only=False, query=None):
     if memorize_only:
         return mem_masks
     plan, qs, slot = query if query is not None else eng.last_query
-    order = [qs.q['r1'][0:1]]
+    # (a sample whose frames went through Engine.query_batch: its activations are slot ``slot`` of the batch list's tensors)
+    acts = qs.acts[qs.n if (qs.n == qs.nq and qs.n in qs.acts and eng._batch is not None and eng._batch[1] is qs) else 1]
+    one = lambda t: t[slot:slot + 1]
+    order = [one(qs.q['r1'])]
     for lname, nb in (('res2', 3), ('res3', 4), ('res4', 6)):
         for bi in range(nb):
-            a = qs.acts[1][(lname, bi)]
-            order += [a['t1'], a['t2'], a['out']]
-    ex = lambda t: t[0:1].expand(K, -1, -1, -1)
+            a = acts[(lname, bi)]
+            order += [one(a['t1']), one(a['t2']), one(a['out'])]
+    ex = lambda t: one(t).expand(K, -1, -1, -1)
     order += [plan.d16[0], plan.d16[1], ex(qs.s8[0]), ex(qs.s8[1]), plan.d8[0], plan.d8[1], ex(qs.s4[0]), ex(qs.s4[1]),
               plan.d4[0], plan.d4[1], plan.d4[2], plan.l2[0], plan.l2[1], plan.l2[2]]
     return mem_masks, [nchw_mask(t) for t in order]

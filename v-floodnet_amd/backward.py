@@ -420,6 +420,7 @@ class ModelBackward:
         self.side = torch.cuda.Stream(dev, priority=_SIDE_PRIORITY) if _SIDE_WGRAD else None
         self._pending, self._inflight, self._by_plan = [], [], {}
         self._pad = {}               # zero-padded operand images of the memory read's small GEMMs (_gemm_nt)
+        self._query_grads = {}       # slot -> gradients entering the query encoder (batched samples: finish_query)
         self._ticket_main = torch.zeros(64, dtype=torch.int32, device=dev)  # (the column sums that stay on the main stream)
 
     def reset(self):
@@ -427,6 +428,7 @@ class ModelBackward:
         self.join()
         self._grads = {}
         self._packed = {}
+        self._query_grads = {}
 
     # ------------------------------------------------------------------ side stream
     def _side_do(self, fn):
@@ -738,7 +740,9 @@ class ModelBackward:
     def segment_sample(self, fb, grad_score, query=None):
         """Backward of the sample ``segment`` ran last (its activations are in the training plan; ``query``: the (plan, query
         set, slot) triple of another segment call, ``engine.last_query`` right after it).  grad_score = dloss/dscores
-        [obj_n,H0,W0].  Accumulates parameter gradients; returns (dL/d bank keys, dL/d bank values) for ``finish_memorize``."""
+        [obj_n,H0,W0].  Accumulates parameter gradients; returns (dL/d bank keys, dL/d bank values) for ``finish_memorize``.
+        When the sample's frames went through ``Engine.query_batch``, the query encoder's part is left to ``finish_query`` (the
+        whole batch at once) and only the decoder / memory-read part runs here."""
         plan, qs, slot = query if query is not None else self.eng.last_query
         if not plan.keep_acts:
             raise RuntimeError('backward needs the training plan: call model.train() before memorize / segment')
@@ -752,6 +756,12 @@ class ModelBackward:
         g_qk, g_bk, g_bv = self.memory_read(plan, fb, kvq[:, :DK].contiguous(), gin['mem'].reshape(K, plan.HW, DV))
         # KeyValue on the query side: dL/d[key | value]
         g_kv = torch.cat([g_qk, gin['q_out'].reshape(plan.HW, DV)], dim=1).view(1, plan.h16, plan.w16, DK + DV).contiguous()
+        batch = self.eng._batch
+        if batch is not None and batch[1] is qs and qs.nq == qs.n:
+            # gradients that enter the query encoder: collected, differentiated for all frames of the sample in finish_query
+            self._query_grads[slot] = (g_kv, gin['r3'], gin['r2'], gin['r1'])
+            self._end_sample(plan)
+            return g_bk, g_bv
         if slot != 0 or qs.stage != 0:
             raise RuntimeError('backward expects the frame-only part of segment to have run in place (no look-ahead in training)')
         acts = qs.acts[1]
@@ -764,6 +774,31 @@ class ModelBackward:
         self._stem(plan, 'encoder_q', m.encoder_q, xn, g_c1, bufs['r1'], 1, [('encoder_q.conv1.weight', 3)])
         self._end_sample(plan)
         return g_bk, g_bv
+
+    @torch.no_grad()
+    def finish_query(self):
+        """The query encoder (KeyValue, res4 .. res2, stem) backwards for ALL frames of the sample that ``Engine.query_batch`` ran
+        in one pass: the per-sample gradients ``segment_sample`` collected are stacked along the batch axis, so every data- and
+        weight-gradient launch sees n times the pixels (the 1/16-resolution layers have 625 of them per frame at 400 x 400)."""
+        if not self._query_grads:
+            return
+        plan, qs = self.eng._batch
+        n = qs.n
+        if sorted(self._query_grads) != list(range(n)):
+            raise RuntimeError(f'finish_query: gradients for slots {sorted(self._query_grads)} of a batch of {n}')
+        m = self.eng.model
+        parts = [self._query_grads[i] for i in range(n)]
+        g_kv, g3, g2, g1 = (torch.cat([t[j] for t in parts], dim=0) for j in range(4))
+        self._query_grads = {}
+        acts = qs.acts[n]
+        bufs = {'r1': qs.q['r1'][0:n]}
+        r4 = acts[('res4', len(m.encoder_q.res4) - 1)]['out']
+        self._keyval(plan, r4, g_kv, n)
+        g_r4 = self._dgrad(plan, self.cb['keyval'], g_kv, n, plan.h16, plan.w16, mask=r4)
+        g_c1 = self._trunk(plan, 'encoder_q', m.encoder_q, acts, bufs, n, g_r4, {'res3': g3, 'res2': g2, 'r1': g1})
+        xn = self._normalised_input(plan, qs.frames[0:n])
+        self._stem(plan, 'encoder_q', m.encoder_q, xn, g_c1, bufs['r1'], n, [('encoder_q.conv1.weight', 3)])
+        self._flush()
 
     def _keyval(self, plan, r4, g_kv, N):
         m = self.eng.model

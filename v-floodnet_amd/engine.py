@@ -357,6 +357,7 @@ class FramePlan:
         self.mask_in = f(K, H0, W0)
         # query side: two sets of frame-only state, two frames (slots) each -- see QuerySet
         self.qsets = [QuerySet(self), QuerySet(self)]
+        self._qbatch = {}
         # memory encoder
         self.m = self._trunk_buffers(K)
         self.kv_m = f(K, self.HW, DK + DV)
@@ -416,7 +417,18 @@ class FramePlan:
         out = [self.mem]
         for qs in self.qsets:
             out += [qs.pre[1], qs.pre[2], qs.post[0], qs.post[1]]
+        for qs in self._qbatch.values():
+            out += [qs.pre[qs.nq]]
         return out
+
+    def batch_set(self, n):
+        """Training: a query set for the n frames of a sample (frame-only part in ONE pass over the batch, Engine.query_batch);
+        built on first use, next to the two sets of the inference loop."""
+        qs = self._qbatch.get(n)
+        if qs is None:
+            qs = self._qbatch[n] = QuerySet(self, nq=n)
+            qs.build()
+        return qs
 
     def _trunk_buffers(self, N):
         dev = self.eng.device
@@ -588,26 +600,29 @@ class QuerySet:
 
     ``pre[n]``: launch list for n frames (n = 1: slot 0 only); ``post[slot]``: the bank-dependent decoder reading slot."""
 
-    def __init__(self, plan):
+    def __init__(self, plan, nq=2):
+        """``nq``: frames the set holds (2 in the inference loop; the training step batches the T - 1 frames of a sample)."""
         self.plan = plan
+        self.nq = nq
         p = plan
         f = lambda *s_: torch.empty(*s_, device=p.eng.device, dtype=torch.float32)
-        self.frames = f(2, 3, p.H0, p.W0)
-        self.q = p._trunk_buffers(2)
-        self.kv_q = f(2, p.HW, DK + DV)
-        self.fm_q = f(2, p.h16, p.w16, 256)
-        self.s8 = [f(2, p.h8, p.w8, 256) for _ in range(3)]
-        self.s4 = [f(2, p.h4, p.w4, 256) for _ in range(3)]
-        self.lq = f(2, p.h2, p.w2, 32)                       # local_convFM over the shared r1 half
-        self.pre = {1: [], 2: []}
-        self.acts = {1: {}, 2: {}}                          # training plans: the bottlenecks' activations per launch list
-        self.post = [[], []]
-        self.split = {1: 0, 2: 0}                           # pre[n][:split[n]] = the first half (by estimated time)
+        self.frames = f(nq, 3, p.H0, p.W0)
+        self.q = p._trunk_buffers(nq)
+        self.kv_q = f(nq, p.HW, DK + DV)
+        self.fm_q = f(nq, p.h16, p.w16, 256)
+        self.s8 = [f(nq, p.h8, p.w8, 256) for _ in range(3)]
+        self.s4 = [f(nq, p.h4, p.w4, 256) for _ in range(3)]
+        self.lq = f(nq, p.h2, p.w2, 32)                      # local_convFM over the shared r1 half
+        self.sizes = sorted({1, nq})                        # batch sizes with a launch list of their own
+        self.pre = {n: [] for n in self.sizes}
+        self.acts = {n: {} for n in self.sizes}             # training plans: the bottlenecks' activations per launch list
+        self.post = [[] for _ in range(nq)]
+        self.split = {n: 0 for n in self.sizes}             # pre[n][:split[n]] = the first half (by estimated time)
         # bookkeeping of Engine.prefetch_*: which frames the slots hold
-        self.keys = [None, None]
-        self.held = [None, None]                            # the frames behind ``keys``: a key is an allocator address, so
+        self.keys = [None] * nq
+        self.held = [None] * nq                             # the frames behind ``keys``: a key is an allocator address, so
                                                             # the set keeps its frames alive until they are consumed
-        self.consumed = [True, True]
+        self.consumed = [True] * nq
         self.stage = 0                                      # 0 idle, 1 first half enqueued, 2 complete
         self.n = 0
         self.done = None
@@ -620,7 +635,7 @@ class QuerySet:
         p, e = self.plan, self.plan.eng
         K = p.obj_n
         D = e.dec
-        for n in (1, 2):
+        for n in self.sizes:
             P = self.pre[n]
             sl = lambda t: t[0:n]
             q = {k: (sl(v) if torch.is_tensor(v) else {kk: ([sl(x) for x in vv] if isinstance(vv, list) else sl(vv)) for kk, vv in v.items()})
@@ -653,7 +668,7 @@ class QuerySet:
         p._ws_cur, p._cnt_cur = p.ws, p.cnt
         # ---- decoder, bank-dependent part, once per slot
         d16, d8, d4 = p.d16, p.d8, p.d4
-        for slot in (0, 1):
+        for slot in range(self.nq):
             L = self.post[slot]
             o = lambda t: t[slot:slot + 1]
             p._conv(L, D['convFM_m'], p.dec_in, d16[0], K, p.h16, p.w16, res=o(self.fm_q), res_mod=p.HW,
@@ -712,6 +727,7 @@ class Engine:
         self.refresher = Refresher(self.device)     # packed filters / folded constants follow the parameters in place (refresh())
         self._backward = None
         self._train_slot = 0
+        self._batch = None           # (plan, query set) of Engine.query_batch: the sample whose frames are being segmented
         self._pack(model)
         self._settle()
 
@@ -904,9 +920,13 @@ class Engine:
         if training and (H % 16 or Wd % 16):
             raise RuntimeError(f'training-mode segment does not pad (AFB_URR.py:278): {H}x{Wd} is not a multiple of 16')
         slot = 0
-        if training and _TRAIN_SLOTS > 1:
-            slot, self._train_slot = self._train_slot, (self._train_slot + 1) % _TRAIN_SLOTS
-        p = self.plan(H, Wd, K, keep_acts=training, slot=slot)
+        batch = self._batched_slot(frame) if training and bs == 1 else None
+        if batch is not None:                               # (query_batch ran the frame-only part for the whole sample)
+            p = batch[0]
+        else:
+            if training and _TRAIN_SLOTS > 1:
+                slot, self._train_slot = self._train_slot, (self._train_slot + 1) % _TRAIN_SLOTS
+            p = self.plan(H, Wd, K, keep_acts=training, slot=slot)
         self._join_backward(p)
         if fb._kbuf is None:
             raise RuntimeError('feature bank is empty: call fb.init_bank() first')
@@ -915,7 +935,10 @@ class Engine:
         out = p.score if bs == 1 else torch.empty(bs, K, H, Wd, device=self.device, dtype=torch.float32)
         for b in range(bs):
             fr = frame[b:b + 1]
-            qs, slot = self._take_prefetched(p, fr, frame._version) if b == 0 else (None, 0)
+            if batch is not None:
+                qs, slot = batch[1], batch[2]
+            else:
+                qs, slot = self._take_prefetched(p, fr, frame._version) if b == 0 else (None, 0)
             if qs is None:
                 # not prefetched (first frame of a clip, a skipped frame, a direct segment() call): the frame-only part runs
                 # here, on this stream, in a set the side stream is not filling
@@ -935,6 +958,39 @@ class Engine:
             if bs > 1:
                 out[b].copy_(p.score[0])
         return out
+
+    # ------------------------------------------------------------------ training: the query side of a whole sample in one pass
+    def query_batch(self, frames, obj_n):
+        """The frame-only part of ``segment`` -- query encoder, KeyValue, the decoder branches that depend on the frame alone -- for
+        ALL n frames of a training sample at once (frames f32[n,3,H,W] on the GPU): every layer sees n times the pixels instead of n
+        launches of a 1/16-resolution layer with 625 of them.  The ``segment(frames[i:i+1], fb, training=True)`` calls that follow
+        find their slot; the activations of the whole batch stay for the backward pass (ModelBackward.finish_query)."""
+        n, H, Wd = frames.shape[0], frames.shape[2], frames.shape[3]
+        if H % 16 or Wd % 16:
+            raise RuntimeError(f'training-mode segment does not pad (AFB_URR.py:278): {H}x{Wd} is not a multiple of 16')
+        self._join_backward()
+        p = self.plan(H, Wd, obj_n, keep_acts=True)
+        qs = p.batch_set(n)
+        if self.refresher._tables is None:                 # (the batch lists registered new derived tensors: Winograd banks)
+            self._settle()
+        qs.frames[:n].copy_(frames)
+        for l in qs.pre[n]:
+            l()
+        qs.keys = [self._key(frames[i:i + 1]) for i in range(n)]
+        qs.held, qs.consumed, qs.n, qs.stage = [frames] * n, [False] * n, n, 2
+        self._batch = (p, qs)
+        return qs
+
+    def _batched_slot(self, frame):
+        if self._batch is None:
+            return None
+        p, qs = self._batch
+        key = self._key(frame)
+        for slot in range(qs.n):
+            if qs.keys[slot] == key and not qs.consumed[slot]:
+                qs.consumed[slot] = True
+                return p, qs, slot
+        return None
 
     # ------------------------------------------------------------------ look-ahead of the query side
     @staticmethod

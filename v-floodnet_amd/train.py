@@ -196,6 +196,7 @@ def forward_backward(model, frames, masks, lu=0.5, budget=300000):
 
 
 last_enqueue_s = 0.0
+_BATCH_QUERY = os.environ.get('VFN_TRAIN_BATCH_QUERY', '1') == '1'   # the query encoder over all frames of a sample at once (fwd + bwd)
 
 
 def _forward_backward(model, frames, masks, lu, budget):
@@ -208,7 +209,10 @@ def _forward_backward(model, frames, masks, lu, budget):
     k4_list, v4_list = model.memorize(frames[0:1], masks[0:1])
     fb.init_bank(k4_list, v4_list)
     label = torch.argmax(masks[1:], dim=1)
-    mb = model.engine().backward()
+    eng = model.engine()
+    if _BATCH_QUERY:
+        eng.query_batch(frames[1:], obj_n)       # the frame-only part of segment for all bs frames at once
+    mb = eng.backward()
     g_bk = g_bv = None
     stats_sum = torch.zeros(3, device=dev)
     for i in range(bs):
@@ -223,6 +227,7 @@ def _forward_backward(model, frames, masks, lu, budget):
         else:
             g_bk = [a + b for a, b in zip(g_bk, bk)]
             g_bv = [a + b for a, b in zip(g_bv, bv)]
+    mb.finish_query()                            # (the query encoder's backward of the batched samples, all frames at once)
     mb.finish_memorize(frames[0:1], masks[0:1], g_bk, g_bv)
     global last_enqueue_s
     last_enqueue_s = time.perf_counter() - t_start                          # host time to enqueue the whole step (bench_train_step.py)
