@@ -418,7 +418,7 @@ def test_pred2_tap_gemm_matches_conv(gpu, N, h, w, cin):
 
 @pytest.mark.parametrize('case', [(2, 12, 20, 64, 64, 3, 1, True), (1, 13, 19, 128, 96, 3, 2, False), (2, 9, 14, 256, 256, 1, 1, False),
                                   (1, 16, 24, 256, 512, 1, 2, False), (2, 30, 40, 32, 32, 3, 1, True), (1, 25, 40, 1024, 640, 3, 1, False),
-                                  (3, 50, 50, 64, 256, 1, 1, False)])
+                                  (3, 50, 50, 64, 256, 1, 1, False), (1, 20, 30, 256, 32, 3, 1, True), (2, 11, 17, 64, 20, 1, 1, False)])
 def test_conv_wgrad_implicit_gemm_vs_autograd(gpu, case):
     """vfn_conv_wgrad_f32 (weight gradient straight from the NHWC tensors, reduction over the pixels) against torch.autograd of
     F.conv2d in float64: with / without ReLU on the input, strides 1 / 2, a frozen-BatchNorm row scale, accumulation into an

@@ -313,6 +313,10 @@ extern "C" int vfn_conv_wgrad_f32(const vfn_wgrad_desc* d, void* stream) {
     if (d->Wo < 2) return VFN_ERR_ARG;                     // (the pixel walk wraps at most one row per two pixels)
     if ((long long)d->N * d->H * d->W * d->ld_x * 4 >= 0x7fffff00LL || (long long)d->N * d->Ho * d->Wo * d->ld_g * 4 >= 0x7fffff00LL) return VFN_ERR_ARG;
     hipStream_t s = (hipStream_t)stream;
+    if (d->Cout <= 32) {                                   // (the local head, the two-filter heads in their 32-channel tensors:
+        if (d->Cin <= 32) return launch_wgrad<1, 1>(*d, s);   //  a 64-row tile would multiply 32 masked rows)
+        return launch_wgrad<1, 2>(*d, s);
+    }
     if (d->Cin <= 32) return launch_wgrad<2, 1>(*d, s);
     return launch_wgrad<2, 2>(*d, s);
 }

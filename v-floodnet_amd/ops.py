@@ -435,7 +435,7 @@ def conv_wgrad(x, gy, k, stride, pad, cin=None, cout=None, ld_x=None, relu=False
         out = torch.empty(cout, Kc, device=x.device, dtype=torch.float32)
     assert out.is_contiguous() and out.numel() == cout * Kc
     M = N * Ho * Wo
-    tiles = ((cout + 63) // 64) * k * k * ((cin + (31 if cin <= 32 else 63)) // (32 if cin <= 32 else 64))
+    tiles = ((cout + 63) // 64 if cout > 32 else 1) * k * k * ((cin + (31 if cin <= 32 else 63)) // (32 if cin <= 32 else 64))
     if ksplit is None:
         # ~2 000 workgroups, at least 300 pixels per slice (swept on the training step's 51 shapes, scripts/bench_wgrad_shapes.py:
         # 20.0 -> 17.5 ms per step against the first rule, 17.3 with the best split of every shape)

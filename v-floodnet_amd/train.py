@@ -12,7 +12,9 @@ with ``criterion = CrossEntropyLoss()`` (:162), ``optimizer = torch.optim.AdamW(
 (:103-106, ``myutils.set_bn_eval``: running statistics, affine parameters still trained), ``update_bank=False`` (:101).
 
 Here: ``train_step`` runs that body.  The bank is fixed while the batch is segmented, so the batch's samples are independent
-given the bank: each sample is segmented, its loss gradient formed (``ops.segment_loss``; the batch means of the cross entropy
+given the bank: the part of ``segment`` that depends on the frame alone (query encoder, KeyValue, the decoder's skip branches) runs
+for all samples in one pass (``Engine.query_batch``) and is differentiated in one pass (``ModelBackward.finish_query``); the rest runs
+sample by sample: each sample is segmented, its loss gradient formed (``ops.segment_loss``; the batch means of the cross entropy
 and of the uncertainty become a factor 1/bs on every sample's gradient) and carried back to the parameters and to the
 bank's keys / values (``backward.ModelBackward.segment_sample``; two activation plans alternate, so the next sample's forward runs
 while the side stream still computes this sample's weight gradients); the
@@ -21,7 +23,7 @@ gradients that reached the bank are summed over the samples and go through ``mem
 flat ``exp_avg`` / ``exp_avg_sq`` buffers, so a step is one ``vfn_adamw_f32`` launch over 38 M floats (HBM-bound: 5 floats
 moved per parameter).  Every convolution, reduction, adjoint and the optimizer run in the HIP library; there is no autograd graph
 and no eager fallback.  What is left to tensor operators is glue (profiles/r04_train_kernel_stats.csv: ~500 small launches, ~2 ms
-of a 40 ms step): concatenations / slices of gradients that cross a layer boundary, the sum over the objects, the zero-padded
+of a 36 ms step): concatenations / slices of gradients that cross a layer boundary, the sum over the objects, the zero-padded
 operands of the memory read's five small GEMMs, the stem's input normalisation.
 
 Across steps nothing is rebuilt: ``train_step`` ends with ``model._refresh()`` (``engine.Engine.refresh``: everything derived from
