@@ -143,6 +143,13 @@ int vfn_winograd_output_f32(const float* Mb, int rows_pad, int N, int H, int W, 
  * convolution over the flipped, transposed filters, so it takes the same transform-domain route (backward.py) */
 int vfn_winograd_output_masked_f32(const float* Mb, int rows_pad, int N, int H, int W, int Cout, const float* res, int res_ld,
                                    const float* mask, int mask_ld, int mask_after, float* out, int out_ld, void* stream);
+/* (ABI 11) the weight gradient of a 3x3 / stride-1 / pad-1 convolution in the transform domain -- the transposition of the forward
+ * algorithm, dW = G^T [ sum_tiles (B^T d B) (.) (A dY A^T) ] G, a quarter of the direct form's multiplies:
+ *   vfn_winograd_input_f32 (above) V[xi][tile][ci]; vfn_winograd_gy_f32  Z[xi][tile][co] = (A dY A^T)[xi] of the 4x4 tiles of
+ *   gy [N,H,W,ld] (C channels used); vfn_conv_wgrad_f32 with k = 1, batch = 36 sums them over the tiles into dU [36][Cout][Cin];
+ *   vfn_winograd_dw_f32  dw [Cout][3][3][Cin] (+)= rowscale[co] * (G^T dU G). */
+int vfn_winograd_gy_f32(const float* gy, int N, int H, int W, int C, int ld, float* Z, int rows_pad, void* stream);
+int vfn_winograd_dw_f32(const float* dU, int Cout, int Cin, const float* rowscale, float* dw, int accumulate, void* stream);
 
 /* ------------------------------------------------------------------ encoder stems
  * vfn_stem_conv7x7_f32: pad_divide_by (myutils/data.py:132-149) + (x-mean)/std + conv1
@@ -248,6 +255,11 @@ typedef struct vfn_wgrad_desc {
     int* tile_counters;      /* (ABI 11) optional, ksplit > 1: one int per dW tile (ceil(Cout / 64) * k * k * ceil(Cin / 64 or 32)), zero
                               * at rest -- the slices are finished INSIDE the launch (write-through partial tiles, the wave that
                               * arrives last adds them in slice order: the same sums, no reduce launch) */
+    int batch;               /* (ABI 11) > 1: that many independent problems of this shape in one launch -- x, gy advance by
+                              * x_bstride / g_bstride floats per problem, dw by Cout * k * k * Cin, partial by ksplit times that, the
+                              * counters by the tile count (the 36 components of a Winograd-domain weight gradient) */
+    int reserved;
+    long long x_bstride, g_bstride;
 } vfn_wgrad_desc;
 int vfn_conv_wgrad_f32(const vfn_wgrad_desc* d, void* stream);
 

@@ -513,3 +513,35 @@ def test_one_launch_column_sums_vs_float64(gpu, M, C, ld, idn):
                                        stream()), 'bn')
     assert (dg2.cpu().double() - 2 * ref_g).abs().max().item() < 2 * tol_g
     assert torch.equal(db2, 2 * db) and int(cnt.abs().sum()) == 0
+
+
+@pytest.mark.parametrize('case', [(2, 24, 40, 256, 256, True), (1, 23, 37, 128, 256, False), (2, 6, 10, 256, 128, True), (3, 50, 50, 64, 64, False)])
+def test_winograd_weight_gradient_vs_direct_and_autograd(gpu, case):
+    """The weight gradient of a 3x3 / stride-1 / pad-1 convolution in the Winograd domain (ops.conv_wgrad_winograd: input transform,
+    transform of the gradient tiles, the 36 component sums as one batched launch of the weight-gradient kernel, back-transform)
+    against float64 autograd and against the direct implicit-GEMM form: ragged tile edges, ReLU on the input, a row scale,
+    accumulation, run-to-run bit-reproducibility."""
+    import torch.nn.functional as F
+    from vfloodnet_amd import ops
+    N, H, W, Cin, Cout, relu = case
+    g = torch.Generator().manual_seed(hash(case) & 0xFFFF)
+    x = torch.randn(N, Cin, H, W, generator=g)
+    w = (torch.randn(Cout, Cin, 3, 3, generator=g) / (Cin * 9) ** 0.5).double().requires_grad_()
+    scale = 1 + 0.1 * torch.randn(Cout, generator=g)
+    y = F.conv2d(F.relu(x.double()) if relu else x.double(), w, padding=1) * scale.double().view(1, -1, 1, 1)
+    gy = torch.randn(y.shape, generator=g)
+    (y * gy.double()).sum().backward()
+    ref = w.grad.permute(0, 2, 3, 1).reshape(Cout, -1)                       # packed (kh, kw, cin)
+    xd = x.permute(0, 2, 3, 1).contiguous().to(gpu)
+    gd = gy.permute(0, 2, 3, 1).contiguous().to(gpu)
+    sc = scale.to(gpu)
+    tol = 5e-4 * ref.abs().max().item()                                      # (the transforms amplify f32 rounding ~10x over the direct sum)
+    got = ops.conv_wgrad_winograd(xd, gd, relu=relu, rowscale=sc)
+    direct = ops.conv_wgrad(xd, gd, 3, 1, 1, relu=relu, rowscale=sc)
+    torch.cuda.synchronize()
+    err = (got.cpu().double() - ref).abs().max().item()
+    assert err < tol, (err, tol, (direct.cpu().double() - ref).abs().max().item())
+    assert torch.equal(got, ops.conv_wgrad_winograd(xd, gd, relu=relu, rowscale=sc))
+    acc = got.clone()
+    ops.conv_wgrad_winograd(xd, gd, relu=relu, rowscale=sc, out=acc, accumulate=True)
+    assert (acc.cpu().double() - 2 * ref).abs().max().item() < 2 * tol

@@ -156,8 +156,9 @@ def test_refresh_rewrites_every_derived_tensor_bit_exactly_and_keeps_the_step(gp
 
 
 def test_training_step_in_the_winograd_domain_matches_the_direct_step(gpu, monkeypatch):
-    """The training step with every eligible 3x3 convolution -- forward (kept activations) AND data gradient (masked output
-    transform, filter banks of the flipped / transposed filters) -- in the Winograd domain against the step with none: the same
+    """The training step with every eligible 3x3 convolution -- forward (kept activations), data gradient (masked output
+    transform, filter banks of the flipped / transposed filters) AND weight gradient (ops.conv_wgrad_winograd) -- in the Winograd
+    domain against the step with none: the same
     loss, the same gradient for every parameter up to the transforms' f32 rounding; and the banks follow an optimizer step
     (refresh kinds WINO / WINO_DGRAD): the second step's loss agrees too."""
     from tools import synth
@@ -168,8 +169,10 @@ def test_training_step_in_the_winograd_domain_matches_the_direct_step(gpu, monke
     lab = torch.stack([torch.roll(m0.long(), (2 * t, 5 * t), (0, 1)) for t in range(3)], 0)
     masks = torch.nn.functional.one_hot(lab, K).permute(0, 3, 1, 2).float()
     res = {}
+    from vfloodnet_amd import backward as Bk
     for mode in ('0', '2'):
         monkeypatch.setattr(E, '_WINOGRAD', mode)
+        monkeypatch.setattr(Bk, '_WINOGRAD_WGRAD_MIN_WORK', 0 if mode == '2' else 1 << 60)      # ... and every eligible weight gradient
         m = AFB_URR(gpu, update_bank=False).to(gpu)
         m.load_state_dict(sd, strict=True)
         m.train()

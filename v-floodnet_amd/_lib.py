@@ -32,7 +32,7 @@ class WgradDesc(C.Structure):
                 ('N', C.c_int), ('H', C.c_int), ('W', C.c_int), ('Cin', C.c_int), ('ld_x', C.c_int),
                 ('Ho', C.c_int), ('Wo', C.c_int), ('Cout', C.c_int), ('ld_g', C.c_int),
                 ('k', C.c_int), ('stride', C.c_int), ('pad', C.c_int), ('relu', C.c_int), ('accumulate', C.c_int), ('ksplit', C.c_int),
-                ('tile_counters', c_fp)]
+                ('tile_counters', c_fp), ('batch', C.c_int), ('reserved', C.c_int), ('x_bstride', C.c_longlong), ('g_bstride', C.c_longlong)]
 
 
 class RefreshFilter(C.Structure):
@@ -188,6 +188,8 @@ SIGNATURES = {
     'vfn_winograd_tiles': [_i, _i, _i],
     'vfn_winograd_input_f32': [_p, _i, _i, _i, _i, _i, _i, _p, _i, _p],
     'vfn_winograd_output_f32': [_p, _i, _i, _i, _i, _i, _p, _p, _p, _i, _i, _i, _p, _i, _p],
+    'vfn_winograd_gy_f32': [_p, _i, _i, _i, _i, _i, _p, _i, _p],
+    'vfn_winograd_dw_f32': [_p, _i, _i, _p, _p, _i, _p],
     'vfn_winograd_output_masked_f32': [_p, _i, _i, _i, _i, _i, _p, _i, _p, _i, _i, _p, _i, _p],
     'vfn_scatter_mean_checked_f32': [_p, _ll, _ll, _p, _ll, _i, _p, _ll, _ll, _i, _ll, _p, _p],
     'vfn_resize_bicubic_f32': [_p, _p, _i, _i, _i, _i, _i, _p],

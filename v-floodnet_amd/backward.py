@@ -30,6 +30,8 @@ from .engine import choose_cfg, apply_choice, DK, DV
 _IMPLICIT_WGRAD = __import__('os').environ.get('VFN_IMPLICIT_WGRAD', '1') == '1'      # 0: the round-3 path (transposed operands)
 _SIDE_WGRAD = __import__('os').environ.get('VFN_SIDE_WGRAD', '1') == '1'              # 0: weight gradients on the main stream
 _SIDE_PRIORITY = int(__import__('os').environ.get('VFN_SIDE_PRIORITY', 0))               # -1: the side stream's kernels are dispatched first
+_WINOGRAD_WGRAD = __import__('os').environ.get('VFN_WINOGRAD_WGRAD', '1') == '1'      # weight gradients of the big 3x3 layers in the Winograd domain
+_WINOGRAD_WGRAD_MIN_WORK = int(__import__('os').environ.get('VFN_WINOGRAD_WGRAD_MIN_WORK', 600000))        # pixels x min(cin, cout)
 _SIDE_DROP = __import__('os').environ.get('VFN_SIDE_DROP', '0') == '1'
 _SIDE_GROUP = int(__import__('os').environ.get('VFN_SIDE_GROUP', 8))                   # deferred launches per side-stream hand-over
 
@@ -501,6 +503,14 @@ class ModelBackward:
         else:
             buf = have[0]
         acc = have is not None
+        if (_WINOGRAD_WGRAD and k == 3 and stride == 1 and pad == 1 and min(cin, cout) >= 32 and cin % 4 == 0 and cout % 4 == 0 and
+                N * H * Wd * min(cin, cout) >= _WINOGRAD_WGRAD_MIN_WORK and gy.shape[-1] == cout):
+            # the 3x3 layers with enough pixels x channels: the weight gradient in the Winograd domain (a quarter of the multiplies;
+            # ops.conv_wgrad_winograd).  scripts/bench_wgrad_winograd.py: 2.2x at 20 000 pixels x 256 channels, 1.5x at 5 000 x 256 or
+            # 50 000 x 64, break-even near 2 500 x 256; slower below
+            self._side_do(lambda: ops.conv_wgrad_winograd(x, gy, cin=cin, cout=cout, ld_x=ld_x, relu=relu, rowscale=rowscale, out=buf,
+                                                          accumulate=acc, N=N, H=H, W=Wd))
+            return True
         self._side_do(lambda: ops.conv_wgrad(x, gy, k, stride, pad, cin=cin, cout=cout, ld_x=ld_x, relu=relu, rowscale=rowscale, out=buf,
                                              accumulate=acc, N=N, H=H, W=Wd))
         return True

@@ -37,6 +37,7 @@ void conv_wgrad_kernel(const vfn_wgrad_desc p) {
     const int col_tiles = kk * ci_tiles;
     const int tiles = ((p.Cout + 32 * TM - 1) / (32 * TM)) * col_tiles;
     const int tile = blockIdx.x % tiles, kz = blockIdx.x / tiles;
+    const int bz = blockIdx.y;                   // batch of independent problems (the 36 components of a Winograd-domain gradient)
     const int ct = tile % col_tiles, rt = tile / col_tiles;
     const int tap = ct / ci_tiles, cit = ct - tap * ci_tiles;
     const int kh = tap / p.k, kw = tap - kh * p.k;
@@ -51,9 +52,9 @@ void conv_wgrad_kernel(const vfn_wgrad_desc p) {
     const int m_end = min(M, m_begin + per);
 
     const __amdgpu_buffer_rsrc_t rg = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<float*>(p.gy), 0, (int)((size_t)M * p.ld_g * sizeof(float)), 0x00020000);
+        const_cast<float*>(p.gy) + (size_t)bz * p.g_bstride, 0, (int)((size_t)M * p.ld_g * sizeof(float)), 0x00020000);
     const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<float*>(p.x), 0, (int)((size_t)p.N * p.H * p.W * p.ld_x * sizeof(float)), 0x00020000);
+        const_cast<float*>(p.x) + (size_t)bz * p.x_bstride, 0, (int)((size_t)p.N * p.H * p.W * p.ld_x * sizeof(float)), 0x00020000);
     constexpr int OOB = 0x7fffff00;
 
     // this lane's pixel: m = m_begin + 2 * step + lh, tracked incrementally (no multiply or divide in the loop): output
@@ -192,7 +193,11 @@ void conv_wgrad_kernel(const vfn_wgrad_desc p) {
     const bool direct = p.ksplit <= 1;
     const bool inlaunch = !direct && p.tile_counters != nullptr;
     const int slab_bytes = p.Cout * Kc * (int)sizeof(float);
-    float* dst = direct ? p.dw : p.partial + (size_t)kz * p.Cout * Kc;
+    const size_t slab = (size_t)p.Cout * Kc;
+    float* const dw = p.dw + (size_t)bz * slab;
+    float* const partial = p.partial + (size_t)bz * p.ksplit * slab;
+    int* const counters = p.tile_counters ? p.tile_counters + (size_t)bz * tiles : nullptr;
+    float* dst = direct ? dw : partial + (size_t)kz * slab;
     const __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc(dst, 0, slab_bytes, 0x00020000);
     constexpr int WT = 17;                       // sc0 sc1: past L1 and the XCD's L2 (the slices of a tile run on any XCD)
 #pragma unroll
@@ -220,15 +225,15 @@ void conv_wgrad_kernel(const vfn_wgrad_desc p) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     int last = 0;
     if (lane == 0) {
-        const int prev = __hip_atomic_fetch_add(p.tile_counters + tile, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int prev = __hip_atomic_fetch_add(counters + tile, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         last = prev == p.ksplit - 1;
-        if (last) __hip_atomic_store(p.tile_counters + tile, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (last) __hip_atomic_store(counters + tile, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     last = __builtin_amdgcn_readfirstlane(last);
     if (!last) return;
     // (the range check covers the per-lane offset only: masked lanes carry OOB >= this size; the slice offset rides in the scalar operand)
-    const __amdgpu_buffer_rsrc_t rp = __builtin_amdgcn_make_buffer_rsrc(p.partial, 0, p.ksplit * slab_bytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(p.dw, 0, slab_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rp = __builtin_amdgcn_make_buffer_rsrc(partial, 0, p.ksplit * slab_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(dw, 0, slab_bytes, 0x00020000);
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
         const int ci = ci0 + j * 32 + li;
@@ -261,9 +266,11 @@ void conv_wgrad_kernel(const vfn_wgrad_desc p) {
 }
 
 // dw[co][c] = (accumulate ? dw[co][c] : 0) + rowscale[co] * (partial[0][co][c] + partial[1][co][c] + ...), slice order
-__global__ void wgrad_reduce_kernel(const vfn_wgrad_desc p) {
+__global__ void wgrad_reduce_kernel(vfn_wgrad_desc p) {
     const int Kc = p.k * p.k * p.Cin;
     const size_t slab = (size_t)p.Cout * Kc;
+    p.dw += (size_t)blockIdx.y * slab;
+    p.partial += (size_t)blockIdx.y * p.ksplit * slab;
     if (Kc % 4 == 0) {
         const size_t total = slab / 4;
         for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
@@ -293,12 +300,13 @@ int launch_wgrad(const vfn_wgrad_desc& p, hipStream_t s) {
     const int tiles = cdiv(p.Cout, 32 * TM) * p.k * p.k * cdiv(p.Cin, 32 * TN);
     const int ks = p.ksplit > 1 ? p.ksplit : 1;
     constexpr size_t lds = (size_t)3 * TM * TN * 16 * 64 * sizeof(float);
-    if (p.relu) hipLaunchKernelGGL((conv_wgrad_kernel<TM, TN, true>), dim3(tiles * ks), dim3(256), lds, s, p);
-    else hipLaunchKernelGGL((conv_wgrad_kernel<TM, TN, false>), dim3(tiles * ks), dim3(256), lds, s, p);
+    const int nb = p.batch > 1 ? p.batch : 1;
+    if (p.relu) hipLaunchKernelGGL((conv_wgrad_kernel<TM, TN, true>), dim3(tiles * ks, nb), dim3(256), lds, s, p);
+    else hipLaunchKernelGGL((conv_wgrad_kernel<TM, TN, false>), dim3(tiles * ks, nb), dim3(256), lds, s, p);
     if (ks > 1 && !p.tile_counters) {
         const size_t total = (size_t)p.Cout * p.k * p.k * p.Cin / ((p.k * p.k * p.Cin) % 4 ? 1 : 4);
         const int blocks = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
-        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, s, p);
+        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks, nb), dim3(256), 0, s, p);
     }
     return vfn_check_launch();
 }

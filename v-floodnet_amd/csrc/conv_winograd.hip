@@ -145,6 +145,102 @@ void winograd_output_kernel(const float* __restrict__ Mb, int rows_pad, int N, i
     }
 }
 
+// ---- the weight gradient in the transform domain (round 4): dW = G^T [ sum_tiles (B^T d B) (.) (A dY A^T) ] G -- the transposition
+// of the forward algorithm: 36 multiplies per (tile, filter, channel) instead of the direct form's 144.
+//   vfn_winograd_input_f32   V[xi][tile][ci] = (B^T d B)[xi]           (the forward's input transform, ReLU included)
+//   vfn_winograd_gy_f32      Z[xi][tile][co] = (A dY A^T)[xi]          dY: the 4x4 tile of dL/dy (zero outside the image)
+//   vfn_conv_wgrad_f32       dU[xi][co][ci]  = sum_tile Z[xi][tile][co] V[xi][tile][ci]     (batch = 36 one-by-one problems)
+//   vfn_winograd_dw_f32      dW[co][a][b][ci] (+)= rowscale[co] * sum_ij G[i][a] dU[6i+j][co][ci] G[j][b]
+// z = A v (4 values -> 6), A = (A^T)^T
+__device__ __forceinline__ void a6(const f32x4 (&v)[4], f32x4 (&z)[6]) {
+    const f32x4 e = v[0] + v[2], o = v[1] + v[3];
+    const f32x4 e4 = v[0] + 4.f * v[2], o8 = 2.f * v[1] + 8.f * v[3];
+    z[0] = v[0];
+    z[1] = e + o;
+    z[2] = e - o;
+    z[3] = e4 + o8;
+    z[4] = e4 - o8;
+    z[5] = v[3];
+}
+
+__global__ __launch_bounds__(256)
+void winograd_gy_kernel(const float* __restrict__ gy, int N, int H, int W, int C, int ld, float* __restrict__ Z, int rows_pad) {
+    const int th = (H + 3) / 4, tw = (W + 3) / 4;
+    const int c4n = C / 4;
+    const long long total = (long long)N * th * tw * c4n;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int c4 = (int)(i % c4n);
+        const int tile = (int)(i / c4n);
+        const int tx = tile % tw, ty = (tile / tw) % th, n = tile / (tw * th);
+        f32x4 t[6][4];                               // t = A dY (columns of dY through A)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            f32x4 col[4], z[6];
+            const int xx = 4 * tx + b;
+#pragma unroll
+            for (int a = 0; a < 4; ++a) {
+                const int yy = 4 * ty + a;
+                f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                if (yy < H && xx < W) v = *reinterpret_cast<const f32x4*>(gy + ((size_t)(n * H + yy) * W + xx) * ld + c4 * 4);
+                col[a] = v;
+            }
+            a6(col, z);
+#pragma unroll
+            for (int a = 0; a < 6; ++a) t[a][b] = z[a];
+        }
+#pragma unroll
+        for (int a = 0; a < 6; ++a) {
+            f32x4 z[6];
+            a6(t[a], z);
+#pragma unroll
+            for (int b = 0; b < 6; ++b)
+                *reinterpret_cast<f32x4*>(Z + ((size_t)(a * 6 + b) * rows_pad + tile) * C + c4 * 4) = z[b];
+        }
+    }
+}
+
+// w = G^T u (6 values -> 3)
+__device__ __forceinline__ void gt3(const f32x4 (&u)[6], f32x4 (&w)[3]) {
+    const f32x4 s12 = u[1] + u[2], d12 = u[2] - u[1], s34 = u[3] + u[4], d34 = u[3] - u[4];
+    w[0] = 0.25f * u[0] - (1.f / 6.f) * s12 + (1.f / 24.f) * s34;
+    w[1] = (1.f / 6.f) * d12 + (1.f / 12.f) * d34;
+    w[2] = -(1.f / 6.f) * s12 + (1.f / 6.f) * s34 + u[5];
+}
+
+__global__ __launch_bounds__(256)
+void winograd_dw_kernel(const float* __restrict__ dU, int Cout, int Cin, const float* __restrict__ rowscale, float* __restrict__ dw,
+                        int accumulate) {
+    const int c4n = Cin / 4;
+    const long long total = (long long)Cout * c4n;
+    const size_t bank = (size_t)Cout * Cin;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int c4 = (int)(i % c4n), co = (int)(i / c4n);
+        f32x4 t[3][6];                               // t = G^T dU (columns through G^T)
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+            f32x4 u[6], w[3];
+#pragma unroll
+            for (int a = 0; a < 6; ++a) u[a] = *reinterpret_cast<const f32x4*>(dU + (size_t)(a * 6 + j) * bank + (size_t)co * Cin + c4 * 4);
+            gt3(u, w);
+#pragma unroll
+            for (int a = 0; a < 3; ++a) t[a][j] = w[a];
+        }
+        const float sc = rowscale ? rowscale[co] : 1.f;
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            f32x4 w[3];
+            gt3(t[a], w);
+#pragma unroll
+            for (int b = 0; b < 3; ++b) {
+                f32x4* o = reinterpret_cast<f32x4*>(dw + ((size_t)co * 9 + a * 3 + b) * Cin + c4 * 4);
+                f32x4 v = w[b] * sc;
+                if (accumulate) v += *o;
+                *o = v;
+            }
+        }
+    }
+}
+
 inline int grid_of(long long total) {
     long long b = (total + 255) / 256;
     return (int)(b < 16384 ? (b ? b : 1) : 16384);
@@ -180,5 +276,19 @@ extern "C" int vfn_winograd_output_masked_f32(const float* Mb, int rows_pad, int
     const long long total = (long long)vfn_winograd_tiles(N, H, W) * (Cout / 4);
     hipLaunchKernelGGL(winograd_output_kernel, dim3(grid_of(total)), dim3(256), 0, (hipStream_t)stream, Mb, rows_pad, N, H, W, Cout,
                        (const float*)nullptr, (const float*)nullptr, res, res_ld, 0, 0, out, out_ld, mask, mask_ld, mask_after);
+    return vfn_check_launch();
+}
+
+extern "C" int vfn_winograd_gy_f32(const float* gy, int N, int H, int W, int C, int ld, float* Z, int rows_pad, void* stream) {
+    if (!gy || !Z || N < 1 || H < 1 || W < 1 || C < 4 || C % 4 || ld < C || ld % 4 || rows_pad < vfn_winograd_tiles(N, H, W)) return VFN_ERR_ARG;
+    const long long total = (long long)vfn_winograd_tiles(N, H, W) * (C / 4);
+    hipLaunchKernelGGL(winograd_gy_kernel, dim3(grid_of(total)), dim3(256), 0, (hipStream_t)stream, gy, N, H, W, C, ld, Z, rows_pad);
+    return vfn_check_launch();
+}
+
+extern "C" int vfn_winograd_dw_f32(const float* dU, int Cout, int Cin, const float* rowscale, float* dw, int accumulate, void* stream) {
+    if (!dU || !dw || Cout < 1 || Cin < 4 || Cin % 4) return VFN_ERR_ARG;
+    hipLaunchKernelGGL(winograd_dw_kernel, dim3(grid_of((long long)Cout * (Cin / 4))), dim3(256), 0, (hipStream_t)stream, dU, Cout, Cin, rowscale,
+                       dw, accumulate);
     return vfn_check_launch();
 }

@@ -416,7 +416,7 @@ _WGRAD_INLAUNCH = os.environ.get('VFN_WGRAD_INLAUNCH', '0') == '1'
 
 
 def conv_wgrad(x, gy, k, stride, pad, cin=None, cout=None, ld_x=None, relu=False, rowscale=None, out=None, accumulate=False,
-               N=None, H=None, W=None, ksplit=None):
+               N=None, H=None, W=None, ksplit=None, batch=1, x_bstride=0, g_bstride=0):
     """dL/dW of y = conv_{k x k, stride, pad}(act(x)) as an implicit GEMM over the pixels (vfn_conv_wgrad_f32): x NHWC
     [N,H,W,ld_x] (``cin`` channels used), gy [N,Ho,Wo,ld_g] (``cout`` used) -> out [cout, k*k*cin] in the packed filter layout
     (kh, kw, cin); ``rowscale`` [cout]: the frozen BatchNorm scale; ``accumulate``: add to ``out``."""
@@ -433,9 +433,10 @@ def conv_wgrad(x, gy, k, stride, pad, cin=None, cout=None, ld_x=None, relu=False
     if out is None:
         assert not accumulate
         out = torch.empty(cout, Kc, device=x.device, dtype=torch.float32)
-    assert out.is_contiguous() and out.numel() == cout * Kc
+    assert out.is_contiguous() and out.numel() == batch * cout * Kc
     M = N * Ho * Wo
     tiles = ((cout + 63) // 64 if cout > 32 else 1) * k * k * ((cin + (31 if cin <= 32 else 63)) // (32 if cin <= 32 else 64))
+    tiles *= batch                               # (``batch`` independent problems of this shape in one launch: vfn_wgrad_desc.batch)
     if ksplit is None:
         # ~2 000 workgroups, at least 300 pixels per slice (swept on the training step's 51 shapes, scripts/bench_wgrad_shapes.py:
         # 20.0 -> 17.5 ms per step against the first rule, 17.3 with the best split of every shape)
@@ -445,10 +446,11 @@ def conv_wgrad(x, gy, k, stride, pad, cin=None, cout=None, ld_x=None, relu=False
     d.N, d.H, d.W, d.Cin, d.ld_x = N, H, W, cin, ld_x
     d.Ho, d.Wo, d.Cout, d.ld_g = Ho, Wo, cout, ld_g
     d.k, d.stride, d.pad, d.relu, d.accumulate, d.ksplit = k, stride, pad, int(relu), int(accumulate), int(ksplit)
+    d.batch, d.x_bstride, d.g_bstride = int(batch), int(x_bstride), int(g_bstride)
     part = None
     if ksplit > 1:
         key = (str(x.device), torch.cuda.current_stream(x.device).cuda_stream)     # (a workspace per stream: the backward pass
-        need = ksplit * cout * Kc                                                  #  runs weight gradients beside the data-gradient chain)
+        need = batch * ksplit * cout * Kc                                               #  runs weight gradients beside the data-gradient chain)
         hit = _wgrad_ws.get(key)
         if hit is None or hit[0].numel() < need:
             # (+ the tiles' arrival counters of the in-launch finish, zero at rest; VFN_WGRAD_INLAUNCH=0: the separate reduce launch)
@@ -460,6 +462,47 @@ def conv_wgrad(x, gy, k, stride, pad, cin=None, cout=None, ld_x=None, relu=False
             d.tile_counters = ptr(hit[1])
     d.partial = ptr(part)
     check(_lib.lib().vfn_conv_wgrad_f32(C.byref(d), stream()), 'vfn_conv_wgrad_f32')
+    return out
+
+
+def winograd_gy(gy, Z, rows_pad, N, H, W, cout, ld_g):
+    check(_lib.lib().vfn_winograd_gy_f32(ptr(gy), N, H, W, cout, ld_g, ptr(Z), rows_pad, stream()), 'vfn_winograd_gy_f32')
+
+
+_wino_wgrad_ws = {}
+
+
+def conv_wgrad_winograd(x, gy, cin=None, cout=None, ld_x=None, relu=False, rowscale=None, out=None, accumulate=False, N=None, H=None, W=None):
+    """dL/dW of a 3x3 / stride-1 / pad-1 convolution in the Winograd domain (csrc/conv_winograd.hip: dW = G^T [sum_tiles (B^T d B)
+    (.) (A dY A^T)] G, a quarter of the direct form's multiplies): input transform of act(x), transform of the gradient tiles,
+    the 36 component sums as ONE batched launch of the weight-gradient kernel, back-transform with the row scale / accumulation.
+    Same arguments and packed result [cout, 9 * cin] as ``conv_wgrad``; scratch per stream."""
+    if N is None:
+        N, H, W = x.shape[0], x.shape[1], x.shape[2]
+    ld_x = ld_x if ld_x is not None else x.stride(-2)
+    cin = cin if cin is not None else x.shape[-1]
+    cout = cout if cout is not None else gy.shape[-1]
+    ld_g = gy.stride(-2)
+    assert cin % 4 == 0 and cout % 4 == 0 and x.stride(-1) == 1 and gy.stride(-1) == 1
+    if out is None:
+        assert not accumulate
+        out = torch.empty(cout, 9 * cin, device=x.device, dtype=torch.float32)
+    tiles = vfn_winograd_tiles(N, H, W)
+    rows = winograd_rows(N, H, W)
+    key = (str(x.device), torch.cuda.current_stream(x.device).cuda_stream)
+    need = (36 * rows * cin, 36 * rows * cout, 36 * cout * cin)
+    ws = _wino_wgrad_ws.get(key)
+    if ws is None or any(t.numel() < n_ for t, n_ in zip(ws, need)):
+        old = ws or (None, None, None)
+        ws = tuple(t if (t is not None and t.numel() >= n_) else torch.empty(n_, device=x.device, dtype=torch.float32) for t, n_ in zip(old, need))
+        _wino_wgrad_ws[key] = ws
+    V, Z, dU = ws[0][:need[0]], ws[1][:need[1]], ws[2][:need[2]]
+    winograd_input(x, V, rows, relu, N, H, W, cin, ld_x)
+    winograd_gy(gy, Z, rows, N, H, W, cout, ld_g)
+    # component 0's rows as a one-row image of ``tiles`` pixels; the other 35 components follow at the batch strides
+    conv_wgrad(V[:tiles * cin].view(1, 1, tiles, cin), Z[:tiles * cout].view(1, 1, tiles, cout), 1, 1, 0, cin=cin, cout=cout, ld_x=cin,
+               out=dU.view(36 * cout, cin), N=1, H=1, W=tiles, batch=36, x_bstride=rows * cin, g_bstride=rows * cout)
+    check(_lib.lib().vfn_winograd_dw_f32(ptr(dU), cout, cin, ptr(rowscale), ptr(out), int(accumulate), stream()), 'vfn_winograd_dw_f32')
     return out
 
 
