@@ -23,7 +23,7 @@ gradients that reached the bank are summed over the samples and go through ``mem
 flat ``exp_avg`` / ``exp_avg_sq`` buffers, so a step is one ``vfn_adamw_f32`` launch over 38 M floats (HBM-bound: 5 floats
 moved per parameter).  Every convolution, reduction, adjoint and the optimizer run in the HIP library; there is no autograd graph
 and no eager fallback.  What is left to tensor operators is glue (profiles/r04_train_kernel_stats.csv: ~500 small launches, ~2 ms
-of a 36 ms step): concatenations / slices of gradients that cross a layer boundary, the sum over the objects, the zero-padded
+of a 32 ms step): concatenations / slices of gradients that cross a layer boundary, the sum over the objects, the zero-padded
 operands of the memory read's five small GEMMs, the stem's input normalisation.
 
 Across steps nothing is rebuilt: ``train_step`` ends with ``model._refresh()`` (``engine.Engine.refresh``: everything derived from
