@@ -26,6 +26,7 @@ def test_main_on_a_resized_clip_does_not_reuse_stale_lookahead_entries(gpu, tmp_
     allocator addresses.  They now own their source tensors, so a recycled address cannot hit an older frame's entry: the masks
     must agree with the run that never looks ahead (VFN_LOOKAHEAD=0; up to the summation order of the batched query pass) --
     before the fix frames from ~19 on were segmented from the pixels of older frames."""
+    monkeypatch.setenv('VFN_AUTOTUNE', '0')      # (an unlisted frame size: the heuristic tile choices; the tuner is exercised elsewhere)
     from PIL import Image
     from tools import synth
     from vfloodnet_amd import video_seg

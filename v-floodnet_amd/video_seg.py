@@ -103,7 +103,7 @@ class ClipRunner:
         self.ori_size = (H0, W0)
         f = self._net_frame(first_frame)
         h, w = f.shape[-2:]
-        if self.autotune:
+        if self.autotune and os.environ.get('VFN_AUTOTUNE', '1') != '0':    # (VFN_AUTOTUNE=0: the heuristic choices for unlisted shapes)
             self.model.engine().autotune(h, w, self.obj_n, only_missing=True)
         m = first_mask_onehot.to(torch.float32).contiguous()
         if (h, w) != (H0, W0):
