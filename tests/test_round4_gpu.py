@@ -183,6 +183,29 @@ def test_training_step_in_the_winograd_domain_matches_the_direct_step(gpu, monke
         l1 = T.train_step(m, opt, frames, masks, 0.5)
         l2 = T.train_step(m, opt, frames, masks, 0.5)
         n_wino = sum(1 for p in m.engine().plans.values() for lst in p.all_lists() for l in lst if l.name.endswith('.wino_gemm') or '.wino_gemm[' in l.name)
+        if mode == '2':
+            # after two optimizer steps every Winograd filter bank (refresh kinds WINO / WINO_DGRAD, KeyValue's two halves included)
+            # equals the float64 transform of the CURRENT parameters
+            from vfloodnet_amd import ops
+            eng = m.engine()
+            checked = 0
+            for layer in eng._layers():
+                U = layer._w_lp.get('wino')
+                if U is None:
+                    continue
+                w = layer.w[:layer.cout].view(layer.cout, 3, 3, layer.cin).permute(0, 3, 1, 2)
+                ref = ops.pack_winograd_weight(w).to(gpu)
+                assert (U - ref).abs().max().item() <= 2e-7 * ref.abs().max().item(), (layer.cout, layer.cin)
+                checked += 1
+            dec = eng.backward().dec
+            for name, U in dec.fw.items():
+                weight, cin_off, _ = dec._fsrc[name]
+                cin = dec.f[name][1]
+                wd = weight.detach().float()[:, cin_off:cin_off + cin].flip(2, 3).transpose(0, 1)
+                ref = ops.pack_winograd_weight(wd).to(gpu)
+                assert (U - ref).abs().max().item() <= 2e-7 * ref.abs().max().item(), name
+                checked += 1
+            assert checked >= 25, checked
         res[mode] = (loss, unc, grads, l1, l2, n_wino, len(m.engine().backward().dec.fw))
     assert res['0'][5] == 0 and res['0'][6] == 0
     assert res['2'][5] >= 20 and res['2'][6] >= 10, res['2'][5:]

@@ -251,7 +251,7 @@ class ConvLayer:
         self._wino_src = None
         if reg is not None and isinstance(conv, torch.nn.Module):
             from .refresh import FORWARD
-            self._wino_src = (reg, conv.weight, cin_range[0] if cin_range is not None else 0)
+            self._wino_src = [(reg, conv.weight, cin_range[0] if cin_range is not None else 0, 0)]      # (parameter, first channel, first filter row)
             reg.add_filter(conv.weight, self.w, FORWARD, cin=self.cin, cin_off=cin_range[0] if cin_range is not None else 0)
             if bn is not None:
                 reg.add_epilogue(self.scale, self.shift if with_bias else None, bn=bn, eps=W.BN_EPS)
@@ -284,9 +284,9 @@ class ConvLayer:
             self._w_lp['wino'] = ops.pack_winograd_weight(w).to(self.w.device)
             if self._wino_src is not None:                 # (follows the parameter after an optimizer step: refresh kind WINO)
                 from .refresh import WINO
-                reg, weight, cin_off = self._wino_src
-                reg.add_filter(weight, self._w_lp['wino'], WINO, cin=self.cin, cin_off=cin_off, dst_ld=self.cin,
-                               cout_ld=self._w_lp['wino'].shape[0] // 36)
+                for reg, weight, cin_off, row0 in self._wino_src:
+                    reg.add_filter(weight, self._w_lp['wino'], WINO, cin=self.cin, cin_off=cin_off, dst_ld=self.cin, dst_row0=row0,
+                                   cout_ld=self._w_lp['wino'].shape[0] // 36)
         return self._w_lp['wino']
 
 
@@ -740,13 +740,13 @@ class Engine:
         except RuntimeError:
             pass
 
-    def refresh(self):
+    def refresh(self, check=True):
         """The parameters changed in place (an optimizer step): rewrite everything derived from them -- the engine's packed
         filters and folded BatchNorm constants, the backward pass's data-gradient filters -- where it lies (two launches,
         csrc/refresh.hip); plans, buffers and descriptors stay.  Raises RuntimeError if a parameter is no longer a contiguous f32
         device tensor (the caller builds a new engine then)."""
-        self.refresher.run()
-        for layer in self._layers():
+        self.refresher.run(verify=check)
+        for layer in self._layers():                       # (reduced-precision operand images; Winograd banks that are not registered)
             if layer._w_lp:
                 layer.refresh_derived()
 
@@ -843,9 +843,11 @@ class Engine:
             self.keyval = ConvLayer(holder, None, dev)
             self.keyval.shift = self.keyval.shift.clone()
             row = 0
+            self.keyval._wino_src = []
             for c in (kv.Key, kv.Value):                                       # the two halves of the 640-filter convolution
                 reg.add_filter(c.weight, self.keyval.w, FORWARD, dst_row0=row)
                 reg.add_epilogue(None, self.keyval.shift[row:row + c.weight.shape[0]], bias=c.bias)
+                self.keyval._wino_src.append((reg, c.weight, 0, row))         # (its Winograd banks, if a plan uses them: w_wino)
                 row += c.weight.shape[0]
             d = m.decoder
             cl = lambda c: ConvLayer(c, None, dev, reg=reg)

@@ -62,14 +62,14 @@ class AFB_URR(nn.Module):
             pass
         return out
 
-    def _refresh(self):
+    def _refresh(self, trusted=False):
         """The parameters were updated in place: the engine's derived tensors follow them where they lie (engine.Engine.refresh:
         two kernel launches; plans, buffers and the cached backward pass stay) -- or, if a parameter moved to another dtype /
         device / layout, the engine is dropped and rebuilt on the next call."""
         if self._engine is None:
             return
         try:
-            self._engine.refresh()
+            self._engine.refresh(check=not trusted)       # (trusted: the caller owns the parameters' storage, refresh.Refresher.run)
             self._engine_version = self._param_version()
         except RuntimeError:
             self._engine = None

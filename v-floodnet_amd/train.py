@@ -23,7 +23,7 @@ gradients that reached the bank are summed over the samples and go through ``mem
 flat ``exp_avg`` / ``exp_avg_sq`` buffers, so a step is one ``vfn_adamw_f32`` launch over 38 M floats (HBM-bound: 5 floats
 moved per parameter).  Every convolution, reduction, adjoint and the optimizer run in the HIP library; there is no autograd graph
 and no eager fallback.  What is left to tensor operators is glue (profiles/r04_train_kernel_stats.csv: ~500 small launches, ~2 ms
-of a 32 ms step): concatenations / slices of gradients that cross a layer boundary, the sum over the objects, the zero-padded
+of a 31 ms step): concatenations / slices of gradients that cross a layer boundary, the sum over the objects, the zero-padded
 operands of the memory read's five small GEMMs, the stem's input normalisation.
 
 Across steps nothing is rebuilt: ``train_step`` ends with ``model._refresh()`` (``engine.Engine.refresh``: everything derived from
@@ -84,6 +84,16 @@ class AdamW:
 
     def zero_grad(self):
         self.grad.zero_()
+
+    def owns(self, model):
+        """Are the model's optimised parameters still the views of this optimizer's flat buffer (nobody re-seated ``p.data``)?
+        One address per parameter against the recorded offset."""
+        base = self.flat.data_ptr()
+        for n, p in model.named_parameters():
+            off = self.offsets.get(n)
+            if off is not None and p.data_ptr() != base + 4 * off[0]:
+                return False
+        return True
 
     def grad_view(self, name):
         o, k, shp = self.offsets[name]
@@ -262,7 +272,11 @@ def train_step(model, optimizer, frames, masks, lu=0.5, budget=300000):
         loss, unc, grads = forward_backward(model, frames, masks, lu, budget)
         optimizer.set_grads(grads)
         optimizer.step()
-        model._refresh()             # the engine's packed filters / folded BatchNorm constants follow the new parameters in place
+        # the engine's packed filters / folded BatchNorm constants follow in place; the address check of the refresh tables is
+        # skipped once they have been verified under THIS optimizer's ownership of the parameters (its constructor re-seats p.data)
+        own = optimizer.owns(model)
+        model._refresh(trusted=own and model.__dict__.get('_refresh_owner') is optimizer)
+        model.__dict__['_refresh_owner'] = optimizer if own else None
         model.engine()               # (or are rebuilt here, inside the single-threaded region, if a parameter moved)
     return loss, unc
 
