@@ -67,6 +67,30 @@ void refresh_filters_kernel(const vfn_refresh_filter* __restrict__ table, int n)
         return;
     }
     const long long total = (long long)e.cout * e.cin * T;
+    if (e.kind <= 1 && T == 9) {
+        // 3x3 filters, a (filter, channel) pair per thread: its nine taps are 36 contiguous bytes of the source (a thread per
+        // destination element read every source sector nine to sixteen times over), and for a fixed tap a wave's stores are contiguous
+        const long long pairs = (long long)e.cout * e.cin;
+        const int per = ELEMS_PER_BLOCK / 9 + 1;     // (the entry's workgroups were counted over cout * cin * 9 elements: >= pairs / per of them)
+        for (int i = threadIdx.x; i < per; i += 256) {
+            const long long idx = (long long)((int)blockIdx.x - e.block0) * per + i;
+            if (idx >= pairs) return;
+            int co, ci;
+            if (e.kind == 0) { ci = (int)(idx % e.cin); co = (int)(idx / e.cin); }
+            else { co = (int)(idx % e.cout); ci = (int)(idx / e.cout); }
+            const float* g = e.src + ((size_t)co * e.cin_total + e.cin_off + ci) * 9;
+            const float sc = e.gamma ? bn_scale(e.gamma, e.var, e.eps, co) : 1.f;
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                float v = g[t];
+                if (e.gamma) v = __fmul_rn(v, sc);
+                const size_t dst = e.kind == 0 ? (size_t)(e.dst_row0 + co) * e.dst_ld + (size_t)t * e.cin + ci
+                                               : (size_t)(e.dst_row0 + ci) * e.dst_ld + (size_t)(8 - t) * e.cout_ld + e.dst_col0 + co;
+                e.dst[dst] = v;
+            }
+        }
+        return;
+    }
     for (int i = threadIdx.x; i < ELEMS_PER_BLOCK; i += 256) {
         const long long idx = base + i;
         if (idx >= total) return;
