@@ -299,3 +299,32 @@ def test_training_steps_are_bit_reproducible_with_and_without_the_side_stream(gp
     # the two forms run the same layers over different batch sizes (other tile choices, other summation orders): close, not equal
     for a, b in zip(first[True], first[False]):
         assert abs(a[0] - b[0]) < 2e-3 * abs(b[0]) and abs(a[1] - b[1]) < 2e-3 * abs(b[1]), (first[True], first[False])
+
+
+@pytest.mark.parametrize('T_frames', [2, 5])
+def test_batched_query_encoder_matches_the_frame_by_frame_step(gpu, monkeypatch, T_frames):
+    """``Engine.query_batch`` / ``ModelBackward.finish_query`` (the query encoder over all frames of a sample at once, forward and
+    backward) against the frame-by-frame form of the same step: a sample of one reference frame + 1 or 4 frames to segment -- the
+    same loss, and every gradient tensor close (other batch sizes pick other tile schedules, so summation orders differ)."""
+    from tools import synth
+    from vfloodnet_amd import AFB_URR, train as T
+    H, W, K = 96, 160, 2
+    sd = synth.make_state_dict(SEED)
+    frames, m0 = synth.clip(9, T_frames, H, W)
+    lab = torch.stack([torch.roll(m0.long(), (2 * t, 5 * t), (0, 1)) for t in range(T_frames)], 0)
+    masks = torch.nn.functional.one_hot(lab, K).permute(0, 3, 1, 2).float()
+    res = {}
+    for batch in (True, False):
+        monkeypatch.setattr(T, '_BATCH_QUERY', batch)
+        m = AFB_URR(gpu, update_bank=False).to(gpu)
+        m.load_state_dict(sd, strict=True)
+        m.train()
+        loss, unc, grads = T.forward_backward(m, frames, masks, 0.5)
+        res[batch] = (loss, unc, {k: v.clone() for k, v in grads.items()})
+        plan = m.engine().plan(H, W, K, keep_acts=True)
+        assert (set(plan._qbatch) == {T_frames - 1}) == batch
+    a, b = res[True], res[False]
+    assert abs(a[0] - b[0]) < 1e-5 * abs(b[0]) and abs(a[1] - b[1]) < 1e-5 * abs(b[1]), (a[:2], b[:2])
+    rel = sorted(((a[2][k] - b[2][k]).norm() / b[2][k].norm().clamp_min(1e-30)).item() for k in b[2])
+    # (measured: median 2e-4, worst 7e-4 of a tensor's norm -- summation order, and the few ReLU flips it brings)
+    assert rel[len(rel) // 2] < 1e-3 and rel[int(0.9 * len(rel))] < 5e-3 and rel[-1] < 5e-2, (rel[len(rel) // 2], rel[int(0.9 * len(rel))], rel[-1])
