@@ -69,6 +69,7 @@ class ConvTimer:
         self.orig = ops.conv2d_launch
         self.records = []        # (kernel key, flops, ev0, ev1)
         self.active = False
+        self.light = False       # this frame: only the memory read's apply kernel is bracketed (behind an idle side stream)
 
     def install(self):
         def timed(desc, cfg, mode=0):
@@ -115,6 +116,12 @@ def parse_args(argv=None):
     ap.add_argument('--no-overlap', action='store_true',
                     help="do not run the next frame's query encoder on a side stream under memorize/update")
     ap.add_argument('--sample-every', type=int, default=16, help='time the conv launches on every n-th frame')
+    ap.add_argument('--apply-sample-every', type=int, default=None,
+                    help='additionally bracket ONLY the dominant kernel (the memory read\'s apply launch) with HIP events on every '
+                         'n-th timed frame -- the main stream first waits for the side stream to go idle, so the kernel is alone on '
+                         'the device, and the rest of the frame keeps its overlap (a fully sampled frame costs about 2 ms of the '
+                         'timed region, such a frame about 0.2).  Default: 5 when --steps < 48 (the driver\'s 20 steps then give '
+                         'roofline.launches_timed = 5), else 0 = off')
     ap.add_argument('--precision', choices=sorted(PEAKS), default='fp32',
                     help='fp32 = BASELINE config C2 (the headline, exact f32); bf16x3 / bf16 = the reduced-precision configs')
     ap.add_argument('--workload', choices=sorted(WORKLOADS), default='C2',
@@ -151,7 +158,7 @@ def launch_check(args):
     lab = torch.full((1, 4, 6, 8), rank + 1, dtype=torch.uint8)
     allm = vdist.gather_masks(lab, world, rank, world)
     ok = all(int(allm[c].min()) == c + 1 and int(allm[c].max()) == c + 1 for c in range(world))
-    if world > 1:
+    if vdist.active(world):
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:
@@ -211,6 +218,7 @@ def main(argv=None):
     import torch.distributed as dist
 
     rank, local_rank, world = vdist.init()
+    dist_on = vdist.active(world)       # the collectives run: N > 1 ranks, or VFN_FORCE_DIST=1 (one rank through the RCCL branches)
     if not torch.cuda.is_available():
         raise RuntimeError('bench.py needs a GPU: the hot path is HIP-only')
     # VFN_SINGLE_DEVICE=1 (+ VFN_DIST_BACKEND=gloo): smoke-run the N > 1 code path on a 1-GPU box
@@ -219,6 +227,7 @@ def main(argv=None):
 
     K, Wm = args.steps, args.warmup
     args.sample_every = max(1, min(args.sample_every, K))       # at least one frame is sampled for the roofline
+    apply_every = args.apply_sample_every if args.apply_sample_every is not None else (5 if K < 48 else 0)
     if world > 1:       # N ranks share the host: keep the CPU-side weight synthesis of each from waking every core
         torch.set_num_threads(len(pinned) if pinned else vdist.host_threads_per_rank(world))
     sd = synth.make_state_dict(20200212)
@@ -260,8 +269,13 @@ def main(argv=None):
     cur_mem = {}
 
     def timed_apply(desc_ref, stream_):
-        if not timer.active:
+        if not (timer.active or timer.light):
             return orig_apply(desc_ref, stream_)
+        if timer.light:                              # (not a sampled frame: the query side of later frames may still be running)
+            busy = getattr(eng, '_side_busy', None)
+            if busy is not None:
+                torch.cuda.current_stream().wait_event(busy)
+            cur_mem.update(entries=sum(runner.fb._len_host), HW=plan.HW)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         rc = orig_apply(desc_ref, stream_)
@@ -311,7 +325,7 @@ def main(argv=None):
     labels_raw = torch.empty(n_lab, H0, W0, dtype=torch.uint8, device=dev)    # before post-processing (parity vs golden)
     labels[0] = m0.to(dev)
     labels_raw[0] = labels[0]
-    if world > 1:
+    if dist_on:
         # the collective of the timed region once, untimed: RCCL sets up its channels / buffers at the first call of a
         # given collective and size, which would otherwise be charged to the clip
         labels[1:].zero_()
@@ -341,6 +355,8 @@ def main(argv=None):
             def is_sampled(u):
                 return s_first <= u <= s_first + K - 1 and ((u - s_first + 1) % args.sample_every == 0)
             timer.active = sampling and is_sampled(t)
+            timer.light = (sampling and not timer.active and apply_every > 0 and s_first <= t <= s_first + K - 1
+                           and (t - s_first + 1) % apply_every == 0)
             nxt = []
             if not args.no_overlap and not timer.active:
                 for u in range(t + 1, min(max(last_iter, t_to), t + 3) + 1):
@@ -349,7 +365,7 @@ def main(argv=None):
                     nxt.append(frames[frame_of(u):frame_of(u) + 1])
             # want_label: the frame's label map goes to pinned host memory (the reference's .cpu(), test_video_seg.py:115)
             runner.launch(frames[idx:idx + 1], next_frames=nxt, want_label=True)
-            timer.active = False
+            timer.active = timer.light = False
             if t < n_lab:                            # device-side copies for the parity checks after the run
                 labels[t].copy_(runner.label_device(), non_blocking=True)
                 labels_raw[t].copy_(runner._label_dev, non_blocking=True)
@@ -360,7 +376,7 @@ def main(argv=None):
 
     def bracket():
         torch.cuda.synchronize()
-        if world > 1:
+        if dist_on:
             dist.barrier()
         return time.perf_counter()
 
@@ -374,13 +390,13 @@ def main(argv=None):
     gather_s = 0.0
     torch.cuda.synchronize()
     g0 = time.perf_counter()                                               # (this rank's K frames are done: compute time = g0 - t0)
-    if world > 1:
+    if dist_on:
         vdist.gather_masks(labels[s_first:s_first + K].unsqueeze(0), world, rank, world)   # one RCCL all-gather
         torch.cuda.synchronize()
         gather_s = time.perf_counter() - g0
     t1 = bracket()
     run_iters(s_first + K, last_iter, False)                               # rest of the clip, untimed
-    if world > 1:
+    if dist_on:
         vdist.gather_masks(labels[1:].unsqueeze(0), world, rank, world)
     clip1 = bracket()
 
@@ -402,8 +418,8 @@ def main(argv=None):
     gc.enable()
 
     def max_over_ranks(x):
-        v = torch.tensor([x], dtype=torch.float64, device=dev if (world == 1 or dist.get_backend() == 'nccl') else 'cpu')
-        if world > 1:
+        v = torch.tensor([x], dtype=torch.float64, device=dev if (not dist_on or dist.get_backend() == 'nccl') else 'cpu')
+        if dist_on:
             dist.all_reduce(v, op=dist.ReduceOp.MAX)
         return float(v.item())
     elapsed = max_over_ranks(t1 - t0)
@@ -411,20 +427,21 @@ def main(argv=None):
 
     def all_ranks(vals):
         """[world][len(vals)] on every rank: one small all-gather (outside every timed region)."""
-        on_dev = (world == 1 or dist.get_backend() == 'nccl')
+        on_dev = (not dist_on or dist.get_backend() == 'nccl')
         v = torch.tensor(vals, dtype=torch.float64, device=dev if on_dev else 'cpu')
-        if world == 1:
+        if not dist_on:
             return [v.tolist()]
         parts = [torch.empty_like(v) for _ in range(world)]
         dist.all_gather(parts, v)
         return [p_.tolist() for p_ in parts]
     per_rank = all_ranks([g0 - t0, gather_s, float(torch.cuda.max_memory_allocated(dev))])
-    dist_info = {'backend': (dist.get_backend() if world > 1 else None),
-                 'world_size': (dist.get_world_size() if world > 1 else 1),
+    dist_info = {'backend': (dist.get_backend() if dist_on else None),
+                 'world_size': (dist.get_world_size() if dist_on else 1),
+                 'forced_single_rank_group': bool(dist_on and world == 1),
                  'device_of_rank0': torch.cuda.get_device_name(dev)}
 
     if rank != 0:
-        if world > 1:
+        if dist_on:
             dist.destroy_process_group()
         return 0
 
@@ -434,9 +451,10 @@ def main(argv=None):
     roof = None
     if per:
         names = ops.conv_cfg_names(ops.MODES[args.precision])
-        cands = []                          # (name, flops, ms, launches)
+        cands = []                          # (name, flops, ms, launches, frames the launches were sampled on)
+        n_full = max(1, len(mem_records))   # fully sampled frames (every instrumented launch bracketed)
         for c, (fl, ms, n) in per.items():
-            cands.append((names[c], fl, ms, n))
+            cands.append((names[c], fl, ms, n, n_full))
         if apply_records:
             a_ms = sum(r_[2].elapsed_time(r_[3]) for r_ in apply_records)
             # (2*128 + 2*512) FLOP per (entry, query): scores + P^T V; with the scores read back from the statistics scan
@@ -447,11 +465,12 @@ def main(argv=None):
             x3 = 'memread_apply_lpw_kernel<true>' if os.environ.get('VFN_LP_IMAGE', '1') == '0' else 'memread_apply_shw_kernel<true>'
             kn = {'fp32': 'memread_apply_ss_kernel' if stored else 'memread_apply_wide_kernel', 'bf16': 'memread_apply_lpw_kernel<false>',
                   'bf16x3': x3}[args.precision]
-            cands.append((kn, a_fl, a_ms, len(apply_records)))
+            cands.append((kn, a_fl, a_ms, len(apply_records), len(apply_records)))      # (one launch per frame)
         tot_fl = sum(v[0] for v in per.values())
         tot_ms = sum(v[1] for v in per.values())
-        all_ms = sum(c_[2] for c_ in cands)
-        kname, fl, ms, n = max(cands, key=lambda c_: c_[2])
+        # dominant = most device time PER FRAME (the apply kernel is bracketed on more frames than the convolutions)
+        all_ms = sum(c_[2] / c_[4] for c_ in cands)
+        kname, fl, ms, n, nfr = max(cands, key=lambda c_: c_[2] / c_[4])
         ach = fl / (ms * 1e-3) / 1e12
         tname = f'{PROFILE_ROUND}_pmc_traffic.json' if args.precision == 'fp32' else f'{PROFILE_ROUND}_pmc_traffic_{args.precision}.json'
         tpath = os.path.join(ROOT, 'profiles', tname)
@@ -468,18 +487,19 @@ def main(argv=None):
                 'traffic_source': f'profiles/{tname} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes of this command, '
                                   f'FETCH doubled per MI355X_MICROARCH.md; not re-measured in this run)',
                 'launches_timed': n, 'avg_launch_us': round(ms * 1e3 / n, 2),
-                'share_of_instrumented_time': round(ms / all_ms, 4),
+                'share_of_instrumented_time': round(ms / nfr / all_ms, 4),
                 'algorithmic_flop': '2*M*Cout*K per conv launch (a Winograd-domain GEMM launch: the FLOP it executes, 2*36*tiles*Cin*Cout); '
                                     'memory-read apply launch: 1024 * bank entries * HW (P^T V; the scores come from the '
                                     'statistics scan, memread_apply_ss_kernel) or 1280 * entries * HW where it recomputes them',
                 'timing': 'HIP events around every launch of frames that take no part in the side-stream overlap (kernel alone '
-                          f'on the device); rocprofv3 counterpart: profiles/{PROFILE_ROUND}_kernel_stats_no_overlap.csv (--no-overlap run); '
+                          f'on the device: {n_full} frame(s) of the timed region); the memory read\'s apply launch additionally on every '
+                          f'{apply_every or "-"}th timed frame behind an idle side stream ({len(apply_records)} launches in all); rocprofv3 counterpart: profiles/{PROFILE_ROUND}_kernel_stats_no_overlap.csv (--no-overlap run); '
                           f'profiles/{PROFILE_ROUND}_kernel_stats.csv is the default command, where overlapped launches run longer',
                 'kernels': [{'kernel': c_[0], 'achieved': round(c_[1] / (c_[2] * 1e-3) / 1e12, 2),
                              'frac': round(c_[1] / (c_[2] * 1e-3) / 1e12 / peak, 4), 'avg_launch_us': round(c_[2] * 1e3 / c_[3], 2),
-                             'launches_timed': c_[3], 'share_of_instrumented_time': round(c_[2] / all_ms, 4),
+                             'launches_timed': c_[3], 'share_of_instrumented_time': round(c_[2] / c_[4] / all_ms, 4),
                              'traffic': traffic_of(c_[0])}
-                            for c_ in sorted(cands, key=lambda c_: -c_[2])],
+                            for c_ in sorted(cands, key=lambda c_: -c_[2] / c_[4])],
                 'all_conv_achieved': round(tot_fl / (tot_ms * 1e-3) / 1e12, 2),
                 'all_conv_frac': round(tot_fl / (tot_ms * 1e-3) / 1e12 / peak, 4)}
 
@@ -586,10 +606,10 @@ def main(argv=None):
     # ---- what a multi-GPU record needs to show that N ranks met over RCCL, and where the time went
     rates = [K / r_[0] for r_ in per_rank]
     out['distributed'] = dict(dist_info, **{
-        'collective': 'one all_gather_into_tensor of the uint8 label blocks [K, H0, W0] per rank inside the timed bracket' if world > 1 else None,
-        'all_gather_ms_max': round(1e3 * max(r_[1] for r_ in per_rank), 3) if world > 1 else None,
-        'all_gather_ms_per_rank': [round(1e3 * r_[1], 3) for r_ in per_rank] if world > 1 else None,
-        'all_gather_bytes_per_rank': int(K * H0 * W0) if world > 1 else None,
+        'collective': 'one all_gather_into_tensor of the uint8 label blocks [K, H0, W0] per rank inside the timed bracket' if dist_on else None,
+        'all_gather_ms_max': round(1e3 * max(r_[1] for r_ in per_rank), 3) if dist_on else None,
+        'all_gather_ms_per_rank': [round(1e3 * r_[1], 3) for r_ in per_rank] if dist_on else None,
+        'all_gather_bytes_per_rank': int(K * H0 * W0) if dist_on else None,
         'frames_per_s_per_rank': [round(x, 3) for x in rates],
         'frames_per_s_per_rank_min': round(min(rates), 3), 'frames_per_s_per_rank_max': round(max(rates), 3),
         'per_rank_note': 'K timed frames / (time until this rank\'s last frame has left the GPU); `value` = world * K / (max over ranks of the '
@@ -623,7 +643,7 @@ def main(argv=None):
     if os.environ.get('VFN_BENCH_DUMP'):            # per-step host times of the whole run (diagnostics)
         with open(os.environ['VFN_BENCH_DUMP'], 'w') as f:
             json.dump({'frame_ms': frame_ms, 'bank_sizes': bank_sizes, 'timed': [s_first, s_first + K - 1]}, f)
-    if world > 1:
+    if dist_on:
         dist.destroy_process_group()
     return 0
 

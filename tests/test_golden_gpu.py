@@ -16,9 +16,18 @@ def model(gpu):
     return m
 
 
+@pytest.mark.parametrize('wino', ['table', 'all'])
 @pytest.mark.parametrize('tag', ['96x160', '90x150'])
-def test_blocks(gpu, model, tag):
+def test_blocks(gpu, model, tag, wino, monkeypatch):
+    """``wino='all'``: every eligible 3x3 / stride-1 layer (KeyValue, the bottlenecks' conv2, the whole decoder but the heads) runs as
+    Winograd F(4x4, 3x3) (VFN_WINOGRAD=2) -- at these frame sizes the measured table keeps them all direct, so this is where the
+    transform-domain path meets the reference's block goldens at the same 5e-4 / 1e-3."""
     from vfloodnet_amd import FeatureBank, ops
+    if wino == 'all':
+        from vfloodnet_amd import AFB_URR, engine as E
+        monkeypatch.setattr(E, '_WINOGRAD', '2')
+        model = AFB_URR(gpu, update_bank=True).to(gpu).eval()
+        model.load_state_dict(state_dict(), strict=True)
     g = load(f'blocks_{tag}.npz')
     frames, m0 = t(g['frames']).to(gpu), t(g['mask'])
     H, W = frames.shape[-2:]
@@ -32,6 +41,11 @@ def test_blocks(gpu, model, tag):
     ok, dl, dp = close_logits(score.cpu(), t(g['score']), 1e-3)
     assert ok, (dl, dp)
     p, qs, slot = model.engine().last_query                 # the query set / slot this frame's features live in
+    n_wino = sum(1 for lst in p.all_lists() for l in lst if 'wino_gemm' in (l.name or ''))
+    if wino == 'all':
+        assert n_wino >= 30, n_wino                          # (KeyValue x2, the bottlenecks, the decoder; query-side lists exist per batch size)
+    else:
+        assert n_wino == 0, n_wino                           # (below the table's / heuristic's size threshold: all direct)
     for n, buf in dict(r1=qs.q['r1'], r2=qs.q['res2']['out'], r3=qs.q['res3']['out'], r4=qs.q['res4']['out']).items():
         x = buf[slot:slot + 1].permute(0, 3, 1, 2).contiguous().cpu()
         assert (x.flatten()[t(g[n + '_idx'])] - t(g[n + '_val'])).abs().max() < 5e-4, n

@@ -343,19 +343,30 @@ def test_overlay_device_on_reference_loop_output(gpu):
     assert np.array_equal(got, g['overlay1'])
 
 
-def test_scatter_mean_rejects_out_of_range_index(gpu):
-    """Validation happens on the device (no host synchronisation inside the operator, as torch_scatter's device-side
-    assert): the offending element is skipped, the others are scattered, and ``scatter.check_status`` raises."""
+def test_scatter_mean_rejects_out_of_range_index(gpu, monkeypatch):
+    """Validation happens on the device: the offending element is skipped, the others are scattered.  Default (strict): the
+    call that met the bad index raises (ADVICE r4: a drop-in for torch_scatter must not produce a wrong merge silently);
+    ``VFN_SCATTER_STRICT=0``: no host synchronisation inside the operator (as torch_scatter's device-side assert) and
+    ``scatter.check_status`` raises."""
     from vfloodnet_amd import scatter_mean, scatter
     src = torch.ones(4, 6, device=gpu)
+    assert scatter.STRICT
+    for bad in (5, -1):
+        out = torch.zeros(4, 5, device=gpu)
+        idx = torch.tensor([0, 1, 2, bad, 3, 4], device=gpu).unsqueeze(0).expand(4, 6)
+        with pytest.raises(RuntimeError, match='outside'):
+            scatter_mean(src, idx, dim=1, out=out)
+        scatter.check_status(gpu)                                   # the flag is cleared by the report
+        assert torch.equal(out.cpu(), torch.ones(4, 5))             # the five valid targets got their element
+    monkeypatch.setattr(scatter, 'STRICT', False)
     for bad in (5, -1):
         out = torch.zeros(4, 5, device=gpu)
         idx = torch.tensor([0, 1, 2, bad, 3, 4], device=gpu).unsqueeze(0).expand(4, 6)
         scatter_mean(src, idx, dim=1, out=out)
         with pytest.raises(RuntimeError, match='outside'):
             scatter.check_status(gpu)
-        scatter.check_status(gpu)                                   # the flag is cleared by the report
-        assert torch.equal(out.cpu(), torch.ones(4, 5))             # the five valid targets got their element
+        scatter.check_status(gpu)
+        assert torch.equal(out.cpu(), torch.ones(4, 5))
     # a materialised [D,S] index whose rows differ is reported the same way; a row-constant one is accepted
     out = torch.zeros(4, 5, device=gpu)
     idx = torch.tensor([0, 1, 2, 2, 3, 4], device=gpu).unsqueeze(0).repeat(4, 1)
@@ -366,6 +377,9 @@ def test_scatter_mean_rejects_out_of_range_index(gpu):
     scatter_mean(src, idx, dim=1, out=torch.zeros(4, 5, device=gpu))
     with pytest.raises(RuntimeError, match='row-broadcast'):
         scatter.check_status(gpu)
+    monkeypatch.setattr(scatter, 'STRICT', True)
+    with pytest.raises(RuntimeError, match='row-broadcast'):
+        scatter_mean(src, idx, dim=1, out=torch.zeros(4, 5, device=gpu))
 
 
 @pytest.mark.parametrize('K,h,w', [(2, 240, 432), (3, 37, 53), (1, 9, 70), (4, 50, 16), (2, 24, 17)])

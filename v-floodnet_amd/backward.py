@@ -44,7 +44,7 @@ def _dgrad_filters(w):
 
 class DecoderBackward:
     NB = 256          # blocks of the column-sum's first stage
-    NB1 = int(__import__('os').environ.get('VFN_COLSUM_BLOCKS', 128))     # ... of the one-launch form (vfn_colsum_acc_f32 with a counter)
+    NB1 = max(1, min(NB, int(__import__('os').environ.get('VFN_COLSUM_BLOCKS', 128))))     # ... of the one-launch form (vfn_colsum_acc_f32 with a counter); <= NB: the scratch rows are sized by NB
 
     def __init__(self, engine):
         self.eng = engine
@@ -376,7 +376,7 @@ class ModelBackward:
     arrived at the bank's keys / values back through KeyValue and the memory encoder.  Gradients accumulate in ``self.grads``
     (state-dict name -> tensor)."""
     NB = 256
-    NB1 = int(__import__('os').environ.get('VFN_COLSUM_BLOCKS', 128))     # blocks of the one-launch column sums (128 / 256: 100.6 / 113.2 ms per step on one box; (the last block adds NB1 partial rows)
+    NB1 = max(1, min(NB, int(__import__('os').environ.get('VFN_COLSUM_BLOCKS', 128))))     # blocks of the one-launch column sums (<= NB: scratch rows are sized by NB) (128 / 256: 100.6 / 113.2 ms per step on one box; (the last block adds NB1 partial rows)
 
     def __init__(self, engine):
         self.eng = engine

@@ -78,7 +78,7 @@ def run(args, run_clip=run_clip_on_gpu, device=None, backend=None):
     assert os.path.isdir(args.benchmark_path)
     clips = list_clips(args.benchmark_path)
     if not clips:                         # every rank sees the same (empty) directory: leave before any collective
-        if world > 1:
+        if vdist.active(world):
             import torch.distributed as dist
             dist.destroy_process_group()
         raise ValueError(f'no clip sub-folders in {args.benchmark_path}')
@@ -98,7 +98,7 @@ def run(args, run_clip=run_clip_on_gpu, device=None, backend=None):
         if args.save_gathered:
             import numpy as np
             np.savez_compressed(args.save_gathered, **{n: m.cpu().numpy() for n, m in zip(names, masks)})
-    if world > 1:
+    if vdist.active(world):
         import torch.distributed as dist
         dist.barrier()
         dist.destroy_process_group()

@@ -1046,6 +1046,14 @@ extern "C" int vfn_conv2d_nhwc_f32(const vfn_conv_desc* d, int cfg, void* stream
         if (!d->partial || d->Cout % 4 || d->out_ld % 4 || (d->res && d->res_ld % 4) || (d->mask && d->mask_ld % 4)) return VFN_ERR_ARG;
         if (d->tile_counters && d->Cout % bn) return VFN_ERR_ARG;      // in-launch finish works on whole filter tiles
         if (cdiv(nk_all, d->ksplit) * (d->ksplit - 1) >= nk_all) return VFN_ERR_ARG;   // every split non-empty
+        if (d->tile_counters) {
+            // the in-launch finish addresses the partial slabs through ONE buffer resource with 32-bit byte offsets
+            // (off + slice * slab): refuse what would wrap instead of dropping stores / loading zeros silently
+            const int nt = cdiv(d->Cout, bn);
+            if (d->split_from < 0 || d->split_from % nt) return VFN_ERR_ARG;
+            const long long m_start = (long long)(d->split_from / nt) * bm;
+            if ((long long)d->ksplit * ((long long)d->M - m_start) * d->Cout * (long long)sizeof(float) >= 0x7fffff00LL) return VFN_ERR_ARG;
+        }
     }
     hipStream_t s = (hipStream_t)stream;
     switch (cfg) {

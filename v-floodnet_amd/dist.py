@@ -22,13 +22,27 @@ def env_rank_world():
     return int(os.environ.get('RANK', 0)), int(os.environ.get('LOCAL_RANK', 0)), int(os.environ.get('WORLD_SIZE', 1))
 
 
+def forced():
+    """VFN_FORCE_DIST=1: bring the process group up and run every collective of the N > 1 code path even with ONE rank -- how the
+    RCCL branches (``all_gather_into_tensor`` on device tensors, the device-side all-reduce / all-gather of bench.py) are
+    exercised on a 1-GPU box (tests/test_round5_gpu.py) before they meet an 8-GPU node (BASELINE.json config 4)."""
+    return os.environ.get('VFN_FORCE_DIST') == '1'
+
+
+def active(world):
+    """Do the collectives run?  More than one rank, or the forced single-rank group above."""
+    return world > 1 or (forced() and dist.is_initialized())
+
+
 def init(backend=None):
-    """Initialise torch.distributed from the torchrun environment (no-op for a single process)."""
+    """Initialise torch.distributed from the torchrun environment (no-op for a single process, unless VFN_FORCE_DIST=1)."""
     rank, local_rank, world = env_rank_world()
-    if world > 1 and not dist.is_initialized():
+    if (world > 1 or forced()) and not dist.is_initialized():
         if backend is None:
             backend = os.environ.get('VFN_DIST_BACKEND') or ('nccl' if torch.cuda.is_available() else 'gloo')
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        if 'MASTER_PORT' not in os.environ:                 # (a forced single rank started without a launcher)
+            os.environ['MASTER_PORT'] = str(free_port())
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
         if backend == 'nccl':
             torch.cuda.set_device(local_rank)
@@ -134,7 +148,7 @@ def clips_per_rank(n_clips, world):
 def gather_masks(local_labels, n_clips, rank, world):
     """local_labels: uint8 [n_local, T, H, W] for ``clips_of_rank`` (same T,H,W on every rank).
     Returns uint8 [n_clips, T, H, W] in clip order on every rank.  One collective."""
-    if world == 1:
+    if not active(world):
         return local_labels
     per = clips_per_rank(n_clips, world)
     T, H, W = local_labels.shape[1:]
@@ -170,7 +184,7 @@ def run_sharded(run_one_clip, n_clips, rank, world, device):
     shape = torch.zeros(3, dtype=torch.int64, device=device)
     if rank == 0:
         shape = torch.tensor(local.shape[1:], dtype=torch.int64, device=device)
-    if world > 1:
+    if active(world):
         dist.broadcast(shape, 0)
     if local is None:
         local = torch.zeros(0, *[int(x) for x in shape], dtype=torch.uint8, device=device)
@@ -185,10 +199,10 @@ def gather_ragged(local_labels, n_clips, rank, world, device):
         return []
     per = clips_per_rank(n_clips, world)
     # (gloo gathers host tensors only; RCCL device tensors only)
-    shp = torch.zeros(per, 3, dtype=torch.int64, device=device if (world > 1 and dist.get_backend() == 'nccl') else 'cpu')
+    shp = torch.zeros(per, 3, dtype=torch.int64, device=device if (active(world) and dist.get_backend() == 'nccl') else 'cpu')
     for i, l in enumerate(local_labels):
         shp[i] = torch.tensor(l.shape, dtype=torch.int64)
-    if world > 1:
+    if active(world):
         parts = [torch.empty_like(shp) for _ in range(world)]
         dist.all_gather(parts, shp)
         shapes = torch.stack(parts, 0).cpu()

@@ -42,11 +42,14 @@ class AFB_URR(nn.Module):
         self.decoder = W.make_decoder()
         self._engine = None
         self._engine_version = -1
+        self._engine_sentinel = -1
+        self._sentinels = None
         self._allow_cpu_container = _allow_cpu_container
 
     # -- weight lifecycle ---------------------------------------------------
     def _invalidate(self):
         self._engine = None
+        self._sentinels = None
 
     def load_state_dict(self, state_dict, strict=True, **kw):
         out = super().load_state_dict(state_dict, strict=strict, **kw)
@@ -71,21 +74,45 @@ class AFB_URR(nn.Module):
         try:
             self._engine.refresh(check=not trusted)       # (trusted: the caller owns the parameters' storage, refresh.Refresher.run)
             self._engine_version = self._param_version()
+            self._engine_sentinel = self._sentinel_version()
         except RuntimeError:
             self._engine = None
 
     def _param_version(self):
         return sum(p._version for p in self.parameters())
 
-    def engine(self):
-        # training: an optimizer that steps the nn.Parameters in place (torch.optim.AdamW, train_video_seg.py:109) leaves the
-        # engine's packed filters / folded BatchNorm constants stale -- every in-place update bumps the tensors' version counters
-        if self._engine is not None and self.training and self._engine_version != self._param_version():
+    def _sentinel_version(self):
+        """Version counters of the first and the last parameter: what the eval-mode calls compare (an optimizer step moves every
+        parameter, so two of them tell; summing all 300 on every ``memorize`` / ``segment`` costs the inference loop 0.2 ms per frame)."""
+        if self._sentinels is None:
+            ps = list(self.parameters())
+            self._sentinels = (ps[0], ps[-1])
+        return self._sentinels[0]._version + self._sentinels[1]._version
+
+    def train(self, mode=True):
+        """``model.eval()`` after the last ``optimizer.step()`` (torch's own AdamW on the nn.Parameters) must
+        not leave the engine one step behind: the switch compares every parameter's version counter and refreshes the derived tensors."""
+        out = super().train(mode)
+        if self._engine is not None and self._engine_version != self._param_version():
             self._refresh()
+        return out
+
+    def engine(self):
+        # an optimizer that steps the nn.Parameters in place (torch.optim.AdamW, train_video_seg.py:109) leaves the engine's packed
+        # filters / folded BatchNorm constants stale -- every in-place update bumps the tensors' version counters.  Training mode
+        # compares all of them on every call, eval mode the two sentinels (and train() / eval() all of them once more)
+        if self._engine is not None:
+            if self.training:
+                stale = self._engine_version != self._param_version()
+            else:
+                stale = self._engine_sentinel != self._sentinel_version()
+            if stale:
+                self._refresh()
         if self._engine is None:
             from .engine import Engine
             self._engine = Engine(self)
             self._engine_version = self._param_version()
+            self._engine_sentinel = self._sentinel_version()
         return self._engine
 
     # -- reference API ------------------------------------------------------

@@ -6,14 +6,22 @@ with torch-scatter 2.0.8 semantics for ``out=``: ``out += scatter_add(src)``, ``
 scatter_add(ones)``, ``count.clamp_(min=1)``, ``out /= count``.  The reference always passes a
 row-broadcast index (``idx.unsqueeze(0).expand(D, -1)``), which is the only form the HIP kernel
 implements.  Sums run in ascending source order (deterministic, unlike the float-atomic CUDA kernel of
-torch_scatter).  The call never synchronises the host: an out-of-range index or an index that is not
-row-broadcast is detected BY THE KERNEL (the element is skipped, a sticky device flag is set) and raised by
-``check_status()`` -- torch_scatter's CUDA kernel reports them through a device-side assert, i.e. asynchronously too.
+torch_scatter).  An out-of-range index or an index that is not row-broadcast is detected BY THE KERNEL (the element
+is skipped, a sticky device flag is set).  By default (``STRICT``, ``VFN_SCATTER_STRICT=1``) the operator reads that flag
+back and raises from the offending call -- one host synchronisation per call, next to the three or four
+``FeatureBank.update`` in the reference already has per object (``nonzero`` / ``unique``, ``FeatureBank.py:73,85,125``); the
+library's own ``FeatureBank`` does not go through this module (its merge runs in ``csrc/bank.hip`` with device-side
+bookkeeping), so the hot path pays nothing.  ``VFN_SCATTER_STRICT=0``: the call never synchronises and the caller polls
+``check_status()`` wherever it synchronises anyway -- torch_scatter's CUDA kernel reports the same conditions through a
+device-side assert, i.e. asynchronously too.
 """
+import os
+
 import torch
 
 from . import ops
 
+STRICT = os.environ.get('VFN_SCATTER_STRICT', '1') != '0'     # raise from the call that met a bad index (a sync per call)
 _status = {}          # device -> int32[1], sticky flags written by the kernel (zero at rest)
 
 
@@ -65,6 +73,8 @@ def scatter_mean(src, index, dim=-1, out=None, dim_size=None):
         index_s0 = index.stride(0)
     else:
         index = (index[0] if index.dim() == 2 else index).contiguous()
-    # range and row-constancy are checked by the kernel (sticky device flags, read by check_status): no host round trip
+    # range and row-constancy are checked by the kernel (sticky device flags, read by check_status)
     ops.scatter_mean_checked_launch(src, index, index_s0, out, _status_word(src.device))
+    if STRICT:
+        check_status(src.device)
     return out

@@ -169,7 +169,9 @@ class AdamW:
         if g.get('amsgrad') or g.get('maximize'):
             raise ValueError('amsgrad / maximize are not implemented (train_video_seg.py:109 uses neither)')
         self.lr, self.betas, self.eps, self.weight_decay = float(g['lr']), (float(g['betas'][0]), float(g['betas'][1])), float(g['eps']), float(g['weight_decay'])
-        self.initial_lr = float(g.get('initial_lr', g['lr']))       # (a group written without a scheduler: the loaded rate is the base)
+        # (a group written without a scheduler has no 'initial_lr': it stays unset, so that StepLR(last_epoch != -1) raises KeyError on
+        # it exactly as torch.optim.lr_scheduler does -- a resumed run is never silently re-based on an already decayed rate)
+        self.initial_lr = float(g['initial_lr']) if 'initial_lr' in g else None
         steps = set()
         self.exp_avg.zero_()
         self.exp_avg_sq.zero_()
