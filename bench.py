@@ -132,6 +132,10 @@ def parse_args(argv=None):
     ap.add_argument('--native', action='store_true',
                     help='run the network at the input resolution instead of the reference semantics (resize to a 480-pixel '
                          'short edge, test_video_seg.py:46,107); only meaningful with --workload C3')
+    ap.add_argument('--checkpoint', default=None,
+                    help='weights from a checkpoint file in the reference\'s schema ({"model": state_dict, ...}, train_video_seg.py:159-177) '
+                         'instead of the synthetic recipe (tools/synth.make_state_dict) -- e.g. the checkpoint scripts/bf16_trained_margins.py '
+                         'trains on the GPU box with the HIP training step; the line says so in `data`')
     ap.add_argument('--launch-check', action='store_true',
                     help='bring the N ranks up, run the mask all-gather on a dummy clip and print the line skeleton without '
                          'touching the GPU (tests/test_bench_launch.py: the launch logic on a CPU-only machine)')
@@ -230,7 +234,10 @@ def main(argv=None):
     apply_every = args.apply_sample_every if args.apply_sample_every is not None else (5 if K < 48 else 0)
     if world > 1:       # N ranks share the host: keep the CPU-side weight synthesis of each from waking every core
         torch.set_num_threads(len(pinned) if pinned else vdist.host_threads_per_rank(world))
-    sd = synth.make_state_dict(20200212)
+    if args.checkpoint:
+        sd = torch.load(args.checkpoint, map_location='cpu')['model']
+    else:
+        sd = synth.make_state_dict(20200212)
     model = AFB_URR(dev, update_bank=True, precision=args.precision).to(dev).eval()
     model.load_state_dict(sd, strict=True)
 
@@ -564,7 +571,7 @@ def main(argv=None):
                   'bank_sizes_equal': bank_sizes[:n_cpu] == ref['bank_sizes'],
                   'oracle_dtype': 'f32 (the reduced-precision modes are compared with the f32 oracle labels)'}
 
-    if world == 1 and golden is not None and seed == int(golden['seed']) and last_iter >= n_iter:
+    if world == 1 and golden is not None and seed == int(golden['seed']) and last_iter >= n_iter and not args.checkpoint:
         import numpy as np
         refl = torch.from_numpy(np.unpackbits(golden['labels'], axis=-1)[..., :W0])
         lab = labels_raw[:n_frames].cpu()
@@ -582,7 +589,8 @@ def main(argv=None):
                                              f'builds the bank, the clip is finished untimed)' if not stream_mode and K < n_iter else ''))
     out = {'metric': 'segmented frames/sec at 480p' if args.workload == 'C2' else f'segmented frames/sec at {H0}p', 'value': round(fps, 3), 'unit': 'frames/s', 'n_gpus': world,
            'steps': K, 'warmup': Wm, 'ms_per_step': round(1e3 * elapsed / K, 3), 'higher_is_better': True,
-           'scaling': 'weak', 'vs_baseline': None, 'dtype': DTYPES[args.precision], 'data': 'synthetic',
+           'scaling': 'weak', 'vs_baseline': None, 'dtype': DTYPES[args.precision],
+           'data': 'synthetic' if not args.checkpoint else f'synthetic frames; weights from {os.path.basename(args.checkpoint)} (trained on synthetic clips)',
            'config': {'workload': f'{args.workload}: {n_frames}-frame {H0}x{W0} synthetic clip per GPU through the test_video_seg.py loop '
                                   f'(' + ('bicubic resize to 480p+' if (Hn, Wn) != (H0, W0) else '') +
                                   f'segment+softmax+memorize' + (f' every {mem_every}th frame' if mem_every > 1 else '') +

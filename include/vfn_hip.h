@@ -27,7 +27,7 @@ extern "C" {
 /* ------------------------------------------------------------------ version
  * vfn_abi_version() == VFN_ABI_VERSION of the header the binding was written against, and
  * vfn_sizeof_desc(which) == sizeof of the binding's own struct: checked when the library is loaded. */
-#define VFN_ABI_VERSION 11
+#define VFN_ABI_VERSION 12
 enum { VFN_DESC_CONV = 0, VFN_DESC_STEM = 1, VFN_DESC_BANKSCAN = 2, VFN_DESC_MEMREAD = 3, VFN_DESC_BANK = 4, VFN_DESC_WGRAD = 5,
        VFN_DESC_REFRESH_FILTER = 6, VFN_DESC_REFRESH_EPILOGUE = 7, VFN_DESC_GATHER = 8 };
 int vfn_abi_version(void);
@@ -89,6 +89,11 @@ typedef struct vfn_conv_desc {
      * with its own filter matrix in ONE launch ---------------------------------------------------------------------------- */
     int w_batch_rows;     /* > 0: output rows [b * w_batch_rows, (b + 1) * w_batch_rows) use filter bank b = w + b * cout_pad * K
                              floats; a multiple of the tile height of the configuration used; 1x1 problems; 0: one filter bank */
+    /* --- K rotation (ABI 12; f32, LDS-tiled configurations, 1x1 problems) ------------------------------------------------ */
+    int k_rot;            /* 1: the workgroup of output-row tile mt walks its K tiles from tile mt % nk and wraps (a fixed, launch-
+                             independent order per tile: results are reproducible, the summation order differs from k_rot = 0).
+                             K tile k of a pixel-major operand is the same 128-byte column of every 1-KB row, so workgroups that
+                             start together would all pull the same byte column -- the same few memory channels -- at once */
 } vfn_conv_desc;
 
 int vfn_conv_cfg_count(void);

@@ -25,6 +25,7 @@ for (ntile, C, Cout, comps) in [(3240, 256, 256, 36), (1620, 256, 256, 36), (810
         d = ops.make_conv_desc(V, U, Cout, 1, 1, 1, 0, out, None, None, None, False, False, N=1, H=1, W=M)
         d.cout_pad = 256
         d.w_batch_rows = rows
+        d.k_rot = int(os.environ.get('VFN_KROT', '1'))
         try:
             for _ in range(2):
                 ops.conv2d_launch(d, c)

@@ -1,0 +1,144 @@
+"""Does plain bf16 meet the 0.99 mIoU bar once the weights have margins?  (BASELINE.json configs C3 / C5.)
+
+Every reduced-precision number so far rests on random synthetic weights whose logits have no margin (std 1 around 0): plain bf16's
+2^-9 operand noise then flips 7 % of the first frame's pixels and the loop feeds that back.  A trained checkpoint has margins, and the
+repo owns a bit-reproducible HIP training step (train.train_step, train_video_seg.py:56-76), so this script, in ONE process on the
+GPU box (no weights travel):
+
+  1. trains the synthetic checkpoint on synthetic clips (tools/synth.frame0: tinted, textured water below a sinusoidal shoreline,
+     translated by a random (dy, dx) per frame; 6 frames of 400 x 400 per sample like Water_Image_Train_DS, ground-truth first mask,
+     CrossEntropy + 0.5 * uncertainty, AdamW) for --steps steps;
+  2. checks that the f32 HIP path still agrees with the CPU oracle on those weights (first frames of a 480 x 854 clip);
+  3. runs the C3 clip (720 x 1280 -> 480p, every 5th frame memorised, 100 frames), the first 120 frames of the C5 stream (1080p) and
+     the C2 clip in fp32 / bf16x3 / bf16 and reports label mIoU against the f32 HIP run (min / mean / first frame), frames/s, final
+     bank sizes, against the ground-truth masks, and the f32 run's logit-margin percentiles |logit_1 - logit_0| -- for the trained
+     AND the untrained weights.
+
+Writes gpurun_out/r05_bf16_trained_margins.json (+ /tmp/vfn_trained.pth in the reference's checkpoint schema, for bench.py --checkpoint).
+usage: bf16_trained_margins.py [--steps 2500] [--lr 1e-4]"""
+import argparse
+import json
+import os
+import sys
+import time
+
+root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, root)
+import numpy as np
+import torch
+import vfloodnet_amd  # noqa: F401
+from vfloodnet_amd import AFB_URR
+from vfloodnet_amd.video_seg import ClipRunner
+from tools import synth
+
+ap = argparse.ArgumentParser()
+ap.add_argument('--steps', type=int, default=3000)
+ap.add_argument('--lr', type=float, default=2e-5)
+ap.add_argument('--size', type=int, default=400)
+ap.add_argument('--out', default=os.path.join(root, 'gpurun_out', 'r05_bf16_trained_margins.json'))
+ap.add_argument('--ckpt', default='/tmp/vfn_trained.pth')
+ap.add_argument('--skip-oracle', action='store_true')
+args = ap.parse_args()
+dev = torch.device('cuda', 0)
+res = {'note': __doc__.split('\n\n')[0], 'train': {}, 'eval': {}}
+
+
+# ------------------------------------------------------------------------------------------------ 1. train
+from tools.train_synth import train_checkpoint
+sd0 = synth.make_state_dict(20200212)
+sd1, res['train'] = train_checkpoint(dev, steps=args.steps, lr=args.lr, size=args.size, log=lambda m: print(m, flush=True))
+print(res['train'], flush=True)
+torch.save({'epoch': 0, 'model': sd1, 'loss': res['train']['loss_last_50'], 'seed': 20200212}, args.ckpt)
+
+
+# ------------------------------------------------------------------------------------------------ helpers
+def miou(a, b):
+    v = []
+    for c in (0, 1):
+        inter = ((a == c) & (b == c)).sum().item()
+        union = ((a == c) | (b == c)).sum().item()
+        v.append(1.0 if union == 0 else inter / union)
+    return sum(v) / 2
+
+
+def run(sd, prec, frames, m0, budget, mem_every, want_margins=False):
+    Tn, _, H0, W0 = frames.shape
+    model = AFB_URR(dev, update_bank=True, precision=prec).to(dev).eval()
+    model.load_state_dict(sd, strict=True)
+    m = (m0 > 0).to(torch.uint8)
+    onehot = torch.stack([1 - m, m], 0).unsqueeze(0).to(dev)
+    for warm in (True, False):
+        runner = ClipRunner(model, 2, budget, size=480, mem_every=mem_every)
+        runner.start(frames[0:1], onehot)
+        n = min(6, Tn) if warm else Tn
+        labels = torch.empty(n, H0, W0, dtype=torch.uint8)
+        labels[0] = m
+        margins = []
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for t in range(1, n):
+            lab = runner.step(frames[t:t + 1], next_frames=[frames[u:u + 1] for u in range(t + 1, min(n, t + 4))])
+            np.copyto(labels.numpy()[t], lab.numpy())
+            if want_margins and not warm and t in (1, Tn // 2, Tn - 1):
+                h, w = runner._net_frame(frames[t:t + 1]).shape[-2:]
+                sc = model.engine().plan(h, w, 2).score[0]
+                d = (sc[1] - sc[0]).abs().flatten().float()
+                q = torch.quantile(d[torch.randperm(d.numel(), device=d.device)[:200000]], torch.tensor([0.01, 0.05, 0.25, 0.5, 0.75], device=d.device))
+                margins.append({'frame': t, 'abs_logit_margin_p1_p5_p25_p50_p75': [round(float(x), 4) for x in q],
+                                'frac_below_0.05': round(float((d < 0.05).float().mean()), 5), 'frac_below_0.5': round(float((d < 0.5).float().mean()), 5)})
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+    out = dict(labels=labels, fps=(Tn - 1) / dt, bank=runner.bank_sizes(), margins=margins)
+    del runner, model
+    return out
+
+
+def truth(m0, Tn):
+    return torch.stack([torch.roll(m0, (2 * t, 5 * t), (0, 1)) for t in range(Tn)], 0)
+
+
+def evaluate(tag, sd, H, W, Tn, mem_every, seed, budget=250000):
+    frames, m0 = synth.clip_on_device(seed, Tn, H, W, dev)
+    gt = truth(m0, Tn)
+    ref = run(sd, 'fp32', frames, m0, budget, mem_every, want_margins=True)
+    e = {'clip': f'{Tn} frames of {H}x{W}, seed {seed}, memorise every {mem_every}', 'fp32': {
+        'fps': round(ref['fps'], 1), 'bank': ref['bank'], 'logit_margins': ref['margins'],
+        'miou_vs_ground_truth_min_mean': [round(min(miou(ref['labels'][t], gt[t]) for t in range(1, Tn)), 4),
+                                          round(float(np.mean([miou(ref['labels'][t], gt[t]) for t in range(1, Tn)])), 4)],
+        'water_fraction_last': round(float((ref['labels'][-1] > 0).float().mean()), 4)}}
+    for prec in ('bf16x3', 'bf16'):
+        r = run(sd, prec, frames, m0, budget, mem_every)
+        ious = [miou(r['labels'][t], ref['labels'][t]) for t in range(1, Tn)]
+        e[prec] = {'fps': round(r['fps'], 1), 'bank': r['bank'], 'bank_sizes_equal': r['bank'] == ref['bank'],
+                   'miou_vs_fp32_min': round(min(ious), 5), 'miou_vs_fp32_mean': round(float(np.mean(ious)), 5), 'miou_vs_fp32_first': round(ious[0], 5),
+                   'miou_vs_fp32_worst_frame': int(np.argmin(ious)) + 1}
+    print(tag, json.dumps(e), flush=True)
+    del frames
+    torch.cuda.empty_cache()
+    return e
+
+
+# ------------------------------------------------------------------------------------------------ 2. the f32 path vs the CPU oracle
+if not args.skip_oracle:
+    from oracle import afb_urr_ref as O
+    Hc, Wc, n_cpu = 480, 854, 4
+    frames, m0 = synth.clip(1, n_cpu, Hc, Wc)
+    torch.set_num_threads(min(16, os.cpu_count() or 1))
+    t0 = time.perf_counter()
+    ref_lab = O.run_clip(sd1, frames, m0)['labels']
+    got = run(sd1, 'fp32', frames.to(dev), m0, 250000, 1)
+    ious = [miou(got['labels'][t], ref_lab[t]) for t in range(1, n_cpu)]
+    res['oracle_check_trained_weights'] = {'frames': n_cpu - 1, 'size': [Hc, Wc], 'miou_hip_f32_vs_cpu_oracle': [round(x, 5) for x in ious],
+                                           'seconds': round(time.perf_counter() - t0, 1)}
+    print(res['oracle_check_trained_weights'], flush=True)
+torch.set_num_threads(1)      # (an idle OpenMP pool spinning on the host's cores starves the launch thread of the runs below)
+time.sleep(2.0)
+
+# ------------------------------------------------------------------------------------------------ 3. the configurations
+for wname, sd in (('trained', sd1), ('untrained', sd0)):
+    res['eval'][wname] = {
+        'C3': evaluate(wname + ' C3', sd, 720, 1280, 100, 5, 3),
+        'C5_first_120': evaluate(wname + ' C5', sd, 1080, 1920, 120, 1, 9, budget=2 * int(1.25 * 2 * 122 * 1620) + 4),
+        'C2': evaluate(wname + ' C2', sd, 480, 854, 100, 1, 1)}
+    json.dump(res, open(args.out, 'w'), indent=1)
+print('wrote', args.out)

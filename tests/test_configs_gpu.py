@@ -182,3 +182,56 @@ def test_c5_shape_plain_bf16_is_measured_not_parity(gpu, sd):
     assert float(runner.fb.replace_n.sum()) == 0.0
     drift = max(abs(a - b) for x, y in zip(sizes[:n_ref], ref['bank_sizes']) for a, b in zip(x, y))
     assert drift <= 0.05 * max(ref['bank_sizes'][-1])
+
+
+# ------------------------------------------------------------------------------------------------ round 5: weights with margins
+@pytest.fixture(scope='module')
+def trained_sd(gpu):
+    """The synthetic checkpoint after 600 steps of the HIP training step on synthetic clips (tools/train_synth.py, ~20 s): the loss
+    falls from 1.0 to ~0.12 and the logits get margins (median |logit_1 - logit_0| ~ 30 instead of 0.1-0.3)."""
+    from tools.train_synth import train_checkpoint
+    sd_t, info = train_checkpoint(gpu, steps=600, lr=2e-5)
+    print('trained checkpoint:', info)
+    assert info['restores_after_collapse'] == 0 and info['loss_last_50'] < 0.25 < info['loss_first_50'], info
+    return sd_t
+
+
+@pytest.mark.parametrize('workload', ['C3', 'C5'])
+def test_plain_bf16_meets_the_bar_on_trained_weights(gpu, trained_sd, workload):
+    """BASELINE.json names *bf16* for C3 (720p, every 5th frame memorised) and C5 (1080p stream).  With the margin-free random
+    weights plain bf16 settles at mIoU 0.55-0.8 (asserted above at what it reaches); with weights that have been TRAINED -- the
+    situation the reference's own checkpoint is in -- the same kernels meet the fidelity bar: label mIoU >= 0.99 on every frame
+    against the f32 CPU oracle run on the same trained weights (which also re-pins the f32 HIP path on them), and against the f32
+    HIP run.  The full-length measurement (3000 steps; C3 100 frames, C5 120 frames, C2 100 frames; logit-margin percentiles):
+    scripts/bf16_trained_margins.py -> profiles/r05_bf16_trained_margins.json (bf16 min mIoU 0.9997-0.9998, bf16x3 1.0)."""
+    from tools import synth
+    from vfloodnet_amd import AFB_URR
+    from vfloodnet_amd.video_seg import run_clip
+    from oracle import afb_urr_ref as O
+    if workload == 'C3':
+        T, H, W, mem_every, seed = 12, 720, 1280, 5, 5
+    else:
+        T, H, W, mem_every, seed = 8, 1080, 1920, 1, 7
+    frames, m0 = synth.clip(seed, T, H, W)
+    torch.set_num_threads(16)
+    ref = O.run_clip(trained_sd, frames, m0, size=480, mem_every=mem_every)
+    torch.set_num_threads(1)
+    labs = {}
+    for precision in ('fp32', 'bf16x3', 'bf16'):
+        model = AFB_URR(gpu, update_bank=True, precision=precision).to(gpu).eval()
+        model.load_state_dict(trained_sd, strict=True)
+        out = run_clip(model, frames.to(gpu), m0, size=480, mem_every=mem_every)
+        labs[precision] = out['labels']
+        ious = [miou(out['labels'][t], ref['labels'][t]) for t in range(1, T)]
+        drift = max(abs(a - b) for x, y in zip(out['bank_sizes'], ref['bank_sizes']) for a, b in zip(x, y))
+        print(f'{workload} {precision} on trained weights: mIoU vs the f32 oracle min {min(ious):.5f} mean {sum(ious) / len(ious):.5f}; '
+              f'bank {out["bank_sizes"][-1]} vs {ref["bank_sizes"][-1]} (drift {drift})')
+        assert min(ious) >= 0.99, (precision, ious)
+        assert drift <= (2 if precision != 'bf16' else 0.01 * max(ref['bank_sizes'][-1]) + 2), (precision, drift)
+    for precision in ('bf16x3', 'bf16'):
+        ious = [miou(labs[precision][t], labs['fp32'][t]) for t in range(1, T)]
+        assert min(ious) >= 0.995, (precision, ious)
+    # the ground truth of the synthetic clip (the mask rolled with the frame): the trained network actually segments it
+    gt = [torch.roll(m0, (2 * t, 5 * t), (0, 1)) for t in range(T)]
+    acc = [miou(labs['fp32'][t], gt[t]) for t in range(1, T)]
+    assert min(acc) >= 0.9, acc

@@ -24,7 +24,7 @@ class ConvDesc(C.Structure):
                 ('KH', C.c_int), ('KW', C.c_int), ('stride', C.c_int), ('pad', C.c_int),
                 ('relu_in', C.c_int), ('relu_out', C.c_int), ('M', C.c_int), ('ksplit', C.c_int),
                 ('split_from', C.c_int), ('res_mod', C.c_int), ('partial', c_fp), ('tile_counters', c_fp),
-                ('w_packed', C.c_int), ('in_lp', C.c_int), ('out_lp_relu', C.c_int), ('out_lp', c_fp), ('mask', c_fp), ('mask_ld', C.c_int), ('mask_after', C.c_int), ('w_batch_rows', C.c_int)]
+                ('w_packed', C.c_int), ('in_lp', C.c_int), ('out_lp_relu', C.c_int), ('out_lp', c_fp), ('mask', c_fp), ('mask_ld', C.c_int), ('mask_after', C.c_int), ('w_batch_rows', C.c_int), ('k_rot', C.c_int)]
 
 
 class WgradDesc(C.Structure):
@@ -92,7 +92,7 @@ class BankDesc(C.Structure):
                 ('obj_n', C.c_int), ('cap', C.c_int), ('rm_class', C.c_int), ('rm_request', C.c_int)]
 
 
-ABI_VERSION = 11         # include/vfn_hip.h VFN_ABI_VERSION; csrc/abi.hip
+ABI_VERSION = 12         # include/vfn_hip.h VFN_ABI_VERSION; csrc/abi.hip
 DESC_IDS = {0: ConvDesc, 1: StemDesc, 2: BankScanDesc, 3: MemReadDesc, 4: BankDesc, 5: WgradDesc, 6: RefreshFilter, 7: RefreshEpilogue, 8: GatherEntry}     # vfn_sizeof_desc(which)
 
 

@@ -38,6 +38,17 @@ __device__ __forceinline__ int wave_sum_i(int v) {
 
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 
+// Workgroups are dealt round-robin over the 8 XCDs (a private 4 MiB L2 each).  A kernel whose neighbouring work items read
+// overlapping bytes (window / halo reads: Winograd 6x6 patches, 3x3 pooling windows, bilinear taps) wants NEIGHBOURS ON ONE
+// XCD, or every overlap is fetched once per L2 (rocprofv3 FETCH_SIZE of winograd_input_kernel: 1.7x its input before this).
+// Maps the hardware block index to a logical one such that XCD x owns one contiguous run of logical blocks; bijective on
+// [0, nb) for any nb; use it in place of blockIdx.x (grid-stride loops: every pass of gridDim.x blocks is mapped the same way).
+__device__ __forceinline__ unsigned vfn_xcd_block(unsigned b, unsigned nb) {
+    if (nb < 16) return b;
+    const unsigned q = nb >> 3, r = nb & 7, xcd = b & 7, loc = b >> 3;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
+}
+
 // ---- the activations' split-bf16 image (vfn_conv_desc.in_lp / out_lp, include/vfn_hip.h)
 typedef __attribute__((ext_vector_type(4))) __bf16 vfn_bf16x4;
 // x = hi + lo with hi = bf16(x), lo = bf16(x - hi): 16 significant bits in two bf16 (the "bf16x3" operands)

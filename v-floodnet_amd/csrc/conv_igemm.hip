@@ -283,6 +283,10 @@ __device__ __forceinline__ void conv_igemm_body(const vfn_conv_desc& p) {
     const int kt_begin = (WK > 1 ? grp : kz) * kper;
     const int nk = max(0, min(kper, nk_all - kt_begin));
     const int nk_loop = WK > 1 ? kper : nk;               // every K group runs the same number of barriers
+    // K rotation (1x1 problems, vfn_conv_desc.k_rot): workgroup (m tile mt) walks its K tiles starting at tile mt % nk and wraps.
+    // Every K tile of a pixel-major / filter-major operand is the SAME 128-byte column of 1-KB rows: workgroups that start
+    // together would otherwise all read byte column 0 of their rows at the same time, i.e. hammer the same few memory channels.
+    const int krot = (p.k_rot && p.KH == 1 && p.KW == 1 && nk > 1) ? (mt % nk) : 0;
 
     // per-thread staging coordinates
     const int c16 = tid % CPR;             // chunk column (4 floats)
@@ -343,6 +347,7 @@ __device__ __forceinline__ void conv_igemm_body(const vfn_conv_desc& p) {
         kh = tap / p.KW;
         kw = tap - kh * p.KW;
     }
+    auto rot_tile = [&](int i) { const int a = i + krot; return kt_begin + (a >= nk ? a - nk : a); };   // i-th tile of the walk
     auto load_a = [&](int slot) {
         const int tap_off = ((kh * p.W + kw) * p.in_ld + cb * BKT) * (int)sizeof(float);     // wave-uniform
 #pragma unroll
@@ -434,7 +439,10 @@ __device__ __forceinline__ void conv_igemm_body(const vfn_conv_desc& p) {
 
 #pragma unroll
     for (int d = 0; d < PD; ++d)
-        if (d < nk) { load_a(d); load_b(kt_begin + d, d); }
+        if (d < nk) {
+            if (krot) { kh = kw = 0; cb = rot_tile(d); load_a(d); load_b(cb, d); }
+            else { load_a(d); load_b(kt_begin + d, d); }
+        }
 #pragma unroll
     for (int d = 0; d < TPB; ++d)
         if (d < nk) { store_a(d, d); store_b(d, d); }
@@ -462,7 +470,7 @@ __device__ __forceinline__ void conv_igemm_body(const vfn_conv_desc& p) {
                 // (tile kt+PD is requested in the first step, tile kt+TPB goes to LDS in the second: as the f32 path.  In the
                 // reduced-precision modes a K tile is a fraction of a microsecond of matrix time, so the K loop of a small
                 // layer runs at the speed of its loads: PD tiles in flight, not one)
-                if (st == 0) { if (more_load) { load_a(u); load_b(kt_begin + kt + PD, u); } }
+                if (st == 0) { if (more_load) { if (krot) { kh = kw = 0; cb = rot_tile(kt + PD); load_a(u); load_b(cb, u); } else { load_a(u); load_b(kt_begin + kt + PD, u); } } }
                 else if (more) { store_a(buf_st, (u + TPB) % PD); store_b(buf_st, (u + TPB) % PD); }
                 const int lc = 2 * st + lh;
                 bf16x8 ah[TM], al[TM], bh[TN], bl[TN];
@@ -508,7 +516,10 @@ __device__ __forceinline__ void conv_igemm_body(const vfn_conv_desc& p) {
         read_frags(0, fa[0], fb[0]);
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) {
-            if (kk == 0 && more_load) { load_a(u); load_b(kt_begin + kt + PD, u); }       // slot u: tile kt is in LDS already
+            if (kk == 0 && more_load) {                                                   // slot u: tile kt is in LDS already
+                if (krot) { kh = kw = 0; cb = rot_tile(kt + PD); load_a(u); load_b(cb, u); }
+                else { load_a(u); load_b(kt_begin + kt + PD, u); }
+            }
             if (more) {
                 if (kk == 2) store_a(buf_st, (u + TPB) % PD);
                 if (kk == 3) store_b(buf_st, (u + TPB) % PD);

@@ -34,7 +34,7 @@ void winograd_input_kernel(const float* __restrict__ x, int N, int H, int W, int
     const int th = (H + 3) / 4, tw = (W + 3) / 4;
     const int c4n = C / 4;
     const long long total = (long long)N * th * tw * c4n;
-    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    for (long long i = vfn_xcd_block(blockIdx.x, gridDim.x) * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
         const int c4 = (int)(i % c4n);
         const int tile = (int)(i / c4n);
         const int tx = tile % tw, ty = (tile / tw) % th, n = tile / (tw * th);
@@ -93,7 +93,7 @@ void winograd_output_kernel(const float* __restrict__ Mb, int rows_pad, int N, i
     const int th = (H + 3) / 4, tw = (W + 3) / 4;
     const int c4n = Cout / 4;
     const long long total = (long long)N * th * tw * c4n;
-    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    for (long long i = vfn_xcd_block(blockIdx.x, gridDim.x) * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
         const int c4 = (int)(i % c4n);
         const int tile = (int)(i / c4n);
         const int tx = tile % tw, ty = (tile / tw) % th, n = tile / (tw * th);
@@ -168,7 +168,7 @@ void winograd_gy_kernel(const float* __restrict__ gy, int N, int H, int W, int C
     const int th = (H + 3) / 4, tw = (W + 3) / 4;
     const int c4n = C / 4;
     const long long total = (long long)N * th * tw * c4n;
-    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    for (long long i = vfn_xcd_block(blockIdx.x, gridDim.x) * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
         const int c4 = (int)(i % c4n);
         const int tile = (int)(i / c4n);
         const int tx = tile % tw, ty = (tile / tw) % th, n = tile / (tw * th);
@@ -213,7 +213,7 @@ void winograd_dw_kernel(const float* __restrict__ dU, int Cout, int Cin, const f
     const int c4n = Cin / 4;
     const long long total = (long long)Cout * c4n;
     const size_t bank = (size_t)Cout * Cin;
-    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    for (long long i = vfn_xcd_block(blockIdx.x, gridDim.x) * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
         const int c4 = (int)(i % c4n), co = (int)(i / c4n);
         f32x4 t[3][6];                               // t = G^T dU (columns through G^T)
 #pragma unroll

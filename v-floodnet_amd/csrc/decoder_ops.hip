@@ -35,7 +35,7 @@ __global__ void upsample2x_add_kernel(const float* __restrict__ s, const float* 
     const int c4n = C / 4;
     const int hi = h / 2, wi = w / 2;
     const size_t total = (size_t)N * h * w * c4n;
-    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    for (size_t i = vfn_xcd_block(blockIdx.x, gridDim.x) * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
         const int c4 = i % c4n;
         size_t t = i / c4n;
         const int x = t % w; t /= w;

@@ -159,7 +159,7 @@ __global__ void maxpool3x3s2_kernel(const float* __restrict__ in, float* __restr
                                     int N, int H, int W, int C, int Ho, int Wo) {
     const int c4n = C / 4;
     const size_t total = (size_t)N * Ho * Wo * c4n;
-    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    for (size_t i = vfn_xcd_block(blockIdx.x, gridDim.x) * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
         const int c4 = i % c4n;
         size_t t = i / c4n;
         const int ox = t % Wo; t /= Wo;

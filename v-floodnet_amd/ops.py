@@ -226,6 +226,7 @@ def conv2d_nhwc(x, wp, cout, kh, kw, stride, pad, scale=None, shift=None, res=No
 _WINO_G = torch.tensor([[1 / 4, 0, 0], [-1 / 6, -1 / 6, -1 / 6], [-1 / 6, 1 / 6, -1 / 6], [1 / 24, 1 / 12, 1 / 6], [1 / 24, -1 / 12, 1 / 6], [0, 0, 1]],
                        dtype=torch.float64)
 WINO_ROW_MULT = 256                   # rows per transform component are padded to a multiple of the tallest tile
+_WINO_KROT = int(os.environ.get('VFN_KROT', '1'))      # vfn_conv_desc.k_rot for the transform-domain GEMMs (0: every workgroup starts at K tile 0)
 
 
 def pack_winograd_weight(w):
@@ -265,6 +266,7 @@ def make_winograd_gemm_desc(V, U, Mb, rows_pad, cin, cout):
     d = make_conv_desc(V, U, cout, 1, 1, 1, 0, Mb, None, None, None, False, False, cin=cin, in_ld=cin, out_ld=cout, N=1, H=1, W=36 * rows_pad)
     d.cout_pad = U.shape[0] // 36
     d.w_batch_rows = rows_pad
+    d.k_rot = _WINO_KROT
     return d
 
 
