@@ -457,11 +457,10 @@ def main(argv=None):
     per = timer.summary()
     roof = None
     if per:
-        names = ops.conv_cfg_names(ops.MODES[args.precision])
         cands = []                          # (name, flops, ms, launches, frames the launches were sampled on)
         n_full = max(1, len(mem_records))   # fully sampled frames (every instrumented launch bracketed)
         for c, (fl, ms, n) in per.items():
-            cands.append((names[c], fl, ms, n, n_full))
+            cands.append((ops.conv_cfg_name(c, ops.MODES[args.precision]), fl, ms, n, n_full))
         if apply_records:
             a_ms = sum(r_[2].elapsed_time(r_[3]) for r_ in apply_records)
             # (2*128 + 2*512) FLOP per (entry, query): scores + P^T V; with the scores read back from the statistics scan

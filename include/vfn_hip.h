@@ -153,6 +153,15 @@ int vfn_winograd_output_masked_f32(const float* Mb, int rows_pad, int N, int H, 
  *   vfn_winograd_input_f32 (above) V[xi][tile][ci]; vfn_winograd_gy_f32  Z[xi][tile][co] = (A dY A^T)[xi] of the 4x4 tiles of
  *   gy [N,H,W,ld] (C channels used); vfn_conv_wgrad_f32 with k = 1, batch = 36 sums them over the tiles into dU [36][Cout][Cin];
  *   vfn_winograd_dw_f32  dw [Cout][3][3][Cin] (+)= rowscale[co] * (G^T dU G). */
+/* (ABI 12) the transform-domain GEMMs as ONE PERSISTENT launch: M [comps][rows_pad][Cout] = V [comps][rows_pad][C] x U [comps][cout_pad][C]^T.
+ * A workgroup walks a list of (component, row tile, filter tile) units as one uninterrupted K loop -- the next unit's operand tiles are
+ * requested while the current one multiplies, the raw accumulators leave through stores straight from the registers -- instead of one
+ * workgroup per unit with a cold prologue and an LDS epilogue around 4-32 K tiles.  Same products in the same order as the batched-filter
+ * launch of vfn_conv2d_nhwc_f32 (w_batch_rows) without split-K: bit-identical.  cfg: 0 = 128x128 tiles, 1 = 64x128, 2 = 128x64 (8 waves),
+ * 3 = 64x64 (4 waves); + 4: operand tiles requested two K tiles ahead.  wgs: workgroups (0 = 512 = two per CU).  rows_pad % tile height
+ * == 0, cout_pad >= Cout rounded up to the tile width, C % 32 == 0, every operand below 2 GiB. */
+int vfn_winograd_gemm_f32(const float* V, const float* U, float* Mb, int comps, int rows_pad, int C, int Cout, int cout_pad, int cfg,
+                          int wgs, void* stream);
 int vfn_winograd_gy_f32(const float* gy, int N, int H, int W, int C, int ld, float* Z, int rows_pad, void* stream);
 int vfn_winograd_dw_f32(const float* dU, int Cout, int Cin, const float* rowscale, float* dw, int accumulate, void* stream);
 

@@ -35,7 +35,11 @@ for lname, lst in lists.items():
         us = e0.elapsed_time(e1) * 1e3 / reps
         cfg = ''
         if l.fn is ops.conv2d_launch:
-            cfg = '%dx%d' % tiles[l.args[1]] + ('/k%d' % l.args[0].ksplit if l.args[0].ksplit > 1 else '') + ('/wk%d' % ops.conv_cfg_wk(l.args[1]) if ops.conv_cfg_wk(l.args[1]) > 1 else '')
+            if l.args[1] >= ops.WINO_GEMM_CFG0:          # the persistent transform-domain GEMM: tile / request depth / workgroups
+                c_ = l.args[1] - ops.WINO_GEMM_CFG0
+                cfg = 'p%dx%d/pd%d/%d' % (ops.WINO_GEMM_TILES[c_ & 3][0], ops.WINO_GEMM_TILES[c_ & 3][1], 1 + ((c_ & 7) >> 2), (c_ >> 3) * 128)
+            else:
+                cfg = '%dx%d' % tiles[l.args[1]] + ('/k%d' % l.args[0].ksplit if l.args[0].ksplit > 1 else '') + ('/wk%d' % ops.conv_cfg_wk(l.args[1]) if ops.conv_cfg_wk(l.args[1]) > 1 else '')
         tf = l.flops / us / 1e6 if l.flops else 0
         rows.append((lname, l.name, cfg, us, tf))
         t = tot.setdefault(lname, [0.0, 0.0]); t[0] += us; t[1] += l.flops

@@ -307,8 +307,40 @@ def test_winograd_f4x4_matches_torch_cpu(gpu, case):
     resd = res.permute(0, 2, 3, 1).contiguous().to(gpu) if use_res else None
     sc, sh = scale.to(gpu), shift.to(gpu)
     tol = 2e-4 * max(1.0, ref.abs().max().item())
-    for cfg in (2, 3, 42, 56):
+    base = None
+    for cfg in (2, 3, 42, 56) + tuple(ops.wino_gemm_cfg(tc, wgs) for tc, wgs in ((0, 512), (1, 256), (2, 768), (3, 512), (5, 512), (7, 256))):
+        # (from 1000 on: the PERSISTENT transform-domain GEMM of round 5, vfn_winograd_gemm_f32 -- every tile shape, both request depths)
+        if cfg >= ops.WINO_GEMM_CFG0 and Cout < 128 and ops.WINO_GEMM_TILES[(cfg - ops.WINO_GEMM_CFG0) & 3][1] > 64:
+            continue
         y = ops.conv2d_winograd(xd, w, sc, sh, resd, relu_in, relu_out, cfg=cfg)
         torch.cuda.synchronize()
         err = (y.permute(0, 3, 1, 2).cpu().double() - ref).abs().max().item()
         assert err < tol, (cfg, err, tol)
+        if cfg == 3:
+            base = y.clone()
+        elif cfg >= ops.WINO_GEMM_CFG0:
+            # the same products in the same order as the un-split LDS-tiled launch: bit-identical, whatever the tile shape
+            assert torch.equal(y, base), (cfg, (y - base).abs().max().item())
+
+
+def test_winograd_persistent_gemm_is_bit_identical_to_the_batched_launch(gpu):
+    """vfn_winograd_gemm_f32 (a workgroup walks a list of (component, row tile, filter tile) units as ONE K loop) against the batched-filter
+    launch of the convolution kernel on the C2 frame's shapes incl. KeyValue's 1024 -> 640 and a 128-channel bottleneck: bit-identical
+    for every tile shape / request depth / workgroup count, ragged unit counts (units not a multiple of the grid) included."""
+    from vfloodnet_amd import ops
+    g = torch.Generator(device=gpu).manual_seed(11)
+    for (ntile, C, Cout) in [(810, 256, 256), (224, 1024, 640), (405, 128, 128), (300, 64, 192)]:
+        rows = (ntile + 255) // 256 * 256
+        cp = (Cout + 255) // 256 * 256
+        V = torch.randn(36 * rows, C, device=gpu, generator=g)
+        U = torch.randn(36 * cp, C, device=gpu, generator=g) * 0.05
+        ref = torch.empty(36 * rows, Cout, device=gpu)
+        ops.conv2d_launch(ops.make_winograd_gemm_desc(V, U, ref, rows, C, Cout), 3, 0)
+        for tc in range(8):
+            for wgs in (128, 512, 640):
+                out = torch.full((36 * rows, Cout), float('nan'), device=gpu)
+                ops.conv2d_launch(ops.make_winograd_gemm_desc(V, U, out, rows, C, Cout), ops.wino_gemm_cfg(tc, wgs), 0)
+                torch.cuda.synchronize()
+                assert torch.equal(out, ref), (ntile, C, Cout, tc, wgs)
+    with pytest.raises(RuntimeError):                      # rows per component must be a multiple of the tile height
+        ops.winograd_gemm(V[:36 * 192], U, out[:36 * 192], 192, 64, 192, cfg=0)

@@ -100,6 +100,9 @@ def _tiles():
 def apply_choice(desc, choice, ws, counters=None):
     """Configure a conv descriptor for a (cfg, ksplit, split_from) choice; returns the cfg index."""
     cfg, ks, split_from = choice
+    if cfg >= ops.WINO_GEMM_CFG0:                         # the persistent transform-domain GEMM: no split, no workspace
+        ops.set_splitk(desc, 1, None)
+        return cfg
     if ops.conv_cfg_kind(cfg) == 2:                       # stream-K: its own workspace + counters, never a K split on top
         if counters is None or ws is None or ws.numel() < ops.SK_WS_FLOATS:
             # (callers with no counters of their own -- the backward pass, LinkNet: main-stream launches, one after the other)
@@ -191,6 +194,18 @@ def tune_desc(d, bf, ws, cnt, iters=3, cfg_filter=None, allow_split=True):
         return best_ms
 
     best, best_t = None, None
+    if d.w_batch_rows > 0 and bf == 0 and d.M // d.w_batch_rows * d.w_batch_rows == d.M:
+        # a Winograd-domain GEMM: the persistent kernel's configurations compete with the batched-filter launches below
+        for c in ops.wino_gemm_cfg_options(d.w_batch_rows, d.Cout):
+            if cfg_filter is not None and not cfg_filter(key, c):
+                continue
+            apply_choice(d, (c, 1, 0), ws, cnt)
+            try:
+                t = timeit(c)
+            except RuntimeError:
+                continue
+            if best_t is None or t < best_t:
+                best, best_t = (c, 1, 0), t
     for c, (bm, bn) in enumerate(tiles):
         if bf and c not in ops.BF16_CFGS:              # no LDS-DMA variants (the DMA cannot convert)
             continue

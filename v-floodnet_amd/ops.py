@@ -199,9 +199,50 @@ MODES = {'fp32': 0, 'bf16': 1, 'bf16x3': 2}
 _CONV_FN = ('vfn_conv2d_nhwc_f32', 'vfn_conv2d_nhwc_bf16', 'vfn_conv2d_nhwc_bf16x3')
 
 
+# Configuration ids from WINO_GEMM_CFG0 on: a Winograd-domain GEMM descriptor (make_winograd_gemm_desc) launched as the PERSISTENT
+# kernel (vfn_winograd_gemm_f32) instead of one workgroup per output tile: id = WINO_GEMM_CFG0 + tile cfg (0..7) + 8 * (workgroups / 128)
+WINO_GEMM_CFG0 = 1000
+WINO_GEMM_TILES = ((128, 128, 4, 2), (64, 128, 2, 4), (128, 64, 4, 2), (64, 64, 2, 2))
+
+
+def wino_gemm_cfg(tile_cfg, wgs=512):
+    return WINO_GEMM_CFG0 + int(tile_cfg) + 8 * (int(wgs) // 128)
+
+
+def wino_gemm_cfg_options(rows_pad, cout):
+    """Every persistent configuration that fits a GEMM with ``rows_pad`` rows per component."""
+    out = []
+    for tc in range(8):
+        bm, bn = WINO_GEMM_TILES[tc & 3][:2]
+        if rows_pad % bm or (bn > 64 and cout < 128):
+            continue
+        out += [wino_gemm_cfg(tc, w) for w in (256, 512, 768)]
+    return out
+
+
 def conv2d_launch(desc, cfg, mode=0):
+    cfg = int(cfg)
+    if cfg >= WINO_GEMM_CFG0:
+        c, rows = cfg - WINO_GEMM_CFG0, desc.w_batch_rows
+        if mode != 0 or rows <= 0:
+            raise RuntimeError('the persistent GEMM takes an f32 Winograd-domain descriptor (w_batch_rows)')
+        check(_lib.lib().vfn_winograd_gemm_f32(desc.inp, desc.w, desc.out, desc.M // rows, rows, desc.Cin, desc.Cout, desc.cout_pad, c & 7,
+                                               (c >> 3) * 128, stream()), 'vfn_winograd_gemm_f32')
+        return
     name = _CONV_FN[int(mode)]
-    check(getattr(_lib.lib(), name)(C.byref(desc), int(cfg), stream()), name)
+    check(getattr(_lib.lib(), name)(C.byref(desc), cfg, stream()), name)
+
+
+def conv_cfg_name(cfg, mode=0, _cache={}):
+    """Kernel instantiation behind configuration id ``cfg`` as rocprofv3 prints it (conv_cfg_names + the persistent GEMM ids)."""
+    cfg = int(cfg)
+    if cfg >= WINO_GEMM_CFG0:
+        c = (cfg - WINO_GEMM_CFG0) & 7
+        bm, bn, wm, wn = WINO_GEMM_TILES[c & 3]
+        return f'wino_gemm_kernel<{bm}, {bn}, {wm}, {wn}, {1 + (c >> 2)}>'
+    if mode not in _cache:
+        _cache[mode] = conv_cfg_names(mode)
+    return _cache[mode][cfg]
 
 
 BF16_CFGS = (0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 17, 19, 22, 23) + tuple(range(26, 38))     # (no LDS-DMA variants: the DMA cannot convert)
@@ -226,7 +267,7 @@ def conv2d_nhwc(x, wp, cout, kh, kw, stride, pad, scale=None, shift=None, res=No
 _WINO_G = torch.tensor([[1 / 4, 0, 0], [-1 / 6, -1 / 6, -1 / 6], [-1 / 6, 1 / 6, -1 / 6], [1 / 24, 1 / 12, 1 / 6], [1 / 24, -1 / 12, 1 / 6], [0, 0, 1]],
                        dtype=torch.float64)
 WINO_ROW_MULT = 256                   # rows per transform component are padded to a multiple of the tallest tile
-_WINO_KROT = int(os.environ.get('VFN_KROT', '1'))      # vfn_conv_desc.k_rot for the transform-domain GEMMs (0: every workgroup starts at K tile 0)
+_WINO_KROT = int(os.environ.get('VFN_KROT', '0'))      # vfn_conv_desc.k_rot for the transform-domain GEMMs (0: every workgroup starts at K tile 0)
 
 
 def pack_winograd_weight(w):
@@ -268,6 +309,13 @@ def make_winograd_gemm_desc(V, U, Mb, rows_pad, cin, cout):
     d.w_batch_rows = rows_pad
     d.k_rot = _WINO_KROT
     return d
+
+
+def winograd_gemm(V, U, Mb, rows_pad, cin, cout, cfg=0, wgs=0, comps=36):
+    """The transform-domain GEMMs as one persistent launch (vfn_winograd_gemm_f32): V [comps * rows_pad, cin], U [comps * cout_pad, cin],
+    Mb [comps * rows_pad, cout]."""
+    check(_lib.lib().vfn_winograd_gemm_f32(ptr(V), ptr(U), ptr(Mb), comps, rows_pad, cin, cout, U.shape[0] // comps, int(cfg), int(wgs), stream()),
+          'vfn_winograd_gemm_f32')
 
 
 def conv2d_winograd(x, w, scale=None, shift=None, res=None, relu_in=False, relu_out=False, cfg=2, res_mod=0):
