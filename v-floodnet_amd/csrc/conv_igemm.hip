@@ -147,6 +147,57 @@ __device__ __forceinline__ bool wide_epilogue(const vfn_conv_desc& p, char* smem
         if (p.scale) sc = *reinterpret_cast<const f32x4*>(p.scale + col);
         if (p.shift) sh = *reinterpret_cast<const f32x4*>(p.shift + col);
     }
+    // Round 5: the finished tiles' path of the forward pass is branch-free.  The residual taps of a round are raw buffer loads issued
+    // BEFORE the accumulators go through LDS (they land behind the transpose instead of one exposed round trip per row, which is what
+    // the per-row `if (row < M) ... v += res[...]` compiled to: load, s_waitcnt vmcnt(0), store, next row), rows past M / columns past
+    // Cout get an out-of-range offset (loads return zeros, stores are dropped) and the row loop is unrolled.  Tensors of 2 GiB or
+    // more, the backward passes' ReLU masks and the split-bf16 image keep the pointer form below (the mask's registers would cost
+    // the 128 x 128 tile its second resident workgroup).
+    constexpr int ITERS = (ROWS + RPP - 1) / RPP;
+    const long long lim = 0x7fffff00LL;
+    const bool fast = !split_tile && !p.out_lp && !p.mask && p.out && (long long)p.M * p.out_ld * 4 < lim &&
+                      (!p.res || (long long)(p.res_mod > 0 ? p.res_mod : p.M) * p.res_ld * 4 < lim);
+    if (fast) {
+        const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc(p.out, 0, (int)((size_t)p.M * p.out_ld * 4), 0x00020000);
+        const __amdgpu_buffer_rsrc_t rr_ = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.res ? p.res : p.in), 0,
+            p.res ? (int)((size_t)(p.res_mod > 0 ? p.res_mod : p.M) * p.res_ld * 4) : 0, 0x00020000);
+        const float floor_ = p.relu_out ? 0.f : -INFINITY;
+#pragma unroll
+        for (int h = 0; h < TM; ++h) {
+            f32x4 rv[ITERS];
+            auto row_of = [&](int it) {
+                const int rr = rr0 + it * RPP;
+                const int row = m0 + (rr >> 5) * (TM * 32) + h * 32 + (rr & 31);
+                return (active && rr < ROWS && row < p.M && col_ok) ? row : -1;
+            };
+#pragma unroll
+            for (int it = 0; it < ITERS; ++it) {               // (an empty resource without a residual: zeros, no traffic)
+                const int row = row_of(it);
+                const int rrow = p.res_mod > 0 ? row % p.res_mod : row;
+                rv[it] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rr_, row >= 0 ? (rrow * p.res_ld + col) * 4 : 0x7ffffff0, 0, 0));
+            }
+            if (h > 0) __syncthreads();                             // the previous round has been read back
+            if (active) {
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        sC[(wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh) * PITCH + (wn * TN + j) * 32 + li] = acc[h][j][r];
+            }
+            __syncthreads();
+#pragma unroll
+            for (int it = 0; it < ITERS; ++it) {
+                const int rr = rr0 + it * RPP;
+                f32x4 v = *reinterpret_cast<const f32x4*>(sC + (rr < ROWS ? rr : 0) * PITCH + c4 * 4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e] * sc[e] + sh[e] + rv[it][e], floor_);
+                const int row = row_of(it);
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((ext_vector_type(4))) unsigned, v), ro,
+                                                       row >= 0 ? (row * p.out_ld + col) * 4 : 0x7ffffff0, 0, 0);
+            }
+        }
+        return true;
+    }
 #pragma unroll
     for (int h = 0; h < TM; ++h) {
         if (h > 0) __syncthreads();                                 // the previous round has been read back
