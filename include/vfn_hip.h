@@ -162,6 +162,11 @@ int vfn_winograd_output_masked_f32(const float* Mb, int rows_pad, int N, int H, 
  * == 0, cout_pad >= Cout rounded up to the tile width, C % 32 == 0, every operand below 2 GiB. */
 int vfn_winograd_gemm_f32(const float* V, const float* U, float* Mb, int comps, int rows_pad, int C, int Cout, int cout_pad, int cfg,
                           int wgs, void* stream);
+/* (ABI 12) a 1x1 / stride-1 / pad-0 convolution descriptor (+ scale / shift, residual incl. res_mod, ReLU in / out) through the same
+ * persistent kernel: one GEMM [M pixels x Cin] x [Cin x Cout] whose workgroups walk their output tiles as one K loop and apply the
+ * epilogue from the accumulator registers (the trunk's conv1 / conv3 / downsample have 2-8 K tiles per output tile).  Products and
+ * order as vfn_conv2d_nhwc_f32 without split-K.  cfg / wgs as above; taps, strides, masks, operand images, split-K: VFN_ERR_ARG. */
+int vfn_conv1x1_persistent_f32(const vfn_conv_desc* d, int cfg, int wgs, void* stream);
 int vfn_winograd_gy_f32(const float* gy, int N, int H, int W, int C, int ld, float* Z, int rows_pad, void* stream);
 int vfn_winograd_dw_f32(const float* dU, int Cout, int Cin, const float* rowscale, float* dw, int accumulate, void* stream);
 

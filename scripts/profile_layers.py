@@ -36,7 +36,7 @@ for lname, lst in lists.items():
         cfg = ''
         if l.fn is ops.conv2d_launch:
             if l.args[1] >= ops.WINO_GEMM_CFG0:          # the persistent transform-domain GEMM: tile / request depth / workgroups
-                c_ = l.args[1] - ops.WINO_GEMM_CFG0
+                c_ = l.args[1] - (ops.PCONV_CFG0 if l.args[1] >= ops.PCONV_CFG0 else ops.WINO_GEMM_CFG0)
                 cfg = 'p%dx%d/pd%d/%d' % (ops.WINO_GEMM_TILES[c_ & 3][0], ops.WINO_GEMM_TILES[c_ & 3][1], 1 + ((c_ & 7) >> 2), (c_ >> 3) * 128)
             else:
                 cfg = '%dx%d' % tiles[l.args[1]] + ('/k%d' % l.args[0].ksplit if l.args[0].ksplit > 1 else '') + ('/wk%d' % ops.conv_cfg_wk(l.args[1]) if ops.conv_cfg_wk(l.args[1]) > 1 else '')

@@ -1,12 +1,14 @@
-"""Re-measure the kernel choice of every Winograd-domain GEMM of the C2 / C3 / C5 plans (and of the training plan) now that the
-persistent kernel (vfn_winograd_gemm_f32, configuration ids >= 1000) competes with the batched-filter launches: the table entry of
-a shape changes hands only when the new choice is at least MARGIN faster than the old one, re-timed alternately.
-Writes gpurun_out/tuned_gfx950.json + gpurun_out/r05_tune_wino_gemm_report.json."""
+"""Re-measure the kernel choice of every Winograd-domain GEMM (default) or of every 1x1 / stride-1 convolution (argument `pconv`) of the
+C2 / C3 / C5 plans (and of the training plan) now that the persistent kernel (vfn_winograd_gemm_f32, configuration ids >= 1000;
+vfn_conv1x1_persistent_f32, ids >= 2000) competes with one-workgroup-per-tile launches: the table entry of a shape changes hands only
+when the new choice is at least MARGIN faster than the old one, re-timed alternately.
+Writes gpurun_out/tuned_gfx950.json + gpurun_out/r05_tune_{wino_gemm,pconv}_report.json."""
 import sys, os, json
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch, vfloodnet_amd
 from vfloodnet_amd import AFB_URR, engine, ops
 MARGIN = float(os.environ.get('VFN_TUNE_MARGIN', 0.97))
+WHICH = sys.argv[1] if len(sys.argv) > 1 else 'wino'
 dev = torch.device('cuda', 0)
 model = AFB_URR(dev, update_bank=True).to(dev).eval()
 eng = model.engine()
@@ -42,13 +44,15 @@ if os.environ.get('VFN_TUNE_TRAIN', '1') == '1':
 for p in plans:
     for lst in p.all_lists():
         for l in lst:
-            if l.fn is ops.conv2d_launch and 'wino_gemm' in (l.name or ''):
-                d = l.args[0]
-                seen.setdefault((d.M, d.Cout, d.Cin), (d, p))
+            if l.fn is not ops.conv2d_launch or int(l.args[2]) != 0:
+                continue
+            d = l.args[0]
+            if (WHICH == 'wino' and 'wino_gemm' in (l.name or '')) or (WHICH == 'pconv' and ops.pconv_eligible(d, 0)):
+                seen.setdefault((d.M, d.Cout, d.KH * d.KW * d.Cin), (d, p))
 for key, (d, p) in sorted(seen.items()):
     old = table.get(key) or engine.choose_cfg(*key, 0)
     cand = []
-    for c in ops.wino_gemm_cfg_options(d.w_batch_rows, d.Cout):
+    for c in (ops.wino_gemm_cfg_options(d.w_batch_rows, d.Cout) if WHICH == 'wino' else ops.pconv_cfg_options(d.Cout)):
         engine.apply_choice(d, (c, 1, 0), p.ws, p.cnt)
         try:
             cand.append((timeit(d, c, 6), c))
@@ -75,6 +79,6 @@ for key, (d, p) in sorted(seen.items()):
         table[key] = (best[1], 1, 0)
 os.makedirs('gpurun_out', exist_ok=True)
 engine.save_tuned('gpurun_out/tuned_gfx950.json', 0)
-json.dump(report, open('gpurun_out/r05_tune_wino_gemm_report.json', 'w'), indent=1)
+json.dump(report, open('gpurun_out/r05_tune_%s_report.json' % ('wino_gemm' if WHICH == 'wino' else 'pconv'), 'w'), indent=1)
 print('shapes', len(report), 'moved', sum(r['taken'] for r in report), 'old total %.1f us, new total %.1f us' % (
     sum(r['old_us'] for r in report), sum(r['new_us'] if r['taken'] else r['old_us'] for r in report)))

@@ -344,3 +344,52 @@ def test_winograd_persistent_gemm_is_bit_identical_to_the_batched_launch(gpu):
                 assert torch.equal(out, ref), (ntile, C, Cout, tc, wgs)
     with pytest.raises(RuntimeError):                      # rows per component must be a multiple of the tile height
         ops.winograd_gemm(V[:36 * 192], U, out[:36 * 192], 192, 64, 192, cfg=0)
+
+
+@pytest.mark.parametrize('case', [(2, 30, 54, 256, 64, False, True, True, 0), (1, 37, 41, 64, 256, False, True, True, 0), (2, 24, 40, 128, 96, True, False, False, 0),
+                                  (3, 16, 20, 512, 256, False, True, True, 320), (1, 9, 7, 32, 20, True, True, False, 0)])
+def test_persistent_1x1_convolution_matches_the_tiled_kernel(gpu, case):
+    """vfn_conv1x1_persistent_f32 (round 5: the trunk's thin-K 1x1 layers as one persistent GEMM with the epilogue applied from the
+    accumulator registers) against the LDS-tiled kernel on the same descriptor -- the same products in the same order, so the
+    results agree to the last bit of the epilogue's fused multiply-add -- and against F.conv2d in float64: ragged M, a filter count
+    that is no multiple of the tile, ReLU on the input / output, a residual and a residual shared by the images of the batch."""
+    from vfloodnet_amd import ops
+    N, H, W, Cin, Cout, relu_in, relu_out, use_res, res_mod = case
+    g = torch.Generator().manual_seed(hash(case) & 0xFFFF)
+    x = torch.randn(N, H, W, Cin, generator=g)
+    w = torch.randn(Cout, Cin, generator=g) / Cin ** 0.5
+    scale, shift = 1 + 0.1 * torch.randn(Cout, generator=g), 0.1 * torch.randn(Cout, generator=g)
+    M = N * H * W
+    res = torch.randn(res_mod if res_mod else M, Cout, generator=g) if use_res else None
+    xin = F.relu(x) if relu_in else x
+    ref = xin.double().reshape(M, Cin) @ w.double().t() * scale.double() + shift.double()
+    if use_res:
+        ref = ref + (res.double()[torch.arange(M) % res_mod] if res_mod else res.double())
+    if relu_out:
+        ref = F.relu(ref)
+    xd, wp = x.to(gpu), ops.pad_rows(w.to(gpu))
+    sc, sh = scale.to(gpu), shift.to(gpu)
+    resd = res.to(gpu) if use_res else None
+
+    def run(cfg):
+        out = torch.full((N, H, W, Cout), float('nan'), device=gpu)
+        d = ops.make_conv_desc(xd, wp, Cout, 1, 1, 1, 0, out, sc, sh, resd, relu_in, relu_out)
+        d.res_mod = res_mod
+        ops.conv2d_launch(d, cfg, 0)
+        torch.cuda.synchronize()
+        return out.reshape(M, Cout)
+    base = run(3 if Cout >= 64 else 5)
+    tol = 2e-4 * max(1.0, ref.abs().max().item())
+    assert (base.cpu().double() - ref).abs().max().item() < tol
+    for tc in range(8):
+        if ops.WINO_GEMM_TILES[tc & 3][1] > 64 and Cout < 64:
+            continue
+        for wgs in (128, 512):
+            y = run(ops.pconv_cfg(tc, wgs))
+            assert not torch.isnan(y).any(), (tc, wgs)
+            assert (y.cpu().double() - ref).abs().max().item() < tol, (tc, wgs)
+            assert (y - base).abs().max().item() <= 2e-6 * max(1.0, base.abs().max().item()), (tc, wgs, (y - base).abs().max().item())
+    # what the kernel does not implement is refused, not mis-computed
+    d = ops.make_conv_desc(xd, ops.pad_rows(torch.randn(Cout, 9 * Cin, device=gpu)), Cout, 3, 3, 1, 1, torch.empty(N, H, W, Cout, device=gpu), sc, sh, None, False, False)
+    with pytest.raises(RuntimeError):
+        ops.conv2d_launch(d, ops.pconv_cfg(3, 512), 0)

@@ -292,9 +292,15 @@ struct wino_gemm_args {
     float* Mb;            // [comps][rows_pad][Cout]
     int comps, rows_pad, C, Cout, cout_pad;
     int mtiles, ntiles;   // rows_pad / BM, ceil(Cout / BN)
+    // CONV form (a 1x1 / stride-1 convolution as ONE such GEMM with the layer's epilogue): V = NHWC input with pixel stride a_ld
+    // (rows_pad = M pixels: rows past M read zeros through the buffer resource), Mb = output with pixel stride out_ld
+    int a_ld, out_ld, res_ld, res_mod, relu_in, relu_out;
+    const float* scale;
+    const float* shift;
+    const float* res;
 };
 
-template <int BM, int BN, int WM, int WN, int PD>
+template <int BM, int BN, int WM, int WN, int PD, bool CONV = false>
 __global__ __launch_bounds__(WM * WN * 64)
 void wino_gemm_kernel(const wino_gemm_args p) {
     constexpr int BK = 32;
@@ -324,11 +330,12 @@ void wino_gemm_kernel(const wino_gemm_args p) {
     if (T == 0) return;
 
     const int c16 = tid & 7, r0 = tid >> 3;
-    const __amdgpu_buffer_rsrc_t rsV = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.V), 0, (int)((size_t)p.comps * p.rows_pad * p.C * 4), 0x00020000);
+    const int a_ld = CONV ? p.a_ld : p.C;
+    const __amdgpu_buffer_rsrc_t rsV = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.V), 0, (int)((size_t)p.comps * p.rows_pad * a_ld * 4), 0x00020000);
     const __amdgpu_buffer_rsrc_t rsU = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.U), 0, (int)((size_t)p.comps * p.cout_pad * p.C * 4), 0x00020000);
     int a_thr[AC], b_thr[BC];
 #pragma unroll
-    for (int j = 0; j < AC; ++j) a_thr[j] = ((r0 + j * RSTEP) * p.C + c16 * 4) * 4;
+    for (int j = 0; j < AC; ++j) a_thr[j] = ((r0 + j * RSTEP) * a_ld + c16 * 4) * 4;
 #pragma unroll
     for (int j = 0; j < BC; ++j) b_thr[j] = ((r0 + j * RSTEP) * p.C + c16 * 4) * 4;
 
@@ -339,9 +346,9 @@ void wino_gemm_kernel(const wino_gemm_args p) {
         const int u = first + ui * gx;
         const int xi = u / per, rem = u - xi * per;
         const int mt = rem / p.ntiles, nt = rem - mt * p.ntiles;
-        a_base = (xi * p.rows_pad + mt * BM) * p.C * 4;
+        a_base = (xi * p.rows_pad + mt * BM) * a_ld * 4;
         b_base = (xi * p.cout_pad + nt * BN) * p.C * 4;
-        o_base = ((size_t)xi * p.rows_pad + mt * BM) * p.Cout + nt * BN;
+        o_base = CONV ? (size_t)mt * BM : ((size_t)xi * p.rows_pad + mt * BM) * p.Cout + nt * BN;      // (CONV: the first row of the tile)
         if (n0) *n0 = nt * BN;
     };
     size_t o_dummy;
@@ -360,13 +367,19 @@ void wino_gemm_kernel(const wino_gemm_args p) {
             if (++lu < n_units) unit_bases(lu, la_base, lb_base, o_dummy);
         }
     };
+    const float relu_floor = (CONV && p.relu_in) ? 0.f : -INFINITY;
     auto stage = [&](int buf, int slot) {                  // staging slot -> LDS image (XOR-swizzled 16-byte chunks)
         float* dA = sA + buf * BM * BK;
         float* dB = sB + buf * BN * BK;
 #pragma unroll
         for (int j = 0; j < AC; ++j) {
             const int r = r0 + j * RSTEP;
-            *reinterpret_cast<f32x4*>(dA + r * BK + ((c16 ^ ((r >> 1) & 7)) << 2)) = ra[slot][j];
+            f32x4 v = ra[slot][j];
+            if constexpr (CONV) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], relu_floor);
+            }
+            *reinterpret_cast<f32x4*>(dA + r * BK + ((c16 ^ ((r >> 1) & 7)) << 2)) = v;
         }
 #pragma unroll
         for (int j = 0; j < BC; ++j) {
@@ -435,6 +448,48 @@ void wino_gemm_kernel(const wino_gemm_args p) {
             }
             if (++ckt == nk) {
                 // the unit is complete: lane = filter column (lane & 31), registers = rows (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
+                if constexpr (CONV) {
+                    // y = act(acc * scale[c] + shift[c] + res): lane = channel, so scale / shift are one value per lane and column tile;
+                    // the residual taps of the whole tile are requested first (buffer loads: rows past M / columns past Cout return
+                    // zeros), the stores of invalid positions are dropped by the hardware
+                    const int m0 = (int)o_base;
+                    const int npix = p.rows_pad;
+                    const __amdgpu_buffer_rsrc_t rso = __builtin_amdgcn_make_buffer_rsrc(p.Mb, 0, (int)((size_t)npix * p.out_ld * 4), 0x00020000);
+                    const __amdgpu_buffer_rsrc_t rsr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.res ? p.res : p.V), 0,
+                        p.res ? (int)((size_t)(p.res_mod > 0 ? p.res_mod : npix) * p.res_ld * 4) : 0, 0x00020000);
+                    const float floor_ = p.relu_out ? 0.f : -INFINITY;
+                    float rv[TM][TN][16];
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) {
+                        const int col = n0_cur + (wn * TN + j) * 32 + li;
+#pragma unroll
+                        for (int i = 0; i < TM; ++i)
+#pragma unroll
+                            for (int r = 0; r < 16; ++r) {
+                                const int row = m0 + (wm * TM + i) * 32 + 4 * lh + (r & 3) + 8 * (r >> 2);
+                                const int rrow = p.res_mod > 0 ? row % p.res_mod : row;
+                                rv[i][j][r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+                                    rsr, (row < npix && col < p.Cout) ? (rrow * p.res_ld + col) * 4 : 0x7ffffff0, 0, 0));
+                            }
+                    }
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) {
+                        const int col = n0_cur + (wn * TN + j) * 32 + li;
+                        const bool cok = col < p.Cout;
+                        const float sc = (p.scale && cok) ? p.scale[col] : 1.f;
+                        const float sh = (p.shift && cok) ? p.shift[col] : 0.f;
+#pragma unroll
+                        for (int i = 0; i < TM; ++i)
+#pragma unroll
+                            for (int r = 0; r < 16; ++r) {
+                                const int row = m0 + (wm * TM + i) * 32 + 4 * lh + (r & 3) + 8 * (r >> 2);
+                                const float v = fmaxf(acc[i][j][r] * sc + sh + rv[i][j][r], floor_);
+                                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rso,
+                                                                      (row < npix && cok) ? (row * p.out_ld + col) * 4 : 0x7ffffff0, 0, 0);
+                                acc[i][j][r] = 0.f;
+                            }
+                    }
+                } else {
                 float* o = p.Mb + o_base;
 #pragma unroll
                 for (int j = 0; j < TN; ++j) {
@@ -450,6 +505,7 @@ void wino_gemm_kernel(const wino_gemm_args p) {
                         }
                     }
                 }
+                }
                 ckt = 0;
                 if (++cu < n_units) unit_bases(cu, ca_dummy, cb_dummy, o_base, &n0_cur);
             }
@@ -458,22 +514,22 @@ void wino_gemm_kernel(const wino_gemm_args p) {
     }
 }
 
-template <int BM, int BN, int WM, int WN, int PD>
+template <int BM, int BN, int WM, int WN, int PD, bool CONV = false>
 int launch_wino_gemm(const wino_gemm_args& a, int wgs, hipStream_t s) {
     constexpr size_t lds = 2 * (size_t)(BM + BN) * 32 * sizeof(float);
     static bool attr_set = false;
     if (!attr_set && lds > 64 * 1024) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&wino_gemm_kernel<BM, BN, WM, WN, PD>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&wino_gemm_kernel<BM, BN, WM, WN, PD, CONV>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = true;
     }
     wino_gemm_args p = a;
-    p.mtiles = a.rows_pad / BM;
+    p.mtiles = (a.rows_pad + BM - 1) / BM;
     p.ntiles = (a.Cout + BN - 1) / BN;
     const int total = p.comps * p.mtiles * p.ntiles;
     int grid = wgs > 0 ? wgs : 512;
     if (grid > total) grid = total;
     grid = (grid + 7) / 8 * 8;                              // (the kernel deals units to blockIdx & 7 = XCD, blockIdx >> 3 = slot)
-    hipLaunchKernelGGL((wino_gemm_kernel<BM, BN, WM, WN, PD>), dim3(grid), dim3(WM * WN * 64), lds, s, p);
+    hipLaunchKernelGGL((wino_gemm_kernel<BM, BN, WM, WN, PD, CONV>), dim3(grid), dim3(WM * WN * 64), lds, s, p);
     return vfn_check_launch();
 }
 
@@ -553,7 +609,7 @@ extern "C" int vfn_winograd_gemm_f32(const float* V, const float* U, float* Mb, 
     const int tc = cfg & 3;
     if (rows_pad % bm[tc] || cout_pad < (Cout + bn[tc] - 1) / bn[tc] * bn[tc]) return VFN_ERR_ARG;
     if ((long long)comps * rows_pad * C * 4 >= 0x7fffff00LL || (long long)comps * cout_pad * C * 4 >= 0x7fffff00LL) return VFN_ERR_ARG;
-    wino_gemm_args a{V, U, Mb, comps, rows_pad, C, Cout, cout_pad, 0, 0};
+    wino_gemm_args a{V, U, Mb, comps, rows_pad, C, Cout, cout_pad, 0, 0, 0, 0, 0, 0, 0, 0, nullptr, nullptr, nullptr};
     hipStream_t s = (hipStream_t)stream;
     switch (cfg) {
         case 0: return launch_wino_gemm<128, 128, 4, 2, 1>(a, wgs, s);
@@ -564,6 +620,38 @@ extern "C" int vfn_winograd_gemm_f32(const float* V, const float* U, float* Mb, 
         case 5: return launch_wino_gemm<64, 128, 2, 4, 2>(a, wgs, s);
         case 6: return launch_wino_gemm<128, 64, 4, 2, 2>(a, wgs, s);
         case 7: return launch_wino_gemm<64, 64, 2, 2, 2>(a, wgs, s);
+    }
+    return VFN_ERR_ARG;
+}
+
+// (ABI 12) a 1x1 / stride-1 convolution (+ eval BatchNorm / bias, residual, ReLU: the trunk's conv1 / conv3 / downsample, AFB_URR.py:59-61,
+// 89-91 through torchvision's Bottleneck) through the same persistent kernel: ONE GEMM [M pixels x Cin] x [Cin x Cout] whose workgroups
+// walk their list of output tiles as one uninterrupted K loop and apply the epilogue from the accumulator registers.  These layers
+// have K = 64 ... 256 -- two to eight K tiles per output tile -- so as one workgroup per tile they are all prologue and epilogue
+// (rocprofv3: matrix pipe busy 20-35 %, 3.8 TB/s on layers that only have to move their tensors once).  Same products in the same
+// order as vfn_conv2d_nhwc_f32 without split-K.  cfg / wgs as vfn_winograd_gemm_f32.  Refuses what it does not implement (taps, strides,
+// masks, operand images, split-K) with VFN_ERR_ARG.
+extern "C" int vfn_conv1x1_persistent_f32(const vfn_conv_desc* d, int cfg, int wgs, void* stream) {
+    if (!d || !d->in || !d->w || !d->out || cfg < 0 || cfg > 7) return VFN_ERR_ARG;
+    if (d->KH != 1 || d->KW != 1 || d->stride != 1 || d->pad != 0 || d->mask || d->in_lp || d->out_lp || d->w_packed || d->ksplit > 1 ||
+        d->w_batch_rows || d->Cin % 32 || d->in_ld % 4 || d->M < 1 || d->M != d->N * d->H * d->W) return VFN_ERR_ARG;
+    static const int bn[4] = {128, 128, 64, 64};
+    if (d->cout_pad < (d->Cout + bn[cfg & 3] - 1) / bn[cfg & 3] * bn[cfg & 3]) return VFN_ERR_ARG;
+    const long long lim = 0x7fffff00LL;
+    if ((long long)d->M * d->in_ld * 4 >= lim || (long long)d->M * d->out_ld * 4 >= lim || (long long)d->cout_pad * d->Cin * 4 >= lim ||
+        (d->res && (long long)(d->res_mod > 0 ? d->res_mod : d->M) * d->res_ld * 4 >= lim)) return VFN_ERR_ARG;
+    wino_gemm_args a{d->in, d->w, d->out, 1, d->M, d->Cin, d->Cout, d->cout_pad, 0, 0,
+                     d->in_ld, d->out_ld, d->res ? d->res_ld : 0, d->res_mod, d->relu_in, d->relu_out, d->scale, d->shift, d->res};
+    hipStream_t s = (hipStream_t)stream;
+    switch (cfg) {
+        case 0: return launch_wino_gemm<128, 128, 4, 2, 1, true>(a, wgs, s);
+        case 1: return launch_wino_gemm<64, 128, 2, 4, 1, true>(a, wgs, s);
+        case 2: return launch_wino_gemm<128, 64, 4, 2, 1, true>(a, wgs, s);
+        case 3: return launch_wino_gemm<64, 64, 2, 2, 1, true>(a, wgs, s);
+        case 4: return launch_wino_gemm<128, 128, 4, 2, 2, true>(a, wgs, s);
+        case 5: return launch_wino_gemm<64, 128, 2, 4, 2, true>(a, wgs, s);
+        case 6: return launch_wino_gemm<128, 64, 4, 2, 2, true>(a, wgs, s);
+        case 7: return launch_wino_gemm<64, 64, 2, 2, 2, true>(a, wgs, s);
     }
     return VFN_ERR_ARG;
 }

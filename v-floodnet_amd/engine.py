@@ -206,6 +206,18 @@ def tune_desc(d, bf, ws, cnt, iters=3, cfg_filter=None, allow_split=True):
                 continue
             if best_t is None or t < best_t:
                 best, best_t = (c, 1, 0), t
+    if ops.pconv_eligible(d, bf) and os.environ.get('VFN_PCONV', '1') == '1':
+        # a 1x1 / stride-1 layer: the persistent kernel with the epilogue in registers competes too
+        for c in ops.pconv_cfg_options(d.Cout):
+            if cfg_filter is not None and not cfg_filter(key, c):
+                continue
+            apply_choice(d, (c, 1, 0), ws, cnt)
+            try:
+                t = timeit(c)
+            except RuntimeError:
+                continue
+            if best_t is None or t < best_t:
+                best, best_t = (c, 1, 0), t
     for c, (bm, bn) in enumerate(tiles):
         if bf and c not in ops.BF16_CFGS:              # no LDS-DMA variants (the DMA cannot convert)
             continue

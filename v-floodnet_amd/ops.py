@@ -220,8 +220,37 @@ def wino_gemm_cfg_options(rows_pad, cout):
     return out
 
 
+# ... and from PCONV_CFG0 on: a 1x1 / stride-1 convolution descriptor through the same persistent kernel with the layer's epilogue
+# (vfn_conv1x1_persistent_f32), same encoding of tile / request depth / workgroups
+PCONV_CFG0 = 2000
+
+
+def pconv_cfg(tile_cfg, wgs=512):
+    return PCONV_CFG0 + int(tile_cfg) + 8 * (int(wgs) // 128)
+
+
+def pconv_eligible(desc, mode=0):
+    return (mode == 0 and desc.KH == 1 and desc.KW == 1 and desc.stride == 1 and desc.pad == 0 and not desc.mask and not desc.in_lp and
+            not desc.out_lp and not desc.w_packed and not desc.w_batch_rows and desc.Cin % 32 == 0)
+
+
+def pconv_cfg_options(cout):
+    out = []
+    for tc in range(8):
+        if WINO_GEMM_TILES[tc & 3][1] > 64 and cout < 128:
+            continue
+        out += [pconv_cfg(tc, w) for w in (256, 512, 768)]
+    return out
+
+
 def conv2d_launch(desc, cfg, mode=0):
     cfg = int(cfg)
+    if cfg >= PCONV_CFG0:
+        c = cfg - PCONV_CFG0
+        if mode != 0:
+            raise RuntimeError('the persistent 1x1 convolution is an f32 kernel')
+        check(_lib.lib().vfn_conv1x1_persistent_f32(C.byref(desc), c & 7, (c >> 3) * 128, stream()), 'vfn_conv1x1_persistent_f32')
+        return
     if cfg >= WINO_GEMM_CFG0:
         c, rows = cfg - WINO_GEMM_CFG0, desc.w_batch_rows
         if mode != 0 or rows <= 0:
@@ -237,9 +266,9 @@ def conv_cfg_name(cfg, mode=0, _cache={}):
     """Kernel instantiation behind configuration id ``cfg`` as rocprofv3 prints it (conv_cfg_names + the persistent GEMM ids)."""
     cfg = int(cfg)
     if cfg >= WINO_GEMM_CFG0:
-        c = (cfg - WINO_GEMM_CFG0) & 7
+        c = (cfg - (PCONV_CFG0 if cfg >= PCONV_CFG0 else WINO_GEMM_CFG0)) & 7
         bm, bn, wm, wn = WINO_GEMM_TILES[c & 3]
-        return f'wino_gemm_kernel<{bm}, {bn}, {wm}, {wn}, {1 + (c >> 2)}>'
+        return f'wino_gemm_kernel<{bm}, {bn}, {wm}, {wn}, {1 + (c >> 2)}, {"true" if cfg >= PCONV_CFG0 else "false"}>'
     if mode not in _cache:
         _cache[mode] = conv_cfg_names(mode)
     return _cache[mode][cfg]
