@@ -1155,11 +1155,14 @@ extern "C" int vfn_conv2d_nhwc_f32(const vfn_conv_desc* d, int cfg, void* stream
 // Same convolution with bf16 operands (rounded to nearest-even as they are staged; f32 accumulate, f32
 // tensors in HBM): BASELINE configs C3 / C5.  Register-staged tile configurations only (LDS-DMA cannot convert).
 extern "C" int vfn_conv2d_nhwc_bf16(const vfn_conv_desc* d, int cfg, void* stream) {
-    if (!d || !d->in || !d->w || !d->out || d->in_lp || d->out_lp || d->w_batch_rows) return VFN_ERR_ARG;
+    if (!d || !d->in || !d->w || !d->out || d->in_lp || d->out_lp) return VFN_ERR_ARG;
+    // (batched filters -- the transform-domain GEMMs of Winograd layers in this mode, round 5 -- take the f32 banks and convert them as staged)
+    if (d->w_batch_rows < 0 || (d->w_batch_rows > 0 && (d->w_packed || d->KH != 1 || d->KW != 1))) return VFN_ERR_ARG;
     if (d->Cin % 64 != 0 || d->in_ld % 4 != 0 || d->M <= 0) return VFN_ERR_ARG;
     int bm, bn;
     if (vfn_conv_cfg_tile(cfg, &bm, &bn) != VFN_OK) return VFN_ERR_ARG;
     if (d->cout_pad < cdiv(d->Cout, bn) * bn) return VFN_ERR_ARG;
+    if (d->w_batch_rows > 0 && d->w_batch_rows % bm) return VFN_ERR_ARG;
     if (d->tile_counters) return VFN_ERR_ARG;
     if (d->ksplit > 1) {
         const int nk_all = d->KH * d->KW * (d->Cin / 64);
@@ -1192,7 +1195,8 @@ extern "C" int vfn_conv2d_nhwc_bf16(const vfn_conv_desc* d, int cfg, void* strea
 // product (hi*hi + hi*lo + lo*hi), f32 accumulate: relative error ~2^-16 per product, against 2^-9 for plain bf16
 // and 2^-24 for f32.  Same tile configurations and K tiling (32 channels) as the f32 kernel's register-staged ones.
 extern "C" int vfn_conv2d_nhwc_bf16x3(const vfn_conv_desc* d, int cfg, void* stream) {
-    if (!d || !d->in || !d->w || (!d->out && !d->out_lp) || d->w_batch_rows) return VFN_ERR_ARG;
+    if (!d || !d->in || !d->w || (!d->out && !d->out_lp)) return VFN_ERR_ARG;
+    if (d->w_batch_rows < 0 || (d->w_batch_rows > 0 && (d->w_packed || d->in_lp || d->out_lp || d->KH != 1 || d->KW != 1))) return VFN_ERR_ARG;
     if (d->in_lp && (d->relu_in || d->in_ld % 32)) return VFN_ERR_ARG;            // ReLU belongs to the image's producer
     // the image is written by the 16-byte epilogue only (4 channels per lane): shapes that fall back to the dword form are refused
     if (d->out_lp && (d->Cout % 32 || d->out_ld % 32 || (d->res && d->res_ld % 4) || d->tile_counters)) return VFN_ERR_ARG;
@@ -1200,6 +1204,7 @@ extern "C" int vfn_conv2d_nhwc_bf16x3(const vfn_conv_desc* d, int cfg, void* str
     int bm, bn;
     if (vfn_conv_cfg_tile(cfg, &bm, &bn) != VFN_OK) return VFN_ERR_ARG;
     if (d->cout_pad < cdiv(d->Cout, bn) * bn) return VFN_ERR_ARG;
+    if (d->w_batch_rows > 0 && d->w_batch_rows % bm) return VFN_ERR_ARG;
     if (d->tile_counters) return VFN_ERR_ARG;
     if (d->ksplit > 1) {
         const int nk_all = d->KH * d->KW * (d->Cin / BK);

@@ -82,6 +82,7 @@ _TRAIN_SLOTS = int(os.environ.get('VFN_TRAIN_SLOTS', 2))      # training plans s
 # (wino_gfx950.json: "M,cin,cout" -> 0 / 1, scripts/tune_winograd.py; shapes it lacks: >= 128 channels either side and at least
 # VFN_WINOGRAD_MIN_M output pixels), 2 = every eligible layer, 0 = off (the direct implicit GEMM everywhere)
 _WINOGRAD = os.environ.get('VFN_WINOGRAD', '1')
+_WINOGRAD_LP = os.environ.get('VFN_WINOGRAD_LP', '0') == '1'        # Winograd layers in the reduced-precision modes too (GEMMs in that mode)
 _WINOGRAD_MIN_M = int(os.environ.get('VFN_WINOGRAD_MIN_M', 10000))
 _WINO_TABLE = {}
 _WINO_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'wino_gfx950.json')
@@ -502,9 +503,9 @@ class FramePlan:
         lp = bf == 2
         if self.eng.mixed:
             f32_out = True                                    # (a consumer in another mode reads the f32 tensor)
-        if (bf == 0 and in_ld is None and (_WINOGRAD_TRAIN or not self.keep_acts) and x.shape[-1] == layer.cin and
-                self.eng.use_winograd(layer, N * H * Wd)):
-            return self._conv_winograd(lst, layer, x, out, N, H, Wd, res, relu_in, relu_out, name, out_ld, res_mod)
+        if ((bf == 0 or (_WINOGRAD_LP and not self.keep_acts and layer.cin % 64 == 0)) and in_ld is None and
+                (_WINOGRAD_TRAIN or not self.keep_acts) and x.shape[-1] == layer.cin and self.eng.use_winograd(layer, N * H * Wd)):
+            return self._conv_winograd(lst, layer, x, out, N, H, Wd, res, relu_in, relu_out, name, out_ld, res_mod, bf)
         d = ops.make_conv_desc(x, layer.w, layer.cout, layer.k, layer.k, layer.stride, layer.pad, out,
                                layer.scale, layer.shift, res, relu_in, relu_out,
                                cin=layer.cin, in_ld=in_ld if in_ld is not None else x.shape[-1],
@@ -531,7 +532,7 @@ class FramePlan:
         lst.append(Launch(ops.conv2d_launch, (d, cfg, bf), f'{name}[{d.M}x{layer.cout}x{K}]', 2.0 * d.M * layer.cout * K))
         return out
 
-    def _conv_winograd(self, lst, layer, x, out, N, H, Wd, res, relu_in, relu_out, name, out_ld, res_mod):
+    def _conv_winograd(self, lst, layer, x, out, N, H, Wd, res, relu_in, relu_out, name, out_ld, res_mod, bf=0):
         """A 3x3 / stride-1 layer as Winograd F(4x4, 3x3): input transform, the 36 transform-domain GEMMs as ONE batched-filter
         launch of the convolution kernels (tile choice from the same tables / tuner, keyed by the GEMM's shape), output transform
         with the layer's epilogue (csrc/conv_winograd.hip)."""
@@ -547,9 +548,16 @@ class FramePlan:
         V, Mb = V[:need_v].view(36 * rows, layer.cin), Mb[:need_m].view(36 * rows, layer.cout)
         lst.append(Launch(ops.winograd_input, (x, V, rows, relu_in, N, H, Wd, layer.cin, x.shape[-1]), name + '.wino_in'))
         dg = ops.make_winograd_gemm_desc(V, layer.w_wino(), Mb, rows, layer.cin, layer.cout)
-        choice = choose_cfg(dg.M, layer.cout, layer.cin, 0)
+        if bf:
+            # VFN_WINOGRAD_LP=1 (experiment, round 5): the transforms stay f32, the 36 GEMMs run in the layer's reduced-precision mode
+            # (operands rounded / split as they are staged; the f32 filter banks are converted on the fly)
+            choice = _TABLES[bf].get((dg.M, layer.cout, layer.cin)) or ((9 if rows % 128 == 0 and layer.cout >= 128 else 3), 1, 0)
+            if choice[0] >= ops.WINO_GEMM_CFG0:
+                choice = (9, 1, 0)
+        else:
+            choice = choose_cfg(dg.M, layer.cout, layer.cin, 0)
         cfg = apply_choice(dg, choice, self._ws_cur, self._cnt_cur)
-        lst.append(Launch(ops.conv2d_launch, (dg, cfg, 0), f'{name}.wino_gemm[{dg.M}x{layer.cout}x{layer.cin}]', 2.0 * dg.M * layer.cout * layer.cin))
+        lst.append(Launch(ops.conv2d_launch, (dg, cfg, bf), f'{name}.wino_gemm[{dg.M}x{layer.cout}x{layer.cin}]', 2.0 * dg.M * layer.cout * layer.cin))
         self._lp_state.pop((out.data_ptr(), tuple(out.shape)), None)
         lst.append(Launch(ops.winograd_output, (Mb, rows, out, N, H, Wd, layer.cout, layer.scale, layer.shift, res,
                                                 res.shape[-1] if res is not None else 0, res_mod, relu_out,
