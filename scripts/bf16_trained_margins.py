@@ -38,6 +38,7 @@ ap.add_argument('--size', type=int, default=400)
 ap.add_argument('--out', default=os.path.join(root, 'gpurun_out', 'r05_bf16_trained_margins.json'))
 ap.add_argument('--ckpt', default='/tmp/vfn_trained.pth')
 ap.add_argument('--skip-oracle', action='store_true')
+ap.add_argument('--only', default='', help='comma list of weights:workload pairs to evaluate, e.g. trained:C3,trained:C5_first_120 (default: all)')
 args = ap.parse_args()
 dev = torch.device('cuda', 0)
 res = {'note': __doc__.split('\n\n')[0], 'train': {}, 'eval': {}}
@@ -135,10 +136,13 @@ torch.set_num_threads(1)      # (an idle OpenMP pool spinning on the host's core
 time.sleep(2.0)
 
 # ------------------------------------------------------------------------------------------------ 3. the configurations
+WORK = {'C3': (720, 1280, 100, 5, 3, 250000), 'C5_first_120': (1080, 1920, 120, 1, 9, 2 * int(1.25 * 2 * 122 * 1620) + 4), 'C2': (480, 854, 100, 1, 1, 250000)}
+only = [x for x in args.only.split(',') if x]
 for wname, sd in (('trained', sd1), ('untrained', sd0)):
-    res['eval'][wname] = {
-        'C3': evaluate(wname + ' C3', sd, 720, 1280, 100, 5, 3),
-        'C5_first_120': evaluate(wname + ' C5', sd, 1080, 1920, 120, 1, 9, budget=2 * int(1.25 * 2 * 122 * 1620) + 4),
-        'C2': evaluate(wname + ' C2', sd, 480, 854, 100, 1, 1)}
+    res['eval'][wname] = {}
+    for cname, (H_, W_, T_, me_, seed_, budget_) in WORK.items():
+        if only and f'{wname}:{cname}' not in only:
+            continue
+        res['eval'][wname][cname] = evaluate(f'{wname} {cname}', sd, H_, W_, T_, me_, seed_, budget=budget_)
     json.dump(res, open(args.out, 'w'), indent=1)
 print('wrote', args.out)

@@ -76,7 +76,7 @@ for key, (d, p) in sorted(seen.items()):
                    'new_tf': round(fl / best[0] / 1e6, 1) if best else None})
     print(report[-1], flush=True)
     if take:
-        table[key] = (best[1], 1, 0)
+        table[key] = (best[1], 1, 0) + (tuple(old[:3]) if WHICH == 'pconv' else ())      # (pconv: the old choice stays as the fallback)
 os.makedirs('gpurun_out', exist_ok=True)
 engine.save_tuned('gpurun_out/tuned_gfx950.json', 0)
 json.dump(report, open('gpurun_out/r05_tune_%s_report.json' % ('wino_gemm' if WHICH == 'wino' else 'pconv'), 'w'), indent=1)

@@ -51,7 +51,11 @@ def _load_tuned():
             path = os.path.join(alt, os.path.basename(path))
         if os.path.isfile(path):
             for k, v in json.load(open(path)).items():
-                table[tuple(int(x) for x in k.split(','))] = (int(v[0]), int(v[1]), int(v[2]) if len(v) > 2 else 0)
+                # (cfg, ksplit, split_from) + optionally the same triple again for descriptors of this shape the first choice cannot
+                # run: a persistent 1x1 configuration (ids >= 2000) does not take the backward passes' masked data-gradient
+                # convolutions, which share the shape key -- apply_choice falls back to the second triple
+                t = (int(v[0]), int(v[1]), int(v[2]) if len(v) > 2 else 0)
+                table[tuple(int(x) for x in k.split(','))] = t + tuple(int(x) for x in v[3:6]) if len(v) >= 6 else t
 
 
 def save_tuned(path=None, mode=0):
@@ -100,8 +104,13 @@ def _tiles():
 
 def apply_choice(desc, choice, ws, counters=None):
     """Configure a conv descriptor for a (cfg, ksplit, split_from) choice; returns the cfg index."""
-    cfg, ks, split_from = choice
-    if cfg >= ops.WINO_GEMM_CFG0:                         # the persistent transform-domain GEMM: no split, no workspace
+    cfg, ks, split_from = choice[:3]
+    if cfg >= ops.PCONV_CFG0 and not ops.pconv_eligible(desc, 0):
+        # the shape's measured choice is the persistent 1x1 kernel, this descriptor (a masked data gradient, an operand image, ...)
+        # is not one it takes: the shape's second entry, else the heuristic
+        fb = tuple(choice[3:6]) if len(choice) >= 6 else choose_cfg(desc.M, desc.Cout, desc.KH * desc.KW * desc.Cin, 0, use_table=False)
+        return apply_choice(desc, fb, ws, counters)
+    if cfg >= ops.WINO_GEMM_CFG0:                         # the persistent kernels: no split, no workspace
         ops.set_splitk(desc, 1, None)
         return cfg
     if ops.conv_cfg_kind(cfg) == 2:                       # stream-K: its own workspace + counters, never a K split on top
@@ -140,13 +149,13 @@ def _scores_buffer(p, fb):
     return p._scores
 
 
-def choose_cfg(M, cout, K, mode=0):
-    """(tile config, split-K factor, first split tile): the measured table if the shape is in it, otherwise
+def choose_cfg(M, cout, K, mode=0, use_table=True):
+    """(tile config, split-K factor, first split tile [, fallback triple]): the measured table if the shape is in it, otherwise
     minimise (rounds over 256 CUs) x (tile work / efficiency), cutting K when there are too few tiles."""
     global _CFG_TILES
     key = (M, cout, K)
     table = _TABLES[mode]
-    if key in table:
+    if use_table and key in table:
         return table[key]
     _tiles()
     nk = K // (64 if mode == 1 else 32)
