@@ -167,6 +167,13 @@ int vfn_winograd_gemm_f32(const float* V, const float* U, float* Mb, int comps, 
  * epilogue from the accumulator registers (the trunk's conv1 / conv3 / downsample have 2-8 K tiles per output tile).  Products and
  * order as vfn_conv2d_nhwc_f32 without split-K.  cfg / wgs as above; taps, strides, masks, operand images, split-K: VFN_ERR_ARG. */
 int vfn_conv1x1_persistent_f32(const vfn_conv_desc* d, int cfg, int wgs, void* stream);
+/* (ABI 12) Winograd layers of the plain-bf16 mode (BASELINE configs C3 / C5; the reference itself has no reduced-precision path):
+ *   vfn_winograd_input_bf16   as vfn_winograd_input_f32 with V [36][rows_pad][C] written as bf16 (f32 transform, one round-to-nearest-even)
+ *   vfn_winograd_gemm_bf16    as vfn_winograd_gemm_f32 on bf16 V and bf16 U [36][cout_pad][C] (v_mfma_f32_32x32x16_bf16, f32 accumulate), M in f32
+ * C a multiple of 64; the output transform is vfn_winograd_output_f32. */
+int vfn_winograd_input_bf16(const float* x, int N, int H, int W, int C, int ld_x, int relu, void* V, int rows_pad, void* stream);
+int vfn_winograd_gemm_bf16(const void* V, const void* U, float* Mb, int comps, int rows_pad, int C, int Cout, int cout_pad, int cfg,
+                           int wgs, void* stream);
 int vfn_winograd_gy_f32(const float* gy, int N, int H, int W, int C, int ld, float* Z, int rows_pad, void* stream);
 int vfn_winograd_dw_f32(const float* dU, int Cout, int Cin, const float* rowscale, float* dw, int accumulate, void* stream);
 

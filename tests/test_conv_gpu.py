@@ -393,3 +393,37 @@ def test_persistent_1x1_convolution_matches_the_tiled_kernel(gpu, case):
     d = ops.make_conv_desc(xd, ops.pad_rows(torch.randn(Cout, 9 * Cin, device=gpu)), Cout, 3, 3, 1, 1, torch.empty(N, H, W, Cout, device=gpu), sc, sh, None, False, False)
     with pytest.raises(RuntimeError):
         ops.conv2d_launch(d, ops.pconv_cfg(3, 512), 0)
+
+
+def test_winograd_layers_of_the_plain_bf16_mode(gpu):
+    """Round 5: in the plain-bf16 mode (BASELINE configs C3 / C5) a Winograd layer writes V as bf16 from the input transform and multiplies
+    it with bf16 filter banks in the persistent GEMM (f32 accumulate).  Pieces against what they claim: V is exactly the f32 transform
+    rounded once (RNE); the GEMM equals the float64 product of exactly those bf16 operands up to the f32 summation order; and the whole
+    layer stays within bf16's operand resolution of the float64 convolution."""
+    from vfloodnet_amd import ops
+    g = torch.Generator().manual_seed(5)
+    N, H, W, Cin, Cout = 2, 30, 54, 256, 192
+    x = torch.randn(N, H, W, Cin, generator=g).to(gpu)
+    w = (torch.randn(Cout, Cin, 3, 3, generator=g) / (Cin * 9) ** 0.5)
+    rows = ops.winograd_rows(N, H, W)
+    Vf = torch.zeros(36 * rows, Cin, device=gpu)
+    Vh = torch.zeros(36 * rows, Cin, device=gpu, dtype=torch.bfloat16)
+    ops.winograd_input(x, Vf, rows, True)
+    ops.winograd_input(x, Vh, rows, True)
+    torch.cuda.synchronize()
+    assert torch.equal(Vh, Vf.to(torch.bfloat16))
+    U = ops.pack_winograd_weight_bf16(w).to(gpu)
+    cp = U.shape[0] // 36
+    ref = torch.einsum('xrc,xoc->xro', Vh.double().view(36, rows, Cin), U.double().view(36, cp, Cin)[:, :Cout]).reshape(36 * rows, Cout)
+    for tc in range(8):
+        for wgs in (256, 512):
+            Mb = torch.full((36 * rows, Cout), float('nan'), device=gpu)
+            ops.conv2d_launch(ops.make_winograd_gemm_desc(Vh, U, Mb, rows, Cin, Cout), ops.wino_gemm_cfg(tc, wgs), 1)
+            torch.cuda.synchronize()
+            err = (Mb.double() - ref).abs().max().item()
+            assert err < 2e-4 * ref.abs().max().item(), (tc, wgs, err)
+    out = torch.empty(N, H, W, Cout, device=gpu)
+    ops.winograd_output(Mb, rows, out, N, H, W, Cout, None, None, None, 0, 0, False)
+    full = torch.nn.functional.conv2d(torch.relu(x).permute(0, 3, 1, 2).double().cpu(), w.double(), padding=1).permute(0, 2, 3, 1)
+    rel = (out.cpu().double() - full).abs().max().item() / full.abs().max().item()
+    assert rel < 3e-2, rel                                  # 8-bit operands through the transforms: per cent level, as the direct bf16 kernel

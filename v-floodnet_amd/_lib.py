@@ -191,6 +191,8 @@ SIGNATURES = {
     'vfn_winograd_gy_f32': [_p, _i, _i, _i, _i, _i, _p, _i, _p],
     'vfn_winograd_gemm_f32': [_p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p],
     'vfn_conv1x1_persistent_f32': [_p, _i, _i, _p],
+    'vfn_winograd_input_bf16': [_p, _i, _i, _i, _i, _i, _i, _p, _i, _p],
+    'vfn_winograd_gemm_bf16': [_p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p],
     'vfn_winograd_dw_f32': [_p, _i, _i, _p, _p, _i, _p],
     'vfn_winograd_output_masked_f32': [_p, _i, _i, _i, _i, _i, _p, _i, _p, _i, _i, _p, _i, _p],
     'vfn_scatter_mean_checked_f32': [_p, _ll, _ll, _p, _ll, _i, _p, _ll, _ll, _i, _ll, _p, _p],

@@ -32,6 +32,8 @@ __device__ __forceinline__ void bt6(const f32x4 (&v)[6], f32x4 (&t)[6]) {
 // image (the hardware returns zeros), so the 36 loads leave back to back and land together.  (The first form tested the bounds
 // per tap: hipcc turned each test into an exec-masked branch with the ReLU behind it -- load, s_waitcnt vmcnt(0), next load: 36
 // dependent round trips per thread, 3.6-4.5 TB/s on a kernel that only moves bytes.)
+// LPOUT (round 5, the plain-bf16 mode): V is written as bf16 (RNE) -- the operand the reduced-precision GEMM multiplies -- half the bytes
+template <bool LPOUT = false>
 __global__ __launch_bounds__(256)
 void winograd_input_kernel(const float* __restrict__ x, int N, int H, int W, int C, int ld_x, int relu, float* __restrict__ V,
                            int rows_pad) {
@@ -77,8 +79,14 @@ void winograd_input_kernel(const float* __restrict__ x, int N, int H, int W, int
             f32x4 t[6];
             bt6(d[a], t);
 #pragma unroll
-            for (int b = 0; b < 6; ++b)
-                *reinterpret_cast<f32x4*>(V + ((size_t)(a * 6 + b) * rows_pad + tile) * C + c4 * 4) = t[b];
+            for (int b = 0; b < 6; ++b) {
+                if constexpr (LPOUT) {
+                    const vfn_bf16x4 h = {(__bf16)t[b][0], (__bf16)t[b][1], (__bf16)t[b][2], (__bf16)t[b][3]};
+                    *reinterpret_cast<vfn_bf16x4*>(reinterpret_cast<__bf16*>(V) + ((size_t)(a * 6 + b) * rows_pad + tile) * C + c4 * 4) = h;
+                } else {
+                    *reinterpret_cast<f32x4*>(V + ((size_t)(a * 6 + b) * rows_pad + tile) * C + c4 * 4) = t[b];
+                }
+            }
         }
     }
 }
@@ -300,10 +308,15 @@ struct wino_gemm_args {
     const float* res;
 };
 
-template <int BM, int BN, int WM, int WN, int PD, bool CONV = false>
+// LP: both operands are bf16 in memory (V from winograd_input_kernel<true>, U packed by the host): a K tile is 64 channels -- the same
+// 128-byte LDS rows, the same staging -- and a 16-byte fragment is one v_mfma_f32_32x32x16_bf16 (k = 16 kk + 8 h .. + 7), f32 accumulate
+template <int BM, int BN, int WM, int WN, int PD, bool CONV = false, bool LP = false>
 __global__ __launch_bounds__(WM * WN * 64)
 void wino_gemm_kernel(const wino_gemm_args p) {
-    constexpr int BK = 32;
+    static_assert(!(CONV && LP), "the reduced-precision form is the transform-domain GEMM only");
+    constexpr int BK = 32;                               // floats per LDS row (128 bytes = 32 f32 / 64 bf16)
+    constexpr int KT = LP ? 64 : 32;                     // K elements per tile
+    constexpr int ES = LP ? 2 : 4;                       // bytes per operand element
     constexpr int NT = WM * WN * 64;
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
     constexpr int AC = BM * 8 / NT, BC = BN * 8 / NT, RSTEP = NT / 8;
@@ -325,19 +338,19 @@ void wino_gemm_kernel(const wino_gemm_args p) {
     const int u_end = u_begin + q + (xcd < r8 ? 1 : 0);
     const int first = u_begin + loc;
     const int n_units = first < u_end ? (u_end - first + gx - 1) / gx : 0;
-    const int nk = p.C / BK;
+    const int nk = p.C / KT;
     const int T = n_units * nk;
     if (T == 0) return;
 
     const int c16 = tid & 7, r0 = tid >> 3;
     const int a_ld = CONV ? p.a_ld : p.C;
-    const __amdgpu_buffer_rsrc_t rsV = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.V), 0, (int)((size_t)p.comps * p.rows_pad * a_ld * 4), 0x00020000);
-    const __amdgpu_buffer_rsrc_t rsU = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.U), 0, (int)((size_t)p.comps * p.cout_pad * p.C * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsV = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.V), 0, (int)((size_t)p.comps * p.rows_pad * a_ld * ES), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsU = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.U), 0, (int)((size_t)p.comps * p.cout_pad * p.C * ES), 0x00020000);
     int a_thr[AC], b_thr[BC];
 #pragma unroll
-    for (int j = 0; j < AC; ++j) a_thr[j] = ((r0 + j * RSTEP) * a_ld + c16 * 4) * 4;
+    for (int j = 0; j < AC; ++j) a_thr[j] = (r0 + j * RSTEP) * a_ld * ES + c16 * 16;
 #pragma unroll
-    for (int j = 0; j < BC; ++j) b_thr[j] = ((r0 + j * RSTEP) * p.C + c16 * 4) * 4;
+    for (int j = 0; j < BC; ++j) b_thr[j] = (r0 + j * RSTEP) * p.C * ES + c16 * 16;
 
     // the tile being requested: (unit, K tile) and its operand bases (wave-uniform)
     int lu = 0, lkt = 0, la_base = 0, lb_base = 0;
@@ -346,8 +359,8 @@ void wino_gemm_kernel(const wino_gemm_args p) {
         const int u = first + ui * gx;
         const int xi = u / per, rem = u - xi * per;
         const int mt = rem / p.ntiles, nt = rem - mt * p.ntiles;
-        a_base = (xi * p.rows_pad + mt * BM) * a_ld * 4;
-        b_base = (xi * p.cout_pad + nt * BN) * p.C * 4;
+        a_base = (xi * p.rows_pad + mt * BM) * a_ld * ES;
+        b_base = (xi * p.cout_pad + nt * BN) * p.C * ES;
         o_base = CONV ? (size_t)mt * BM : ((size_t)xi * p.rows_pad + mt * BM) * p.Cout + nt * BN;      // (CONV: the first row of the tile)
         if (n0) *n0 = nt * BN;
     };
@@ -355,7 +368,7 @@ void wino_gemm_kernel(const wino_gemm_args p) {
     unit_bases(0, la_base, lb_base, o_dummy);
     f32x4 ra[PD][AC], rb[PD][BC];
     auto request = [&](int slot) {                         // global loads of the next tile in line into staging slot `slot`
-        const int koff = lkt * BK * 4;
+        const int koff = lkt * 128;                        // (a K tile is 128 bytes of every operand row in either arithmetic)
 #pragma unroll
         for (int j = 0; j < AC; ++j)
             ra[slot][j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsV, a_thr[j], la_base + koff, 0));
@@ -438,6 +451,15 @@ void wino_gemm_kernel(const wino_gemm_args p) {
                 if (kk == 1 && more_req) request(uu);
                 if (PD == 1 && kk == 3 && more) stage(buf ^ 1, 0);
                 if (kk + 1 < 4) read_frags(kk + 1, fa[(kk + 1) & 1], fb[(kk + 1) & 1]);
+                if constexpr (LP) {
+                    typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_;
+#pragma unroll
+                    for (int i = 0; i < TM; ++i)
+#pragma unroll
+                        for (int j = 0; j < TN; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_, fa[kk & 1][i]), __builtin_bit_cast(bf16x8_, fb[kk & 1][j]),
+                                                                                acc[i][j], 0, 0, 0);
+                } else {
 #pragma unroll
                 for (int e = 0; e < 4; ++e)
 #pragma unroll
@@ -445,6 +467,7 @@ void wino_gemm_kernel(const wino_gemm_args p) {
 #pragma unroll
                         for (int j = 0; j < TN; ++j)
                             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[kk & 1][i][e], fb[kk & 1][j][e], acc[i][j], 0, 0, 0);
+                }
             }
             if (++ckt == nk) {
                 // the unit is complete: lane = filter column (lane & 31), registers = rows (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
@@ -514,12 +537,12 @@ void wino_gemm_kernel(const wino_gemm_args p) {
     }
 }
 
-template <int BM, int BN, int WM, int WN, int PD, bool CONV = false>
+template <int BM, int BN, int WM, int WN, int PD, bool CONV = false, bool LP = false>
 int launch_wino_gemm(const wino_gemm_args& a, int wgs, hipStream_t s) {
     constexpr size_t lds = 2 * (size_t)(BM + BN) * 32 * sizeof(float);
     static bool attr_set = false;
     if (!attr_set && lds > 64 * 1024) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&wino_gemm_kernel<BM, BN, WM, WN, PD, CONV>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&wino_gemm_kernel<BM, BN, WM, WN, PD, CONV, LP>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = true;
     }
     wino_gemm_args p = a;
@@ -529,7 +552,7 @@ int launch_wino_gemm(const wino_gemm_args& a, int wgs, hipStream_t s) {
     int grid = wgs > 0 ? wgs : 512;
     if (grid > total) grid = total;
     grid = (grid + 7) / 8 * 8;                              // (the kernel deals units to blockIdx & 7 = XCD, blockIdx >> 3 = slot)
-    hipLaunchKernelGGL((wino_gemm_kernel<BM, BN, WM, WN, PD, CONV>), dim3(grid), dim3(WM * WN * 64), lds, s, p);
+    hipLaunchKernelGGL((wino_gemm_kernel<BM, BN, WM, WN, PD, CONV, LP>), dim3(grid), dim3(WM * WN * 64), lds, s, p);
     return vfn_check_launch();
 }
 
@@ -552,7 +575,7 @@ extern "C" int vfn_winograd_input_f32(const float* x, int N, int H, int W, int C
     if (!x || !V || N < 1 || H < 1 || W < 1 || C < 4 || C % 4 || ld_x < C || ld_x % 4 || rows_pad < vfn_winograd_tiles(N, H, W)) return VFN_ERR_ARG;
     const long long total = (long long)vfn_winograd_tiles(N, H, W) * (C / 4);
     if (!tensors_fit_32bit(N, H, W, ld_x, 0, 0, 0)) return VFN_ERR_ARG;
-    hipLaunchKernelGGL(winograd_input_kernel, dim3(grid_of(total)), dim3(256), 0, (hipStream_t)stream, x, N, H, W, C, ld_x, relu, V, rows_pad);
+    hipLaunchKernelGGL(winograd_input_kernel<false>, dim3(grid_of(total)), dim3(256), 0, (hipStream_t)stream, x, N, H, W, C, ld_x, relu, V, rows_pad);
     return vfn_check_launch();
 }
 
@@ -652,6 +675,42 @@ extern "C" int vfn_conv1x1_persistent_f32(const vfn_conv_desc* d, int cfg, int w
         case 5: return launch_wino_gemm<64, 128, 2, 4, 2, true>(a, wgs, s);
         case 6: return launch_wino_gemm<128, 64, 4, 2, 2, true>(a, wgs, s);
         case 7: return launch_wino_gemm<64, 64, 2, 2, 2, true>(a, wgs, s);
+    }
+    return VFN_ERR_ARG;
+}
+
+// (ABI 12) the plain-bf16 mode's Winograd layers (BASELINE configs C3 / C5): the input transform writes V as bf16 (computed in f32, rounded to
+// nearest-even once -- the rounding the bf16 convolution applies to its operands as it stages them), the filter banks U are bf16 (packed by
+// the host from the float64 transform), the persistent GEMM multiplies them on v_mfma_f32_32x32x16_bf16 with f32 accumulation and writes M in
+// f32 for vfn_winograd_output_f32.  C a multiple of 64.
+extern "C" int vfn_winograd_input_bf16(const float* x, int N, int H, int W, int C, int ld_x, int relu, void* V, int rows_pad, void* stream) {
+    if (!x || !V || N < 1 || H < 1 || W < 1 || C < 4 || C % 4 || ld_x < C || ld_x % 4 || rows_pad < vfn_winograd_tiles(N, H, W)) return VFN_ERR_ARG;
+    const long long total = (long long)vfn_winograd_tiles(N, H, W) * (C / 4);
+    if (!tensors_fit_32bit(N, H, W, ld_x, 0, 0, 0)) return VFN_ERR_ARG;
+    hipLaunchKernelGGL(winograd_input_kernel<true>, dim3(grid_of(total)), dim3(256), 0, (hipStream_t)stream, x, N, H, W, C, ld_x, relu,
+                       reinterpret_cast<float*>(V), rows_pad);
+    return vfn_check_launch();
+}
+
+extern "C" int vfn_winograd_gemm_bf16(const void* V, const void* U, float* Mb, int comps, int rows_pad, int C, int Cout, int cout_pad, int cfg,
+                                      int wgs, void* stream) {
+    if (!V || !U || !Mb || comps < 1 || rows_pad < 1 || C < 64 || C % 64 || Cout < 1 || cout_pad < Cout || cfg < 0 || cfg > 7) return VFN_ERR_ARG;
+    static const int bm[4] = {128, 64, 128, 64}, bn[4] = {128, 128, 64, 64};
+    const int tc = cfg & 3;
+    if (rows_pad % bm[tc] || cout_pad < (Cout + bn[tc] - 1) / bn[tc] * bn[tc]) return VFN_ERR_ARG;
+    if ((long long)comps * rows_pad * C * 2 >= 0x7fffff00LL || (long long)comps * cout_pad * C * 2 >= 0x7fffff00LL) return VFN_ERR_ARG;
+    wino_gemm_args a{reinterpret_cast<const float*>(V), reinterpret_cast<const float*>(U), Mb, comps, rows_pad, C, Cout, cout_pad, 0, 0, 0, 0, 0, 0, 0, 0,
+                     nullptr, nullptr, nullptr};
+    hipStream_t s = (hipStream_t)stream;
+    switch (cfg) {
+        case 0: return launch_wino_gemm<128, 128, 4, 2, 1, false, true>(a, wgs, s);
+        case 1: return launch_wino_gemm<64, 128, 2, 4, 1, false, true>(a, wgs, s);
+        case 2: return launch_wino_gemm<128, 64, 4, 2, 1, false, true>(a, wgs, s);
+        case 3: return launch_wino_gemm<64, 64, 2, 2, 1, false, true>(a, wgs, s);
+        case 4: return launch_wino_gemm<128, 128, 4, 2, 2, false, true>(a, wgs, s);
+        case 5: return launch_wino_gemm<64, 128, 2, 4, 2, false, true>(a, wgs, s);
+        case 6: return launch_wino_gemm<128, 64, 4, 2, 2, false, true>(a, wgs, s);
+        case 7: return launch_wino_gemm<64, 64, 2, 2, 2, false, true>(a, wgs, s);
     }
     return VFN_ERR_ARG;
 }

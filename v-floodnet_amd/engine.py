@@ -86,7 +86,7 @@ _TRAIN_SLOTS = int(os.environ.get('VFN_TRAIN_SLOTS', 2))      # training plans s
 # (wino_gfx950.json: "M,cin,cout" -> 0 / 1, scripts/tune_winograd.py; shapes it lacks: >= 128 channels either side and at least
 # VFN_WINOGRAD_MIN_M output pixels), 2 = every eligible layer, 0 = off (the direct implicit GEMM everywhere)
 _WINOGRAD = os.environ.get('VFN_WINOGRAD', '1')
-_WINOGRAD_LP = os.environ.get('VFN_WINOGRAD_LP', '0') == '1'        # Winograd layers in the reduced-precision modes too (GEMMs in that mode)
+_WINOGRAD_LP = os.environ.get('VFN_WINOGRAD_LP', '1') == '1'        # Winograd layers in the plain-bf16 mode too (bf16 V / U, vfn_winograd_gemm_bf16)
 _WINOGRAD_MIN_M = int(os.environ.get('VFN_WINOGRAD_MIN_M', 10000))
 _WINO_TABLE = {}
 _WINO_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'wino_gfx950.json')
@@ -303,6 +303,9 @@ class ConvLayer:
                     continue
                 w = self.w[:self.cout].view(self.cout, 3, 3, self.cin).permute(0, 3, 1, 2)
                 t.copy_(ops.pack_winograd_weight(w).to(t.device))
+            elif mode == 'wino_bf16':
+                w = self.w[:self.cout].view(self.cout, 3, 3, self.cin).permute(0, 3, 1, 2)
+                t.copy_(ops.pack_winograd_weight_bf16(w).to(t.device))
             else:
                 new = ops.pack_weights_lp(self.w, mode)
                 t.copy_(new)
@@ -325,6 +328,14 @@ class ConvLayer:
                     reg.add_filter(weight, self._w_lp['wino'], WINO, cin=self.cin, cin_off=cin_off, dst_ld=self.cin, dst_row0=row0,
                                    cout_ld=self._w_lp['wino'].shape[0] // 36)
         return self._w_lp['wino']
+
+    def w_wino_bf16(self):
+        """... rounded once to bf16: the filter operand of the plain-bf16 mode's Winograd layers (vfn_winograd_gemm_bf16)."""
+        if 'wino_bf16' not in self._w_lp:
+            assert self.k == 3
+            w = self.w[:self.cout].view(self.cout, 3, 3, self.cin).permute(0, 3, 1, 2)
+            self._w_lp['wino_bf16'] = ops.pack_winograd_weight_bf16(w).to(self.w.device)
+        return self._w_lp['wino_bf16']
 
 
 class Pred2Layer:
@@ -512,7 +523,7 @@ class FramePlan:
         lp = bf == 2
         if self.eng.mixed:
             f32_out = True                                    # (a consumer in another mode reads the f32 tensor)
-        if ((bf == 0 or (_WINOGRAD_LP and not self.keep_acts and layer.cin % 64 == 0)) and in_ld is None and
+        if ((bf == 0 or (bf == 1 and _WINOGRAD_LP and not self.keep_acts and layer.cin % 64 == 0)) and in_ld is None and
                 (_WINOGRAD_TRAIN or not self.keep_acts) and x.shape[-1] == layer.cin and self.eng.use_winograd(layer, N * H * Wd)):
             return self._conv_winograd(lst, layer, x, out, N, H, Wd, res, relu_in, relu_out, name, out_ld, res_mod, bf)
         d = ops.make_conv_desc(x, layer.w, layer.cout, layer.k, layer.k, layer.stride, layer.pad, out,
@@ -554,15 +565,22 @@ class FramePlan:
             V = torch.zeros(max(need_v, V.numel() if V is not None else 0), device=dev)
             Mb = torch.empty(max(need_m, Mb.numel() if Mb is not None else 0), device=dev)
             self._wino[key] = (V, Mb)                      # (launches built earlier keep their own, smaller buffers alive)
-        V, Mb = V[:need_v].view(36 * rows, layer.cin), Mb[:need_m].view(36 * rows, layer.cout)
+        Mb = Mb[:need_m].view(36 * rows, layer.cout)
+        if bf == 1:
+            # the plain-bf16 mode (round 5): V is written as bf16 by the input transform (f32 arithmetic, one rounding -- what the bf16
+            # convolution does to its operands as it stages them), the filter banks are bf16, the persistent GEMM accumulates in f32
+            V = V.view(torch.bfloat16)[:need_v].view(36 * rows, layer.cin)
+            U = layer.w_wino_bf16()
+        else:
+            V = V[:need_v].view(36 * rows, layer.cin)
+            U = layer.w_wino()
         lst.append(Launch(ops.winograd_input, (x, V, rows, relu_in, N, H, Wd, layer.cin, x.shape[-1]), name + '.wino_in'))
-        dg = ops.make_winograd_gemm_desc(V, layer.w_wino(), Mb, rows, layer.cin, layer.cout)
+        dg = ops.make_winograd_gemm_desc(V, U, Mb, rows, layer.cin, layer.cout)
         if bf:
-            # VFN_WINOGRAD_LP=1 (experiment, round 5): the transforms stay f32, the 36 GEMMs run in the layer's reduced-precision mode
-            # (operands rounded / split as they are staged; the f32 filter banks are converted on the fly)
-            choice = _TABLES[bf].get((dg.M, layer.cout, layer.cin)) or ((9 if rows % 128 == 0 and layer.cout >= 128 else 3), 1, 0)
-            if choice[0] >= ops.WINO_GEMM_CFG0:
-                choice = (9, 1, 0)
+            choice = _TABLES[bf].get((dg.M, layer.cout, layer.cin))
+            if choice is None or choice[0] < ops.WINO_GEMM_CFG0:
+                tc = 5 if rows % 64 == 0 and layer.cout >= 128 and rows >= 1024 else 3
+                choice = (ops.wino_gemm_cfg(tc, 512), 1, 0)
         else:
             choice = choose_cfg(dg.M, layer.cout, layer.cin, 0)
         cfg = apply_choice(dg, choice, self._ws_cur, self._cnt_cur)

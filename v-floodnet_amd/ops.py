@@ -253,8 +253,12 @@ def conv2d_launch(desc, cfg, mode=0):
         return
     if cfg >= WINO_GEMM_CFG0:
         c, rows = cfg - WINO_GEMM_CFG0, desc.w_batch_rows
+        if mode == 1 and rows > 0:           # plain bf16: the descriptor's `inp` / `w` point at bf16 V / bf16 U (make_winograd_gemm_desc on them)
+            check(_lib.lib().vfn_winograd_gemm_bf16(desc.inp, desc.w, desc.out, desc.M // rows, rows, desc.Cin, desc.Cout, desc.cout_pad, c & 7,
+                                                    (c >> 3) * 128, stream()), 'vfn_winograd_gemm_bf16')
+            return
         if mode != 0 or rows <= 0:
-            raise RuntimeError('the persistent GEMM takes an f32 Winograd-domain descriptor (w_batch_rows)')
+            raise RuntimeError('the persistent GEMM takes an f32 (or plain-bf16) Winograd-domain descriptor (w_batch_rows)')
         check(_lib.lib().vfn_winograd_gemm_f32(desc.inp, desc.w, desc.out, desc.M // rows, rows, desc.Cin, desc.Cout, desc.cout_pad, c & 7,
                                                (c >> 3) * 128, stream()), 'vfn_winograd_gemm_f32')
         return
@@ -268,7 +272,7 @@ def conv_cfg_name(cfg, mode=0, _cache={}):
     if cfg >= WINO_GEMM_CFG0:
         c = (cfg - (PCONV_CFG0 if cfg >= PCONV_CFG0 else WINO_GEMM_CFG0)) & 7
         bm, bn, wm, wn = WINO_GEMM_TILES[c & 3]
-        return f'wino_gemm_kernel<{bm}, {bn}, {wm}, {wn}, {1 + (c >> 2)}, {"true" if cfg >= PCONV_CFG0 else "false"}>'
+        return f'wino_gemm_kernel<{bm}, {bn}, {wm}, {wn}, {1 + (c >> 2)}, {"true" if cfg >= PCONV_CFG0 else "false"}, {"true" if mode == 1 else "false"}>'
     if mode not in _cache:
         _cache[mode] = conv_cfg_names(mode)
     return _cache[mode][cfg]
@@ -317,11 +321,19 @@ def winograd_rows(N, H, W):
     return (t + WINO_ROW_MULT - 1) // WINO_ROW_MULT * WINO_ROW_MULT
 
 
+def pack_winograd_weight_bf16(w):
+    """The 36 transform-domain filter banks (pack_winograd_weight: float64 transform) rounded once to bf16: [36 * cout_pad, Cin] bf16."""
+    return pack_winograd_weight(w).to(torch.bfloat16).contiguous()
+
+
 def winograd_input(x, V, rows_pad, relu, N=None, H=None, W=None, cin=None, ld_x=None):
     if N is None:
         N, H, W = x.shape[0], x.shape[1], x.shape[2]
     cin = cin if cin is not None else x.shape[-1]
     ld_x = ld_x if ld_x is not None else x.shape[-1]
+    if V.dtype == torch.bfloat16:            # the plain-bf16 mode: V written as bf16
+        check(_lib.lib().vfn_winograd_input_bf16(ptr(x), N, H, W, cin, ld_x, int(relu), ptr(V), rows_pad, stream()), 'vfn_winograd_input_bf16')
+        return
     check(_lib.lib().vfn_winograd_input_f32(ptr(x), N, H, W, cin, ld_x, int(relu), ptr(V), rows_pad, stream()), 'vfn_winograd_input_f32')
 
 
