@@ -204,6 +204,16 @@ def tune_desc(d, bf, ws, cnt, iters=3, cfg_filter=None, allow_split=True):
         return best_ms
 
     best, best_t = None, None
+    if d.w_batch_rows > 0 and bf == 1:
+        # a transform-domain GEMM of the plain-bf16 mode: its operands ARE bf16 in memory (vfn_winograd_input_bf16), which only the
+        # persistent kernel reads -- the tiled bf16 kernels would take them for f32 tensors
+        for c in ops.wino_gemm_cfg_options(d.w_batch_rows, d.Cout):
+            if cfg_filter is not None and not cfg_filter(key, c):
+                continue
+            t = timeit(c)
+            if best_t is None or t < best_t:
+                best, best_t = (c, 1, 0), t
+        return best
     if d.w_batch_rows > 0 and bf == 0 and d.M // d.w_batch_rows * d.w_batch_rows == d.M:
         # a Winograd-domain GEMM: the persistent kernel's configurations compete with the batched-filter launches below
         for c in ops.wino_gemm_cfg_options(d.w_batch_rows, d.Cout):
