@@ -47,7 +47,7 @@ PEAKS = {'fp32': PEAK_F32_MATRIX_TFLOPS, 'bf16': PEAK_BF16_MATRIX_TFLOPS, 'bf16x
 DTYPES = {'fp32': 'f32', 'bf16': 'bf16 operands, f32 accumulate/storage', 'bf16x3': 'bf16x3 (split-bf16 operands, 3 MFMAs per product), f32 accumulate/storage'}
 WORKLOADS = {'C2': (480, 854, 1), 'C3': (720, 1280, 5), 'C5': (1080, 1920, 1)}      # H0, W0, memorize every n-th frame
 CLIP_FRAMES = 100                     # BASELINE.json configs[1]: "100-frame 480p synthetic clip"
-PROFILE_ROUND = 'r04'
+PROFILE_ROUND = 'r05'
 
 
 def miou(a, b):
