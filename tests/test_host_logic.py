@@ -86,6 +86,41 @@ def test_nsplit_and_cfg_choices():
     engine._load_tuned()
 
 
+def test_persistent_choices_fall_back_for_descriptors_they_do_not_take():
+    """Round 5: a shape's measured choice may be the persistent 1x1 kernel (configuration ids >= 2000), which does not implement the
+    backward passes' ReLU masks, operand images or taps -- and the table is keyed by shape alone.  ``apply_choice`` must hand such a
+    descriptor the shape's second entry (or the heuristic), never the persistent id; every persistent 1x1 entry of the shipped table
+    carries that second entry; the ids' encoding round-trips."""
+    import json
+    from vfloodnet_amd import engine, ops
+    from vfloodnet_amd._lib import ConvDesc
+    d = ConvDesc()
+    d.KH = d.KW = d.stride = 1
+    d.pad, d.Cin, d.in_ld, d.Cout, d.cout_pad, d.out_ld, d.M, d.N, d.H, d.W = 0, 256, 256, 64, 256, 64, 51840, 2, 120, 216
+    assert ops.pconv_eligible(d, 0) and not ops.pconv_eligible(d, 1)
+    pc = ops.pconv_cfg(5, 512)
+    assert pc == 2000 + 5 + 8 * 4 and ops.conv_cfg_name(pc) == 'wino_gemm_kernel<64, 128, 2, 4, 2, true, false>'
+    assert ops.conv_cfg_name(ops.wino_gemm_cfg(2, 768), 1) == 'wino_gemm_kernel<128, 64, 4, 2, 1, false, true>'
+    assert engine.apply_choice(d, (pc, 1, 0, 10, 1, 0), None) == pc             # eligible: the persistent kernel
+    d.mask, d.mask_ld = 4096, 256                                              # a masked data gradient of the same shape
+    assert not ops.pconv_eligible(d, 0)
+    assert engine.apply_choice(d, (pc, 1, 0, 10, 1, 0), None) == 10            # the shape's fallback entry
+    assert engine.apply_choice(d, (pc, 1, 0), None) < ops.WINO_GEMM_CFG0       # none recorded: the heuristic
+    d.mask, d.KH, d.KW, d.pad = None, 3, 3, 1
+    assert not ops.pconv_eligible(d, 0)
+    table = json.load(open(engine._TUNED_PATH))
+    n = 0
+    for k, v in table.items():
+        if v[0] >= ops.PCONV_CFG0:
+            n += 1
+            assert len(v) == 6 and v[3] < ops.WINO_GEMM_CFG0, (k, v)
+        elif v[0] >= ops.WINO_GEMM_CFG0:
+            assert int(k.split(',')[0]) % 36 == 0, (k, v)                       # transform-domain GEMM shapes only (36 components)
+    assert n >= 20, n
+    for k, v in json.load(open(engine._TUNED_BF16_PATH)).items():
+        assert v[0] < ops.PCONV_CFG0                                           # (the bf16 table: persistent ids for the Winograd GEMMs only)
+
+
 def test_video_ds_and_palette(tmp_path):
     from PIL import Image
     from vfloodnet_amd.dataset import Video_DS, to_onehot
