@@ -89,9 +89,12 @@ _WINOGRAD = os.environ.get('VFN_WINOGRAD', '1')
 _WINOGRAD_LP = os.environ.get('VFN_WINOGRAD_LP', '1') == '1'        # Winograd layers in the plain-bf16 mode too (bf16 V / U, vfn_winograd_gemm_bf16)
 _WINOGRAD_MIN_M = int(os.environ.get('VFN_WINOGRAD_MIN_M', 10000))
 _WINO_TABLE = {}
+_WINO_TABLE_BF16 = {}                 # the plain-bf16 mode's own decisions (its direct kernels are faster, its transforms the same)
 _WINO_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'wino_gfx950.json')
-if os.path.isfile(_WINO_PATH) and os.environ.get('VFN_IGNORE_TUNED') != '1':
-    _WINO_TABLE = {tuple(int(x) for x in k.split(',')): int(v) for k, v in __import__('json').load(open(_WINO_PATH)).items()}
+if os.environ.get('VFN_IGNORE_TUNED') != '1':
+    for _path, _tab in ((_WINO_PATH, _WINO_TABLE), (_WINO_PATH.replace('.json', '_bf16.json'), _WINO_TABLE_BF16)):
+        if os.path.isfile(_path):
+            _tab.update({tuple(int(x) for x in k.split(',')): int(v) for k, v in __import__('json').load(open(_path)).items()})
 _INLAUNCH_SPLITK = __import__('os').environ.get('VFN_INLAUNCH_SPLITK', '1') == '1'
 
 
@@ -534,7 +537,7 @@ class FramePlan:
         if self.eng.mixed:
             f32_out = True                                    # (a consumer in another mode reads the f32 tensor)
         if ((bf == 0 or (bf == 1 and _WINOGRAD_LP and not self.keep_acts and layer.cin % 64 == 0)) and in_ld is None and
-                (_WINOGRAD_TRAIN or not self.keep_acts) and x.shape[-1] == layer.cin and self.eng.use_winograd(layer, N * H * Wd)):
+                (_WINOGRAD_TRAIN or not self.keep_acts) and x.shape[-1] == layer.cin and self.eng.use_winograd(layer, N * H * Wd, bf)):
             return self._conv_winograd(lst, layer, x, out, N, H, Wd, res, relu_in, relu_out, name, out_ld, res_mod, bf)
         d = ops.make_conv_desc(x, layer.w, layer.cout, layer.k, layer.k, layer.stride, layer.pad, out,
                                layer.scale, layer.shift, res, relu_in, relu_out,
@@ -843,15 +846,18 @@ class Engine:
         self._backward.reset()
         return self._backward
 
-    def use_winograd(self, layer, M):
-        """Winograd F(4x4, 3x3) for this layer (M = N * H * W output pixels)?  See _WINOGRAD above."""
+    def use_winograd(self, layer, M, bf=0):
+        """Winograd F(4x4, 3x3) for this layer (M = N * H * W output pixels)?  See _WINOGRAD above.  ``bf`` = 1: the plain-bf16 mode's
+        table where it has the shape (else the f32 one's answer)."""
         if _WINOGRAD == '0' or getattr(layer, 'k', 0) != 3 or layer.stride != 1 or layer.pad != 1:
             return False
         if layer.cin % 32 or layer.cout % 4 or layer.cout < 32:
             return False
         if _WINOGRAD == '2':
             return True
-        hit = _WINO_TABLE.get((M, layer.cin, layer.cout))
+        hit = (_WINO_TABLE_BF16.get((M, layer.cin, layer.cout)) if bf == 1 else None)
+        if hit is None:
+            hit = _WINO_TABLE.get((M, layer.cin, layer.cout))
         if hit is not None:
             return bool(hit)
         return layer.cin >= 128 and layer.cout >= 128 and M >= _WINOGRAD_MIN_M
