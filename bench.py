@@ -646,7 +646,7 @@ def main(argv=None):
                               'frames_per_s': round(1e3 * blk / sum(ms_blk), 2)})
         out['bank_curve'] = {'block_frames': blk, 'points': curve,
                              'note': 'host wall between step completions, this rank; sampled frames (events around every launch) included'}
-    print(json.dumps(out))
+    print(json.dumps(out), flush=True)
     if os.environ.get('VFN_BENCH_DUMP'):            # per-step host times of the whole run (diagnostics)
         with open(os.environ['VFN_BENCH_DUMP'], 'w') as f:
             json.dump({'frame_ms': frame_ms, 'bank_sizes': bank_sizes, 'timed': [s_first, s_first + K - 1]}, f)

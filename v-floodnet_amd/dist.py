@@ -44,6 +44,8 @@ def init(backend=None):
         if 'MASTER_PORT' not in os.environ:                 # (a forced single rank started without a launcher)
             os.environ['MASTER_PORT'] = str(free_port())
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        # RCCL writes its version banner (and anything NCCL_DEBUG asks for) to stdout, where rank 0's ONE JSON line lives: send it to a file
+        os.environ.setdefault('NCCL_DEBUG_FILE', '/tmp/vfn_rccl_%h_%p.log')
         if backend == 'nccl':
             torch.cuda.set_device(local_rank)
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
