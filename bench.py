@@ -362,6 +362,7 @@ def main(argv=None):
             def is_sampled(u):
                 return s_first <= u <= s_first + K - 1 and ((u - s_first + 1) % args.sample_every == 0)
             timer.active = sampling and is_sampled(t)
+            eng.eager = timer.active                 # (a sampled frame's launches are bracketed one by one: no graph replay)
             timer.light = (sampling and not timer.active and apply_every > 0 and s_first <= t <= s_first + K - 1
                            and (t - s_first + 1) % apply_every == 0)
             nxt = []
@@ -373,6 +374,7 @@ def main(argv=None):
             # want_label: the frame's label map goes to pinned host memory (the reference's .cpu(), test_video_seg.py:115)
             runner.launch(frames[idx:idx + 1], next_frames=nxt, want_label=True)
             timer.active = timer.light = False
+            eng.eager = False
             if t < n_lab:                            # device-side copies for the parity checks after the run
                 labels[t].copy_(runner.label_device(), non_blocking=True)
                 labels_raw[t].copy_(runner._label_dev, non_blocking=True)

@@ -139,3 +139,35 @@ def test_bench_line_through_the_rccl_branch_and_with_five_apply_samples(gpu):
     roof = out['roofline']
     assert roof['kernel'] == 'memread_apply_ss_kernel' and roof['launches_timed'] >= 3, roof
     assert 0.5 < roof['frac'] < 1.0
+
+
+def test_graph_replay_of_the_launch_lists_is_bit_identical(gpu):
+    """The fixed-shape launch lists (memory encoder, query side in two halves, decoder per slot) are captured into HIP graphs on their third
+    run and replayed with one host call each (engine.GraphCache).  Replay must be the same kernels on the same buffers: a clip run with
+    the graphs equals the launch-by-launch run (Engine.eager) bit for bit -- labels, logits of the last frame, bank sizes -- and the
+    graphs must really have been captured."""
+    from tools import synth
+    from vfloodnet_amd import AFB_URR, engine as E
+    from vfloodnet_amd.video_seg import ClipRunner
+    assert E._GRAPHS
+    sd = synth.make_state_dict(SEED)
+    frames, m0 = synth.clip(4, 14, 96, 160)
+    frames = frames.to(gpu)
+    onehot = synth.onehot(m0).unsqueeze(0).to(gpu)
+    out = {}
+    for mode in ('graphs', 'eager'):
+        model = AFB_URR(gpu, update_bank=True).to(gpu).eval()
+        model.load_state_dict(sd, strict=True)
+        model.engine().eager = (mode == 'eager')
+        runner = ClipRunner(model, 2, 250000)
+        runner.start(frames[0:1], onehot)
+        labs = []
+        for t in range(1, frames.shape[0]):
+            lab = runner.step(frames[t:t + 1], next_frames=[frames[u:u + 1] for u in range(t + 1, min(frames.shape[0], t + 4))])
+            labs.append(torch.from_numpy(lab.numpy().copy()))
+        plan = model.engine().plan(96, 160, 2)
+        out[mode] = (torch.stack(labs), plan.score.clone(), runner.bank_sizes(), len(plan.graphs.graphs))
+    assert out['eager'][3] == 0 and out['graphs'][3] >= 4, (out['eager'][3], out['graphs'][3])
+    assert torch.equal(out['graphs'][0], out['eager'][0])
+    assert torch.equal(out['graphs'][1], out['eager'][1])
+    assert out['graphs'][2] == out['eager'][2]
