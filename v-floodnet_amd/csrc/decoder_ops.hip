@@ -300,24 +300,29 @@ __global__ void pred2_gather_kernel(const float* __restrict__ z, const float* __
                                     int N, int h, int w, int ldz) {
     const size_t total = (size_t)N * h * w;
     const float b0 = bias[0], b1 = bias[1];
+    const __amdgpu_buffer_rsrc_t rz = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(z), 0, (int)(total * ldz * 4), 0x00020000);
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
         const int x = i % w;
         size_t t = i / w;
         const int y = t % h;
         const int n = t / h;
-        float a0 = 0.f, a1 = 0.f;
+        // (branch-free since round 5: the nine taps are raw buffer loads -- a tap outside the image has an out-of-range offset and reads 0 --
+        // requested together; the first form tested each tap and waited for each load.  Same terms in the same order.)
+        float2 v[9];
 #pragma unroll
         for (int dy = 0; dy < 3; ++dy) {
             const int yy = y + dy - 1;
-            if ((unsigned)yy >= (unsigned)h) continue;
 #pragma unroll
             for (int dx = 0; dx < 3; ++dx) {
                 const int xx = x + dx - 1;
-                if ((unsigned)xx >= (unsigned)w) continue;
-                const float2 v = *reinterpret_cast<const float2*>(z + (((size_t)n * h + yy) * w + xx) * ldz + (dy * 3 + dx) * 2);
-                a0 += v.x; a1 += v.y;
+                const bool ok = (unsigned)yy < (unsigned)h && (unsigned)xx < (unsigned)w;
+                v[dy * 3 + dx] = __builtin_bit_cast(float2, __builtin_amdgcn_raw_buffer_load_b64(
+                    rz, ok ? (int)(((((size_t)n * h + yy) * w + xx) * ldz + (dy * 3 + dx) * 2) * 4) : 0x7ffffff0, 0, 0));
             }
         }
+        float a0 = 0.f, a1 = 0.f;
+#pragma unroll
+        for (int k = 0; k < 9; ++k) { a0 += v[k].x; a1 += v[k].y; }
         *reinterpret_cast<float2*>(out + i * 2) = make_float2(a0 + b0, a1 + b1);
     }
 }
@@ -488,7 +493,7 @@ extern "C" int vfn_local_stats_f32(const float* r1, const float* rough, float* l
 }
 
 extern "C" int vfn_pred2_gather_f32(const float* z, const float* bias, float* out, int N, int h, int w, int ldz, void* stream) {
-    if (!z || !bias || !out || ldz < 18 || ldz % 2) return VFN_ERR_ARG;
+    if (!z || !bias || !out || ldz < 18 || ldz % 2 || (long long)N * h * w * ldz * 4 >= 0x7fffff00LL) return VFN_ERR_ARG;
     hipLaunchKernelGGL(pred2_gather_kernel, dim3(grid_for((size_t)N * h * w)), dim3(256), 0, (hipStream_t)stream, z, bias, out, N, h, w, ldz);
     return vfn_check_launch();
 }

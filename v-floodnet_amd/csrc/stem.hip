@@ -54,25 +54,45 @@ void stem_kernel(const vfn_stem_desc p) {
 
     // input patch -> LDS, with pad + normalisation semantics: planes [c_lo, c_hi) of image n
     const int gy0 = oy0 * 2 - 3, gx0 = ox0 * 2 - 3;     // padded-frame coordinates
+    // Round 5: branch-free and batched.  The first form was `for (i = tid; ...; i += 256) { if (inside) v = frame[...]; ... sP[...] = v; }`:
+    // one dword load and one full wait per iteration, ten dependent round trips per thread for the frame planes (six per object for the
+    // mask planes) -- most of the kernel's 40 / 88 us.  Now a thread requests ALL its elements first (raw buffer loads: an element outside
+    // the raw frame gets an out-of-range offset and reads 0, which is exactly the zero padding the reference applies BEFORE it
+    // normalises, myutils/data.py:132-149) and converts / stores them afterwards.  Same arithmetic per element.
+    const __amdgpu_buffer_rsrc_t rs_frame = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.frame), 0, 3 * p.H0 * p.W0 * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_mask = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.mask ? p.mask : p.frame), 0,
+                                                                             p.mask ? p.N * p.H0 * p.W0 * 4 : 0, 0x00020000);
     auto load_planes = [&](int c_lo, int c_hi, int n) {
-        for (int i = c_lo * PH * PW + tid; i < c_hi * PH * PW; i += 256) {
+        constexpr int MAXIT = (3 * PH * PW + 255) / 256;
+        const int base = c_lo * PH * PW, end = c_hi * PH * PW;
+        const bool is_frame = c_lo < 3;
+        float raw[MAXIT];
+#pragma unroll
+        for (int it = 0; it < MAXIT; ++it) {
+            const int i = base + tid + it * 256;
+            const int c = i / (PH * PW);
+            const int r = i - c * PH * PW;
+            const int y = r / PW, x = r - y * PW;
+            const int ry = gy0 + y - p.pad_top, rx = gx0 + x - p.pad_left;
+            const bool inside = i < end && x < PW - 1 && (unsigned)ry < (unsigned)p.H0 && (unsigned)rx < (unsigned)p.W0;
+            const int plane = is_frame ? c : n;
+            const int off = inside ? ((plane * p.H0 + ry) * p.W0 + rx) * 4 : 0x7ffffff0;
+            raw[it] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(is_frame ? rs_frame : rs_mask, off, 0, 0));
+        }
+#pragma unroll
+        for (int it = 0; it < MAXIT; ++it) {
+            const int i = base + tid + it * 256;      // (no `break` here: it made hipcc index raw[] dynamically, i.e. spill it to scratch)
             const int c = i / (PH * PW);
             const int r = i - c * PH * PW;
             const int y = r / PW, x = r - y * PW;
             const int gy = gy0 + y, gx = gx0 + x;
             float v = 0.f;
             if (x < PW - 1 && (unsigned)gy < (unsigned)p.Hp && (unsigned)gx < (unsigned)p.Wp) {
-                const int ry = gy - p.pad_top, rx = gx - p.pad_left;
-                const bool inside = (unsigned)ry < (unsigned)p.H0 && (unsigned)rx < (unsigned)p.W0;
-                if (c < 3) {
-                    const float raw = inside ? p.frame[((size_t)c * p.H0 + ry) * p.W0 + rx] : 0.f;
-                    v = (raw - p.mean[c]) / p.std[c];
-                } else {
-                    const float m = inside ? p.mask[((size_t)n * p.H0 + ry) * p.W0 + rx] : 0.f;
-                    v = (c == 3) ? m : fminf(fmaxf(1.f - m, 0.f), 1.f);
-                }
+                if (c < 3) v = (raw[it] - p.mean[c]) / p.std[c];      // (a load from the kernel-argument segment; hoisting the six
+                // constants into selects made hipcc build a private array and spill the whole descriptor to scratch: 41 -> 64 us)
+                else v = (c == 3) ? raw[it] : fminf(fmaxf(1.f - raw[it], 0.f), 1.f);
             }
-            sP[((c < 3 ? c : c - 3) * PH + y) * PROW + (x & 1) * PP + (x >> 1)] = v;
+            if (i < end) sP[((c < 3 ? c : c - 3) * PH + y) * PROW + (x & 1) * PP + (x >> 1)] = v;
         }
     };
     load_planes(0, 3, 0);
@@ -165,19 +185,22 @@ __global__ void maxpool3x3s2_kernel(const float* __restrict__ in, float* __restr
         const int ox = t % Wo; t /= Wo;
         const int oy = t % Ho;
         const int n = t / Ho;
-        f32x4 m = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+        // Branch-free (round 5): a tap outside the image is CLAMPED onto the border row / column, which lies inside the same 3x3 window
+        // (2 oy - 1 = -1 -> 0 = 2 oy; 2 oy + 1 = H -> H - 1 = 2 oy), and a maximum does not change when one of its arguments is repeated:
+        // nine unconditional loads in flight instead of nine tested ones with a wait each.
+        f32x4 v[9];
 #pragma unroll
         for (int dy = 0; dy < 3; ++dy) {
-            const int y = oy * 2 - 1 + dy;
-            if ((unsigned)y >= (unsigned)H) continue;
+            const int y = min(max(oy * 2 - 1 + dy, 0), H - 1);
 #pragma unroll
             for (int dx = 0; dx < 3; ++dx) {
-                const int x = ox * 2 - 1 + dx;
-                if ((unsigned)x >= (unsigned)W) continue;
-                const f32x4 v = *reinterpret_cast<const f32x4*>(in + (((size_t)n * H + y) * W + x) * C + c4 * 4);
-                m.x = fmaxf(m.x, v.x); m.y = fmaxf(m.y, v.y); m.z = fmaxf(m.z, v.z); m.w = fmaxf(m.w, v.w);
+                const int x = min(max(ox * 2 - 1 + dx, 0), W - 1);
+                v[dy * 3 + dx] = *reinterpret_cast<const f32x4*>(in + (((size_t)n * H + y) * W + x) * C + c4 * 4);
             }
         }
+        f32x4 m = v[0];
+#pragma unroll
+        for (int k = 1; k < 9; ++k) { m.x = fmaxf(m.x, v[k].x); m.y = fmaxf(m.y, v[k].y); m.z = fmaxf(m.z, v[k].z); m.w = fmaxf(m.w, v[k].w); }
         *reinterpret_cast<f32x4*>(out + i * 4) = m;
     }
 }
