@@ -33,6 +33,7 @@ _SIDE_PRIORITY = int(__import__('os').environ.get('VFN_SIDE_PRIORITY', 0))      
 _WINOGRAD_WGRAD = __import__('os').environ.get('VFN_WINOGRAD_WGRAD', '1') == '1'      # weight gradients of the big 3x3 layers in the Winograd domain
 _WINOGRAD_WGRAD_MIN_WORK = int(__import__('os').environ.get('VFN_WINOGRAD_WGRAD_MIN_WORK', 600000))        # pixels x min(cin, cout)
 _SIDE_DROP = __import__('os').environ.get('VFN_SIDE_DROP', '0') == '1'
+_NO_WAIT_PLAN = __import__('os').environ.get('VFN_UNSAFE_NO_WAIT_PLAN', '0') == '1'   # measurement only (WRONG gradients): what the per-sample wait costs
 _SIDE_GROUP = int(__import__('os').environ.get('VFN_SIDE_GROUP', 8))                   # deferred launches per side-stream hand-over
 
 
@@ -163,10 +164,12 @@ class DecoderBackward:
               'vfn_winograd_output_masked_f32')
         return out
 
-    def wgrad(self, plan, x, gy, relu, x_ld=None, x_c=None, gy_c=None, name=None):
+    def wgrad(self, plan, x, gy, relu, x_ld=None, x_c=None, gy_c=None, name=None, bias=None):
         """(dL/dW [Cout,Cin,3,3], dL/db [Cout]) of y = conv3x3(act(x)) + b given gy [N,H,W,Cout] (``gy_c``: the first gy_c
         channels of a wider gradient tensor).  ``name`` (with a ``sink``): the weight gradient is accumulated into the sink's
-        buffer of that parameter by the kernel and None is returned in its place."""
+        buffer of that parameter by the kernel and None is returned in its place.  ``name`` may be one input-channel half of a
+        parameter ('decoder.convFM.weight#m': ModelBackward.SPLIT puts the halves together); ``bias``: the bias parameter's name
+        (default: ``name`` with 'weight' replaced), False = this call contributes no bias gradient."""
         L = _lib.lib()
         N, H, Wd = gy.shape[0], gy.shape[1], gy.shape[2]
         cout = gy_c if gy_c is not None else gy.shape[-1]
@@ -185,8 +188,10 @@ class DecoderBackward:
                                              'vfn_colsum_acc_f32'))
             return None, None
         if name is not None and self.sink is not None and self.sink.wgrad_into(name, x, gy, 3, 1, 1, cin, cout, ld_x, relu, None, N, H, Wd):
+            if bias is False:
+                return None, None
             # the bias gradient accumulates in the kernel too, beside the data-gradient chain (ModelBackward's side stream)
-            db, have = self.sink._small(name[:-len('weight')] + 'bias', cout)
+            db, have = self.sink._small(bias or name[:-len('weight')] + 'bias', cout)
             part = self._buf('colsum', self.NB * cout)
             ld_g, ticket, nb1 = gy.shape[-1], self._ticket, self.NB1
             self.sink._side_do(lambda: check(L.vfn_colsum_acc_f32(ptr(gy), M, cout, ld_g, ptr(part), nb1, ptr(db), have, ptr(ticket), stream()),
@@ -271,13 +276,19 @@ class DecoderBackward:
         # ResMM(convFM(patch_match)) (AFB_URR.py:209); patch_match = cat([mem_i, q_out]) per object (:159)
         g = self.resblock(p, grads, 'ResMM', p.d16[0], p.d16[1], g, K, p.h16, p.w16)
         g_mem = self.dgrad(p, 'convFM.m', g, K, p.h16, p.w16)
-        dw_m, db = self.wgrad(p, p.dec_in, g, False)
+        # (round 5: the two input halves of convFM / local_convFM accumulate like every other weight gradient -- in the kernel, on
+        # the side stream, under half-parameter names that ModelBackward.grads concatenates once per step; they were the last
+        # weight-gradient launches on the data-gradient chain, 0.28 ms per sample)
+        split = self.sink is not None
+        dw_m, db = self.wgrad(p, p.dec_in, g, False, name='decoder.convFM.weight#m' if split else None, bias='decoder.convFM.bias')
         g_q = self._sum_objects(g)                                           # the query half is shared: sum over the objects
         kvq_val = o(qs.kv_q)[:, :, DK:]                                        # [1, HW, 512] view, pixel stride 640
-        dw_q, _ = self.wgrad(p, kvq_val, g_q, False, x_ld=DK + DV, x_c=DV)
+        dw_q, _ = self.wgrad(p, kvq_val, g_q, False, x_ld=DK + DV, x_c=DV, name='decoder.convFM.weight#q' if split else None, bias=False)
         g_qv = self.dgrad(p, 'convFM.q', g_q, 1, p.h16, p.w16)
-        grads['decoder.convFM.weight'] = torch.cat([dw_m, dw_q], dim=1)
-        grads['decoder.convFM.bias'] = db
+        if dw_m is not None or dw_q is not None:
+            assert dw_m is not None and dw_q is not None
+            grads['decoder.convFM.weight'] = torch.cat([dw_m, dw_q], dim=1)
+            grads['decoder.convFM.bias'] = db
         # patch_match[i] = cat([mem_i, q_out]) (AFB_URR.py:159): dL/dmem per object, dL/dq_out summed over the objects
         return grads, {'mem': g_mem, 'q_out': g_qv, 'r3': g_r3, 'r2': g_r2}
 
@@ -313,12 +324,15 @@ class DecoderBackward:
         grads['decoder.local_pred2.weight'], grads['decoder.local_pred2.bias'] = self.wgrad(p, l2[2], g_q, True, gy_c=2, name='decoder.local_pred2.weight')
         g = self.resblock(p, grads, 'local_ResMM', l2[0], l2[1], g, K, h2, w2)
         g_lm = self.dgrad(p, 'local_convFM.loc', g, K, h2, w2)
-        dw_loc, _ = self.wgrad(p, p.lm, g, False)
+        split = self.sink is not None
+        dw_loc, _ = self.wgrad(p, p.lm, g, False, name='decoder.local_convFM.weight#loc' if split else None, bias=False)
         g_lq = self._sum_objects(g)                                            # the r1 half is shared by the objects (:231)
-        dw_r1, db = self.wgrad(p, r1, g_lq, False)
+        dw_r1, db = self.wgrad(p, r1, g_lq, False, name='decoder.local_convFM.weight#r1' if split else None, bias='decoder.local_convFM.bias')
         g_r1 = self.dgrad(p, 'local_convFM.r1', g_lq, 1, h2, w2)
-        grads['decoder.local_convFM.weight'] = torch.cat([dw_r1, dw_loc], dim=1)
-        grads['decoder.local_convFM.bias'] = db
+        if dw_loc is not None or dw_r1 is not None:
+            assert dw_loc is not None and dw_r1 is not None
+            grads['decoder.local_convFM.weight'] = torch.cat([dw_r1, dw_loc], dim=1)
+            grads['decoder.local_convFM.bias'] = db
         # r1_local, conf, uncertainty, the two softmaxes -> interpolate(p)
         dA = torch.empty(K, h2, w2, 64, device=dev)
         dBv = torch.empty(K, h2, w2, device=dev)
@@ -376,6 +390,9 @@ class ModelBackward:
     arrived at the bank's keys / values back through KeyValue and the memory encoder.  Gradients accumulate in ``self.grads``
     (state-dict name -> tensor)."""
     NB = 256
+    # parameters whose weight gradient is accumulated per input-channel half (DecoderBackward.wgrad): name -> the halves' suffixes in
+    # torch's channel order (AFB_URR.py:159 cat([mem, q_out]); :231 cat([r1, r1_local]))
+    SPLIT = {'decoder.convFM.weight': ('#m', '#q'), 'decoder.local_convFM.weight': ('#r1', '#loc')}
     NB1 = max(1, min(NB, int(__import__('os').environ.get('VFN_COLSUM_BLOCKS', 128))))     # blocks of the one-launch column sums (<= NB: scratch rows are sized by NB) (128 / 256: 100.6 / 113.2 ms per step on one box; (the last block adds NB1 partial rows)
 
     def __init__(self, engine):
@@ -422,7 +439,8 @@ class ModelBackward:
         self.side = torch.cuda.Stream(dev, priority=_SIDE_PRIORITY) if _SIDE_WGRAD else None
         self._pending, self._inflight, self._by_plan = [], [], {}
         self._pad = {}               # zero-padded operand images of the memory read's small GEMMs (_gemm_nt)
-        self._query_grads = {}       # slot -> gradients entering the query encoder (batched samples: finish_query)
+        self._query_grads = {}       # slot -> gradients entering the memory read / the query encoder (batched samples: finish_query)
+        self._batch_fb = None        # ... and the bank they were segmented against
         self._ticket_main = torch.zeros(64, dtype=torch.int32, device=dev)  # (the column sums that stay on the main stream)
 
     def reset(self):
@@ -474,7 +492,7 @@ class ModelBackward:
     def wait_plan(self, plan):
         """The main stream is about to overwrite ``plan``'s activations: wait for the side-stream launches that read them."""
         hit = self._by_plan.pop(id(plan), None)
-        if hit is not None:
+        if hit is not None and not _NO_WAIT_PLAN:
             torch.cuda.current_stream().wait_event(hit[0])
 
     @property
@@ -488,6 +506,10 @@ class ModelBackward:
             else:
                 self._grads[name] = g
             del self._packed[name]
+        for full, parts in self.SPLIT.items():                     # input-channel halves accumulated under their own names
+            if all(full + s_ in self._grads for s_ in parts):
+                g = torch.cat([self._grads.pop(full + s_) for s_ in parts], dim=1)
+                self._grads[full] = self._grads[full] + g if full in self._grads else g
         return self._grads
 
     def wgrad_into(self, name, x, gy, k, stride, pad, cin, cout, ld_x, relu, rowscale, N, H, Wd, rows=None):
@@ -762,16 +784,18 @@ class ModelBackward:
         for n_, g_ in g_dec.items():
             if g_ is not None:                                                # (None: accumulated by the kernel, wgrad_into)
                 self._acc(n_, g_)
+        batch = self.eng._batch
+        if batch is not None and batch[1] is qs and qs.nq == qs.n:
+            # gradients that enter the memory read and the query encoder: collected, differentiated for all frames of the sample in
+            # finish_query (which also returns the bank's gradients: the bank is the same for every frame of the sample)
+            self._query_grads[slot] = (gin['mem'].reshape(K, plan.HW, DV), gin['q_out'].reshape(1, plan.HW, DV), gin['r3'], gin['r2'], gin['r1'])
+            self._batch_fb = fb
+            self._end_sample(plan)
+            return None, None
         kvq = qs.kv_q[slot]                                                   # [HW,640]
         g_qk, g_bk, g_bv = self.memory_read(plan, fb, kvq[:, :DK].contiguous(), gin['mem'].reshape(K, plan.HW, DV))
         # KeyValue on the query side: dL/d[key | value]
         g_kv = torch.cat([g_qk, gin['q_out'].reshape(plan.HW, DV)], dim=1).view(1, plan.h16, plan.w16, DK + DV).contiguous()
-        batch = self.eng._batch
-        if batch is not None and batch[1] is qs and qs.nq == qs.n:
-            # gradients that enter the query encoder: collected, differentiated for all frames of the sample in finish_query
-            self._query_grads[slot] = (g_kv, gin['r3'], gin['r2'], gin['r1'])
-            self._end_sample(plan)
-            return g_bk, g_bv
         if slot != 0 or qs.stage != 0:
             raise RuntimeError('backward expects the frame-only part of segment to have run in place (no look-ahead in training)')
         acts = qs.acts[1]
@@ -789,16 +813,25 @@ class ModelBackward:
     def finish_query(self):
         """The query encoder (KeyValue, res4 .. res2, stem) backwards for ALL frames of the sample that ``Engine.query_batch`` ran
         in one pass: the per-sample gradients ``segment_sample`` collected are stacked along the batch axis, so every data- and
-        weight-gradient launch sees n times the pixels (the 1/16-resolution layers have 625 of them per frame at 400 x 400)."""
+        weight-gradient launch sees n times the pixels (the 1/16-resolution layers have 625 of them per frame at 400 x 400).  The
+        memory read is differentiated here too, for all frames at once; returns (dL/d bank keys, dL/d bank values) of the sample
+        (``segment_sample`` returned (None, None) for its frames), or (None, None) when nothing was batched."""
         if not self._query_grads:
-            return
+            return None, None
         plan, qs = self.eng._batch
         n = qs.n
         if sorted(self._query_grads) != list(range(n)):
             raise RuntimeError(f'finish_query: gradients for slots {sorted(self._query_grads)} of a batch of {n}')
         m = self.eng.model
         parts = [self._query_grads[i] for i in range(n)]
-        g_kv, g3, g2, g1 = (torch.cat([t[j] for t in parts], dim=0) for j in range(4))
+        g_qv, g3, g2, g1 = (torch.cat([t[j] for t in parts], dim=0) for j in range(1, 5))
+        # the memory read backwards for the n frames at once: n * HW query columns against the one bank -- six GEMMs and two softmax
+        # kernels per object instead of per object and frame (0.48 ms per frame of 625 pixels, launch-bound)
+        fb, self._batch_fb = self._batch_fb, None
+        g_mem = torch.cat([t[0] for t in parts], dim=1)                       # [K, n*HW, 512]
+        q_keys = qs.kv_q[0:n].reshape(n * plan.HW, DK + DV)[:, :DK].contiguous()
+        g_qk, g_bk, g_bv = self.memory_read(plan, fb, q_keys, g_mem)
+        g_kv = torch.cat([g_qk.view(n, plan.HW, DK), g_qv], dim=2).view(n, plan.h16, plan.w16, DK + DV)
         self._query_grads = {}
         acts = qs.acts[n]
         bufs = {'r1': qs.q['r1'][0:n]}
@@ -809,6 +842,7 @@ class ModelBackward:
         xn = self._normalised_input(plan, qs.frames[0:n])
         self._stem(plan, 'encoder_q', m.encoder_q, xn, g_c1, bufs['r1'], n, [('encoder_q.conv1.weight', 3)])
         self._flush()
+        return g_bk, g_bv
 
     def _keyval(self, plan, r4, g_kv, N):
         m = self.eng.model

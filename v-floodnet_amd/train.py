@@ -196,6 +196,12 @@ def forward_backward(model, frames, masks, lu=0.5, budget=300000):
     the model must be on the GPU and in training mode (``model.train()``, update_bank False).
     Returns (loss, uncertainty, grads): python floats as ``loss.item()`` / ``uncertainty.item()`` give them, and
     state-dict name -> gradient tensor for every parameter."""
+    _check_step_inputs(model, frames, masks)
+    with _host_single_threaded():
+        return _forward_backward(model, frames, masks, lu, budget)
+
+
+def _check_step_inputs(model, frames, masks):
     if not model.training:
         raise RuntimeError('forward_backward needs model.train() (the training branch of segment keeps its activations)')
     if model.update_bank:
@@ -205,15 +211,13 @@ def forward_backward(model, frames, masks, lu=0.5, budget=300000):
         raise ValueError('a training sample needs a reference frame and at least one frame to segment')
     if obj_n < 2:      # as model.segment: the reference fails in calc_uncertainty's top-2 (myutils/data.py:40-46)
         raise RuntimeError('segment needs at least two objects (background + 1): selected index k out of range')
-    with _host_single_threaded():
-        return _forward_backward(model, frames, masks, lu, budget)
 
 
 last_enqueue_s = 0.0
 _BATCH_QUERY = os.environ.get('VFN_TRAIN_BATCH_QUERY', '1') == '1'   # the query encoder over all frames of a sample at once (fwd + bwd)
 
 
-def _forward_backward(model, frames, masks, lu, budget):
+def _forward_backward(model, frames, masks, lu, budget, lazy=False):
     t_start = time.perf_counter()
     T, obj_n = frames.shape[0], masks.shape[1]
     dev = model.device
@@ -236,15 +240,22 @@ def _forward_backward(model, frames, masks, lu, budget):
         if bs > 1:
             dscore *= 1.0 / bs                                              # mean over the batch: CE over bs*H*W pixels, uncertainty.mean()
         bk, bv = mb.segment_sample(fb, dscore[0])
+        if bk is None:                           # (batched sample: the memory read is differentiated in finish_query)
+            continue
         if g_bk is None:
             g_bk, g_bv = bk, bv
         else:
             g_bk = [a + b for a, b in zip(g_bk, bk)]
             g_bv = [a + b for a, b in zip(g_bv, bv)]
-    mb.finish_query()                            # (the query encoder's backward of the batched samples, all frames at once)
+    bk, bv = mb.finish_query()                   # (the memory read's and the query encoder's backward of the batched samples, all frames at once)
+    if bk is not None:
+        assert g_bk is None
+        g_bk, g_bv = bk, bv
     mb.finish_memorize(frames[0:1], masks[0:1], g_bk, g_bv)
     global last_enqueue_s
     last_enqueue_s = time.perf_counter() - t_start                          # host time to enqueue the whole step (bench_train_step.py)
+    if lazy:                                     # (train_step: the optimizer's launches are enqueued before the host waits for the loss)
+        return stats_sum / bs, mb.grads
     st = (stats_sum / bs).tolist()                                          # one D2H per step, as loss.item() is
     return st[0], st[2], mb.grads
 
@@ -271,7 +282,8 @@ def train_step(model, optimizer, frames, masks, lu=0.5, budget=300000):
     """train_video_seg.py:56-76 for one sample of the dataloader.  Returns (loss, uncertainty) as python floats."""
     with _host_single_threaded():
         optimizer.zero_grad()
-        loss, unc, grads = forward_backward(model, frames, masks, lu, budget)
+        _check_step_inputs(model, frames, masks)
+        stats, grads = _forward_backward(model, frames, masks, lu, budget, lazy=True)
         optimizer.set_grads(grads)
         optimizer.step()
         # the engine's packed filters / folded BatchNorm constants follow in place; the address check of the refresh tables is
@@ -280,7 +292,10 @@ def train_step(model, optimizer, frames, masks, lu=0.5, budget=300000):
         model._refresh(trusted=own and model.__dict__.get('_refresh_owner') is optimizer)
         model.__dict__['_refresh_owner'] = optimizer if own else None
         model.engine()               # (or are rebuilt here, inside the single-threaded region, if a parameter moved)
-    return loss, unc
+        # the step's one device-to-host read, AFTER the optimizer and the refresh have been enqueued: read right behind the backward
+        # pass (round 4) it left the device idle while the host built the optimizer's launches (0.4 + 0.7 ms in a kernel trace)
+        st = stats.tolist()
+    return st[0], st[2]
 
 
 class StepLR:
