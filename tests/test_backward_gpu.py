@@ -209,7 +209,7 @@ def test_training_loss_and_its_gradient(gpu, bs, K, H, W):
     assert _rel(grad.cpu(), z.grad) < 1e-4
 
 
-def _hip_relu_masks(eng, K, memorize_only=False, query=None):
+def _hip_relu_masks(eng, K, memorize_only=False, query=None, batch=None):
     """The ReLU activation patterns of the HIP forward (memorize, then the sample segment ran last), in the order the oracle
     calls F.relu; NCHW bool on the CPU."""
     pm = eng.last_memorize
@@ -222,7 +222,13 @@ def _hip_relu_masks(eng, K, memorize_only=False, query=None):
     mem_masks = [nchw_mask(t) for t in order]
     if memorize_only:
         return mem_masks
-    plan, qs, slot = query if query is not None else eng.last_query
+    if batch is not None:
+        # (Engine.segment_batch: frame g's images inside the DecoderBatch, its frame-only state in slot g of the batch query set)
+        import types
+        b, qs, slot = batch
+        plan = types.SimpleNamespace(**{k: [b.grp(t, slot) for t in getattr(b, k)] for k in ('d16', 'd8', 'd4', 'l2')})
+    else:
+        plan, qs, slot = query if query is not None else eng.last_query
     # (a sample whose frames went through Engine.query_batch: its activations are slot ``slot`` of the batch list's tensors)
     acts = qs.acts[qs.n if (qs.n == qs.nq and qs.n in qs.acts and eng._batch is not None and eng._batch[1] is qs) else 1]
     one = lambda t: t[slot:slot + 1]
@@ -424,11 +430,20 @@ def test_train_step_vs_reference_loop(gpu):
     def spy(self, fb, grad_score, query=None):
         pats.append(_hip_relu_masks(self.eng, K, query=query)[1])
         return orig(self, fb, grad_score, query)
+    orig_b = ModelBackward.segment_batch
+
+    def spy_batch(self, fb, grad_scores):
+        b, qs = self.eng.last_batch
+        for g in range(qs.n):
+            pats.append(_hip_relu_masks(self.eng, K, batch=(b, qs, g))[1])
+        return orig_b(self, fb, grad_scores)
     ModelBackward.segment_sample = spy
+    ModelBackward.segment_batch = spy_batch
     try:
         loss, unc, grads = T.forward_backward(model, frames, masks, lu)
     finally:
         ModelBackward.segment_sample = orig
+        ModelBackward.segment_batch = orig_b
     mem_masks = _hip_relu_masks(model.engine(), K, memorize_only=True)
     assert len(pats) == 2
 

@@ -239,52 +239,58 @@ class DecoderBackward:
         grads[f'decoder.{name}.conv1.weight'], grads[f'decoder.{name}.conv1.bias'] = self.wgrad(plan, x, g_r, True, name=f'decoder.{name}.conv1.weight')
         return g_x
 
-    def refine(self, plan, grads, name, f, s, dm, g_out, N, H, Wd):
-        """Refine.forward (AFB_URR.py:122-127) backwards.  f: skip feature [1,H,W,Cf]; s = [convFS(f), ResFS.conv1 out, ResFS out]
-        (one image, shared by the N objects); dm = [m, ResMM.conv1 out] for the N objects.  Returns (dL/df, dL/dpm)."""
+    def refine(self, plan, grads, name, f, s, dm, g_out, N, H, Wd, G=1):
+        """Refine.forward (AFB_URR.py:122-127) backwards.  f: skip feature [G,H,W,Cf]; s = [convFS(f), ResFS.conv1 out, ResFS out]
+        (one image per frame, shared by that frame's objects); dm = [m, ResMM.conv1 out] for the N = G * objects images
+        (frame-major).  Returns (dL/df, dL/dpm)."""
         L = _lib.lib()
+        K = N // G
         g_m = self.resblock(plan, grads, name + '.ResMM', dm[0], dm[1], g_out, N, H, Wd)
         C = g_m.shape[-1]
-        g_s = torch.empty(1, H, Wd, C, device=self.dev)
+        g_s = torch.empty(G, H, Wd, C, device=self.dev)
         g_pm = torch.empty(N, H // 2, Wd // 2, C, device=self.dev)
-        check(L.vfn_upsample2x_add_backward_f32(ptr(g_m), ptr(g_s), ptr(g_pm), N, H, Wd, C, 1, stream()), 'vfn_upsample2x_add_backward_f32')
-        g_s0 = self.resblock(plan, grads, name + '.ResFS', s[0], s[1], g_s, 1, H, Wd)
+        for g in range(G):                                                     # (the skip's gradient sums over ONE frame's objects)
+            check(L.vfn_upsample2x_add_backward_f32(ptr(g_m[g * K:(g + 1) * K]), ptr(g_s[g:g + 1]), ptr(g_pm[g * K:(g + 1) * K]), K, H, Wd, C, 1,
+                                                    stream()), 'vfn_upsample2x_add_backward_f32')
+        g_s0 = self.resblock(plan, grads, name + '.ResFS', s[0], s[1], g_s, G, H, Wd)
         grads[f'decoder.{name}.convFS.weight'], grads[f'decoder.{name}.convFS.bias'] = self.wgrad(plan, f, g_s0, False, name=f'decoder.{name}.convFS.weight')
-        g_f = self.dgrad(plan, name + '.convFS', g_s0, 1, H, Wd)
+        g_f = self.dgrad(plan, name + '.convFS', g_s0, G, H, Wd)
         return g_f, g_pm
 
     # ------------------------------------------------------------------ the slice
     @torch.no_grad()
-    def run(self, plan, grad_p, qs=None, slot=0):
-        """grad_p: dL/dp, f32 [obj_n, h/4, w/4, 2] (NHWC, the layout of ``plan.pp``) for the frame ``segment`` ran last.
-        Returns (dict state-dict name -> gradient, dict input name -> gradient)."""
+    def run(self, plan, grad_p, qs=None, slot=0, G=1):
+        """grad_p: dL/dp, f32 [G * obj_n, h/4, w/4, 2] (NHWC, the layout of ``plan.pp``) for the frame ``segment`` ran last (G = 1:
+        ``plan`` is the FramePlan, the frame sits in ``slot`` of the query set) or for the G frames of ``Engine.segment_batch``
+        (``plan`` is its DecoderBatch; images frame-major).  Returns (dict state-dict name -> gradient, dict input name -> gradient)."""
         p = plan
         qs = qs or p.qsets[0]
         K = p.obj_n
-        o = lambda t: t[slot:slot + 1]
+        N = G * K
+        o = (lambda t: t[slot:slot + 1]) if G == 1 else (lambda t: t[0:G])     # the frame-only tensors of the query set
         grads = {}
-        g32 = torch.zeros(K, p.h4, p.w4, 32, device=self.dev)
+        g32 = torch.zeros(N, p.h4, p.w4, 32, device=self.dev)
         g32[..., :2].copy_(grad_p)
         # pred2(relu(x)), x = RF2's output (AFB_URR.py:212)
         x = p.d4[2]
-        g = self.dgrad(p, 'pred2', g32, K, p.h4, p.w4, mask=x)
+        g = self.dgrad(p, 'pred2', g32, N, p.h4, p.w4, mask=x)
         grads['decoder.pred2.weight'], grads['decoder.pred2.bias'] = self.wgrad(p, x, g32 if self.sink is not None else grad_p.contiguous(), True,
                                                                                 gy_c=2, name='decoder.pred2.weight')
         # RF2, RF3 (AFB_URR.py:210-211)
-        g_r2, g = self.refine(p, grads, 'RF2', o(qs.q['res2']['out']), [o(t) for t in qs.s4], p.d4, g, K, p.h4, p.w4)
-        g_r3, g = self.refine(p, grads, 'RF3', o(qs.q['res3']['out']), [o(t) for t in qs.s8], p.d8, g, K, p.h8, p.w8)
+        g_r2, g = self.refine(p, grads, 'RF2', o(qs.q['res2']['out']), [o(t) for t in qs.s4], p.d4, g, N, p.h4, p.w4, G)
+        g_r3, g = self.refine(p, grads, 'RF3', o(qs.q['res3']['out']), [o(t) for t in qs.s8], p.d8, g, N, p.h8, p.w8, G)
         # ResMM(convFM(patch_match)) (AFB_URR.py:209); patch_match = cat([mem_i, q_out]) per object (:159)
-        g = self.resblock(p, grads, 'ResMM', p.d16[0], p.d16[1], g, K, p.h16, p.w16)
-        g_mem = self.dgrad(p, 'convFM.m', g, K, p.h16, p.w16)
+        g = self.resblock(p, grads, 'ResMM', p.d16[0], p.d16[1], g, N, p.h16, p.w16)
+        g_mem = self.dgrad(p, 'convFM.m', g, N, p.h16, p.w16)
         # (round 5: the two input halves of convFM / local_convFM accumulate like every other weight gradient -- in the kernel, on
         # the side stream, under half-parameter names that ModelBackward.grads concatenates once per step; they were the last
         # weight-gradient launches on the data-gradient chain, 0.28 ms per sample)
         split = self.sink is not None
         dw_m, db = self.wgrad(p, p.dec_in, g, False, name='decoder.convFM.weight#m' if split else None, bias='decoder.convFM.bias')
-        g_q = self._sum_objects(g)                                           # the query half is shared: sum over the objects
-        kvq_val = o(qs.kv_q)[:, :, DK:]                                        # [1, HW, 512] view, pixel stride 640
+        g_q = self._sum_objects(g, G)                                        # the query half is shared: sum over the frame's objects
+        kvq_val = o(qs.kv_q)[:, :, DK:]                                        # [G, HW, 512] view, pixel stride 640
         dw_q, _ = self.wgrad(p, kvq_val, g_q, False, x_ld=DK + DV, x_c=DV, name='decoder.convFM.weight#q' if split else None, bias=False)
-        g_qv = self.dgrad(p, 'convFM.q', g_q, 1, p.h16, p.w16)
+        g_qv = self.dgrad(p, 'convFM.q', g_q, G, p.h16, p.w16)
         if dw_m is not None or dw_q is not None:
             assert dw_m is not None and dw_q is not None
             grads['decoder.convFM.weight'] = torch.cat([dw_m, dw_q], dim=1)
@@ -293,66 +299,76 @@ class DecoderBackward:
         return grads, {'mem': g_mem, 'q_out': g_qv, 'r3': g_r3, 'r2': g_r2}
 
     @torch.no_grad()
-    def run_tail(self, plan, grad_score, qs=None, slot=0):
+    def run_tail(self, plan, grad_score, qs=None, slot=0, G=1):
         """The whole decoder backwards: ``grad_score`` = dL/d(logits ``segment`` returned) f32 [obj_n, H0, W0] for the frame
-        ``segment`` ran last (AFB_URR.py:208-239 + :300,309-316).  Runs the tail and the local refinement head, then
-        ``run`` for the global branch.  Returns (dict state-dict name -> gradient for every ``decoder.*`` parameter, dict of
-        input gradients: mem, q_out, r3, r2, r1)."""
+        ``segment`` ran last (AFB_URR.py:208-239 + :300,309-316) -- or, G > 1, [G, obj_n, H0, W0] for the frames of
+        ``Engine.segment_batch`` with ``plan`` = its DecoderBatch: the convolutions' data and weight gradients run once over the
+        G * obj_n images, the kernels that couple the objects of a frame once per frame.  Runs the tail and the local refinement
+        head, then ``run`` for the global branch.  Returns (dict state-dict name -> gradient for every ``decoder.*`` parameter, dict
+        of input gradients: mem, q_out, r3, r2, r1 -- the shared ones with a leading axis of G frames)."""
         L = _lib.lib()
         p = plan
         qs = qs or p.qsets[0]
         K, h2, w2 = p.obj_n, p.h2, p.w2
+        N = G * K
         npix = h2 * w2
         dev = self.dev
         s = stream()
-        r1 = qs.q['r1'][slot:slot + 1]                                         # [1,h2,w2,64]
-        G = grad_score.contiguous()
-        g_o = torch.zeros(K, 2 * h2, 2 * w2, 4, device=dev)
-        check(L.vfn_tail_grad_o_f32(ptr(G), ptr(p.p_up), ptr(p.unc), ptr(p.conf), ptr(p.qq), ptr(g_o), K, h2, w2,
-                                    p.pad[2], p.pad[0], p.H0, p.W0, s), 'vfn_tail_grad_o_f32')
-        g_p2 = torch.empty(K, h2, w2, 4, device=dev)
-        check(L.vfn_upsample2x_add_backward_f32(ptr(g_o), None, ptr(g_p2), K, 2 * h2, 2 * w2, 4, 0, s), 'vfn_upsample2x_add_backward_f32')
-        g_q = torch.zeros(K, h2, w2, 32, device=dev)
-        g_cf = torch.empty(K, h2, w2, device=dev)
-        g_u = torch.empty(h2, w2, device=dev)
-        check(L.vfn_tail_split_f32(ptr(g_p2), ptr(p.unc), ptr(p.conf), ptr(p.qq), ptr(g_q), ptr(g_cf), ptr(g_u), K, npix, s),
-              'vfn_tail_split_f32')
+        grp = lambda t, g: t[g * K:(g + 1) * K]
+        r1 = qs.q['r1'][slot:slot + 1] if G == 1 else qs.q['r1'][0:G]           # [G,h2,w2,64]
+        unc = p.unc.view(G, h2, w2)
+        Gs = grad_score.contiguous().view(G, K, p.H0, p.W0)
+        g_o = torch.zeros(N, 2 * h2, 2 * w2, 4, device=dev)
+        for g in range(G):
+            check(L.vfn_tail_grad_o_f32(ptr(Gs[g]), ptr(grp(p.p_up, g)), ptr(unc[g]), ptr(grp(p.conf, g)), ptr(grp(p.qq, g)), ptr(grp(g_o, g)),
+                                        K, h2, w2, p.pad[2], p.pad[0], p.H0, p.W0, s), 'vfn_tail_grad_o_f32')
+        g_p2 = torch.empty(N, h2, w2, 4, device=dev)
+        check(L.vfn_upsample2x_add_backward_f32(ptr(g_o), None, ptr(g_p2), N, 2 * h2, 2 * w2, 4, 0, s), 'vfn_upsample2x_add_backward_f32')
+        g_q = torch.zeros(N, h2, w2, 32, device=dev)
+        g_cf = torch.empty(N, h2, w2, device=dev)
+        g_u = torch.empty(G, h2, w2, device=dev)
+        for g in range(G):
+            check(L.vfn_tail_split_f32(ptr(grp(g_p2, g)), ptr(unc[g]), ptr(grp(p.conf, g)), ptr(grp(p.qq, g)), ptr(grp(g_q, g)), ptr(grp(g_cf, g)),
+                                       ptr(g_u[g]), K, npix, s), 'vfn_tail_split_f32')
         grads = {}
         # q = conf * local_pred2(relu(local_ResMM(local_convFM(cat([r1, r1_local])))))   (AFB_URR.py:231-234)
         l2 = p.l2
-        g = self.dgrad(p, 'local_pred2', g_q, K, h2, w2, mask=l2[2])
+        g = self.dgrad(p, 'local_pred2', g_q, N, h2, w2, mask=l2[2])
         grads['decoder.local_pred2.weight'], grads['decoder.local_pred2.bias'] = self.wgrad(p, l2[2], g_q, True, gy_c=2, name='decoder.local_pred2.weight')
-        g = self.resblock(p, grads, 'local_ResMM', l2[0], l2[1], g, K, h2, w2)
-        g_lm = self.dgrad(p, 'local_convFM.loc', g, K, h2, w2)
+        g = self.resblock(p, grads, 'local_ResMM', l2[0], l2[1], g, N, h2, w2)
+        g_lm = self.dgrad(p, 'local_convFM.loc', g, N, h2, w2)
         split = self.sink is not None
         dw_loc, _ = self.wgrad(p, p.lm, g, False, name='decoder.local_convFM.weight#loc' if split else None, bias=False)
-        g_lq = self._sum_objects(g)                                            # the r1 half is shared by the objects (:231)
+        g_lq = self._sum_objects(g, G)                                         # the r1 half is shared by the frame's objects (:231)
         dw_r1, db = self.wgrad(p, r1, g_lq, False, name='decoder.local_convFM.weight#r1' if split else None, bias='decoder.local_convFM.bias')
-        g_r1 = self.dgrad(p, 'local_convFM.r1', g_lq, 1, h2, w2)
+        g_r1 = self.dgrad(p, 'local_convFM.r1', g_lq, G, h2, w2)
         if dw_loc is not None or dw_r1 is not None:
             assert dw_loc is not None and dw_r1 is not None
             grads['decoder.local_convFM.weight'] = torch.cat([dw_r1, dw_loc], dim=1)
             grads['decoder.local_convFM.bias'] = db
         # r1_local, conf, uncertainty, the two softmaxes -> interpolate(p)
-        dA = torch.empty(K, h2, w2, 64, device=dev)
+        dA = torch.empty(K, h2, w2, 64, device=dev)                           # (scratch of one frame's launch)
         dBv = torch.empty(K, h2, w2, device=dev)
         amax = torch.empty(K, h2, w2, dtype=torch.int32, device=dev)
-        g_pup = torch.empty(K, h2, w2, 4, device=dev)
-        check(L.vfn_local_stats_backward_f32(ptr(g_lm), ptr(p.lm), ptr(g_cf), ptr(g_u), ptr(g_p2), ptr(r1), ptr(p.rough), ptr(p.p_up),
-                                             ptr(dA), ptr(dBv), ptr(amax), ptr(g_r1), ptr(g_pup), K, h2, w2, 64, s),
-              'vfn_local_stats_backward_f32')
-        g_p4 = torch.empty(K, p.h4, p.w4, 4, device=dev)
-        check(L.vfn_upsample2x_add_backward_f32(ptr(g_pup), None, ptr(g_p4), K, h2, w2, 4, 0, s), 'vfn_upsample2x_add_backward_f32')
-        g2, inputs = self.run(p, g_p4[..., :2].contiguous(), qs, slot)
+        g_pup = torch.empty(N, h2, w2, 4, device=dev)
+        for g in range(G):
+            check(L.vfn_local_stats_backward_f32(ptr(grp(g_lm, g)), ptr(grp(p.lm, g)), ptr(grp(g_cf, g)), ptr(g_u[g]), ptr(grp(g_p2, g)), ptr(r1[g]),
+                                                 ptr(grp(p.rough, g)), ptr(grp(p.p_up, g)), ptr(dA), ptr(dBv), ptr(amax), ptr(g_r1[g]),
+                                                 ptr(grp(g_pup, g)), K, h2, w2, 64, s), 'vfn_local_stats_backward_f32')
+        g_p4 = torch.empty(N, p.h4, p.w4, 4, device=dev)
+        check(L.vfn_upsample2x_add_backward_f32(ptr(g_pup), None, ptr(g_p4), N, h2, w2, 4, 0, s), 'vfn_upsample2x_add_backward_f32')
+        g2, inputs = self.run(p, g_p4[..., :2].contiguous(), qs, slot, G)
         grads.update(g2)
         inputs['r1'] = g_r1
         return grads, inputs
 
-    def _sum_objects(self, g):
-        """[N,h,w,C] -> [1,h,w,C], summed over the objects in index order."""
-        out = g[0:1].clone()
-        for n in range(1, g.shape[0]):
-            out += g[n:n + 1]
+    def _sum_objects(self, g, G=1):
+        """[G * K, h, w, C] (frame-major) -> [G, h, w, C], summed over each frame's K objects in index order."""
+        K = g.shape[0] // G
+        g5 = g.view(G, K, *g.shape[1:])
+        out = g5[:, 0].clone(memory_format=torch.contiguous_format)
+        for k in range(1, K):
+            out += g5[:, k]
         return out
 
 
@@ -810,6 +826,24 @@ class ModelBackward:
         return g_bk, g_bv
 
     @torch.no_grad()
+    def segment_batch(self, fb, grad_scores):
+        """Backward of ``Engine.segment_batch`` (all frames of the sample through the decoder at once): grad_scores = dloss/dscores
+        [n, obj_n, H0, W0].  The decoder's data and weight gradients run over n * obj_n images (DecoderBackward.run_tail with G = n);
+        what enters the memory read and the query encoder is left to ``finish_query``, as for ``segment_sample`` on a batched sample."""
+        b, qs = self.eng.last_batch
+        plan = b.plan
+        G, K = qs.n, plan.obj_n
+        g_dec, gin = self.dec.run_tail(b, grad_scores, qs, 0, G)
+        for n_, g_ in g_dec.items():
+            if g_ is not None:                                                # (None: accumulated by the kernel, wgrad_into)
+                self._acc(n_, g_)
+        # dL/dmem arrives frame-major [n * K, HW, 512]; the memory read differentiates object by object over all frames' queries
+        g_mem = gin['mem'].view(G, K, plan.HW, DV).permute(1, 0, 2, 3).reshape(K, G * plan.HW, DV)
+        self._query_grads = {'batch': (g_mem, gin['q_out'].view(G, plan.HW, DV), gin['r3'], gin['r2'], gin['r1'])}
+        self._batch_fb = fb
+        self._end_sample(b)
+
+    @torch.no_grad()
     def finish_query(self):
         """The query encoder (KeyValue, res4 .. res2, stem) backwards for ALL frames of the sample that ``Engine.query_batch`` ran
         in one pass: the per-sample gradients ``segment_sample`` collected are stacked along the batch axis, so every data- and
@@ -820,15 +854,18 @@ class ModelBackward:
             return None, None
         plan, qs = self.eng._batch
         n = qs.n
-        if sorted(self._query_grads) != list(range(n)):
-            raise RuntimeError(f'finish_query: gradients for slots {sorted(self._query_grads)} of a batch of {n}')
         m = self.eng.model
-        parts = [self._query_grads[i] for i in range(n)]
-        g_qv, g3, g2, g1 = (torch.cat([t[j] for t in parts], dim=0) for j in range(1, 5))
+        if 'batch' in self._query_grads:                                       # (segment_batch: already stacked)
+            g_mem, g_qv, g3, g2, g1 = self._query_grads['batch']
+        else:
+            if sorted(self._query_grads) != list(range(n)):
+                raise RuntimeError(f'finish_query: gradients for slots {sorted(self._query_grads)} of a batch of {n}')
+            parts = [self._query_grads[i] for i in range(n)]
+            g_qv, g3, g2, g1 = (torch.cat([t[j] for t in parts], dim=0) for j in range(1, 5))
+            g_mem = torch.cat([t[0] for t in parts], dim=1)                   # [K, n*HW, 512]
         # the memory read backwards for the n frames at once: n * HW query columns against the one bank -- six GEMMs and two softmax
         # kernels per object instead of per object and frame (0.48 ms per frame of 625 pixels, launch-bound)
         fb, self._batch_fb = self._batch_fb, None
-        g_mem = torch.cat([t[0] for t in parts], dim=1)                       # [K, n*HW, 512]
         q_keys = qs.kv_q[0:n].reshape(n * plan.HW, DK + DV)[:, :DK].contiguous()
         g_qk, g_bk, g_bv = self.memory_read(plan, fb, q_keys, g_mem)
         g_kv = torch.cat([g_qk.view(n, plan.HW, DK), g_qv], dim=2).view(n, plan.h16, plan.w16, DK + DV)

@@ -762,6 +762,12 @@ class QuerySet:
         self.stage = 0                                      # 0 idle, 1 first half enqueued, 2 complete
         self.n = 0
         self.done = None
+        self._dec_batch = None                              # training: DecoderBatch over the nq frames (built on first use)
+
+    def dec_batch(self):
+        if self._dec_batch is None:
+            self._dec_batch = DecoderBatch(self.plan, self)
+        return self._dec_batch
 
     @staticmethod
     def _sl(t, n):
@@ -826,6 +832,82 @@ class QuerySet:
             p._conv(L, D['local_pred2'], l2[2], p.z2, K, p.h2, p.w2, relu_in=True, name='decoder.local_pred2.taps')
             L.append(Launch(ops.pred2_gather, (p.z2, D['local_pred2'].bias, p.qq), 'decoder.local_pred2.gather'))
             L.append(Launch(ops.final_logits, (p.p_up, p.unc, p.conf, p.qq, p.score, p.pad, p.H0, p.W0), 'decoder.final_logits'))
+
+
+class DecoderBatch:
+    """Training: the bank-dependent half of the decoder for ALL G frames of a sample in one pass (round 5).  The bank is fixed while
+    a sample's frames are segmented (train_video_seg.py:65-69), so after ``Engine.query_batch`` the G memory read-outs exist
+    together and the decoder's convolutions run once over G * obj_n images (sample-major: image g * obj_n + k) instead of G times
+    over obj_n -- the 1/16-resolution layers see 6 250 pixels instead of 1 250, five times fewer launches on the dependent chain and,
+    in the backward pass, five times fewer (and larger) weight-gradient launches.  What mixes the objects of ONE frame (the shared
+    residuals of convFM / local_convFM, the skip additions, uncertainty, the local statistics, the final softmax) keeps its kernels and
+    runs once per frame on that frame's images.  Attributes the backward pass reads (d16, d8, d4, dec_in, pp, p_up, rough, unc, lm,
+    conf, l2, qq, score) have the plan's names; geometry, workspaces and everything else fall through to the plan."""
+
+    def __init__(self, plan, qs):
+        self.plan, self.qs, self.G = plan, qs, qs.nq
+        p, G, K = plan, qs.nq, plan.obj_n
+        N = G * K
+        self.N = N
+        f = lambda *s_: torch.empty(*s_, device=p.eng.device, dtype=torch.float32)
+        self.dec_in = f(N, p.h16, p.w16, DV)
+        self.d16 = [f(N, p.h16, p.w16, 256) for _ in range(3)]
+        self.d8 = [f(N, p.h8, p.w8, 256) for _ in range(3)]
+        self.d4 = [f(N, p.h4, p.w4, 256) for _ in range(3)]
+        self.pp = f(N, p.h4, p.w4, 2)
+        self.z4 = f(N, p.h4, p.w4, Pred2Layer.TAPS)
+        self.z2 = f(N, p.h2, p.w2, Pred2Layer.TAPS)
+        self.p_up = f(N, p.h2, p.w2, 2)
+        self.rough = f(N, p.h2, p.w2)
+        self.unc = f(G, p.h2, p.w2)
+        self.lm = f(N, p.h2, p.w2, 64)
+        self.conf = f(N, p.h2, p.w2)
+        self.l2 = [f(N, p.h2, p.w2, 32) for _ in range(3)]
+        self.qq = f(N, p.h2, p.w2, 2)
+        self.score = f(G, K, p.H0, p.W0)
+        self.post = []
+        self._build()
+
+    def __getattr__(self, name):               # (only what is not set above: geometry, workspaces, obj_n, ...)
+        return getattr(self.plan, name)
+
+    def grp(self, t, g):
+        """The images of frame g in a sample-major tensor."""
+        K = self.plan.obj_n
+        return t[g * K:(g + 1) * K]
+
+    def _build(self):
+        p, qs, G = self.plan, self.qs, self.G
+        K, N = p.obj_n, self.N
+        D = p.eng.dec
+        L = self.post
+        grp = self.grp
+        p._ws_cur, p._cnt_cur = p.ws, p.cnt
+        d16, d8, d4, l2 = self.d16, self.d8, self.d4, self.l2
+        for g in range(G):                      # convFM: the query-value half is frame g's shared residual
+            p._conv(L, D['convFM_m'], grp(self.dec_in, g), grp(d16[0], g), K, p.h16, p.w16, res=qs.fm_q[g:g + 1], res_mod=p.HW,
+                    name='decoder.convFM.mem', lp_out='relu')
+        p._resblock(L, D['ResMM'], d16[0], d16[1], d16[2], N, p.h16, p.w16, 'decoder.ResMM')
+        for g in range(G):
+            L.append(Launch(ops.upsample2x_add, (qs.s8[2][g:g + 1], grp(d16[2], g), grp(d8[0], g), True), 'decoder.RF3.up_add'))
+        p._resblock(L, D['RF3']['ResMM'], d8[0], d8[1], d8[2], N, p.h8, p.w8, 'decoder.RF3.ResMM')
+        for g in range(G):
+            L.append(Launch(ops.upsample2x_add, (qs.s4[2][g:g + 1], grp(d8[2], g), grp(d4[0], g), True), 'decoder.RF2.up_add'))
+        p._resblock(L, D['RF2']['ResMM'], d4[0], d4[1], d4[2], N, p.h4, p.w4, 'decoder.RF2.ResMM')
+        p._conv(L, D['pred2'], d4[2], self.z4, N, p.h4, p.w4, relu_in=True, name='decoder.pred2.taps')
+        L.append(Launch(ops.pred2_gather, (self.z4, D['pred2'].bias, self.pp), 'decoder.pred2.gather'))
+        for g in range(G):
+            L.append(Launch(ops.rough_uncertainty, (grp(self.pp, g), grp(self.p_up, g), grp(self.rough, g), self.unc[g]), 'decoder.rough_unc'))
+            L.append(Launch(ops.local_stats, (qs.q['r1'][g], grp(self.rough, g), p.hs, p.hr, p.hm, grp(self.lm, g), grp(self.conf, g)),
+                            'decoder.local_stats'))
+            p._conv(L, D['local_convFM_loc'], grp(self.lm, g), grp(l2[0], g), K, p.h2, p.w2, res=qs.lq[g:g + 1],
+                    res_mod=p.h2 * p.w2, name='decoder.local_convFM.local', lp_out='relu')
+        p._resblock(L, D['local_ResMM'], l2[0], l2[1], l2[2], N, p.h2, p.w2, 'decoder.local_ResMM')
+        p._conv(L, D['local_pred2'], l2[2], self.z2, N, p.h2, p.w2, relu_in=True, name='decoder.local_pred2.taps')
+        L.append(Launch(ops.pred2_gather, (self.z2, D['local_pred2'].bias, self.qq), 'decoder.local_pred2.gather'))
+        for g in range(G):
+            L.append(Launch(ops.final_logits, (grp(self.p_up, g), self.unc[g], grp(self.conf, g), grp(self.qq, g), self.score[g:g + 1],
+                                               p.pad, p.H0, p.W0), 'decoder.final_logits'))
 
 
 class Engine:
@@ -1120,6 +1202,29 @@ class Engine:
         self._batch = (p, qs)
         return qs
 
+    def segment_batch(self, fb):
+        """The bank-dependent part of ``segment`` for all frames ``query_batch`` holds (training): one memory read per frame into the
+        frame's images of the batch, then the decoder once over frames x objects (DecoderBatch).  Returns the logits f32
+        [n, obj_n, H, W]; the activations stay for ``ModelBackward.segment_batch``."""
+        if self._batch is None:
+            raise RuntimeError('segment_batch follows query_batch')
+        p, qs = self._batch
+        if fb.obj_n != p.obj_n or fb._kbuf is None or fb._hw != p.HW:
+            raise RuntimeError('feature bank does not match the batch (objects / frame size), or is empty')
+        self._join_backward()
+        b = qs.dec_batch()
+        if self.refresher._tables is None:
+            self._settle()
+        K = p.obj_n
+        for g in range(qs.n):
+            self._memory_read(p, fb, False, qs.kv_q[g:g + 1], out=b.grp(b.dec_in, g))
+        for l in b.post:
+            l()
+        qs.consumed = [True] * qs.n
+        self.fwd_count += qs.n
+        self.last_batch = (b, qs)
+        return b.score
+
     def _batched_slot(self, frame):
         if self._batch is None:
             return None
@@ -1225,11 +1330,12 @@ class Engine:
         """One frame of look-ahead (round-1/2 API): ``prefetch_begin([frame], full=True)``."""
         return self.prefetch_begin([frame], obj_n, full=True)
 
-    def _memory_read(self, p, fb, update_bank, kv_q=None):
-        """Matcher.forward (AFB_URR.py:136-178) on the bank slabs."""
+    def _memory_read(self, p, fb, update_bank, kv_q=None, out=None):
+        """Matcher.forward (AFB_URR.py:136-178) on the bank slabs; ``out`` [obj_n, h16, w16, 512] (default: the plan's ``dec_in``)."""
         L = _lib.lib()
         s = stream()
         kv_q = p.kv_q if kv_q is None else kv_q
+        out = p.dec_in if out is None else out
         K, HW, cap = fb.obj_n, p.HW, fb._cap
         nsplit_scan = pick_scan_slices(HW, K, fb.len_upper())
         scale = 1.0 / math.sqrt(DK)
@@ -1257,10 +1363,10 @@ class Engine:
         m.qv = None                       # the query value joins through decoder.convFM.q instead of a concat
         m.bank_k, m.bank_v, m.bank_len, m.ml, m.o_part = ptr(fb._kbuf), ptr(fb._vbuf), ptr(fb._len_dev), ptr(p.ml), ptr(p.o_part)
         m.cnt = ptr(fb._cnt) if update_bank else None
-        m.info, m.out = ptr(fb._ibuf), ptr(p.dec_in)
+        m.info, m.out = ptr(fb._ibuf), ptr(out)
         m.stride_k, m.stride_v, m.stride_cnt, m.stride_info = cap * DK, cap * DV, cap, cap * 2
         m.scale, m.thres = scale, 1e-3
-        m.ldq, m.ldqv, m.ld_out, m.HW, m.obj_n = DK + DV, DK + DV, p.dec_in.shape[-1], HW, K
+        m.ldq, m.ldqv, m.ld_out, m.HW, m.obj_n = DK + DV, DK + DV, out.shape[-1], HW, K
         m.precision = mr_mode
         # 128 query columns per workgroup (8 waves)
         m.nsplit = pick_nsplit(HW, K, fb.len_upper(), QT_SCAN, MAX_SPLIT)

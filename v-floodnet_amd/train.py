@@ -215,6 +215,7 @@ def _check_step_inputs(model, frames, masks):
 
 last_enqueue_s = 0.0
 _BATCH_QUERY = os.environ.get('VFN_TRAIN_BATCH_QUERY', '1') == '1'   # the query encoder over all frames of a sample at once (fwd + bwd)
+_BATCH_DECODER = os.environ.get('VFN_TRAIN_BATCH_DECODER', '1') == '1'   # ... and the decoder (fwd + bwd); needs the batched query encoder
 
 
 def _forward_backward(model, frames, masks, lu, budget, lazy=False):
@@ -233,7 +234,17 @@ def _forward_backward(model, frames, masks, lu, budget, lazy=False):
     mb = eng.backward()
     g_bk = g_bv = None
     stats_sum = torch.zeros(3, device=dev)
-    for i in range(bs):
+    if _BATCH_QUERY and _BATCH_DECODER:
+        # round 5: the bank-dependent half too -- one memory read per frame, then the decoder forward and backward once over
+        # frames x objects (engine.DecoderBatch); the criterion over the whole batch is train_video_seg.py:72-74 as written
+        scores = eng.segment_batch(fb)
+        stats, dscore = ops.segment_loss(scores, label, lu)
+        stats_sum = stats[:3] * bs
+        mb.segment_batch(fb, dscore)
+        bs_loop = 0
+    else:
+        bs_loop = bs
+    for i in range(bs_loop):
         score, _ = model.segment(frames[1 + i:2 + i], fb)
         stats, dscore = ops.segment_loss(score.contiguous(), label[i:i + 1], lu)
         stats_sum += stats[:3]
