@@ -22,10 +22,16 @@ for s in range(steps + 2):
     loss, unc = T.train_step(model, opt, frames, masks, 0.5)
     torch.cuda.synchronize(); t1 = time.perf_counter()
     times.append(t1 - t0); losses.append(loss); enq = T.last_enqueue_s
+# the same steps back to back, as train_model runs them (train_step returns when the loss has arrived, the optimizer's launches may
+# still be running; nothing synchronises between steps)
+torch.cuda.synchronize(); t0 = time.perf_counter()
+for s in range(steps):
+    T.train_step(model, opt, frames, masks, 0.5)
+torch.cuda.synchronize(); b2b = (time.perf_counter() - t0) / steps
 # phases of one more step
 torch.cuda.synchronize(); t0 = time.perf_counter()
 model.engine(); torch.cuda.synchronize(); t1 = time.perf_counter()
 l, u, g = T.forward_backward(model, frames, masks, 0.5); torch.cuda.synchronize(); t2 = time.perf_counter()
 opt.zero_grad(); opt.set_grads(g); opt.step(); torch.cuda.synchronize(); t3 = time.perf_counter()
-print(f'train step {Tn}x{H}x{W}, {K} objects: {1e3 * min(times[2:]):.1f} ms/step (median {1e3 * sorted(times[2:])[len(times[2:]) // 2]:.1f}, max {1e3 * max(times[2:]):.1f}, first {1e3 * times[0]:.0f}; host enqueue of forward+backward {1e3 * enq:.1f} ms); engine rebuild {1e3 * (t1 - t0):.1f}, '
+print(f'train step {Tn}x{H}x{W}, {K} objects: {1e3 * min(times[2:]):.1f} ms/step, {1e3 * b2b:.1f} ms/step back to back (median {1e3 * sorted(times[2:])[len(times[2:]) // 2]:.1f}, max {1e3 * max(times[2:]):.1f}, first {1e3 * times[0]:.0f}; host enqueue of forward+backward {1e3 * enq:.1f} ms); engine rebuild {1e3 * (t1 - t0):.1f}, '
       f'forward+backward {1e3 * (t2 - t1):.1f}, optimizer {1e3 * (t3 - t2):.1f} ms; losses {[round(x, 4) for x in losses]}')

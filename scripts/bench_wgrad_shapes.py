@@ -24,11 +24,11 @@ def timed(x, gy, k, stride, pad, **kw):
     cin = kw.get('cin') or x.shape[-1]
     cout = kw.get('cout') or gy.shape[-1]
     M = N * gy.shape[1] * gy.shape[2]
-    key = (M, cout, cin, k, stride, bool(kw.get('relu')))
+    key = (M, cout, cin, k, stride, bool(kw.get('relu')), kw.get('batch', 1))
     if key not in rows:
         # sweep the split on a scratch output (the real launch follows)
         sweep = {}
-        kw2 = dict(kw); kw2['out'] = torch.empty(cout, k * k * cin, device=dev); kw2['accumulate'] = False
+        kw2 = dict(kw); kw2['out'] = torch.empty(kw.get('batch', 1) * cout, k * k * cin, device=dev); kw2['accumulate'] = False
         for ks in (None, 1, 2, 4, 8, 16, 32, 64):
             if ks is not None and ks > max(1, M // 64):
                 continue
@@ -53,12 +53,12 @@ ops.conv_wgrad = orig
 tot = 0.0
 print('     M  cout   cin k s relu calls | default us (TF/s) | best split us | sweep')
 for key in sorted(rows):
-    M, cout, cin, k, s, relu = key
+    M, cout, cin, k, s, relu, nb = key
     calls, sweep = rows[key]
-    fl = 2.0 * M * cout * cin * k * k
+    fl = 2.0 * M * cout * cin * k * k * nb
     d = sweep[None]
     best = min((v, ks) for ks, v in sweep.items() if ks is not None)
     tot += calls * d
-    print(f'{M:6d} {cout:5d} {cin:5d} {k} {s} {int(relu)} {calls:5d} | {d:8.1f} ({fl / d / 1e6:6.1f}) | {best[0]:8.1f} @{best[1]:<3d}| ' +
+    print(f'{M:6d} {cout:5d} {cin:5d} {k} {s} {int(relu)} x{nb:<2d} {calls:5d} | {d:8.1f} ({fl / d / 1e6:6.1f}) | {best[0]:8.1f} @{best[1]:<3d}| ' +
           ' '.join(f'{ks}:{v:.0f}' for ks, v in sweep.items() if ks is not None))
 print(f'total at the default split: {tot / 1e3:.2f} ms per step')

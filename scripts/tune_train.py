@@ -18,7 +18,7 @@ masks = torch.nn.functional.one_hot(lab, K).permute(0, 3, 1, 2).float().to(dev)
 frames = frames.to(dev)
 before = set(engine._TABLES[0])
 t0 = time.time()
-model.engine().plan(H, W, K).batch_set(Tn - 1)        # (the query encoder over all frames of the sample: Engine.query_batch)
+model.engine().plan(H, W, K).batch_set(Tn - 1).dec_batch()     # (the query encoder and the decoder over all frames of the sample: Engine.query_batch / segment_batch)
 model.engine().autotune(H, W, K, iters=8, only_missing=True)
 print('forward shapes tuned:', len(set(engine._TABLES[0]) - before), f'{time.time() - t0:.0f} s', flush=True)
 

@@ -81,6 +81,7 @@ def pad_divide_by(h, w, d=16):
 
 WS_FLOATS = 16 * 1024 * 1024        # split-K workspace (64 MB), shared by all launches of a plan
 _WINOGRAD_TRAIN = os.environ.get('VFN_WINOGRAD_TRAIN', '1') == '1'     # the training plans' forward convolutions too
+_BATCH_MEMREAD = os.environ.get('VFN_TRAIN_BATCH_MEMREAD', '1') == '1'     # segment_batch: one memory read for all frames of the sample
 _TRAIN_SLOTS = int(os.environ.get('VFN_TRAIN_SLOTS', 2))      # training plans segment() alternates between (see Engine.plan)
 # Winograd F(4x4, 3x3) for the 3x3 / stride-1 layers (csrc/conv_winograd.hip): 1 (default) = where the measured table says so
 # (wino_gfx950.json: "M,cin,cout" -> 0 / 1, scripts/tune_winograd.py; shapes it lacks: >= 128 channels either side and at least
@@ -541,6 +542,8 @@ class FramePlan:
             out += [qs.pre[1], qs.pre[2], qs.post[0], qs.post[1]]
         for qs in self._qbatch.values():
             out += [qs.pre[qs.nq]]
+            if qs._dec_batch is not None:
+                out += [qs._dec_batch.post]
         return out
 
     def batch_set(self, n):
@@ -865,6 +868,12 @@ class DecoderBatch:
         self.l2 = [f(N, p.h2, p.w2, 32) for _ in range(3)]
         self.qq = f(N, p.h2, p.w2, 2)
         self.score = f(G, K, p.H0, p.W0)
+        # the memory read of all G frames in one pass: G * HW query columns against the bank, read-out object-major [K, G * HW, 512]
+        # (then one strided copy into the frame-major ``dec_in``); its own statistics / partial buffers, sized by G * HW
+        import types
+        HWb = G * p.HW
+        self.mr = types.SimpleNamespace(HW=HWb, ml=f(K, HWb, 2), ml_part=f(K, MAX_SPLIT_SCAN, HWb, 2), o_part=f(K, MAX_SPLIT, HWb, DV),
+                                        work=torch.zeros(4, dtype=torch.int32, device=p.eng.device), dec_in=f(K, HWb, DV))
         self.post = []
         self._build()
 
@@ -1215,9 +1224,13 @@ class Engine:
         b = qs.dec_batch()
         if self.refresher._tables is None:
             self._settle()
-        K = p.obj_n
-        for g in range(qs.n):
-            self._memory_read(p, fb, False, qs.kv_q[g:g + 1], out=b.grp(b.dec_in, g))
+        K, G = p.obj_n, qs.n
+        if _BATCH_MEMREAD:
+            self._memory_read(b.mr, fb, False, qs.kv_q[0:G])
+            b.dec_in.view(G, K, p.HW, DV).copy_(b.mr.dec_in.view(K, G, p.HW, DV).permute(1, 0, 2, 3))
+        else:
+            for g in range(G):
+                self._memory_read(p, fb, False, qs.kv_q[g:g + 1], out=b.grp(b.dec_in, g))
         for l in b.post:
             l()
         qs.consumed = [True] * qs.n

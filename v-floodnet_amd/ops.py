@@ -532,6 +532,12 @@ def conv_wgrad(x, gy, k, stride, pad, cin=None, cout=None, ld_x=None, relu=False
         # ~2 000 workgroups, at least 300 pixels per slice (swept on the training step's 51 shapes, scripts/bench_wgrad_shapes.py:
         # 20.0 -> 17.5 ms per step against the first rule, 17.3 with the best split of every shape)
         ksplit = max(1, min(64, 2048 // tiles, M // 300))
+        if batch == 1 and cin > 32:
+            # round 5 (the step's launches are five times fewer and larger since the decoder is batched over a sample's frames): the
+            # 1x1 / 3x3 layers with 3 000 ... 50 000 pixels are fastest with at least 256 workgroups and about 800 pixels per slice --
+            # 12 500 x 256 x 512: 71 -> 56 us, 3 125 x 1024 x 256: 40 -> 35 (profiles/r05_wgrad_shapes.txt); the 7x7 stems and the
+            # Winograd-domain batches keep the rule above
+            ksplit = max(1, min(64, M // 300, max((256 + tiles - 1) // tiles, M // 800)))
     d = WgradDesc()
     d.x, d.gy, d.rowscale, d.dw = ptr(x), ptr(gy), ptr(rowscale), ptr(out)
     d.N, d.H, d.W, d.Cin, d.ld_x = N, H, W, cin, ld_x

@@ -214,6 +214,7 @@ def _check_step_inputs(model, frames, masks):
 
 
 last_enqueue_s = 0.0
+_stats_host = {}                 # device -> pinned f32[3] the step's (loss, cross entropy, uncertainty) land in
 _BATCH_QUERY = os.environ.get('VFN_TRAIN_BATCH_QUERY', '1') == '1'   # the query encoder over all frames of a sample at once (fwd + bwd)
 _BATCH_DECODER = os.environ.get('VFN_TRAIN_BATCH_DECODER', '1') == '1'   # ... and the decoder (fwd + bwd); needs the batched query encoder
 
@@ -265,8 +266,17 @@ def _forward_backward(model, frames, masks, lu, budget, lazy=False):
     mb.finish_memorize(frames[0:1], masks[0:1], g_bk, g_bv)
     global last_enqueue_s
     last_enqueue_s = time.perf_counter() - t_start                          # host time to enqueue the whole step (bench_train_step.py)
-    if lazy:                                     # (train_step: the optimizer's launches are enqueued before the host waits for the loss)
-        return stats_sum / bs, mb.grads
+    if lazy:
+        # train_step: the statistics travel to pinned host memory behind the backward pass and an event marks their arrival; the host
+        # reads them after it has enqueued the optimizer and the refresh, WITHOUT waiting for those -- the next step's first launches
+        # are built while the device still runs AdamW and the filter refresh (0.7 ms), instead of after them
+        host = _stats_host.get(dev)
+        if host is None:
+            host = _stats_host[dev] = torch.empty(3, dtype=torch.float32, pin_memory=True)
+        host.copy_(stats_sum / bs, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        return (host, ev), mb.grads
     st = (stats_sum / bs).tolist()                                          # one D2H per step, as loss.item() is
     return st[0], st[2], mb.grads
 
@@ -305,7 +315,9 @@ def train_step(model, optimizer, frames, masks, lu=0.5, budget=300000):
         model.engine()               # (or are rebuilt here, inside the single-threaded region, if a parameter moved)
         # the step's one device-to-host read, AFTER the optimizer and the refresh have been enqueued: read right behind the backward
         # pass (round 4) it left the device idle while the host built the optimizer's launches (0.4 + 0.7 ms in a kernel trace)
-        st = stats.tolist()
+        host, ev = stats
+        ev.synchronize()
+        st = host.tolist()
     return st[0], st[2]
 
 
