@@ -289,6 +289,17 @@ typedef struct vfn_wgrad_desc {
 } vfn_wgrad_desc;
 int vfn_conv_wgrad_f32(const vfn_wgrad_desc* d, void* stream);
 
+/* vfn_stem_wgrad_f32 (ABI 12, round 5)   the weight gradient of the encoders' 7x7 / stride-2 / pad-3 stems (AFB_URR.py:44-46,67-69 under
+ * train_video_seg.py:73 loss.backward()): x [N,Hp,Wp,C] dense NHWC, C = 3 (query encoder: conv1 over the frame) or 5 (memory encoder:
+ * conv1 + conv1_m + conv1_o over frame | mask | other-objects planes), g [N,Ho,Wo,64] dense = dL/d(bn1 output), Ho = (Hp - 1) / 2 + 1,
+ * rowscale [64] = the frozen bn1 scale (NULL: 1) -> dw [64][7][7][C] in vfn_conv_wgrad_f32's packed layout (accumulate: added to it).
+ * The operand columns are (kw, c) of one filter row -- 7 C contiguous floats of the NHWC planes -- so one pixel walk feeds all seven
+ * filter rows (vfn_conv_wgrad_f32 walks the pixels once per tap with 3 of 32 columns in use).  partial: scratch of at least
+ * vfn_stem_wgrad_scratch_floats(C) floats.  Fixed summation order: bit-reproducible. */
+int vfn_stem_wgrad_scratch_floats(int C);
+int vfn_stem_wgrad_f32(const float* x, const float* g, const float* rowscale, float* dw, float* partial, long long partial_floats,
+                       int N, int Hp, int Wp, int C, int Ho, int Wo, int accumulate, void* stream);
+
 /* Derived-parameter refresh (ABI 11; csrc/refresh.hip).  After ``optimizer.step()`` (train_video_seg.py:76) everything this library
  * derives from the parameters -- packed filters in the forward layout, in the layout of the data-gradient convolution, the stems'
  * padded taps, the tap form of the two-filter heads; folded BatchNorm scale / shift (the reference freezes the statistics only,

@@ -559,3 +559,42 @@ def test_winograd_weight_gradient_vs_direct_and_autograd(gpu, case):
     acc = got.clone()
     ops.conv_wgrad_winograd(xd, gd, relu=relu, rowscale=sc, out=acc, accumulate=True)
     assert (acc.cpu().double() - 2 * ref).abs().max().item() < 2 * tol
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('case', [(2, 96, 160, 3, True), (1, 50, 70, 5, True), (5, 64, 48, 3, False), (2, 33, 39, 5, False), (1, 16, 16, 3, True)])
+def test_stem_weight_gradient_vs_autograd_and_the_generic_kernel(gpu, case, monkeypatch):
+    """The 7x7 / stride-2 / pad-3 stems' weight gradient (vfn_stem_wgrad_f32: the operand columns are (kw, c) of one filter row, one pixel
+    walk for all 49 taps; 3 planes for the query encoder, 5 for the memory encoder) against float64 autograd and against the generic
+    implicit-GEMM kernel it replaces on this shape: odd sizes (a last pixel without a partner, segments that end inside a row), the
+    frozen-BatchNorm row scale, accumulation, run-to-run bit-reproducibility."""
+    import torch.nn.functional as F
+    from vfloodnet_amd import ops
+    N, H, W, C, with_scale = case
+    g = torch.Generator().manual_seed(hash(case) & 0xFFFF)
+    x = torch.randn(N, C, H, W, generator=g)
+    w = (torch.randn(64, C, 7, 7, generator=g) / (C * 49) ** 0.5).double().requires_grad_()
+    scale = 1 + 0.1 * torch.randn(64, generator=g)
+    y = F.conv2d(x.double(), w, stride=2, padding=3)
+    if with_scale:
+        y = y * scale.double().view(1, -1, 1, 1)
+    gy = torch.randn(y.shape, generator=g)
+    (y * gy.double()).sum().backward()
+    ref = w.grad.permute(0, 2, 3, 1).reshape(64, -1)                          # packed (kh, kw, c)
+    xd = x.permute(0, 2, 3, 1).contiguous().to(gpu)
+    gd = gy.permute(0, 2, 3, 1).contiguous().to(gpu)
+    sc = scale.to(gpu) if with_scale else None
+    assert ops._STEM_WGRAD
+    got = ops.conv_wgrad(xd, gd, 7, 2, 3, rowscale=sc)
+    monkeypatch.setattr(ops, '_STEM_WGRAD', False)
+    generic = ops.conv_wgrad(xd, gd, 7, 2, 3, rowscale=sc)
+    monkeypatch.setattr(ops, '_STEM_WGRAD', True)
+    torch.cuda.synchronize()
+    tol = 2e-5 * ref.abs().max().item() * max(1.0, (N * y.shape[2] * y.shape[3]) ** 0.5 / 30)
+    err, err_g = (got.cpu().double() - ref).abs().max().item(), (generic.cpu().double() - ref).abs().max().item()
+    assert err < tol and err_g < tol, (err, err_g, tol)
+    assert not torch.equal(got, generic) or N * H * W < 2000                   # (two kernels, two summation orders: the new one did run)
+    assert torch.equal(got, ops.conv_wgrad(xd, gd, 7, 2, 3, rowscale=sc))
+    acc = got.clone()
+    ops.conv_wgrad(xd, gd, 7, 2, 3, rowscale=sc, out=acc, accumulate=True)
+    assert (acc.cpu().double() - 2 * ref).abs().max().item() < 2 * tol

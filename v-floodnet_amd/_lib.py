@@ -147,6 +147,8 @@ def _declare(L):
     L.vfn_bank_refresh_norms.argtypes = [C.POINTER(BankDesc), p, p, p, p]
     L.vfn_conv_wgrad_f32.argtypes = [C.POINTER(WgradDesc), p]
     L.vfn_bank_refresh_lp.argtypes = [C.POINTER(BankDesc), p, p, i, p]
+    L.vfn_stem_wgrad_scratch_floats.argtypes = [i]
+    L.vfn_stem_wgrad_scratch_floats.restype = i
     for name, args in SIGNATURES.items():
         fn = getattr(L, name)
         fn.argtypes = args
@@ -223,12 +225,14 @@ SIGNATURES = {
     'vfn_ln_scale_cols_f32': [_p, _p, _p, _i, _i, _p],
     'vfn_ln_add_f32': [_p, _p, _p, _ll, _p],
     'vfn_ln_head_f32': [_p, _p, _f, _p, _ll, _i, _i, _i, _p],
+    'vfn_stem_wgrad_f32': [_p, _p, _p, _p, _p, _ll, _i, _i, _i, _i, _i, _i, _i, _p],
 }
 # every symbol include/vfn_hip.h declares (checked by tests/test_abi.py)
 ALL_SYMBOLS = sorted(list(SIGNATURES) + [
     'vfn_abi_version', 'vfn_sizeof_desc', 'vfn_conv_cfg_count', 'vfn_conv_cfg_tile', 'vfn_conv_cfg_info', 'vfn_conv_cfg_wk', 'vfn_conv_cfg_tpb', 'vfn_conv_cfg_kind', 'vfn_conv_cfg_name', 'vfn_conv2d_nhwc_f32', 'vfn_conv2d_nhwc_bf16', 'vfn_conv2d_nhwc_bf16x3',
     'vfn_stem_conv7x7_f32',
-    'vfn_bank_scan', 'vfn_memread_apply', 'vfn_memread_finish', 'vfn_bank_merge', 'vfn_bank_append', 'vfn_bank_remove', 'vfn_bank_refresh_norms', 'vfn_bank_refresh_lp', 'vfn_conv_wgrad_f32'])
+    'vfn_bank_scan', 'vfn_memread_apply', 'vfn_memread_finish', 'vfn_bank_merge', 'vfn_bank_append', 'vfn_bank_remove', 'vfn_bank_refresh_norms', 'vfn_bank_refresh_lp', 'vfn_conv_wgrad_f32',
+    'vfn_stem_wgrad_scratch_floats'])
 
 
 def check(status, what):

@@ -311,6 +311,178 @@ int launch_wgrad(const vfn_wgrad_desc& p, hipStream_t s) {
     return vfn_check_launch();
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// The 7x7 / stride-2 stems (AFB_URR.py:44,67-69: conv1 over 3 frame planes; conv1 + conv1_m + conv1_o over 5), round 5.
+// conv_wgrad_kernel gives every (tap, 32-channel tile) its own pixel walk; with 3 or 5 input planes that is 49 walks with 3 of
+// 32 operand columns in use -- 558 us for the query encoder's five frames (6.7 TFLOP/s), 238 us for the memory encoder, both on the
+// END of the step's dependent chain.  Here the columns of the operand are (kw, c) of ONE filter row: the 7 * C values
+// x[iy][2 ox - 3 .. 2 ox + 3][0 .. C) are CONTIGUOUS in the NHWC planes, so a half wave loads them with one buffer load (lane =
+// column; 21 of 32 in use for C = 3, 35 of 64 for C = 5), the other operand is 32 channels of gy at the same pixel, and one
+// pixel walk feeds all 7 (x NT) filter-row tiles of a 32-channel output tile:
+//
+//   wave        (output-channel tile cot, pixel half ph): 7 * NT accumulators of 32 x 32, units (output row, column segment)
+//               dealt round-robin; per pixel pair 1 + 7 NT buffer loads (three pairs in flight) and 7 NT MFMAs (32x32x2)
+//   workgroup   2 x 2 waves; the two pixel halves are summed through LDS, the block's tiles go to `partial`
+//   stem_wgrad_reduce_kernel   sums the blocks' tiles in block order (deterministic), applies rowscale / accumulate and writes
+//               dW [64][7][7][C] (the packed layout of vfn_conv_wgrad_f32)
+template <int C, int NT>
+__global__ __launch_bounds__(256, NT == 1 ? 2 : 1)
+void stem_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ g, float* __restrict__ partial, int N, int Hp, int Wp,
+                       int Ho, int Wo, int segs, int seg_len) {
+    constexpr int NACC = 7 * NT, PD = NT == 1 ? 4 : 3;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* sR = reinterpret_cast<float*>(smem);          // [cot][NACC][16][64]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 31, lh = lane >> 5;
+    const int cot = wave & 1, ph = wave >> 1;
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(x), 0, (int)((size_t)N * Hp * Wp * C * sizeof(float)), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rg = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g), 0, (int)((size_t)N * Ho * Wo * 64 * sizeof(float)), 0x00020000);
+    constexpr int OOB = 0x7fffff00;
+
+    f32x16 acc[NACC];
+#pragma unroll
+    for (int a = 0; a < NACC; ++a)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[a][r] = 0.f;
+
+    // this lane's operand columns: jj = tt * 32 + li -> input column offset jj / C (jj < 7 C)
+    int jx[NT];
+    bool jok[NT];
+#pragma unroll
+    for (int tt = 0; tt < NT; ++tt) { const int jj = tt * 32 + li; jx[tt] = jj / C; jok[tt] = jj < 7 * C; }
+
+    const int units = N * Ho * segs;
+    for (int u = blockIdx.x * 2 + ph; u < units; u += gridDim.x * 2) {
+        const int row = u / segs, seg = u - row * segs;
+        const int n = row / Ho, oy = row - n * Ho;
+        const int ox0 = seg * seg_len, ox1 = min(Wo, ox0 + seg_len);
+        const int npairs = (ox1 - ox0 + 1) >> 1;
+        int rowoff[7];                                   // byte offset of input row 2 oy + kh - 3 (OOB: a padding row)
+#pragma unroll
+        for (int kh = 0; kh < 7; ++kh) {
+            const int iy = 2 * oy + kh - 3;
+            rowoff[kh] = (unsigned)iy < (unsigned)Hp ? ((n * Hp + iy) * Wp) * C * 4 : OOB;
+        }
+        const int goff = (row * Wo * 64 + cot * 32 + li) * 4;
+
+        float av[PD];
+        float bv[PD][NACC];
+        auto load = [&](int t, int slot) {
+            const int ox = ox0 + 2 * t + lh;
+            const bool pv = ox < ox1;
+            av[slot] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rg, pv ? goff + ox * 256 : OOB, 0, 0));
+            const int ixb = 2 * ox - 3;
+#pragma unroll
+            for (int tt = 0; tt < NT; ++tt) {
+                const int ix = ixb + jx[tt];
+                const bool ok = pv && jok[tt] && (unsigned)ix < (unsigned)Wp;
+                // one select per tile, no branch: a column outside the image (or past the segment) gets an offset that stays out of
+                // range whatever row offset is added; a padding ROW's offset (OOB) stays out of range plus any in-row offset
+                const unsigned coff = ok ? (unsigned)((ixb * C + tt * 32 + li) * 4) : 0x40000000u;
+#pragma unroll
+                for (int kh = 0; kh < 7; ++kh)
+                    bv[slot][kh * NT + tt] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rx, (int)((unsigned)rowoff[kh] + coff), 0, 0));
+            }
+        };
+#pragma unroll
+        for (int d = 0; d < PD; ++d) { load(d, d); __builtin_amdgcn_sched_barrier(0); }      // (in THIS order: the loop waits for slot 0 first)
+        for (int t0 = 0; t0 < npairs; t0 += PD) {
+#pragma unroll
+            for (int d = 0; d < PD; ++d) {
+                // slot d holds pair t0 + d (the oldest loads in flight: the wait leaves the 2 (1 + 7 NT) younger ones outstanding);
+                // its registers are refilled for pair t0 + d + PD right behind the MFMAs that read them (pairs past the segment
+                // load zeros).  The scheduling barriers keep this order -- without them hipcc gathers the three slots' uses at the
+                // loop top behind one vmcnt(0)
+#pragma unroll
+                for (int q = 0; q < NACC; ++q) acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[d], bv[d][q], acc[q], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                load(t0 + d + PD, d);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    }
+
+    // the two pixel halves of an output-channel tile, summed in LDS; then the block's tiles -> partial[block][cot][NACC][16][64]
+    if (ph == 1) {
+#pragma unroll
+        for (int a = 0; a < NACC; ++a)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) sR[((cot * NACC + a) * 16 + r) * 64 + lane] = acc[a][r];
+    }
+    __syncthreads();
+    if (ph == 0) {
+        float* dst = partial + ((size_t)blockIdx.x * 2 + cot) * NACC * 1024;
+#pragma unroll
+        for (int a = 0; a < NACC; ++a)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) dst[(a * 16 + r) * 64 + lane] = acc[a][r] + sR[((cot * NACC + a) * 16 + r) * 64 + lane];
+    }
+}
+
+// dW[co][kh][kw][c] = rowscale[co] * sum_blocks partial[block][cot][kh * NT + tt][r][lane]  (+ dW)    co = 32 cot + (r & 3) + 8 (r >> 2)
+// + 4 (lane >> 5), column (lane & 31) + 32 tt = kw * C + c.  256 threads = 64 elements (one r of one tile) x 4 groups of blocks.
+template <int C, int NT>
+__global__ void stem_wgrad_reduce_kernel(const float* __restrict__ partial, int nblocks, const float* __restrict__ rowscale,
+                                         float* __restrict__ dw, int accumulate) {
+    constexpr int NACC = 7 * NT;
+    __shared__ float sS[4][64];
+    const int lane = threadIdx.x & 63, grp = threadIdx.x >> 6;
+    const int e = blockIdx.x;                            // (cot, a, r)
+    const int r = e & 15, a = (e >> 4) % NACC, cot = e / (16 * NACC);
+    const int per = (nblocks + 3) / 4;
+    const int b0 = grp * per, b1 = min(nblocks, b0 + per);
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    const float* src = partial + ((size_t)cot * NACC + a) * 1024 + r * 64 + lane;
+    const size_t bstride = (size_t)2 * NACC * 1024;
+    int b = b0;
+    for (; b + 4 <= b1; b += 4) {
+        s0 += src[(size_t)b * bstride];
+        s1 += src[(size_t)(b + 1) * bstride];
+        s2 += src[(size_t)(b + 2) * bstride];
+        s3 += src[(size_t)(b + 3) * bstride];
+    }
+    for (; b < b1; ++b) s0 += src[(size_t)b * bstride];
+    sS[grp][lane] = (s0 + s1) + (s2 + s3);
+    __syncthreads();
+    if (grp == 0) {
+        const float v = (sS[0][lane] + sS[1][lane]) + (sS[2][lane] + sS[3][lane]);
+        const int kh = a / NT, tt = a - kh * NT;
+        const int jj = tt * 32 + (lane & 31);
+        const int co = cot * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        if (jj < 7 * C) {
+            float* o = dw + (size_t)co * 49 * C + kh * 7 * C + jj;
+            const float w = v * (rowscale ? rowscale[co] : 1.f);
+            *o = accumulate ? *o + w : w;
+        }
+    }
+}
+
+template <int C, int NT>
+int launch_stem_wgrad(const float* x, const float* g, const float* rowscale, float* dw, float* partial, long long partial_floats,
+                      int N, int Hp, int Wp, int Ho, int Wo, int accumulate, hipStream_t s) {
+    constexpr int NACC = 7 * NT;
+    constexpr size_t lds = (size_t)2 * NACC * 1024 * sizeof(float);
+    const int rows = N * Ho;
+    int nblocks = 256;
+    int segs = cdiv(2048, rows);
+    if (segs > Wo / 16) segs = Wo / 16 > 0 ? Wo / 16 : 1;
+    int seg_len = cdiv(Wo, segs);
+    seg_len += seg_len & 1;
+    segs = cdiv(Wo, seg_len);
+    if (rows * segs < 2 * nblocks) nblocks = cdiv(rows * segs, 2);
+    if (partial_floats < (long long)nblocks * 2 * NACC * 1024) return VFN_ERR_ARG;
+    static bool once = false;
+    if (!once) {
+        hipFuncSetAttribute(reinterpret_cast<const void*>(stem_wgrad_kernel<C, NT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        once = true;
+    }
+    hipLaunchKernelGGL((stem_wgrad_kernel<C, NT>), dim3(nblocks), dim3(256), lds, s, x, g, partial, N, Hp, Wp, Ho, Wo, segs, seg_len);
+    hipLaunchKernelGGL((stem_wgrad_reduce_kernel<C, NT>), dim3(2 * NACC * 16), dim3(256), 0, s, partial, nblocks, rowscale, dw, accumulate);
+    return vfn_check_launch();
+}
+
 }  // namespace
 
 extern "C" int vfn_conv_wgrad_f32(const vfn_wgrad_desc* d, void* stream) {
@@ -327,4 +499,21 @@ extern "C" int vfn_conv_wgrad_f32(const vfn_wgrad_desc* d, void* stream) {
     }
     if (d->Cin <= 32) return launch_wgrad<2, 1>(*d, s);
     return launch_wgrad<2, 2>(*d, s);
+}
+
+// (ABI 12, round 5) the weight gradient of the encoders' 7x7 / stride-2 / pad-3 stems: x [N,Hp,Wp,C] dense (C = 3: conv1 of the query
+// encoder, AFB_URR.py:67; C = 5: conv1 + conv1_m + conv1_o of the memory encoder over the concatenated planes, :44-46), g [N,Ho,Wo,64]
+// dense = dL/d(bn1 output), rowscale [64] the frozen bn1 scale (or NULL) -> dw [64][7][7][C] (vfn_conv_wgrad_f32's packed layout);
+// partial: scratch of at least vfn_stem_wgrad_scratch_floats(C) floats.  Deterministic (fixed summation order).
+extern "C" int vfn_stem_wgrad_scratch_floats(int C) { return C == 3 ? 256 * 2 * 7 * 1024 : C == 5 ? 256 * 2 * 14 * 1024 : -1; }
+
+extern "C" int vfn_stem_wgrad_f32(const float* x, const float* g, const float* rowscale, float* dw, float* partial, long long partial_floats,
+                                  int N, int Hp, int Wp, int C, int Ho, int Wo, int accumulate, void* stream) {
+    if (!x || !g || !dw || !partial || N < 1 || Hp < 1 || Wp < 1) return VFN_ERR_ARG;
+    if (Ho != (Hp - 1) / 2 + 1 || Wo != (Wp - 1) / 2 + 1) return VFN_ERR_ARG;
+    if ((long long)N * Hp * Wp * C * 4 >= 0x7fffff00LL || (long long)N * Ho * Wo * 64 * 4 >= 0x7fffff00LL) return VFN_ERR_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    if (C == 3) return launch_stem_wgrad<3, 1>(x, g, rowscale, dw, partial, partial_floats, N, Hp, Wp, Ho, Wo, accumulate, s);
+    if (C == 5) return launch_stem_wgrad<5, 2>(x, g, rowscale, dw, partial, partial_floats, N, Hp, Wp, Ho, Wo, accumulate, s);
+    return VFN_ERR_ARG;
 }

@@ -504,6 +504,7 @@ _wgrad_ws = {}
 # step (49.6 against 43.1 ms: the wave that arrives last walks ksplit x 64 dwords alone, where the reduce launch spreads them over
 # the chip), so it is off; tests/test_kernels_gpu.py keeps the path correct.
 _WGRAD_INLAUNCH = os.environ.get('VFN_WGRAD_INLAUNCH', '0') == '1'
+_STEM_WGRAD = os.environ.get('VFN_STEM_WGRAD', '1') == '1'        # the 7x7 stems' weight gradient through vfn_stem_wgrad_f32 (0: the generic kernel)
 
 
 def conv_wgrad(x, gy, k, stride, pad, cin=None, cout=None, ld_x=None, relu=False, rowscale=None, out=None, accumulate=False,
@@ -526,6 +527,18 @@ def conv_wgrad(x, gy, k, stride, pad, cin=None, cout=None, ld_x=None, relu=False
         out = torch.empty(cout, Kc, device=x.device, dtype=torch.float32)
     assert out.is_contiguous() and out.numel() == batch * cout * Kc
     M = N * Ho * Wo
+    if (_STEM_WGRAD and k == 7 and stride == 2 and pad == 3 and cout == 64 and cin in (3, 5) and ld_x == cin and ld_g == 64 and batch == 1
+            and not relu and ksplit is None and Ho == (H - 1) // 2 + 1 and Wo == (W - 1) // 2 + 1):
+        # the encoders' stems: the operand columns are (kw, c) of one filter row, one pixel walk for all 49 taps (vfn_stem_wgrad_f32)
+        L = _lib.lib()
+        key = (str(x.device), torch.cuda.current_stream(x.device).cuda_stream, 'stem')
+        need = L.vfn_stem_wgrad_scratch_floats(cin)
+        part = _wgrad_ws.get(key)
+        if part is None or part.numel() < need:
+            part = _wgrad_ws[key] = torch.empty(need, device=x.device, dtype=torch.float32)
+        check(L.vfn_stem_wgrad_f32(ptr(x), ptr(gy), ptr(rowscale), ptr(out), ptr(part), part.numel(), N, H, W, cin, Ho, Wo, int(accumulate),
+                                   stream()), 'vfn_stem_wgrad_f32')
+        return out
     tiles = ((cout + 63) // 64 if cout > 32 else 1) * k * k * ((cin + (31 if cin <= 32 else 63)) // (32 if cin <= 32 else 64))
     tiles *= batch                               # (``batch`` independent problems of this shape in one launch: vfn_wgrad_desc.batch)
     if ksplit is None:
