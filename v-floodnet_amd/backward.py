@@ -34,6 +34,9 @@ _WINOGRAD_WGRAD = __import__('os').environ.get('VFN_WINOGRAD_WGRAD', '1') == '1'
 _WINOGRAD_WGRAD_MIN_WORK = int(__import__('os').environ.get('VFN_WINOGRAD_WGRAD_MIN_WORK', 600000))        # pixels x min(cin, cout)
 _SIDE_DROP = __import__('os').environ.get('VFN_SIDE_DROP', '0') == '1'
 _NO_WAIT_PLAN = __import__('os').environ.get('VFN_UNSAFE_NO_WAIT_PLAN', '0') == '1'   # measurement only (WRONG gradients): what the per-sample wait costs
+_SIDE2 = __import__('os').environ.get('VFN_SIDE2', '1') == '1'                       # a second side stream for the memory encoder's weight gradients
+_SIDE3 = __import__('os').environ.get('VFN_SIDE3', '0') == '1'                       # ... and a third for the query encoder's (the first keeps the decoder's): measured
+#                                                                                      no gain (22.0 / 22.1 against 21.9 / 21.8 ms per step, profiles/r05_train_side_streams.txt): off
 _SIDE_GROUP = int(__import__('os').environ.get('VFN_SIDE_GROUP', 8))                   # deferred launches per side-stream hand-over
 
 
@@ -454,6 +457,15 @@ class ModelBackward:
         # side stream before the next forward overwrites the activations and before the gradients are read (join).
         self.side = torch.cuda.Stream(dev, priority=_SIDE_PRIORITY) if _SIDE_WGRAD else None
         self._pending, self._inflight, self._by_plan = [], [], {}
+        # round 5: with the decoder batched the side stream IS the step's critical path (12.8 ms of weight-gradient launches that cannot
+        # start before the backward pass does, one after the other).  The memory encoder's (finish_memorize: the last to be produced,
+        # parameters no other launch touches) go to a second side stream and run beside the query encoder's.  ``_lane`` = where
+        # _side_do queues; per-lane scratch for the BatchNorm sums (the convolution kernels' workspaces are keyed by stream already)
+        self.side2 = torch.cuda.Stream(dev, priority=_SIDE_PRIORITY) if (_SIDE_WGRAD and _SIDE2) else None
+        self.side3 = torch.cuda.Stream(dev, priority=_SIDE_PRIORITY) if (_SIDE_WGRAD and _SIDE2 and _SIDE3) else None
+        self._pending2, self._pending3, self._lane = [], [], 0        # lane 0: decoder + KeyValue, 1: memory encoder, 2: query encoder
+        self._ticket2 = torch.zeros(64, dtype=torch.int32, device=dev)
+        self._ticket3 = torch.zeros(64, dtype=torch.int32, device=dev)
         self._pad = {}               # zero-padded operand images of the memory read's small GEMMs (_gemm_nt)
         self._query_grads = {}       # slot -> gradients entering the memory read / the query encoder (batched samples: finish_query)
         self._batch_fb = None        # ... and the bank they were segmented against
@@ -473,6 +485,14 @@ class ModelBackward:
             return
         if self.side is None:
             fn()
+        elif self._lane == 1 and self.side2 is not None:
+            self._pending2.append(fn)
+            if len(self._pending2) >= _SIDE_GROUP:
+                self._flush()
+        elif self._lane == 2 and self.side3 is not None:
+            self._pending3.append(fn)
+            if len(self._pending3) >= _SIDE_GROUP:
+                self._flush()
         else:
             self._pending.append(fn)
             if len(self._pending) >= _SIDE_GROUP:
@@ -480,14 +500,17 @@ class ModelBackward:
 
     def _flush(self):
         """Issue the deferred launches on the side stream, behind everything the main stream has enqueued so far."""
-        if not self._pending:
+        if not self._pending and not self._pending2 and not self._pending3:
             return
-        self.side.wait_event(torch.cuda.current_stream().record_event())
-        with torch.cuda.stream(self.side):
-            for fn in self._pending:
-                fn()
-        self._inflight += self._pending            # (operands stay referenced until the main stream has joined the side stream)
-        self._pending = []
+        ev = torch.cuda.current_stream().record_event()
+        for side, pend in ((self.side, self._pending), (self.side2, self._pending2), (self.side3, self._pending3)):
+            if pend:
+                side.wait_event(ev)
+                with torch.cuda.stream(side):
+                    for fn in pend:
+                        fn()
+                self._inflight += pend             # (operands stay referenced until the main stream has joined the side streams)
+        self._pending, self._pending2, self._pending3 = [], [], []
 
     def join(self):
         """The main stream waits for the side stream: before the gradients are handed out (and before a forward overwrites
@@ -495,6 +518,9 @@ class ModelBackward:
         self._flush()
         if self._inflight or self._by_plan:
             torch.cuda.current_stream().wait_stream(self.side)
+            for extra in (self.side2, self.side3):
+                if extra is not None:
+                    torch.cuda.current_stream().wait_stream(extra)
             self._inflight = []
             self._by_plan = {}
 
@@ -502,14 +528,16 @@ class ModelBackward:
         """Everything deferred for the sample that used ``plan`` is on the side stream now: remember where it ends."""
         self._flush()
         if self._inflight:
-            self._by_plan[id(plan)] = (self.side.record_event(), self._inflight)
+            evs = [st.record_event() for st in (self.side, self.side2, self.side3) if st is not None]
+            self._by_plan[id(plan)] = (evs, self._inflight)
             self._inflight = []
 
     def wait_plan(self, plan):
         """The main stream is about to overwrite ``plan``'s activations: wait for the side-stream launches that read them."""
         hit = self._by_plan.pop(id(plan), None)
         if hit is not None and not _NO_WAIT_PLAN:
-            torch.cuda.current_stream().wait_event(hit[0])
+            for ev in hit[0]:
+                torch.cuda.current_stream().wait_event(ev)
 
     @property
     def grads(self):
@@ -644,8 +672,9 @@ class ModelBackward:
         dg, acc_g = self._small(name + '.weight', C)                          # accumulated by the kernel: no torch add per sample
         db, acc_b = self._small(name + '.bias', C)
         assert acc_g == acc_b
-        part = self.dec._buf('bn', 2 * self.NB1 * C)
-        beta, gamma, ticket, nb1 = bn.bias.detach(), bn.weight.detach(), self._ticket, self.NB1
+        lane = self._lane if self._lane and (self.side2, self.side3)[self._lane - 1] is not None else 0
+        part = self.dec._buf(('bn', 'bn2', 'bn3')[lane], 2 * self.NB1 * C)
+        beta, gamma, ticket, nb1 = bn.bias.detach(), bn.weight.detach(), (self._ticket, self._ticket2, self._ticket3)[lane], self.NB1
         self._side_do(lambda: check(_lib.lib().vfn_bn_param_grads_acc_f32(ptr(g), ptr(y), ptr(idn), ptr(beta), ptr(gamma), M, C, ptr(part), nb1,
                                                                           ptr(dg), ptr(db), acc_g, ptr(ticket), stream()),
                                     'vfn_bn_param_grads_acc_f32'))
@@ -873,11 +902,16 @@ class ModelBackward:
         acts = qs.acts[n]
         bufs = {'r1': qs.q['r1'][0:n]}
         r4 = acts[('res4', len(m.encoder_q.res4) - 1)]['out']
-        self._keyval(plan, r4, g_kv, n)
+        self._keyval(plan, r4, g_kv, n)              # (KeyValue: first side stream, with the memory side's)
         g_r4 = self._dgrad(plan, self.cb['keyval'], g_kv, n, plan.h16, plan.w16, mask=r4)
-        g_c1 = self._trunk(plan, 'encoder_q', m.encoder_q, acts, bufs, n, g_r4, {'res3': g3, 'res2': g2, 'r1': g1})
-        xn = self._normalised_input(plan, qs.frames[0:n])
-        self._stem(plan, 'encoder_q', m.encoder_q, xn, g_c1, bufs['r1'], n, [('encoder_q.conv1.weight', 3)])
+        self._flush()
+        self._lane = 2                               # the query encoder's own parameters: third side stream
+        try:
+            g_c1 = self._trunk(plan, 'encoder_q', m.encoder_q, acts, bufs, n, g_r4, {'res3': g3, 'res2': g2, 'r1': g1})
+            xn = self._normalised_input(plan, qs.frames[0:n])
+            self._stem(plan, 'encoder_q', m.encoder_q, xn, g_c1, bufs['r1'], n, [('encoder_q.conv1.weight', 3)])
+        finally:
+            self._lane = 0
         self._flush()
         return g_bk, g_bv
 
@@ -904,9 +938,14 @@ class ModelBackward:
         g_kv = torch.stack([torch.cat([g_bank_k[k], g_bank_v[k]], dim=1) for k in range(K)], 0).view(K, plan.h16, plan.w16, DK + DV).contiguous()
         acts = plan.acts_m
         r4 = acts[('res4', len(m.encoder_m.res4) - 1)]['out']
-        self._keyval(plan, r4, g_kv, K)
+        self._keyval(plan, r4, g_kv, K)              # (KeyValue is shared with the query side: its gradients stay on the first side stream)
         g_r4 = self._dgrad(plan, self.cb['keyval'], g_kv, K, plan.h16, plan.w16, mask=r4)
-        g_c1 = self._trunk(plan, 'encoder_m', m.encoder_m, acts, plan.m, K, g_r4, {})
-        xn = self._normalised_input(plan, frame, mask)
-        self._stem(plan, 'encoder_m', m.encoder_m, xn, g_c1, plan.m['r1'], K,
-                   [('encoder_m.conv1.weight', 3), ('encoder_m.conv1_m.weight', 1), ('encoder_m.conv1_o.weight', 1)])
+        self._flush()
+        self._lane = 1                               # the memory encoder's own parameters: second side stream
+        try:
+            g_c1 = self._trunk(plan, 'encoder_m', m.encoder_m, acts, plan.m, K, g_r4, {})
+            xn = self._normalised_input(plan, frame, mask)
+            self._stem(plan, 'encoder_m', m.encoder_m, xn, g_c1, plan.m['r1'], K,
+                       [('encoder_m.conv1.weight', 3), ('encoder_m.conv1_m.weight', 1), ('encoder_m.conv1_o.weight', 1)])
+        finally:
+            self._lane = 0
