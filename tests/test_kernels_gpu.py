@@ -598,3 +598,48 @@ def test_stem_weight_gradient_vs_autograd_and_the_generic_kernel(gpu, case, monk
     acc = got.clone()
     ops.conv_wgrad(xd, gd, 7, 2, 3, rowscale=sc, out=acc, accumulate=True)
     assert (acc.cpu().double() - 2 * ref).abs().max().item() < 2 * tol
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('case', [(2, 17, 23, 64, True), (1, 8, 8, 4, False), (5, 40, 36, 64, True), (1, 7, 9, 6, True), (1, 2, 3, 8, False)])
+def test_maxpool_backward_vs_autograd_and_the_scalar_kernel(gpu, case):
+    """MaxPool2d(3, 2, 1) backwards (vfn_maxpool3x3s2_backward_f32): the four-channel kernel (one thread per 2 x 2 input block, the 5 x 5
+    patch loaded once) against float64 autograd -- inputs quantised so that windows hold ties (PyTorch routes the gradient to the FIRST
+    maximum in row-major order) -- with the second gradient and the ReLU mask of the encoders' r1, odd sizes; and bit-identical to the
+    scalar kernel it replaces (reached through a 4-byte-misaligned view; 6 channels take it anyway)."""
+    import torch.nn.functional as F
+    from vfloodnet_amd import _lib
+    from vfloodnet_amd._lib import ptr, stream, check
+    N, H, W, C, with_add = case
+    gen = torch.Generator().manual_seed(hash(case) & 0xFFFF)
+    x = (torch.randn(N, C, H, W, generator=gen) * 2).round() / 2                 # multiples of 0.5: plenty of equal values
+    xr = x.double().requires_grad_()
+    y = F.max_pool2d(F.relu(xr), 3, 2, 1)
+    g = torch.randn(y.shape, generator=gen)
+    add = torch.randn(N, C, H, W, generator=gen) if with_add else None
+    (y * g.double()).sum().backward()
+    # the kernel's contract: x is the ReLU's OUTPUT (r1), the pooled gradient plus ``add`` is masked where x <= 0
+    r1 = F.relu(x)
+    ref = xr.grad.clone()
+    if add is not None:
+        ref = ref + add.double() * (x > 0)
+    nhwc = lambda t: t.permute(0, 2, 3, 1).contiguous()
+    L = _lib.lib()
+
+    def run(misalign):
+        def dev(t):
+            if t is None:
+                return None
+            flat = torch.empty(t.numel() + 4, device=gpu)
+            v = flat[1:1 + t.numel()] if misalign else flat[4:4 + t.numel()]
+            v.copy_(nhwc(t).reshape(-1))
+            return v
+        xd, gd, ad = dev(r1), dev(g), dev(add)
+        out = torch.empty(N * H * W * C + 4, device=gpu)
+        ov = out[1:1 + N * H * W * C] if misalign else out[4:4 + N * H * W * C]
+        check(L.vfn_maxpool3x3s2_backward_f32(ptr(xd), ptr(gd), ptr(ov), N, H, W, C, ptr(ad), 1, stream()), 'vfn_maxpool3x3s2_backward_f32')
+        torch.cuda.synchronize()
+        return ov.view(N, H, W, C).permute(0, 3, 1, 2).cpu()
+    fast, scalar = run(False), run(True)
+    assert torch.equal(fast, scalar)
+    assert (fast.double() - ref).abs().max().item() < 1e-5 * max(1.0, ref.abs().max().item())

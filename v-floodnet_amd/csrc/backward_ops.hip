@@ -904,6 +904,92 @@ __global__ void maxpool3x3s2_bwd_kernel(const float* __restrict__ x, const float
     }
 }
 
+// The same, four channels per thread and one thread per 2 x 2 block of input pixels (round 5).  The kernel above re-evaluates up to four
+// windows of nine scalar loads for every input ELEMENT (113 us for the query encoder's five 200 x 200 x 64 planes, 0.42 ms per training
+// step on the dependent chain).  The four windows that can select one of the block's pixels -- output rows k, k + 1, columns j, j + 1 --
+// cover a 5 x 5 input patch: it is loaded once (25 float4, clamped addresses, out-of-image = -inf), the four arg-max scans run on
+// registers in PyTorch's order (row-major, first maximum wins), and the four pixels take the windows' gradients in the order of the
+// kernel above (bit-identical sums).
+__global__ __launch_bounds__(256)
+void maxpool3x3s2_bwd4_kernel(const float* __restrict__ x, const float* __restrict__ g, float* __restrict__ gx,
+                              int N, int H, int W, int C, int Ho, int Wo, const float* __restrict__ add, int relu_mask) {
+    const int C4 = C >> 2, Hb = (H + 1) >> 1, Wb = (W + 1) >> 1;
+    const size_t total = (size_t)N * Hb * Wb * C4;
+    const size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int c4 = i % C4;
+    size_t t = i / C4;
+    const int j = t % Wb; t /= Wb;
+    const int k = t % Hb;
+    const int n = t / Hb;
+    f32x4 P[5][5];
+#pragma unroll
+    for (int r = 0; r < 5; ++r) {
+        const int yy = 2 * k - 1 + r;
+        const bool rv = (unsigned)yy < (unsigned)H;
+        const int yc = min(max(yy, 0), H - 1);
+#pragma unroll
+        for (int c = 0; c < 5; ++c) {
+            const int xx = 2 * j - 1 + c;
+            const bool ok = rv && (unsigned)xx < (unsigned)W;
+            const int xc = min(max(xx, 0), W - 1);
+            const f32x4 v = *reinterpret_cast<const f32x4*>(x + (((size_t)n * H + yc) * W + xc) * C + c4 * 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) P[r][c][e] = ok ? v[e] : -INFINITY;
+        }
+    }
+    f32x4 acc[2][2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int v = 0; v < 2; ++v) acc[u][v] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            const int yo = k + a, xo = j + b;
+            const bool wv = yo < Ho && xo < Wo;
+            const int yoc = min(yo, Ho - 1), xoc = min(xo, Wo - 1);
+            f32x4 gv = *reinterpret_cast<const f32x4*>(g + (((size_t)n * Ho + yoc) * Wo + xoc) * C + c4 * 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float best = -INFINITY;
+                int pos = -1;
+#pragma unroll
+                for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+                    for (int dx = 0; dx < 3; ++dx) {
+                        const float v = P[2 * a + dy][2 * b + dx][e];
+                        if (v > best) { best = v; pos = (2 * a + dy) * 5 + 2 * b + dx; }
+                    }
+                const float ge = wv ? gv[e] : 0.f;
+#pragma unroll
+                for (int u = a; u < 2; ++u)               // (window row a holds patch rows 2a .. 2a + 2: pixel row 1 + u needs u >= a)
+#pragma unroll
+                    for (int v = b; v < 2; ++v)
+                        if (wv && pos == (1 + u) * 5 + 1 + v) acc[u][v][e] += ge;
+            }
+        }
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const int yy = 2 * k + u;
+#pragma unroll
+        for (int v = 0; v < 2; ++v) {
+            const int xx = 2 * j + v;
+            if (yy < H && xx < W) {
+                const size_t o = (((size_t)n * H + yy) * W + xx) * C + c4 * 4;
+                f32x4 r = acc[u][v];
+                if (add) r += *reinterpret_cast<const f32x4*>(add + o);
+                if (relu_mask) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) if (!(P[1 + u][1 + v][e] > 0.f)) r[e] = 0.f;
+                }
+                *reinterpret_cast<f32x4*>(gx + o) = r;
+            }
+        }
+    }
+}
+
 // ------------------------------------------------------------------ memory read, backwards (training: the bank is one frame)
 // P[b][q] = softmax over b of scale * S[b][q] (AFB_URR.py:144-145).  64 query columns per workgroup, the bank rows dealt to
 // SM_R row groups (round 3 walked all B rows three times on ONE thread per column: 340 us at B = Q = 625); the groups' maxima
@@ -1131,6 +1217,12 @@ extern "C" int vfn_maxpool3x3s2_backward_f32(const float* x, const float* g, flo
                                              int relu_mask, void* stream) {
     if (!x || !g || !gx || N < 1 || H < 1 || W < 1 || C < 1) return VFN_ERR_ARG;
     const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
+    if (C % 4 == 0 && (((size_t)x | (size_t)g | (size_t)gx | (size_t)add) & 15) == 0) {
+        const size_t total = (size_t)N * ((H + 1) / 2) * ((W + 1) / 2) * (C / 4);
+        hipLaunchKernelGGL(maxpool3x3s2_bwd4_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, g, gx, N, H, W, C, Ho, Wo,
+                           add, relu_mask);
+        return vfn_check_launch();
+    }
     hipLaunchKernelGGL(maxpool3x3s2_bwd_kernel, dim3(grid_for((size_t)N * H * W * C)), dim3(256), 0, (hipStream_t)stream, x, g, gx, N, H, W, C, Ho, Wo,
                        add, relu_mask);
     return vfn_check_launch();
