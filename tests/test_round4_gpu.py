@@ -301,17 +301,22 @@ def test_training_steps_are_bit_reproducible_with_and_without_the_side_stream(gp
         assert abs(a[0] - b[0]) < 2e-3 * abs(b[0]) and abs(a[1] - b[1]) < 2e-3 * abs(b[1]), (first[True], first[False])
 
 
-@pytest.mark.parametrize('T_frames', [2, 5])
-def test_batched_query_encoder_matches_the_frame_by_frame_step(gpu, monkeypatch, T_frames):
-    """``Engine.query_batch`` / ``ModelBackward.finish_query`` (the query encoder over all frames of a sample at once, forward and
-    backward) against the frame-by-frame form of the same step: a sample of one reference frame + 1 or 4 frames to segment -- the
-    same loss, and every gradient tensor close (other batch sizes pick other tile schedules, so summation orders differ)."""
+@pytest.mark.parametrize('T_frames,K', [(2, 2), (5, 2), (3, 3)])
+def test_batched_query_encoder_matches_the_frame_by_frame_step(gpu, monkeypatch, T_frames, K):
+    """``Engine.query_batch`` / ``segment_batch`` / ``ModelBackward.segment_batch`` / ``finish_query`` (query encoder, memory read and
+    decoder over all frames of a sample at once, forward and backward; round 5: the decoder over frames x objects) against the
+    frame-by-frame form of the same step: a sample of one reference frame + 1, 2 or 4 frames to segment, two or three objects (the
+    reference trains with up to three, train_video_seg.py:42) -- the same loss, and every gradient tensor close (other batch sizes pick
+    other tile schedules, so summation orders differ)."""
     from tools import synth
     from vfloodnet_amd import AFB_URR, train as T
-    H, W, K = 96, 160, 2
+    H, W = 96, 160
     sd = synth.make_state_dict(SEED)
     frames, m0 = synth.clip(9, T_frames, H, W)
-    lab = torch.stack([torch.roll(m0.long(), (2 * t, 5 * t), (0, 1)) for t in range(T_frames)], 0)
+    lab0 = m0.long()
+    if K == 3:                                     # (a third object: the right half of the water)
+        lab0 = lab0 + lab0 * (torch.arange(W).view(1, W) >= W // 2).long()
+    lab = torch.stack([torch.roll(lab0, (2 * t, 5 * t), (0, 1)) for t in range(T_frames)], 0)
     masks = torch.nn.functional.one_hot(lab, K).permute(0, 3, 1, 2).float()
     res = {}
     for batch in (True, False):
