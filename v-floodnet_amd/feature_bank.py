@@ -287,13 +287,18 @@ class FeatureBank:
         self._hist = {0: list(lens)}         # update count -> exact lengths after that update (the last three)
         for i in range(self.obj_n):
             self.peak_n[i] = max(self.peak_n[i], lens[i])
-        st = torch.zeros(self.obj_n, 4, dtype=torch.int32)
+        # through pinned memory, without blocking: a copy from pageable memory holds the host until the stream has reached it -- in the
+        # training step that was the end of memorize's forward pass, once per step, with the device idle behind it (round 5)
+        st = torch.zeros(self.obj_n, 4, dtype=torch.int32, pin_memory=True)
         for i in range(self.obj_n):
             st[i, 0] = lens[i]
             st[i, 1] = int(self.peak_n[i])
             st[i, 2] = int(self.replace_n[i])
-        self._stats.copy_(st)
-        self._len_dev.copy_(torch.tensor(lens, dtype=torch.int32))
+        self._stats.copy_(st, non_blocking=True)
+        ln = torch.empty(len(lens), dtype=torch.int32, pin_memory=True)
+        for i, v in enumerate(lens):
+            ln[i] = v
+        self._len_dev.copy_(ln, non_blocking=True)
         self._dirty = False
 
     def append(self, keys, values, frame_idx=0):
