@@ -27,5 +27,5 @@ with torch.no_grad():
         ref = R.forward(sd, x)
     t_cpu = (time.perf_counter() - t0) / 3
 
-print(f'LinknetB4 416x416: HIP {1e3 * t_gpu:.2f} ms per predict (host-paced: ~230 small launches), torch CPU restatement {1e3 * t_cpu:.0f} ms '
+print(f'LinknetB4 416x416: HIP {1e3 * t_gpu:.2f} ms per predict (~230 small launches, replayed as one HIP graph from the third call on), torch CPU restatement {1e3 * t_cpu:.0f} ms '
       f'({torch.get_num_threads()} threads); max |dprob| {(p.cpu() - ref).abs().max().item():.1e}')

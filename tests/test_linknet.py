@@ -88,6 +88,23 @@ def test_linknet_hip_vs_oracle(gpu, H, W):
     assert torch.equal((p > 0.5)[sure], (p_ref > 0.5)[sure])
     with pytest.raises(RuntimeError):
         model.predict(torch.zeros(1, 3, 100, 96, device=gpu))
+    # from the third call at one size on, predict is one captured HIP graph (static input / output): bit-identical to the
+    # launch-by-launch path, for the same and for another input, and dropped when the weights move
+    from vfloodnet_amd import engine as E
+    if E._GRAPHS:
+        xg = x.to(gpu)
+        eager = model.predict(xg, logits=True)                  # (second logits call at this size: still eager)
+        third = model.predict(xg, logits=True)                   # capture + first replay
+        assert (H, W, True) in model._graphs
+        fourth = model.predict(xg, logits=True)
+        assert torch.equal(eager, third) and torch.equal(eager, fourth)
+        x2 = S.frame(4, H, W).to(gpu)
+        replayed = model.predict(x2, logits=True)
+        model._graphs.clear()
+        model._graph_runs.clear()
+        assert torch.equal(replayed, model.predict(x2, logits=True))
+        model.load_state_dict(sd)
+        assert not model._graphs
 
 
 @pytest.mark.gpu

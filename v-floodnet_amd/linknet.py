@@ -130,6 +130,7 @@ class LinknetB4(nn.Module):
         self.decoder = _Decoder()
         self.segmentation_head = nn.Sequential(nn.Conv2d(32, 1, 1), nn.Identity(), nn.Identity())
         self._packed = None
+        self._graphs, self._graph_runs = {}, {}        # (H, W, logits) -> (captured graph, static input, static output) / eager calls so far
         if device is not None:
             self.to(device)
         self.eval()
@@ -138,11 +139,13 @@ class LinknetB4(nn.Module):
     def load_state_dict(self, state_dict, strict=True, **kw):
         out = super().load_state_dict(state_dict, strict=strict, **kw)
         self._packed = None
+        self._graphs, self._graph_runs = {}, {}        # (the captured launches point at the packed weights)
         return out
 
     def _apply(self, fn, *a, **k):
         out = super()._apply(fn, *a, **k)
         self._packed = None
+        self.__dict__['_graphs'], self.__dict__['_graph_runs'] = {}, {}
         return out
 
     @classmethod
@@ -250,6 +253,39 @@ class LinknetB4(nn.Module):
         if x.shape[0] != 1:
             return torch.cat([self.predict(x[i:i + 1], logits) for i in range(x.shape[0])], 0)
         P = self._packed or self._pack()
+        # ≈ 230 launches of a few microseconds each, paced by the host (3.3 ms per 416 x 416 call): from the third call at one input size
+        # on they are ONE captured HIP graph per (size, logits) -- static input / output buffers, the intermediates in the graph's pool
+        # (round 5; VFN_GRAPHS=0 or a failed capture: the launch-by-launch path below)
+        from .engine import _GRAPHS
+        key = (x.shape[2], x.shape[3], bool(logits))
+        g = self._graphs.get(key) if _GRAPHS else None
+        if g is not None:
+            g[1].copy_(x)
+            g[0].replay()
+            return g[2].clone()
+        if _GRAPHS:
+            n = self._graph_runs.get(key, 0)
+            self._graph_runs[key] = n + 1
+            if n == 2:
+                try:
+                    xs = x.float().contiguous().clone()
+                    graph = torch.cuda.CUDAGraph()
+                    cur = torch.cuda.current_stream()
+                    cap = torch.cuda.Stream(device=cur.device)
+                    cap.wait_stream(cur)
+                    with torch.cuda.graph(graph, stream=cap, capture_error_mode='thread_local'):
+                        out_s = self._predict_eager(P, xs, logits)
+                    cur.wait_stream(cap)
+                    self._graphs[key] = (graph, xs, out_s)
+                    graph.replay()
+                    return out_s.clone()
+                except Exception:
+                    import warnings
+                    warnings.warn('vfloodnet_amd: HIP graph capture of LinknetB4.predict failed; running it launch by launch')
+                    self._graph_runs[key] = -10 ** 9
+        return self._predict_eager(P, x, logits)
+
+    def _predict_eager(self, P, x, logits):
         L = _lib.lib()
         dev = P['dev']
         x = x.float().contiguous()
