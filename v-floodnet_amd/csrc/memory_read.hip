@@ -611,24 +611,15 @@ void memread_apply_lpw_kernel(const vfn_memread_desc p) {
 
         // value rows of step 0 (16 bank rows; this lane half: rows 8*lh .. +7) -- they land behind the score GEMM
         f32x2 raw[8];
-        const bool full = b0 + CH <= B;              // uniform; all but the last chunk of the bank
-        // buffer descriptor over this chunk's 64 value rows: scalar base + scalar row offset + one per-lane byte offset
+        // buffer descriptor over this chunk's value rows, ending at the bank's last row (rows past it read 0; P is exactly 0 there):
+        // one load form for every chunk, no per-load address arithmetic beyond one vector add (round 5: the branch between this
+        // form and a clamped plain-load form for the bank's last chunk cost hipcc's wait insertion the count of the loads in flight)
         const __amdgpu_buffer_rsrc_t vrsrc = __builtin_amdgcn_make_buffer_rsrc(
-            const_cast<float*>(V + (size_t)b0 * DV), 0, CH * DV * 4, 0x00020000);
+            const_cast<float*>(V + (size_t)b0 * DV), 0, min(CH, B - b0) * DV * 4, 0x00020000);
         auto load_raw = [&](int st) {
-            if (full) {
-                // buffer loads: no per-load address arithmetic on the vector ALU (the clamped 64-bit form below costs
-                // ~7 VALU instructions per load, a fifth of the loop's VALU work)
 #pragma unroll
-                for (int j = 0; j < 8; ++j)
-                    raw[j] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(vrsrc, vlane_off, (16 * st + j) * DV * 4, 0));
-            } else {
-#pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const int rr = min(b0 + 16 * st + 8 * lh + j, B - 1);  // rows past the end: P is exactly 0 there
-                    raw[j] = *reinterpret_cast<const f32x2*>(vcol + (size_t)rr * DV);
-                }
-            }
+            for (int j = 0; j < 8; ++j)
+                raw[j] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(vrsrc, vlane_off + (unsigned)((16 * st + j) * DV * 4), 0, 0));
         };
         load_raw(0);
 
@@ -970,21 +961,13 @@ void memread_apply_wide_kernel(const vfn_memread_desc p) {
         // whole chunks read their value rows through a buffer descriptor (scalar base and row offset, one per-lane byte
         // offset): the 64-bit clamped addresses of the tail form cost ~7 vector-ALU instructions per load, and VALU
         // issue comes straight out of the MFMA pipe's time on this SIMD
-        const bool full = b0 + CH <= B;
+        // (round 5: the resource ends at the bank's last row -- one load form for every chunk, see memread_apply_ss_kernel)
         const __amdgpu_buffer_rsrc_t vrsrc = __builtin_amdgcn_make_buffer_rsrc(
-            const_cast<float*>(V + (size_t)b0 * DV), 0, CH * DV * 4, 0x00020000);
+            const_cast<float*>(V + (size_t)b0 * DV), 0, min(CH, B - b0) * DV * 4, 0x00020000);
         auto load_v = [&](int kk, int slot) {
-            if (full) {
 #pragma unroll
-                for (int t = 0; t < 4; ++t)
-                    vb[slot][t] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(vrsrc, vlane_off, (8 * kk + t) * DV * 4, 0));
-            } else {
-#pragma unroll
-                for (int t = 0; t < 4; ++t) {
-                    const int rr = min(b0 + 8 * kk + 4 * lh + t, B - 1);  // past the end: P is exactly 0 there
-                    vb[slot][t] = *reinterpret_cast<const f32x2*>(vcol + (size_t)rr * DV);
-                }
-            }
+            for (int t = 0; t < 4; ++t)
+                vb[slot][t] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(vrsrc, vlane_off + (unsigned)((8 * kk + t) * DV * 4), 0, 0));
         };
         load_v(0, 0);
         load_v(1, 1);
@@ -1123,25 +1106,23 @@ void memread_apply_ss_kernel(const vfn_memread_desc p) {
         const bool nxt = c + 1 < c_hi;
 
         f32x2 vb[3][4];                              // ring: value rows two k-groups ahead of their MFMAs
-        const bool full = b0 + CH <= B;
+        // Round 5: ONE load form for every chunk.  The last chunk of a bank used to take plain loads with clamped rows behind a
+        // (wave-uniform) branch per k-group; with two load forms merging at every group hipcc's wait insertion lost count of the ring
+        // and drained it -- `vmcnt(3) .. vmcnt(0)` in front of k-group 0 AND again behind the score loads: every value row of the
+        // first three groups landed before the chunk's first MFMAs finished, three times the memory latency exposed per 6.8-us
+        // chunk.  The buffer resource now ends at the bank's last row (rows past it read 0; P is exactly 0 there), the row offset
+        // rides in the vector offset (the range check covers it), and the loop is straight-line code again.
+        const int rows_here = min(CH, B - b0);
         const __amdgpu_buffer_rsrc_t vrsrc = __builtin_amdgcn_make_buffer_rsrc(
-            const_cast<float*>(V + (size_t)b0 * DV), 0, CH * DV * 4, 0x00020000);
+            const_cast<float*>(V + (size_t)b0 * DV), 0, rows_here * DV * 4, 0x00020000);
         auto load_v = [&](int kk, int slot) {
-            if (full) {
 #pragma unroll
-                for (int t = 0; t < 4; ++t)
+            for (int t = 0; t < 4; ++t)
 #ifdef VFN_ABLATE_V
-                    vb[slot][t] = f32x2{1.f * kk + lane, 2.f * t};
+                vb[slot][t] = f32x2{1.f * kk + lane, 2.f * t};
 #else
-                    vb[slot][t] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(vrsrc, vlane_off, (8 * kk + t) * DV * 4, 0));
+                vb[slot][t] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(vrsrc, vlane_off + (unsigned)((8 * kk + t) * DV * 4), 0, 0));
 #endif
-            } else {
-#pragma unroll
-                for (int t = 0; t < 4; ++t) {
-                    const int rr = min(b0 + 8 * kk + 4 * lh + t, B - 1);  // past the end: P is exactly 0 there
-                    vb[slot][t] = *reinterpret_cast<const f32x2*>(vcol + (size_t)rr * DV);
-                }
-            }
         };
         load_v(0, 0);
         load_v(1, 1);
