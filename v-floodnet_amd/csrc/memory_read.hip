@@ -1088,7 +1088,25 @@ void memread_apply_ss_kernel(const vfn_memread_desc p) {
         }
     };
 
+    // value rows: a ring of four k-groups that runs ACROSS the chunks (round 5).  Within a chunk a group is requested two groups ahead of
+    // its MFMAs; the last two groups of a chunk request the first two of the NEXT chunk (8 groups per chunk, 8 % 4 = 0: the slots stay
+    // compile-time constants), so a chunk no longer opens with the matrix pipe waiting a full memory latency for its first value rows --
+    // both waves of a SIMD leave the chunk barrier together and used to wait there together.  A chunk's buffer resource ends at the
+    // bank's last row (rows past it read 0; P is exactly 0 there); behind the slice's last chunk it is empty (loads return 0, no traffic).
+    f32x2 vb[4][4];
+    auto chunk_rsrc = [&](int c) {
+        const int rows = c < c_hi ? min(CH, B - c * CH) : 0;
+        return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(V + (size_t)min(c, max(c_hi - 1, 0)) * CH * DV), 0, rows * DV * 4, 0x00020000);
+    };
+    auto load_v = [&](const __amdgpu_buffer_rsrc_t& rs, int kk, int slot) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+            vb[slot][t] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(rs, vlane_off + (unsigned)((8 * kk + t) * DV * 4), 0, 0));
+    };
     if (c_lo < c_hi) {
+        const __amdgpu_buffer_rsrc_t rs0 = chunk_rsrc(c_lo);
+        load_v(rs0, 0, 0);
+        load_v(rs0, 1, 1);
         load_scores(c_lo);
         softmax_to(c_lo, sP);
         if (c_lo + 1 < c_hi) load_scores(c_lo + 1);
@@ -1105,35 +1123,16 @@ void memread_apply_ss_kernel(const vfn_memread_desc p) {
         float* sPn = sP + (buf ^ 1) * (QTW * CH);
         const bool nxt = c + 1 < c_hi;
 
-        f32x2 vb[3][4];                              // ring: value rows two k-groups ahead of their MFMAs
-        // Round 5: ONE load form for every chunk.  The last chunk of a bank used to take plain loads with clamped rows behind a
-        // (wave-uniform) branch per k-group; with two load forms merging at every group hipcc's wait insertion lost count of the ring
-        // and drained it -- `vmcnt(3) .. vmcnt(0)` in front of k-group 0 AND again behind the score loads: every value row of the
-        // first three groups landed before the chunk's first MFMAs finished, three times the memory latency exposed per 6.8-us
-        // chunk.  The buffer resource now ends at the bank's last row (rows past it read 0; P is exactly 0 there), the row offset
-        // rides in the vector offset (the range check covers it), and the loop is straight-line code again.
-        const int rows_here = min(CH, B - b0);
-        const __amdgpu_buffer_rsrc_t vrsrc = __builtin_amdgcn_make_buffer_rsrc(
-            const_cast<float*>(V + (size_t)b0 * DV), 0, rows_here * DV * 4, 0x00020000);
-        auto load_v = [&](int kk, int slot) {
-#pragma unroll
-            for (int t = 0; t < 4; ++t)
-#ifdef VFN_ABLATE_V
-                vb[slot][t] = f32x2{1.f * kk + lane, 2.f * t};
-#else
-                vb[slot][t] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(vrsrc, vlane_off + (unsigned)((8 * kk + t) * DV * 4), 0, 0));
-#endif
-        };
-        load_v(0, 0);
-        load_v(1, 1);
+        const __amdgpu_buffer_rsrc_t vrsrc = chunk_rsrc(c), vrsrc_n = chunk_rsrc(c + 1);
         f32x4 a[2][4];                               // P^T fragments, one k-group ahead of their MFMAs
 #pragma unroll
         for (int tq = 0; tq < 4; ++tq) a[0][tq] = *reinterpret_cast<const f32x4*>(sPc + swz64(tq * 32 + li, lh));
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int kk = 0; kk < CH / 8; ++kk) {
-            const int cur = kk % 3;
-            if (kk + 2 < CH / 8) load_v(kk + 2, (kk + 2) % 3);
+            const int cur = kk % 4;
+            if (kk + 2 < CH / 8) load_v(vrsrc, kk + 2, (kk + 2) % 4);
+            else load_v(vrsrc_n, kk + 2 - CH / 8, (kk + 2) % 4);
             if (kk + 1 < CH / 8) {
 #pragma unroll
                 for (int tq = 0; tq < 4; ++tq)
