@@ -260,6 +260,17 @@ void bank_scan_kernel(const vfn_bankscan_desc p) {
         if (c + 1 < c_hi)
             chunk_load_async(sKb + ((c + 1 - c_lo) & 1) * CH * DK, K + (size_t)(b0 + CH) * DK, min(CH, B - b0 - CH), wave, lane);
 #endif
+        // MODE 1: the chunk's 32 row scales per lane (1 / |key|), requested BEFORE the score MFMAs (round 5: they were loaded behind
+        // them, inside a range test per group, and used at once -- one exposed L2 round trip at the end of every chunk).  Rows past the
+        // bank's end lie inside the slab (finite scratch) and are ignored by the comparison below.
+        f32x4 scv[MODE == 1 ? 2 : 1][MODE == 1 ? 4 : 1];
+        if constexpr (MODE == 1) {
+            const float* rs = p.rowscale + (size_t)obj * p.stride_rs;
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) scv[i][g] = *reinterpret_cast<const f32x4*>(rs + b0 + 32 * i + 4 * lh + 8 * g);
+        }
         f32x16 acc[2];
 #pragma unroll
         for (int i = 0; i < 2; ++i)
@@ -369,14 +380,12 @@ void bank_scan_kernel(const vfn_bankscan_desc p) {
                 }
             }
         } else {
-            const float* rs = p.rowscale + (size_t)obj * p.stride_rs;
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {            // registers 4g..4g+3 = rows +8g .. +3: one 16-byte load
                     const int row0 = b0 + 32 * i + 4 * lh + 8 * g;
-                    f32x4 sc = {0.f, 0.f, 0.f, 0.f};
-                    if (row0 < B) sc = *reinterpret_cast<const f32x4*>(rs + row0);     // (slab rows past B are finite scratch)
+                    const f32x4 sc = scv[MODE == 1 ? i : 0][MODE == 1 ? g : 0];
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
                         const int row = row0 + j;
