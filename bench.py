@@ -470,9 +470,12 @@ def main(argv=None):
             stored = all(r_[4] for r_ in apply_records)
             a_fl = sum((1024.0 if r_[4] else 1280.0) * r_[0] * r_[1] for r_ in apply_records)
             # bf16x3 reads the bank's kept split-bf16 image (FeatureBank.lp_image) unless VFN_LP_IMAGE=0
-            x3 = 'memread_apply_lpw_kernel<true>' if os.environ.get('VFN_LP_IMAGE', '1') == '0' else 'memread_apply_shw_kernel<true>'
-            kn = {'fp32': 'memread_apply_ss_kernel' if stored else 'memread_apply_wide_kernel', 'bf16': 'memread_apply_lpw_kernel<false>',
-                  'bf16x3': x3}[args.precision]
+            img = os.environ.get('VFN_LP_IMAGE', '1') != '0'
+            x3 = 'memread_apply_shw_kernel<true>' if img else 'memread_apply_lpw_kernel<true>'
+            # (plain bf16 takes the image kernel too unless VFN_APPLY_IMG_BF16=0; lines written before the end of round 5 name
+            # memread_apply_lpw_kernel<false> here while rocprof shows memread_apply_shw_kernel<false>: profiles/r05_kernel_stats_bf16.csv)
+            b1 = 'memread_apply_shw_kernel<false>' if (img and os.environ.get('VFN_APPLY_IMG_BF16', '1') != '0') else 'memread_apply_lpw_kernel<false>'
+            kn = {'fp32': 'memread_apply_ss_kernel' if stored else 'memread_apply_wide_kernel', 'bf16': b1, 'bf16x3': x3}[args.precision]
             cands.append((kn, a_fl, a_ms, len(apply_records), len(apply_records)))      # (one launch per frame)
         tot_fl = sum(v[0] for v in per.values())
         tot_ms = sum(v[1] for v in per.values())
