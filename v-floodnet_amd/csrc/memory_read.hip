@@ -790,7 +790,12 @@ void memread_apply_shw_kernel(const vfn_memread_desc p) {
         const __amdgpu_buffer_rsrc_t vrsrc = __builtin_amdgcn_make_buffer_rsrc(
             const_cast<char*>(V + (size_t)(b0 >> 3) * VBLK), 0, ((live + 7) >> 3) * VBLK, 0x00020000);
 
-        u32x4 vop[2][8];                             // two steps of operands: [tc][hi, lo]
+        // bf16x3: two steps of operands in flight, [tc][hi, lo].  Plain bf16 (round 5): its steps are 8 MFMAs = 256 cycles, one step of
+        // lead left the kernel waiting on memory (PMC: 0.64 of the wave cycles, mfma_util 0.27) -- three of the chunk's four steps
+        // are requested here, in front of the score GEMM, the fourth into step 0's slot behind step 0's MFMAs (a fourth slot spills:
+        // 52 bytes of scratch at 256 registers)
+        constexpr int NSLOT = X3 ? 2 : 3;
+        u32x4 vop[NSLOT][8];
         auto load_v = [&](int st, u32x4 (&dst)[8]) {
 #pragma unroll
             for (int tc = 0; tc < 4; ++tc) {
@@ -803,7 +808,11 @@ void memread_apply_shw_kernel(const vfn_memread_desc p) {
 #endif
             }
         };
-        load_v(0, vop[0]);                           // lands behind the score GEMM
+        if constexpr (X3) load_v(0, vop[0]);         // lands behind the score GEMM
+        else {
+#pragma unroll
+            for (int st = 0; st < 3; ++st) load_v(st, vop[st]);
+        }
 
         f32x16 acc;
 #pragma unroll
@@ -845,8 +854,8 @@ void memread_apply_shw_kernel(const vfn_memread_desc p) {
         // O^T[q][ch] += sum_b P^T[q][b] V[b][ch]: A = P^T (2 query tiles), B = value rows (4 channel tiles)
 #pragma unroll
         for (int st = 0; st < CH / 16; ++st) {
-            if (st + 1 < CH / 16) load_v(st + 1, vop[(st + 1) & 1]);
-            const u32x4 (&vv)[8] = vop[st & 1];
+            if constexpr (X3) { if (st + 1 < CH / 16) load_v(st + 1, vop[(st + 1) & 1]); }
+            const u32x4 (&vv)[8] = vop[X3 ? (st & 1) : st % 3];
 #pragma unroll
             for (int tq = 0; tq < 2; ++tq) {
                 const int prow = qhalf * 64 + tq * 32 + li;
@@ -859,6 +868,9 @@ void memread_apply_shw_kernel(const vfn_memread_desc p) {
                     const bf16x8 vl = X3 ? __builtin_bit_cast(bf16x8, vv[2 * tc + 1]) : vh;
                     mfma_lp<X3>(o[tq][tc], ph, pl, vh, vl);
                 }
+            }
+            if constexpr (!X3) {
+                if (st == 0) { __builtin_amdgcn_sched_barrier(0); load_v(3, vop[0]); }
             }
         }
         __syncthreads();
