@@ -47,7 +47,7 @@ PEAKS = {'fp32': PEAK_F32_MATRIX_TFLOPS, 'bf16': PEAK_BF16_MATRIX_TFLOPS, 'bf16x
 DTYPES = {'fp32': 'f32', 'bf16': 'bf16 operands, f32 accumulate/storage', 'bf16x3': 'bf16x3 (split-bf16 operands, 3 MFMAs per product), f32 accumulate/storage'}
 WORKLOADS = {'C2': (480, 854, 1), 'C3': (720, 1280, 5), 'C5': (1080, 1920, 1)}      # H0, W0, memorize every n-th frame
 CLIP_FRAMES = 100                     # BASELINE.json configs[1]: "100-frame 480p synthetic clip"
-PROFILE_ROUND = 'r05'
+PROFILE_ROUND = 'r06'
 
 
 def miou(a, b):
@@ -394,8 +394,10 @@ def main(argv=None):
     gc.disable()            # a cyclic collection in the middle of the timed frames is a 10-70 ms hiccup of the launch thread
     clip0 = bracket()
     run_iters(1, s_first - 1, False)                                       # untimed pre-roll
+    captures0 = sum(pl.graphs.captures for pl in eng.plans.values())
     t0 = bracket()
     run_iters(s_first, s_first + K - 1, True)                              # ---- exactly K timed steps
+    captures_in_window = sum(pl.graphs.captures for pl in eng.plans.values()) - captures0
     gather_s = 0.0
     torch.cuda.synchronize()
     g0 = time.perf_counter()                                               # (this rank's K frames are done: compute time = g0 - t0)
@@ -408,6 +410,9 @@ def main(argv=None):
     if dist_on:
         vdist.gather_masks(labels[1:].unsqueeze(0), world, rank, world)
     clip1 = bracket()
+    # the int32 [T, obj_n] bank-size vector of every rank's clip travels beside the masks: one more, tiny
+    # all-gather, outside every timed bracket
+    sizes_all = vdist.gather_bank_sizes([bank_sizes[:last_iter]], world, rank, world, dev)
 
     # ---- sustained rate beyond the clip: the loop keeps cycling through the clip's frames with the bank at its budget
     # (every update evicts -- the regime a stream longer than 100 frames lives in); not part of `value`
@@ -485,6 +490,9 @@ def main(argv=None):
         ach = fl / (ms * 1e-3) / 1e12
         tname = f'{PROFILE_ROUND}_pmc_traffic.json' if args.precision == 'fp32' else f'{PROFILE_ROUND}_pmc_traffic_{args.precision}.json'
         tpath = os.path.join(ROOT, 'profiles', tname)
+        if not os.path.isfile(tpath):       # (this round's counter passes are not committed yet: the previous round's, named as such)
+            tname = tname.replace(PROFILE_ROUND, 'r05')
+            tpath = os.path.join(ROOT, 'profiles', tname)
         pmc = json.load(open(tpath)).get('kernels', {}) if os.path.isfile(tpath) else {}
 
         def traffic_of(name_):              # HBM bytes per launch of this kernel from the committed PMC passes
@@ -612,6 +620,14 @@ def main(argv=None):
                       'winograd_layers': sorted(set(wino_names)),
                       'frame_mfma_frac_Fref_reference_equivalent': round(frame_frac_ref, 4) if mem_every == 1 else None},
            'full_clip_fps': round(full_clip_fps, 3),
+           # `value` is K frames (0.12 s at the driver's --steps 20): a 1-2 % effect cannot be read off it.  The same run's other clocks
+           # on the same kernels: every iteration of the clip (pre-roll + window + rest; includes the instrumented frames, so it is a
+           # lower bound) and the median host wall between consecutive step completions inside the window
+           'value_ci': {'window_fps': round(fps, 3), 'full_clip_fps': round(full_clip_fps, 3), 'frames_full_clip': int(world * last_iter),
+                        'p50_frame_fps': round(world * 1e3 / tms[len(tms) // 2], 3),
+                        'low': round(min(fps, full_clip_fps), 3), 'high': round(max(fps, full_clip_fps, world * 1e3 / tms[len(tms) // 2]), 3),
+                        'graph_captures_in_window': int(captures_in_window),
+                        'note': 'quote A/Bs below 2 % from full_clip_fps (99 steps) of alternating runs on one box, not from `value`'},
            'full_clip_frame_mfma_frac_Fmin': round((full_clip_fps / world) * f_min_clip / (peak * 1e12), 4) if mem_every == 1 else None,
            'frame_ms': frame_stats, 'sustained': sustained,
            'roofline': roof, 'memory_read': memread, 'cpu_baseline': cpu, 'parity': parity}
@@ -622,6 +638,9 @@ def main(argv=None):
         'all_gather_ms_max': round(1e3 * max(r_[1] for r_ in per_rank), 3) if dist_on else None,
         'all_gather_ms_per_rank': [round(1e3 * r_[1], 3) for r_ in per_rank] if dist_on else None,
         'all_gather_bytes_per_rank': int(K * H0 * W0) if dist_on else None,
+        'bank_sizes_gathered': {'clips': len(sizes_all), 'shape_per_clip': [int(v) for v in sizes_all[0].shape], 'dtype': 'int32',
+                                'own_block_intact': bool(torch.equal(sizes_all[0], torch.tensor(bank_sizes[:last_iter], dtype=torch.int32))),
+                                'note': 'int32 [T, obj_n] live bank entries per frame of every rank\'s clip, gathered beside the masks outside the timed bracket (dist.gather_bank_sizes)'},
         'frames_per_s_per_rank': [round(x, 3) for x in rates],
         'frames_per_s_per_rank_min': round(min(rates), 3), 'frames_per_s_per_rank_max': round(max(rates), 3),
         'per_rank_note': 'K timed frames / (time until this rank\'s last frame has left the GPU); `value` = world * K / (max over ranks of the '

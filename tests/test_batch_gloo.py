@@ -42,6 +42,13 @@ def _standin_clip(args, device):
     return torch.stack([torch.from_numpy((np.array(Image.open(f).convert('RGB'))[:, :, 0] > 127).astype(np.uint8)) for f in files], 0)
 
 
+def _standin_sizes(m):
+    """A stand-in for the per-frame bank sizes int32 [T, 2] (they travel beside the masks): derived from the masks."""
+    T = m.shape[0]
+    water = m.reshape(T, -1).sum(1).to(torch.int32)
+    return torch.stack([water, torch.full((T,), m.shape[1] * m.shape[2], dtype=torch.int32) - water], 1)
+
+
 def _worker(rank, world, port, bench_dir, q):
     os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), LOCAL_RANK=str(rank),
                       WORLD_SIZE=str(world), LOCAL_WORLD_SIZE=str(world))
@@ -53,9 +60,10 @@ def _worker(rank, world, port, bench_dir, q):
 
     def clip(a, d):
         ran.append(a.test_name)
-        return _standin_clip(a, d)
+        m = _standin_clip(a, d)
+        return m, _standin_sizes(m)
     names, masks = B.run(args, run_clip=clip, device=torch.device('cpu'), backend='gloo')
-    q.put((rank, ran, names, [m.numpy() for m in masks], sorted(os.sched_getaffinity(0))))
+    q.put((rank, ran, names, [m.numpy() for m in masks], sorted(os.sched_getaffinity(0)), [z.numpy() for z in B.run.last_bank_sizes]))
 
 
 @pytest.mark.parametrize('shapes', [[(3, 10, 12), (2, 8, 16)], [(3, 10, 12), (2, 8, 16), (4, 6, 6)]], ids=['2clips', '3clips_ragged'])
@@ -76,11 +84,13 @@ def test_batch_driver_world2_gloo(tmp_path, shapes):
     names = [f'clip_{c:02d}' for c in range(len(shapes))]
     assert res[0][1] == names[0::2] and res[1][1] == names[1::2]             # clip c -> rank c mod 2
     args = type('A', (), {})()
-    for rank, _, got_names, masks, _ in res:
+    for rank, _, got_names, masks, _, sizes in res:
         assert got_names == names
         for c, m in enumerate(masks):                                        # every rank holds every clip's masks
             args.test_path = os.path.join(bench, names[c])
             assert m.shape == shapes[c] and np.array_equal(m, _standin_clip(args, None).numpy())
+            # ... and every clip's int32 [T, obj_n] bank-size vector (ragged T), in clip order
+            assert sizes[c].dtype == np.int32 and np.array_equal(sizes[c], _standin_sizes(torch.from_numpy(m)).numpy())
     if len(os.sched_getaffinity(0)) >= 2:                                     # disjoint CPU slices per rank
         assert not (set(res[0][4]) & set(res[1][4]))
 

@@ -21,6 +21,12 @@ def _fake_clip(c, T=3, H=5, W=7):
     return (torch.rand(T, H, W, generator=g) > 0.5).to(torch.uint8)
 
 
+def _fake_sizes(c):
+    """Bank sizes int32 [T_c, 2] of clip c: T_c differs from clip to clip."""
+    T = 3 + c % 3
+    return (torch.arange(T * 2, dtype=torch.int32).view(T, 2) * (c + 1) + 1620)
+
+
 def _worker(rank, world, port, n_clips, q):
     os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), LOCAL_RANK=str(rank),
                       WORLD_SIZE=str(world))
@@ -33,6 +39,9 @@ def _worker(rank, world, port, n_clips, q):
     mine = vdist.clips_of_rank(n_clips, rank, world)
     out = vdist.run_sharded(_fake_clip, n_clips, rank, world, torch.device('cpu'))
     ok = all(torch.equal(out[c], _fake_clip(c)) for c in range(n_clips))
+    # the int32 bank-size vectors beside the masks: ragged lengths, clip order, every rank holds all of them
+    sizes = vdist.gather_bank_sizes([_fake_sizes(c) for c in mine], n_clips, rank, world, torch.device('cpu'))
+    ok = ok and len(sizes) == n_clips and all(z.dtype == torch.int32 and torch.equal(z, _fake_sizes(c)) for c, z in enumerate(sizes))
     q.put((rank, mine, ok, tuple(out.shape)))
     dist.barrier()
     dist.destroy_process_group()
@@ -62,6 +71,9 @@ def test_single_process_is_identity():
     from vfloodnet_amd import dist as vdist
     out = vdist.run_sharded(_fake_clip, 3, 0, 1, torch.device('cpu'))
     assert all(torch.equal(out[c], _fake_clip(c)) for c in range(3))
+    sizes = vdist.gather_bank_sizes([_fake_sizes(c) for c in range(3)], 3, 0, 1, torch.device('cpu'))
+    assert all(torch.equal(z, _fake_sizes(c)) for c, z in enumerate(sizes))
+    assert vdist.gather_bank_sizes([], 0, 0, 1, torch.device('cpu')) == []
 
 
 def test_no_clips_reports_instead_of_crashing(tmp_path):

@@ -58,7 +58,7 @@ def run_clip_on_gpu(args, device):
     from . import video_seg
     args.keep_labels = True
     runner = video_seg.main(args, device)
-    return runner.kept_labels
+    return runner.kept_labels, runner.kept_sizes
 
 
 def run(args, run_clip=run_clip_on_gpu, device=None, backend=None):
@@ -83,17 +83,25 @@ def run(args, run_clip=run_clip_on_gpu, device=None, backend=None):
             dist.destroy_process_group()
         raise ValueError(f'no clip sub-folders in {args.benchmark_path}')
     mine = vdist.clips_of_rank(len(clips), rank, world)
-    local = []
+    local, local_sizes = [], []
     for c in mine:
         args.test_name, args.test_path = clips[c]
         print(f'[rank {rank}] Process video', args.test_name, 'from path', args.test_path, flush=True)
-        local.append(run_clip(args, device))
+        res = run_clip(args, device)
+        # ``run_clip`` returns the masks, or (masks, int [T, obj_n] bank sizes per frame): SURVEY.md 8(e) sends both
+        lab, sz = res if isinstance(res, tuple) else (res, torch.zeros(int(res.shape[0]), 0, dtype=torch.int32))
+        local.append(lab)
+        local_sizes.append(sz)
     masks = vdist.gather_ragged(local, len(clips), rank, world, device)
+    sizes = vdist.gather_bank_sizes(local_sizes, len(clips), rank, world, device)      # one more, tiny all-gather beside the masks
+    run.last_bank_sizes = sizes
     names = [n for n, _ in clips]
     if rank == 0:
         summary = {'clips': len(clips), 'ranks': world,
                    'per_clip': [{'name': n, 'rank': c % world, 'frames': int(m.shape[0]), 'size': [int(m.shape[1]), int(m.shape[2])],
-                                 'water_fraction': round(float((m > 0).float().mean()), 6)} for c, (n, m) in enumerate(zip(names, masks))]}
+                                 'water_fraction': round(float((m > 0).float().mean()), 6),
+                                 'final_bank_entries': [int(v) for v in z[-1]] if z.numel() else None}
+                                for c, (n, m, z) in enumerate(zip(names, masks, sizes))]}
         print(json.dumps(summary), flush=True)
         if args.save_gathered:
             import numpy as np

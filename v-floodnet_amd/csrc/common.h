@@ -38,6 +38,11 @@ __device__ __forceinline__ int wave_sum_i(int v) {
 
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 
+// max(v, floor) for the branch-free ReLU-or-nothing epilogues (floor = 0 or -inf) that KEEPS a NaN: fmaxf returns the non-NaN
+// operand, so under floor = -inf a NaN would leave as -inf and the next layer's ReLU would turn it into 0 -- a diverging
+// training run (the reference's loss.backward() goes NaN) would be kept alive silently.  v_cmp + v_cndmask, no branch.
+__device__ __forceinline__ float vfn_floor_nan(float v, float floor_) { return v < floor_ ? floor_ : v; }
+
 // Workgroups are dealt round-robin over the 8 XCDs (a private 4 MiB L2 each).  A kernel whose neighbouring work items read
 // overlapping bytes (window / halo reads: Winograd 6x6 patches, 3x3 pooling windows, bilinear taps) wants NEIGHBOURS ON ONE
 // XCD, or every overlap is fetched once per L2 (rocprofv3 FETCH_SIZE of winograd_input_kernel: 1.7x its input before this).

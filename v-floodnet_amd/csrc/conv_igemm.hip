@@ -190,7 +190,7 @@ __device__ __forceinline__ bool wide_epilogue(const vfn_conv_desc& p, char* smem
                 const int rr = rr0 + it * RPP;
                 f32x4 v = *reinterpret_cast<const f32x4*>(sC + (rr < ROWS ? rr : 0) * PITCH + c4 * 4);
 #pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e] * sc[e] + sh[e] + rv[it][e], floor_);
+                for (int e = 0; e < 4; ++e) v[e] = vfn_floor_nan(v[e] * sc[e] + sh[e] + rv[it][e], floor_);
                 const int row = row_of(it);
                 __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((ext_vector_type(4))) unsigned, v), ro,
                                                        row >= 0 ? (row * p.out_ld + col) * 4 : 0x7ffffff0, 0, 0);

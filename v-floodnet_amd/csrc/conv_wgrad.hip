@@ -511,7 +511,9 @@ extern "C" int vfn_stem_wgrad_f32(const float* x, const float* g, const float* r
                                   int N, int Hp, int Wp, int C, int Ho, int Wo, int accumulate, void* stream) {
     if (!x || !g || !dw || !partial || N < 1 || Hp < 1 || Wp < 1) return VFN_ERR_ARG;
     if (Ho != (Hp - 1) / 2 + 1 || Wo != (Wp - 1) / 2 + 1) return VFN_ERR_ARG;
-    if ((long long)N * Hp * Wp * C * 4 >= 0x7fffff00LL || (long long)N * Ho * Wo * 64 * 4 >= 0x7fffff00LL) return VFN_ERR_ARG;
+    // x below 1 GiB: the kernel marks a column outside the image with byte offset 0x40000000, which must lie past the end of the
+    // tensor whatever valid row offset is added to it (with a larger x the sentinel would land on real pixels)
+    if ((long long)N * Hp * Wp * C * 4 >= 0x40000000LL || (long long)N * Ho * Wo * 64 * 4 >= 0x7fffff00LL) return VFN_ERR_ARG;
     hipStream_t s = (hipStream_t)stream;
     if (C == 3) return launch_stem_wgrad<3, 1>(x, g, rowscale, dw, partial, partial_floats, N, Hp, Wp, Ho, Wo, accumulate, s);
     if (C == 5) return launch_stem_wgrad<5, 2>(x, g, rowscale, dw, partial, partial_floats, N, Hp, Wp, Ho, Wo, accumulate, s);

@@ -63,7 +63,7 @@ void winograd_input_kernel(const float* __restrict__ x, int N, int H, int W, int
 #pragma unroll
             for (int b = 0; b < 6; ++b)
 #pragma unroll
-                for (int e = 0; e < 4; ++e) d[a][b][e] = fmaxf(d[a][b][e], floor_);
+                for (int e = 0; e < 4; ++e) d[a][b][e] = vfn_floor_nan(d[a][b][e], floor_);
         // columns: d <- B^T d, then rows: V = d B
 #pragma unroll
         for (int b = 0; b < 6; ++b) {
@@ -179,7 +179,7 @@ void winograd_output_kernel(const float* __restrict__ Mb, int rows_pad, int N, i
                     }
                 }
 #pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], floor_);
+                for (int e = 0; e < 4; ++e) v[e] = vfn_floor_nan(v[e], floor_);
                 const int row = rowi[a][b];
                 __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((ext_vector_type(4))) unsigned, v), ro,
                                                        row >= 0 ? (row * out_ld + c4 * 4) * 4 : 0x7ffffff0, 0, 0);
@@ -506,7 +506,7 @@ void wino_gemm_kernel(const wino_gemm_args p) {
 #pragma unroll
                             for (int r = 0; r < 16; ++r) {
                                 const int row = m0 + (wm * TM + i) * 32 + 4 * lh + (r & 3) + 8 * (r >> 2);
-                                const float v = fmaxf(acc[i][j][r] * sc + sh + rv[i][j][r], floor_);
+                                const float v = vfn_floor_nan(acc[i][j][r] * sc + sh + rv[i][j][r], floor_);
                                 __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rso,
                                                                       (row < npix && cok) ? (row * p.out_ld + col) * 4 : 0x7ffffff0, 0, 0);
                                 acc[i][j][r] = 0.f;

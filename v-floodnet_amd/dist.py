@@ -171,6 +171,49 @@ def gather_masks(local_labels, n_clips, rank, world):
     return out
 
 
+def gather_bank_sizes(local_sizes, n_clips, rank, world, device):
+    """The feature bank's live entries per object after every frame, beside the masks ("plus an int32[T] bank-size
+    vector"): ``local_sizes`` = list of int [T_c, obj_n] tensors (or nested lists) for ``clips_of_rank``.  Returns the list of
+    int32 [T_c, obj_n] tensors (host) in clip order on every rank.  One tiny all-gather (a few KB), outside any timed bracket:
+    the blocks are padded to the longest clip, row 0 of every block carries the clip's (T_c, obj_n)."""
+    if n_clips <= 0:
+        return []
+    per = clips_per_rank(n_clips, world)
+    loc = [torch.as_tensor(x, dtype=torch.int32).reshape(len(x), -1).cpu() for x in local_sizes]
+    dims = torch.zeros(2, dtype=torch.int64)
+    if loc:
+        dims = torch.tensor([max(int(x.shape[0]) for x in loc), max(int(x.shape[1]) for x in loc)], dtype=torch.int64)
+    on_dev = active(world) and dist.get_backend() == 'nccl'
+    if active(world):                     # (the padded block shape: the maximum over all ranks)
+        d_ = dims.to(device) if on_dev else dims
+        dist.all_reduce(d_, op=dist.ReduceOp.MAX)
+        dims = d_.cpu()
+    T, K = int(dims[0]), max(2, int(dims[1]))
+    send = torch.zeros(per, T + 1, K, dtype=torch.int32)
+    for i, x in enumerate(loc):
+        send[i, 0, 0], send[i, 0, 1] = int(x.shape[0]), int(x.shape[1])
+        send[i, 1:1 + x.shape[0], :x.shape[1]] = x
+    if active(world):
+        if on_dev:
+            send_d = send.to(device)
+            recv = torch.empty(world * per, T + 1, K, dtype=torch.int32, device=device)
+            dist.all_gather_into_tensor(recv, send_d)
+            recv = recv.cpu()
+        else:
+            parts = [torch.empty_like(send) for _ in range(world)]
+            dist.all_gather(parts, send)
+            recv = torch.stack(parts, 0)
+        recv = recv.view(world, per, T + 1, K)
+    else:
+        recv = send.view(1, per, T + 1, K)
+    out = []
+    for c in range(n_clips):
+        blk = recv[c % world, c // world]
+        t, k = int(blk[0, 0]), int(blk[0, 1])
+        out.append(blk[1:1 + t, :k].clone())
+    return out
+
+
 def run_sharded(run_one_clip, n_clips, rank, world, device):
     """``run_one_clip(c) -> uint8 [T,H,W]`` (host or device) for every clip of this rank; gather all."""
     if n_clips <= 0:                      # nothing to run: no collective is entered (every rank sees the same n_clips)

@@ -109,6 +109,10 @@ def _tiles():
 def apply_choice(desc, choice, ws, counters=None):
     """Configure a conv descriptor for a (cfg, ksplit, split_from) choice; returns the cfg index."""
     cfg, ks, split_from = choice[:3]
+    if ks > 1 and (desc.out_ld % 4 or (desc.res and desc.res_ld % 4)):
+        # (the split-K paths move 16 bytes at a time; checked HERE, on the triple actually used: the callers' guard only saw the
+        # first triple of a six-entry table row, whose fallback may be a split-K choice -- ADVICE r5)
+        ks, split_from = 1, 0
     if cfg >= ops.PCONV_CFG0 and not ops.pconv_eligible(desc, 0):
         # the shape's measured choice is the persistent 1x1 kernel, this descriptor (a masked data gradient, an operand image, ...)
         # is not one it takes: the shape's second entry, else the heuristic
@@ -416,6 +420,8 @@ class GraphCache:
         self.graphs = {}
         self.runs = {}                     # key -> eager runs so far (a list is captured on its THIRD run: tile choices, lazy
                                            # hipFuncSetAttribute calls and first-use tuning are behind it by then)
+        self.captures = 0                  # captures performed so far (bench.py reports how many fell inside its timed region:
+                                           # torch.cuda.graph() enters with a device-wide synchronize + gc.collect + empty_cache)
 
     def invalidate(self):
         self.graphs.clear()
@@ -450,12 +456,27 @@ class GraphCache:
             import warnings
             warnings.warn('vfloodnet_amd: HIP graph capture of a launch list failed; running it eagerly')
             self.runs[key] = -10 ** 9
+            # the context manager has ended the capture on its way out; if the capture stream is somehow still recording, running
+            # the list "eagerly" would only extend a dead graph -- fail loudly instead of returning without having computed anything
+            if torch.cuda.is_current_stream_capturing():
+                raise RuntimeError('vfloodnet_amd: the stream is still capturing after a failed HIP graph capture')
+            cur.wait_stream(cap)
             for l in lst[lo:hi]:
                 l()
             return
         cur.wait_stream(cap)
         self.graphs[key] = g
+        self.captures += 1
         g.replay()
+
+    def warm(self, lst, lo=0, hi=None):
+        """Run a list until it is captured (three runs), outside any timed / latency-sensitive loop (Engine.capture)."""
+        hi = len(lst) if hi is None else hi
+        if not _GRAPHS or hi - lo < 4:
+            return
+        key = (id(lst), lo, hi)
+        while key not in self.graphs and self.runs.get(key, 0) >= 0:
+            self.run(lst, lo, hi)
 
 
 class FramePlan:
@@ -1389,6 +1410,30 @@ class Engine:
             m.scores, m.stride_scores = ptr(scores), scores.shape[1]
         check(L.vfn_memread_apply(_lib.C.byref(m), s), 'vfn_memread_apply')
         check(L.vfn_memread_finish(_lib.C.byref(m), s), 'vfn_memread_finish')
+
+    def capture(self, H0, W0, obj_n):
+        """Capture the HIP graphs of this frame size's launch lists NOW -- at plan warm-up, before the frame loop -- instead of on
+        each list's third run inside the loop (torch.cuda.graph() enters with a device-wide synchronize, a gc.collect and
+        an empty_cache; inside the loop those one-off stalls land in a timed region and drain the side stream's prefetch).  The
+        lists only write the plan's own activation buffers, which every real frame overwrites before reading; call it while no
+        prefetch is outstanding (ClipRunner.start does, after the first frame's memorize)."""
+        p = self.plan(H0, W0, obj_n)
+        if not _GRAPHS or self.eager or p.keep_acts:
+            return 0
+        before = p.graphs.captures
+        torch.cuda.current_stream().synchronize()
+        p.graphs.warm(p.mem)
+        for qs in p.qsets:
+            for n in qs.sizes:
+                lst = qs.pre[n]
+                p.graphs.warm(lst)                                   # the whole list (prefetch_begin(full=True), segment())
+                if 0 < qs.split[n] < len(lst):                       # ... and its two halves (prefetch_begin / prefetch_finish)
+                    p.graphs.warm(lst, 0, qs.split[n])
+                    p.graphs.warm(lst, qs.split[n], None)
+            for L in qs.post:
+                p.graphs.warm(L)
+        torch.cuda.current_stream().synchronize()
+        return p.graphs.captures - before
 
     # ------------------------------------------------------------------ tuning
     def autotune(self, H0, W0, obj_n, iters=3, only_missing=False, shape_filter=None, cfg_filter=None):

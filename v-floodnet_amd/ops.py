@@ -230,8 +230,14 @@ def pconv_cfg(tile_cfg, wgs=512):
 
 
 def pconv_eligible(desc, mode=0):
+    """Does vfn_conv1x1_persistent_f32 take this descriptor?  Mirrors every VFN_ERR_ARG condition of that entry point (csrc/
+    conv_winograd.hip), so that a descriptor it refuses falls back to the tiled kernels instead of raising at launch."""
+    lim = 0x7fffff00
     return (mode == 0 and desc.KH == 1 and desc.KW == 1 and desc.stride == 1 and desc.pad == 0 and not desc.mask and not desc.in_lp and
-            not desc.out_lp and not desc.w_packed and not desc.w_batch_rows and desc.Cin % 32 == 0)
+            not desc.out_lp and not desc.w_packed and not desc.w_batch_rows and desc.Cin % 32 == 0 and desc.in_ld % 4 == 0 and
+            desc.M >= 1 and desc.M == desc.N * desc.H * desc.W and desc.M * desc.in_ld * 4 < lim and desc.M * desc.out_ld * 4 < lim and
+            desc.cout_pad * desc.Cin * 4 < lim and
+            (not desc.res or (desc.res_mod if desc.res_mod > 0 else desc.M) * desc.res_ld * 4 < lim))
 
 
 def pconv_cfg_options(cout):

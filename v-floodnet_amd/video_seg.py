@@ -110,6 +110,10 @@ class ClipRunner:
             m = ops.resize_nearest(m, h, w)                      # TF.resize(mask, 480, NEAREST) (:89)
         k, v = self.model.memorize(f, m)
         self.fb.init_bank(k, v)
+        if os.environ.get('VFN_CAPTURE_AT_START', '1') == '1':
+            # the launch lists' HIP graphs are captured here, before the loop (engine.Engine.capture), not on their third run inside it;
+            # the first frame's keys / values are already in the bank (init_bank copies them out of the plan's buffers)
+            self.graph_captures_at_start = self.model.engine().capture(h, w, self.obj_n)
         self.t = 0
         self._net_cache = {}                                     # no look-ahead carried over from a previous clip
         # two sets of per-frame outputs: frame t+1 may be enqueued (launch) before the host has looked at frame t
@@ -123,6 +127,7 @@ class ClipRunner:
         self._label_dev, self._post_dev, self._pinned = self._cur['label'], self._cur['post'], self._cur['pinned']
         self._ccl_scratch = torch.empty(2 * H0 * W0 + 8, dtype=torch.int32, device=self.device)
         self._pending = []
+        self.size_log = [list(self.fb._len_host)]                 # live entries per object: after init_bank, then after every collected frame
 
     def _net_cached(self, frame):
         """The network-resolution tensor of ``frame``, resized once however often the look-ahead sees it.  The key is an
@@ -210,6 +215,7 @@ class ClipRunner:
         buf = self._pending.pop(0)
         buf['done'].synchronize()
         self.fb.absorb_stats(buf['stats'], in_flight=len(self._pending))
+        self.size_log.append(list(self.fb._len_host))
         return buf['pinned']
 
     def step(self, frame, want_label=True, next_frame=None, next_frames=None):
@@ -417,6 +423,7 @@ def main(args, device):
 
     runner.fb.print_peak_mem()
     runner.kept_labels = torch.stack(keep, 0) if keep is not None else None    # uint8 [T,H0,W0] on the device, frame 0 = given mask
+    runner.kept_sizes = torch.tensor(runner.size_log, dtype=torch.int32)       # int32 [T,obj_n]: the bank after frame 0, 1, ... (dist.gather_bank_sizes)
     return runner
 
 
