@@ -27,6 +27,8 @@
 // (buffer loads, two k-groups ahead).
 #include "common.h"
 #include "../../include/vfn_hip.h"
+#include <type_traits>
+#include <cstdlib>
 
 namespace {
 
@@ -889,6 +891,261 @@ void memread_apply_shw_kernel(const vfn_memread_desc p) {
         }
 }
 
+// ------------------------------------------------------------------ pass 2, plain bf16, software-pipelined (round 6)
+// memread_apply_shw_kernel<false> walks a chunk as  [score GEMM -> softmax -> P^T to LDS] barrier [P^T V] barrier : all eight waves do
+// the vector work (exp, threshold ballots, bf16 conversion: ~850 VALU cycles per wave and chunk, v_exp at quarter rate) TOGETHER
+// between two barriers, with the matrix pipe idle, then the matrix work together with the vector pipe idle -- and its value rows are
+// requested at most one chunk phase ahead (rocprofv3, round 5: mfma_util 0.27, 0.64 of the wave cycles waiting; 0.27 of the bf16 peak
+// on the kernel that is 50-70 % of a C5 frame).  Here the loop is skewed by one chunk INSIDE every wave:
+//
+//     iteration c:   score GEMM of chunk c+1 (8 MFMAs)
+//                    4 x { P^T V step of chunk c (8 MFMAs)  ||  a quarter of chunk c+1's softmax (VALU, in the MFMAs' shadow)
+//                          -> its quarter of P^T(c+1) into the OTHER P^T buffer;  the value rows of (c+1, step) requested into the
+//                          operand registers the step has just consumed: a whole chunk of lead }
+//                    hit counts of chunk c+1; keys of chunk c+2: registers -> LDS        ONE barrier per chunk
+//
+// Keys go through registers (two 16-byte loads per thread at the top of an iteration, stored to LDS in front of its barrier), not by
+// LDS-DMA: with a DMA in flight hipcc turns every wait for a register load into a full drain, which would
+// put the value rows' latency back on the chain.  Only the hi plane of the key image is staged (256-byte rows: 16 KB per chunk).
+// Registers are what the structure costs (128 accumulators + 64 value operands + 16 scores + 8 keys of 256): every LDS address is
+// ONE xor away from a per-lane base (the swizzles are xors with lane constants), and the bases are made opaque once per iteration so
+// that hipcc does not hoist the 30 derived addresses into registers of their own (a first form spilled 21 registers; each reload of a
+// spilled ADDRESS was a scratch load with a full vmcnt(0) drain in front of the LDS access -- the value rows' lead thrown away).
+// Same products in the same order as memread_apply_shw_kernel<false> (same fragments, same k order, same chunk order): bit-identical.
+// LDS: query image 32 KB + 2 key chunks 32 KB + 2 P^T 32 KB = 96 KB; one workgroup of 8 waves per CU.
+constexpr size_t APPLY_PIPE_LDS = (size_t)QTW * DK * 2 + 2 * (size_t)CH * DK * 2 + 2 * (size_t)QTW * CH * 2;
+constexpr unsigned PIPE_K0 = QTW * DK * 2;                    // byte offsets inside the dynamic LDS: key buffers
+constexpr unsigned PIPE_P0 = PIPE_K0 + 2 * CH * DK * 2;       // P^T buffers
+constexpr unsigned PIPE_KB = CH * DK * 2, PIPE_PB = QTW * CH * 2;     // bytes of one key / P^T buffer
+
+__global__ __launch_bounds__(512, 1)
+void memread_apply_pipe_kernel(const vfn_memread_desc p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* sQh = smem;                                         // [128 q][256 B] bf16, swzq
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 31, lh = lane >> 5;
+    const int wr = wave >> 2, wq = wave & 3;                  // score tile: key rows 32wr.., query columns 32wq..
+    const int qhalf = wave >> 2, cq = wave & 3;               // P^T V: queries 64qhalf.., channels 128cq..
+    int split, qt, obj;
+    apply_item(p, split, qt, obj);
+    const int q0 = qt * QTW;
+    const int B = p.bank_len[obj];
+    const char* Kimg = reinterpret_cast<const char*>(p.bank_k_lp) + (size_t)obj * p.stride_k * 4;   // image rows of 512 B: [128 hi | 128 lo]
+    const char* V = reinterpret_cast<const char*>(p.bank_v_lp) + (size_t)obj * p.stride_v * 4;      // blocks of 8 rows, 16 KB
+
+    {   // query image
+        const int c = tid & 31;
+        for (int r = tid >> 5; r < QTW; r += 16) {
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (q0 + r < p.HW) v = *reinterpret_cast<const f32x4*>(p.q + (size_t)(q0 + r) * p.ldq + c * 4);
+            const bf16x4 h = {(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
+            *reinterpret_cast<bf16x4*>(sQh + swzq(r, c >> 1) + (c & 1) * 8) = h;
+        }
+    }
+
+    int c_lo, c_hi;
+    chunk_range(B, p.nsplit, split, c_lo, c_hi);
+    const int n = c_hi - c_lo;
+
+    f32x16 o[2][4];                                           // O^T tiles: [query tile][channel tile]
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[a][b][r] = 0.f;
+
+    const int qcol = wq * 32 + li;
+    const bool qok = (q0 + qcol) < p.HW;
+    float qm = 1e30f, qinv = 0.f;
+    if (qok) {
+        qm = p.ml[((size_t)obj * p.HW + q0 + qcol) * 2];
+        qinv = 1.f / p.ml[((size_t)obj * p.HW + q0 + qcol) * 2 + 1];
+    }
+    const float sm = -qm;
+    const int rloc = wr * 32 + 4 * lh;                        // this lane's first score row inside a chunk (+ (r & 3) + 8 (r >> 2))
+
+    if (n > 0) {
+        const unsigned vlane_off = (unsigned)lh * VBLK + (unsigned)(cq * 128 + li) * 16u;      // bytes: row block lh of a step, channel
+        const int krow = tid >> 3, kc2 = (tid & 7) * 2;                                        // key staging: row, first of two 16-byte chunks
+        const unsigned klane_off = (unsigned)krow * 512u + (unsigned)kc2 * 16u;
+        // LDS byte addresses, each ONE xor away from a per-lane base (swzq / swzp are xors of the 16-byte chunk index with lane constants):
+        //   key fragment g of the score GEMM     bK ^ 32 g  (+ buffer)     bK = swzq(32 wr + li, lh)
+        //   query fragment g                     bQ ^ 32 g                 bQ = swzq(32 wq + li, lh)
+        //   P^T fragment of step st, tile tq     bR ^ 32 st + 4096 tq (+ buffer)      bR = swzp(64 qhalf + li, lh)
+        //   P^T store of softmax quarter g       bW ^ 16 g  (+ buffer)     bW = swzp(qcol, 4 wr) + 8 lh   (rows rloc + 8 g: chunk 4 wr + g, half lh)
+        //   key staging store                    swzq(krow, kc2), swzq(krow, kc2 + 1)  (+ buffer)
+        unsigned bK = PIPE_K0 + (unsigned)swzq(wr * 32 + li, lh);
+        unsigned bQ = (unsigned)swzq(wq * 32 + li, lh);
+        unsigned bR = PIPE_P0 + (unsigned)swzp(qhalf * 64 + li, lh);
+        unsigned bW = PIPE_P0 + (unsigned)swzp(qcol, 4 * wr) + 8u * lh;
+        unsigned bS = PIPE_K0 + (unsigned)swzq(krow, kc2);
+        const unsigned bS1 = (unsigned)(swzq(krow, kc2 + 1) - swzq(krow, kc2));                 // (+16 or -16: the pair's second chunk)
+        auto lds = [&](unsigned a) { return smem + a; };
+        u32x4 vop[4][4];                                      // value operands: [step][channel tile] (8 bank rows x 1 channel, bf16)
+        u32x4 kreg[2];
+        f32x16 acc;
+        int mycnt = 0;
+
+        // buffer descriptors over ONE chunk's live rows: key rows / value row blocks past the bank end read zeros through the range check
+        auto vres = [&](int c) {
+            const int b0 = c * CH;
+            return __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(V + (size_t)(b0 >> 3) * VBLK), 0, ((min(CH, B - b0) + 7) >> 3) * (int)VBLK, 0x00020000);
+        };
+        auto kres = [&](int c) {
+            const int b0 = c * CH;
+            return __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(Kimg + (size_t)b0 * 512), 0, min(CH, B - b0) * 512, 0x00020000);
+        };
+        auto load_v = [&](const __amdgpu_buffer_rsrc_t& r, int st, auto SLOT_) {
+            constexpr int slot = decltype(SLOT_)::value;
+#pragma unroll
+            for (int tc = 0; tc < 4; ++tc) vop[slot][tc] = __builtin_amdgcn_raw_buffer_load_b128(r, vlane_off, 2 * st * (int)VBLK + tc * 512, 0);
+        };
+        auto load_k = [&](int c) {
+            const __amdgpu_buffer_rsrc_t r = kres(c);
+            kreg[0] = __builtin_amdgcn_raw_buffer_load_b128(r, klane_off, 0, 0);
+            kreg[1] = __builtin_amdgcn_raw_buffer_load_b128(r, klane_off, 16, 0);
+        };
+        auto store_k = [&](int buf) {
+            const unsigned a = bS + buf * PIPE_KB;
+            *reinterpret_cast<u32x4*>(lds(a)) = kreg[0];
+            *reinterpret_cast<u32x4*>(lds(a + bS1)) = kreg[1];
+        };
+        auto score = [&](int buf) {
+            const unsigned ak = bK + buf * PIPE_KB;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+            // fragments of k-group g + 1 are requested in front of the MFMA of g (a first form read, waited, multiplied: eight exposed LDS
+            // round trips with the matrix pipe idle -- both waves of a SIMD are in this section together)
+            bf16x8 fa[2], fb[2];
+            fa[0] = *reinterpret_cast<const bf16x8*>(lds(ak));
+            fb[0] = *reinterpret_cast<const bf16x8*>(lds(bQ));
+#pragma unroll
+            for (int g = 0; g < 8; ++g) {
+                if (g + 1 < 8) {
+                    fa[(g + 1) & 1] = *reinterpret_cast<const bf16x8*>(lds(ak ^ (32u * (g + 1))));
+                    fb[(g + 1) & 1] = *reinterpret_cast<const bf16x8*>(lds(bQ ^ (32u * (g + 1))));
+                }
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[g & 1], fb[g & 1], acc, 0, 0, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);      // 2 LDS reads, then 1 MFMA: keeps the requests one group ahead
+                __builtin_amdgcn_sched_group_barrier(0x8, 1, 0);
+            }
+        };
+        // a quarter of a chunk's softmax: score registers 4g .. 4g+3 = bank rows rloc + 8g + (0..3) of query qcol -> p, hit ballots, P^T
+        auto softmax_quarter = [&](auto G_, int pbuf) {
+            constexpr int g = decltype(G_)::value;
+            float pv[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) pv[e] = fast_exp(fmaf(acc[4 * g + e], p.scale, sm)) * qinv;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const unsigned long long hit = __ballot(pv[e] > p.thres);
+                const int h_lo = __popcll(hit & 0xffffffffull), h_hi = __popcll(hit >> 32);      // wave-uniform
+                asm volatile("v_writelane_b32 %0, %1, %2" : "+v"(mycnt) : "s"(h_lo), "n"(e + 8 * g));
+                asm volatile("v_writelane_b32 %0, %1, %2" : "+v"(mycnt) : "s"(h_hi), "n"(e + 8 * g + 4));
+            }
+            const bf16x4 h = {(__bf16)pv[0], (__bf16)pv[1], (__bf16)pv[2], (__bf16)pv[3]};
+            *reinterpret_cast<bf16x4*>(lds((bW + pbuf * PIPE_PB) ^ (16u * g))) = h;
+        };
+        // the bank's last chunk may be partial: its rows past the end got p = exp(0 - m) / l from the zero keys -- exactly 0 is required
+        // (their value rows are stale).  Rare (one chunk per object): a fix-up of the lane's own P^T entries, outside the pipelined stream
+        auto zero_dead_rows = [&](int pbuf, int nvalid) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (rloc + 8 * g + e >= nvalid) *reinterpret_cast<unsigned short*>(lds(((bW + pbuf * PIPE_PB) ^ (16u * g)) + e * 2)) = 0;
+        };
+        auto add_hits = [&](int c) {                          // one wave per 32 x 32 score tile: lane i (0..31) holds the hits of chunk row 32wr + i
+            if (p.cnt && lh == 0 && mycnt > 0) {
+                const int row = c * CH + wr * 32 + li;
+                if (row < B) atomicAdd(p.cnt + (size_t)obj * p.stride_cnt + row, mycnt);
+            }
+            mycnt = 0;
+        };
+        auto pv_step = [&](auto ST_, auto SLOT_, int pbuf) {   // O^T[q][ch] += sum_b P^T[q][b] V[b][ch], 16 bank rows: 2 query tiles x 4 channel tiles
+            constexpr int st = decltype(ST_)::value, slot = decltype(SLOT_)::value;
+            const unsigned ar = (bR + pbuf * PIPE_PB) ^ (32u * st);
+#pragma unroll
+            for (int tq = 0; tq < 2; ++tq) {
+                const bf16x8 ph = *reinterpret_cast<const bf16x8*>(lds(ar + tq * 4096));
+#pragma unroll
+                for (int tc = 0; tc < 4; ++tc)
+                    o[tq][tc] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ph, __builtin_bit_cast(bf16x8, vop[slot][tc]), o[tq][tc], 0, 0, 0);
+            }
+        };
+        using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>;
+        using I2 = std::integral_constant<int, 2>; using I3 = std::integral_constant<int, 3>;
+        auto opaque = [&]() {                                  // (keeps the derived LDS addresses out of loop-invariant registers)
+            asm volatile("" : "+v"(bK), "+v"(bQ), "+v"(bR), "+v"(bW), "+v"(bS));
+        };
+
+        // ---- prologue: chunk c_lo's keys, value operands and P^T; chunk c_lo + 1's keys
+        {
+            const __amdgpu_buffer_rsrc_t vr = vres(c_lo);
+            load_k(c_lo);
+            load_v(vr, 0, I0{}); load_v(vr, 1, I1{}); load_v(vr, 2, I2{}); load_v(vr, 3, I3{});
+            store_k(0);
+            if (n > 1) load_k(c_lo + 1);
+            __syncthreads();
+            score(0);
+            softmax_quarter(I0{}, 0); softmax_quarter(I1{}, 0); softmax_quarter(I2{}, 0); softmax_quarter(I3{}, 0);
+            if (B - c_lo * CH < CH) zero_dead_rows(0, B - c_lo * CH);
+            add_hits(c_lo);
+            if (n > 1) store_k(1);
+            __syncthreads();
+        }
+
+        // one iteration: chunk c = c_lo + i.  NEXT: chunk c + 1 exists (its scores / softmax / value requests ride along);
+        // KNEXT: chunk c + 2 exists (its keys are staged)
+        auto iter = [&](auto NEXT_, auto KNEXT_, int i) {
+            constexpr bool NEXT = decltype(NEXT_)::value, KNEXT = decltype(KNEXT_)::value;
+            const int c = c_lo + i;
+            const int pc = i & 1, pn = pc ^ 1;
+            opaque();
+            if constexpr (KNEXT) load_k(c + 2);
+            const __amdgpu_buffer_rsrc_t vr1 = vres(NEXT ? c + 1 : c);
+            if constexpr (NEXT) score(pn);
+            pv_step(I0{}, I0{}, pc);
+            if constexpr (NEXT) { load_v(vr1, 0, I0{}); softmax_quarter(I0{}, pn); }
+            __builtin_amdgcn_sched_barrier(0);
+            pv_step(I1{}, I1{}, pc);
+            if constexpr (NEXT) { load_v(vr1, 1, I1{}); softmax_quarter(I1{}, pn); }
+            __builtin_amdgcn_sched_barrier(0);
+            pv_step(I2{}, I2{}, pc);
+            if constexpr (NEXT) { load_v(vr1, 2, I2{}); softmax_quarter(I2{}, pn); }
+            __builtin_amdgcn_sched_barrier(0);
+            pv_step(I3{}, I3{}, pc);
+            if constexpr (NEXT) { load_v(vr1, 3, I3{}); softmax_quarter(I3{}, pn); }
+            if constexpr (NEXT) {
+                if (B - (c + 1) * CH < CH) zero_dead_rows(pn, B - (c + 1) * CH);
+                add_hits(c + 1);
+            }
+            if constexpr (KNEXT) store_k(pc);                        // (chunk c's keys, read by the previous iteration's score GEMM, are dead)
+            __syncthreads();
+        };
+        const std::true_type T{};
+        const std::false_type F{};
+        int i = 0;
+        for (; i + 2 < n; ++i) iter(T, T, i);
+        if (i + 1 < n) { iter(T, F, i); ++i; }
+        iter(F, F, i);
+    }
+
+    float* dst = p.o_part + ((size_t)obj * p.nsplit + split) * p.HW * DV;
+#pragma unroll
+    for (int tq = 0; tq < 2; ++tq)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int q = q0 + qhalf * 64 + tq * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+            if (q < p.HW) {
+#pragma unroll
+                for (int tc = 0; tc < 4; ++tc) dst[(size_t)q * DV + cq * 128 + tc * 32 + li] = o[tq][tc][r];
+            }
+        }
+}
+
 #ifdef VFN_CENSUS
 #define PH_DECL unsigned long long ph_t = __builtin_amdgcn_s_memtime(), ph_acc[5] = {0, 0, 0, 0, 0}
 #define PH_MARK(k) do { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); ph_acc[k] += t_ - ph_t; ph_t = t_; } while (0)
@@ -1318,7 +1575,14 @@ extern "C" int vfn_memread_apply(const vfn_memread_desc* d, void* stream) {
                 if (e) img_bf16 = atoi(e);
                 once_s = true;
             }
+            // plain bf16 (round 6): the software-pipelined kernel; VFN_APPLY_PIPE=0 (read at every call: A/B in one process) restores
+            // memread_apply_shw_kernel<false>
+            static bool once_p = false;
+            if (!once_p) { allow_lds(memread_apply_pipe_kernel, APPLY_PIPE_LDS); once_p = true; }
+            const char* ep = getenv("VFN_APPLY_PIPE");
+            const bool pipe = !(ep && atoi(ep) == 0);
             if (d->precision == 2) hipLaunchKernelGGL(memread_apply_shw_kernel<true>, gridw, dim3(512), LDS_W2, (hipStream_t)stream, *d);
+            else if (img_bf16 && pipe) hipLaunchKernelGGL(memread_apply_pipe_kernel, gridw, dim3(512), APPLY_PIPE_LDS, (hipStream_t)stream, *d);
             else if (img_bf16) hipLaunchKernelGGL(memread_apply_shw_kernel<false>, gridw, dim3(512), LDS_W1, (hipStream_t)stream, *d);
             if (d->precision == 2 || img_bf16) return vfn_check_launch();
         }
