@@ -479,7 +479,9 @@ def main(argv=None):
             x3 = 'memread_apply_shw_kernel<true>' if img else 'memread_apply_lpw_kernel<true>'
             # (plain bf16 takes the image kernel too unless VFN_APPLY_IMG_BF16=0; lines written before the end of round 5 name
             # memread_apply_lpw_kernel<false> here while rocprof shows memread_apply_shw_kernel<false>: profiles/r05_kernel_stats_bf16.csv)
-            b1 = 'memread_apply_shw_kernel<false>' if (img and os.environ.get('VFN_APPLY_IMG_BF16', '1') != '0') else 'memread_apply_lpw_kernel<false>'
+            # (round 6: plain bf16 on the kept image runs the software-pipelined kernel unless VFN_APPLY_PIPE=0)
+            b1 = (('memread_apply_pipe_kernel' if os.environ.get('VFN_APPLY_PIPE', '1') != '0' else 'memread_apply_shw_kernel<false>')
+                  if (img and os.environ.get('VFN_APPLY_IMG_BF16', '1') != '0') else 'memread_apply_lpw_kernel<false>')
             kn = {'fp32': 'memread_apply_ss_kernel' if stored else 'memread_apply_wide_kernel', 'bf16': b1, 'bf16x3': x3}[args.precision]
             cands.append((kn, a_fl, a_ms, len(apply_records), len(apply_records)))      # (one launch per frame)
         tot_fl = sum(v[0] for v in per.values())

@@ -111,6 +111,8 @@ __device__ __forceinline__ void score_tile(const float* sK, const float* sQ, int
 // 8 consecutive k of one operand row -> one v_mfma_f32_32x32x16_bf16 fragment.  bf16x3: x = hi + lo (two bf16,
 // 16 significant bits); a product is hi*hi + hi*lo + lo*hi, the 2^-16 lo*lo term is dropped.
 typedef __attribute__((ext_vector_type(2))) float f32x2;
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 
@@ -134,6 +136,8 @@ __device__ __forceinline__ void split8(const f32x4& a, const f32x4& b, bf16x8& h
 // fragments it read in registers -- the same key row was converted by every wave that used it (4x in the scan and in the
 // 128-query apply kernel) and the conversion VALU equalled the MFMA time of the score GEMM.  NT threads, two barriers.
 __device__ __forceinline__ int swzk(int row, int half, int chunk) { return row * 512 + half * 256 + ((chunk ^ (row & 15)) << 4); }   // bytes
+// rows of 256 B (query image; hi plane of a key chunk): 16-byte chunk index XOR (row & 15)
+__device__ __forceinline__ int swzq(int row, int chunk) { return row * 256 + ((chunk ^ (row & 15)) << 4); }          // bytes
 
 template <int NT, bool X3>
 __device__ __forceinline__ void convert_chunk_inplace(float* sK, int tid) {
@@ -436,6 +440,204 @@ void bank_scan_kernel(const vfn_bankscan_desc p) {
   }
 }
 
+// ------------------------------------------------------------------ pass 1, plain bf16 on the kept key image: register-staged keys (round 6)
+// bank_scan_kernel<MODE, 1> brings every key chunk in by LDS-DMA ONE chunk ahead and ends every chunk on a barrier that drains the
+// DMA: a chunk is 16 MFMAs + ~230 vector slots per wave (0.7 us), the DMA's round trip to L2 / HBM is longer, so the loop runs at
+// the memory latency (rocprofv3, round 5: mfma_util 0.17-0.18 at C5 sizes, where the two scans are a quarter of the frame).
+// Here the keys go through registers, requested TWO iterations before their chunk is multiplied: issued at the top of iteration
+// c - 1, stored into the other LDS buffer at the end of iteration c, read in iteration c + 1 -- two register sets of 64 bytes per
+// thread, no DMA (so hipcc's waits stay counted, also around the row-scale loads of MODE 1), and only the hi plane of the image is
+// staged (256-byte rows: 16 KB per chunk instead of 32).  Same fragments, same products, same statistics in the same order as the
+// image path of bank_scan_kernel<MODE, 1>: bit-identical.  LDS 32 KB; two workgroups per CU as before.
+// (MODE 1: the chunk's 64 row scales travel with its keys -- one 16-byte load on 16 threads, through registers into 256 bytes of LDS
+// beside the key buffer, read back as broadcast ds_read_b128.  As register loads of their own, issued behind the key requests, the
+// in-order load counter made their wait a wait for the keys two chunks ahead: 0.76-1.04 x the DMA kernel instead of 1.4 x.)
+constexpr size_t SCAN_PIPE_LDS = 2 * (size_t)CH * DK * 2 + 2 * CH * sizeof(float);
+constexpr unsigned SCAN_PIPE_SC0 = 2 * CH * DK * 2;         // byte offset of the two row-scale buffers
+
+template <int MODE>
+__global__ __launch_bounds__(256, 2)
+void bank_scan_pipe_kernel(const vfn_bankscan_desc p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];      // 2 x [64 rows][256 B] bf16 hi plane, swzq
+    __shared__ int s_item;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 31, lh = lane >> 5;
+    const int qtiles = (p.HW + QTS - 1) / QTS;
+    const int total = p.nsplit * qtiles * p.obj_n;
+    const int krow = tid >> 2, kc4 = (tid & 3) * 4;                   // key staging: row, first of four 16-byte chunks
+    const unsigned klane_off = (unsigned)krow * 512u + (unsigned)kc4 * 16u;
+  for (;;) {
+    if (tid == 0) s_item = atomicAdd(p.work_counter, 1);
+    __syncthreads();
+    const int item = s_item;
+    __syncthreads();                                   // (everyone has the item before thread 0 draws the next one)
+    if (item >= total) break;
+    const int obj = item % p.obj_n;
+    const int qt = (item / p.obj_n) % qtiles;
+    const int split = item / (p.obj_n * qtiles);
+    const int q0 = qt * QTS + wave * 32;             // first query of this wave
+    const int B = p.bank_len[obj];
+    const char* Kimg = reinterpret_cast<const char*>(p.bank_k_lp) + (size_t)obj * p.stride_k * 4;    // image rows of 512 B: [128 hi | 128 lo]
+    const float* Q = p.q + (size_t)(p.q_per_obj ? obj : 0) * p.stride_q;
+
+    int c_lo, c_hi;
+    chunk_range(B, p.nsplit, split, c_lo, c_hi);
+
+    u32x4 kst[2][4];                                    // two chunks of keys in flight: 64 bytes per thread each
+    f32x4 sst[2];                                       // (MODE 1) ... and their row scales: rows 4 tid .. + 3 on threads 0..15
+    const float* rs = MODE == 1 ? p.rowscale + (size_t)obj * p.stride_rs : nullptr;
+    auto load_k = [&](int c, auto SET_) {
+        constexpr int set = decltype(SET_)::value;
+        const int b0 = c * CH;
+        const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(Kimg + (size_t)b0 * 512), 0, min(CH, B - b0) * 512, 0x00020000);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) kst[set][j] = __builtin_amdgcn_raw_buffer_load_b128(r, klane_off, 16 * j, 0);
+        // (rows past the bank's end lie inside the slab -- finite scratch -- and are ignored by the comparison below)
+        if constexpr (MODE == 1) { if (tid < 16) sst[set] = *reinterpret_cast<const f32x4*>(rs + b0 + 4 * tid); }
+    };
+    auto store_k = [&](int buf, auto SET_) {
+        constexpr int set = decltype(SET_)::value;
+        char* d = smem + buf * (CH * DK * 2);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) *reinterpret_cast<u32x4*>(d + swzq(krow, kc4 + j)) = kst[set][j];
+        if constexpr (MODE == 1) { if (tid < 16) *reinterpret_cast<f32x4*>(smem + SCAN_PIPE_SC0 + buf * (CH * 4) + tid * 16) = sst[set]; }
+    };
+    using Z0 = std::integral_constant<int, 0>; using Z1 = std::integral_constant<int, 1>;
+    if (c_lo < c_hi) load_k(c_lo, Z0{});
+    if (c_lo + 1 < c_hi) load_k(c_lo + 1, Z1{});
+
+    bf16x8 qh[8];                                      // B operand: this lane's query column, k = 16g + 8lh + j
+    {
+        const int q = min(q0 + li, p.HW - 1);                    // columns past HW are never written out
+        const float* qrow = Q + (size_t)q * p.ldq + 8 * lh;
+#pragma unroll
+        for (int g = 0; g < 8; ++g) {
+            const f32x4 x0 = *reinterpret_cast<const f32x4*>(qrow + 16 * g);
+            const f32x4 x1 = *reinterpret_cast<const f32x4*>(qrow + 16 * g + 4);
+            qh[g] = cvt8(x0, x1);
+        }
+    }
+
+    float run_m = -INFINITY, run_l = 0.f;
+    int run_i = 0x7fffffff;
+    if (c_lo < c_hi) store_k(0, Z0{});
+    __syncthreads();
+
+    auto body = [&](auto PAR_, int c) {                 // PAR = (c - c_lo) & 1: LDS buffer of chunk c, register set of chunk c + 2
+        constexpr int PAR = decltype(PAR_)::value;
+        const int b0 = c * CH;
+        const char* kb = smem + PAR * (CH * DK * 2);
+        if (c + 2 < c_hi) load_k(c + 2, PAR_);          // (set PAR held chunk c: stored to LDS an iteration ago)
+        f32x4 scv[MODE == 1 ? 2 : 1][MODE == 1 ? 4 : 1];
+        if constexpr (MODE == 1) {
+            const float* sS = reinterpret_cast<const float*>(smem + SCAN_PIPE_SC0 + PAR * (CH * 4));
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) scv[i][g] = *reinterpret_cast<const f32x4*>(sS + 32 * i + 4 * lh + 8 * g);
+        }
+        f32x16 acc[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+#pragma unroll
+        for (int g = 0; g < 8; ++g) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const bf16x8 ah = *reinterpret_cast<const bf16x8*>(kb + swzq(32 * i + li, 2 * g + lh));
+                acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, qh[g], acc[i], 0, 0, 0);
+            }
+        }
+        if (MODE == 0) {
+            if (b0 + CH <= B) {                          // whole chunk inside the bank (all but the last): no row checks
+                float mx = acc[0][0];
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) mx = fmaxf(mx, acc[i][r]);
+                const float mn = fmaxf(run_m, mx * p.scale);     // scale > 0: max commutes with it
+                float sum = 0.f;
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) sum += fast_exp(acc[i][r] * p.scale - mn);
+                run_l = run_l * expf(run_m - mn) + sum;       // exp(-inf)=0 on the first chunk
+                run_m = mn;
+            } else {
+                float mx = -INFINITY;
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int row = b0 + 32 * i + 4 * lh + (r & 3) + 8 * (r >> 2);
+                        const float s_ = acc[i][r] * p.scale;
+                        acc[i][r] = s_;
+                        if (row < B) mx = fmaxf(mx, s_);
+                    }
+                const float mn = fmaxf(run_m, mx);
+                if (mn > -INFINITY) {
+                    float sum = 0.f;
+#pragma unroll
+                    for (int i = 0; i < 2; ++i)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            const int row = b0 + 32 * i + 4 * lh + (r & 3) + 8 * (r >> 2);
+                            if (row < B) sum += fast_exp(acc[i][r] - mn);
+                        }
+                    run_l = run_l * expf(run_m - mn) + sum;
+                    run_m = mn;
+                }
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {            // registers 4g..4g+3 = rows +8g .. +3: one 16-byte load
+                    const int row0 = b0 + 32 * i + 4 * lh + 8 * g;
+                    const f32x4 sc = scv[MODE == 1 ? i : 0][MODE == 1 ? g : 0];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int row = row0 + j;
+                        if (row < B) {
+                            const float s_ = acc[i][4 * g + j] * sc[j];
+                            if (s_ > run_m) { run_m = s_; run_i = row; }   // (ties: smaller row wins, below)
+                        }
+                    }
+                }
+        }
+        if (c + 1 < c_hi) store_k(PAR ^ 1, std::integral_constant<int, PAR ^ 1>{});   // chunk c + 1 (requested an iteration ago) into the buffer chunk c - 1 has left
+        __syncthreads();
+    };
+    for (int c = c_lo; c < c_hi; c += 2) {
+        body(std::integral_constant<int, 0>{}, c);
+        if (c + 1 < c_hi) body(std::integral_constant<int, 1>{}, c + 1);
+    }
+
+    // combine the two lane halves of a query; lanes 0..31 write the slice result
+    {
+        const float om = __shfl_xor(run_m, 32, 64);
+        if (MODE == 0) {
+            const float ol = __shfl_xor(run_l, 32, 64);
+            const float mn = fmaxf(run_m, om);
+            float l = 0.f;
+            if (mn > -INFINITY) l = run_l * expf(run_m - mn) + ol * expf(om - mn);
+            run_m = mn; run_l = l;
+        } else {
+            const int oi = __shfl_xor(run_i, 32, 64);
+            if (om > run_m || (om == run_m && oi < run_i)) { run_m = om; run_i = oi; }
+        }
+    }
+    const int q = q0 + li;
+    if (lh == 0 && q < p.HW) {
+        float* dst = p.part + (((size_t)obj * p.nsplit + split) * p.HW + q) * 2;
+        dst[0] = run_m;
+        dst[1] = (MODE == 0) ? run_l : __int_as_float(run_i);
+    }
+  }
+}
+
 // combine bank-split partials.  MODE 0 -> ml[obj][q] = (m, l); MODE 1 -> idx[obj][q], corr[obj][q]
 // Eight lanes per query column: lane j folds the slices j, j + 8, ... (a fixed order), then the eight partial results are folded
 // in lane order -- 8 + 7 steps instead of a 59-long chain on one thread (the kernel sits between the scan and the apply kernel of
@@ -533,7 +735,6 @@ __device__ __forceinline__ void apply_item(const vfn_memread_desc& p, int& split
 // every precision mode and were the only ones the default path had selected since.)
 // LDS swizzles of the reduced-precision kernels (bytes): query image rows of 256 B, P^T rows of 128 B.  k is in natural
 // order everywhere: step g of a 32x32x16 MFMA takes k = 16g + 8*(lane>>5) + j.
-__device__ __forceinline__ int swzq(int row, int chunk) { return row * 256 + ((chunk ^ (row & 15)) << 4); }          // bytes
 __device__ __forceinline__ int swzp(int row, int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); }    // bytes
 
 // ------------------------------------------------------------------ pass 2, bf16 / bf16x3, wide query tile
@@ -720,8 +921,6 @@ void memread_apply_lpw_kernel(const vfn_memread_desc p) {
 // 16-byte buffer load per channel tile and plane, 32 lanes = 512 contiguous bytes -- no transposition in registers.
 // P^T V mapping: wave = (query half qh, channel quarter cq): 2 query tiles x 4 channel tiles (channel = 128cq + 32tc + li),
 // so P^T fragments are read from LDS half as often as with 4 query tiles x 2 channel tiles.
-typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 constexpr unsigned VBLK = 8 * DV * 4;       // bytes of one 8-row block of the value image
 
 template <bool X3>
@@ -926,7 +1125,17 @@ void memread_apply_pipe_kernel(const vfn_memread_desc p) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 31, lh = lane >> 5;
     const int wr = wave >> 2, wq = wave & 3;                  // score tile: key rows 32wr.., query columns 32wq..
-    const int qhalf = wave >> 2, cq = wave & 3;               // P^T V: queries 64qhalf.., channels 128cq..
+#ifdef PIPE_2X4
+    constexpr int TQN = 2, TCN = 4;                           // P^T V tiles per wave: 2 query tiles x 4 channel tiles (memread_apply_shw_kernel's)
+    const int qbase = (wave >> 2) * 64, cbase = (wave & 3) * 128;
+#else
+    // 4 query tiles x 2 channel tiles: every value row is requested by ONE wave of the workgroup.  With 2 x 4 the two waves that share
+    // a channel quarter both request it -- 144 KB per chunk and CU through L1 / L2 instead of 80 KB, 15 TB/s chip-wide at the rate this
+    // kernel runs: the L2's limit (an ablation with constant value operands ran 28 % faster).  P^T fragments are read from LDS twice as
+    // often instead (128 KB per chunk: 1024 of ~5000 cycles), and the operand registers halve (32 instead of 64).
+    constexpr int TQN = 4, TCN = 2;
+    const int qbase = 0, cbase = wave * 64;
+#endif
     int split, qt, obj;
     apply_item(p, split, qt, obj);
     const int q0 = qt * QTW;
@@ -948,11 +1157,11 @@ void memread_apply_pipe_kernel(const vfn_memread_desc p) {
     chunk_range(B, p.nsplit, split, c_lo, c_hi);
     const int n = c_hi - c_lo;
 
-    f32x16 o[2][4];                                           // O^T tiles: [query tile][channel tile]
+    f32x16 o[TQN][TCN];                                       // O^T tiles: [query tile][channel tile]
 #pragma unroll
-    for (int a = 0; a < 2; ++a)
+    for (int a = 0; a < TQN; ++a)
 #pragma unroll
-        for (int b = 0; b < 4; ++b)
+        for (int b = 0; b < TCN; ++b)
 #pragma unroll
             for (int r = 0; r < 16; ++r) o[a][b][r] = 0.f;
 
@@ -967,23 +1176,23 @@ void memread_apply_pipe_kernel(const vfn_memread_desc p) {
     const int rloc = wr * 32 + 4 * lh;                        // this lane's first score row inside a chunk (+ (r & 3) + 8 (r >> 2))
 
     if (n > 0) {
-        const unsigned vlane_off = (unsigned)lh * VBLK + (unsigned)(cq * 128 + li) * 16u;      // bytes: row block lh of a step, channel
+        const unsigned vlane_off = (unsigned)lh * VBLK + (unsigned)(cbase + li) * 16u;         // bytes: row block lh of a step, channel
         const int krow = tid >> 3, kc2 = (tid & 7) * 2;                                        // key staging: row, first of two 16-byte chunks
         const unsigned klane_off = (unsigned)krow * 512u + (unsigned)kc2 * 16u;
         // LDS byte addresses, each ONE xor away from a per-lane base (swzq / swzp are xors of the 16-byte chunk index with lane constants):
         //   key fragment g of the score GEMM     bK ^ 32 g  (+ buffer)     bK = swzq(32 wr + li, lh)
         //   query fragment g                     bQ ^ 32 g                 bQ = swzq(32 wq + li, lh)
-        //   P^T fragment of step st, tile tq     bR ^ 32 st + 4096 tq (+ buffer)      bR = swzp(64 qhalf + li, lh)
+        //   P^T fragment of step st, tile tq     bR ^ 32 st + 4096 tq (+ buffer)      bR = swzp(qbase + li, lh)
         //   P^T store of softmax quarter g       bW ^ 16 g  (+ buffer)     bW = swzp(qcol, 4 wr) + 8 lh   (rows rloc + 8 g: chunk 4 wr + g, half lh)
         //   key staging store                    swzq(krow, kc2), swzq(krow, kc2 + 1)  (+ buffer)
         unsigned bK = PIPE_K0 + (unsigned)swzq(wr * 32 + li, lh);
         unsigned bQ = (unsigned)swzq(wq * 32 + li, lh);
-        unsigned bR = PIPE_P0 + (unsigned)swzp(qhalf * 64 + li, lh);
+        unsigned bR = PIPE_P0 + (unsigned)swzp(qbase + li, lh);
         unsigned bW = PIPE_P0 + (unsigned)swzp(qcol, 4 * wr) + 8u * lh;
         unsigned bS = PIPE_K0 + (unsigned)swzq(krow, kc2);
         const unsigned bS1 = (unsigned)(swzq(krow, kc2 + 1) - swzq(krow, kc2));                 // (+16 or -16: the pair's second chunk)
         auto lds = [&](unsigned a) { return smem + a; };
-        u32x4 vop[4][4];                                      // value operands: [step][channel tile] (8 bank rows x 1 channel, bf16)
+        u32x4 vop[4][TCN];                                    // value operands: [step][channel tile] (8 bank rows x 1 channel, bf16)
         u32x4 kreg[2];
         f32x16 acc;
         int mycnt = 0;
@@ -999,8 +1208,12 @@ void memread_apply_pipe_kernel(const vfn_memread_desc p) {
         };
         auto load_v = [&](const __amdgpu_buffer_rsrc_t& r, int st, auto SLOT_) {
             constexpr int slot = decltype(SLOT_)::value;
+#ifdef PIPE_ABLATE_V
+            for (int tc = 0; tc < TCN; ++tc) vop[slot][tc] = u32x4{0x3f803f80u + (unsigned)st, 0x3f803f80u, 0x3f803f80u + (unsigned)tc, 0x3f803f80u};
+#else
 #pragma unroll
-            for (int tc = 0; tc < 4; ++tc) vop[slot][tc] = __builtin_amdgcn_raw_buffer_load_b128(r, vlane_off, 2 * st * (int)VBLK + tc * 512, 0);
+            for (int tc = 0; tc < TCN; ++tc) vop[slot][tc] = __builtin_amdgcn_raw_buffer_load_b128(r, vlane_off, 2 * st * (int)VBLK + tc * 512, 0);
+#endif
         };
         auto load_k = [&](int c) {
             const __amdgpu_buffer_rsrc_t r = kres(c);
@@ -1038,6 +1251,7 @@ void memread_apply_pipe_kernel(const vfn_memread_desc p) {
             float pv[4];
 #pragma unroll
             for (int e = 0; e < 4; ++e) pv[e] = fast_exp(fmaf(acc[4 * g + e], p.scale, sm)) * qinv;
+#ifndef PIPE_NO_HITS
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const unsigned long long hit = __ballot(pv[e] > p.thres);
@@ -1045,6 +1259,7 @@ void memread_apply_pipe_kernel(const vfn_memread_desc p) {
                 asm volatile("v_writelane_b32 %0, %1, %2" : "+v"(mycnt) : "s"(h_lo), "n"(e + 8 * g));
                 asm volatile("v_writelane_b32 %0, %1, %2" : "+v"(mycnt) : "s"(h_hi), "n"(e + 8 * g + 4));
             }
+#endif
             const bf16x4 h = {(__bf16)pv[0], (__bf16)pv[1], (__bf16)pv[2], (__bf16)pv[3]};
             *reinterpret_cast<bf16x4*>(lds((bW + pbuf * PIPE_PB) ^ (16u * g))) = h;
         };
@@ -1064,15 +1279,21 @@ void memread_apply_pipe_kernel(const vfn_memread_desc p) {
             }
             mycnt = 0;
         };
-        auto pv_step = [&](auto ST_, auto SLOT_, int pbuf) {   // O^T[q][ch] += sum_b P^T[q][b] V[b][ch], 16 bank rows: 2 query tiles x 4 channel tiles
+        auto pv_step = [&](auto ST_, auto SLOT_, int pbuf) {   // O^T[q][ch] += sum_b P^T[q][b] V[b][ch], 16 bank rows: TQN query tiles x TCN channel tiles
             constexpr int st = decltype(ST_)::value, slot = decltype(SLOT_)::value;
             const unsigned ar = (bR + pbuf * PIPE_PB) ^ (32u * st);
 #pragma unroll
-            for (int tq = 0; tq < 2; ++tq) {
+            for (int tq = 0; tq < TQN; ++tq) {
                 const bf16x8 ph = *reinterpret_cast<const bf16x8*>(lds(ar + tq * 4096));
+#ifdef PIPE_SETPRIO
+                __builtin_amdgcn_s_setprio(1);
+#endif
 #pragma unroll
-                for (int tc = 0; tc < 4; ++tc)
+                for (int tc = 0; tc < TCN; ++tc)
                     o[tq][tc] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ph, __builtin_bit_cast(bf16x8, vop[slot][tc]), o[tq][tc], 0, 0, 0);
+#ifdef PIPE_SETPRIO
+                __builtin_amdgcn_s_setprio(0);
+#endif
             }
         };
         using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>;
@@ -1106,18 +1327,38 @@ void memread_apply_pipe_kernel(const vfn_memread_desc p) {
             opaque();
             if constexpr (KNEXT) load_k(c + 2);
             const __amdgpu_buffer_rsrc_t vr1 = vres(NEXT ? c + 1 : c);
+#ifdef PIPE_NO_SCHEDBAR
+#define PIPE_SB()
+#else
+#define PIPE_SB() __builtin_amdgcn_sched_barrier(0)
+#endif
+#ifdef PIPE_SCORE_LATE
+            // (experiment) the score GEMM behind step 0's MFMAs, the softmax quarters one step later
+            pv_step(I0{}, I0{}, pc);
+            if constexpr (NEXT) { load_v(vr1, 0, I0{}); score(pn); }
+            PIPE_SB();
+            pv_step(I1{}, I1{}, pc);
+            if constexpr (NEXT) { load_v(vr1, 1, I1{}); softmax_quarter(I0{}, pn); }
+            PIPE_SB();
+            pv_step(I2{}, I2{}, pc);
+            if constexpr (NEXT) { load_v(vr1, 2, I2{}); softmax_quarter(I1{}, pn); }
+            PIPE_SB();
+            pv_step(I3{}, I3{}, pc);
+            if constexpr (NEXT) { load_v(vr1, 3, I3{}); softmax_quarter(I2{}, pn); softmax_quarter(I3{}, pn); }
+#else
             if constexpr (NEXT) score(pn);
             pv_step(I0{}, I0{}, pc);
             if constexpr (NEXT) { load_v(vr1, 0, I0{}); softmax_quarter(I0{}, pn); }
-            __builtin_amdgcn_sched_barrier(0);
+            PIPE_SB();
             pv_step(I1{}, I1{}, pc);
             if constexpr (NEXT) { load_v(vr1, 1, I1{}); softmax_quarter(I1{}, pn); }
-            __builtin_amdgcn_sched_barrier(0);
+            PIPE_SB();
             pv_step(I2{}, I2{}, pc);
             if constexpr (NEXT) { load_v(vr1, 2, I2{}); softmax_quarter(I2{}, pn); }
-            __builtin_amdgcn_sched_barrier(0);
+            PIPE_SB();
             pv_step(I3{}, I3{}, pc);
             if constexpr (NEXT) { load_v(vr1, 3, I3{}); softmax_quarter(I3{}, pn); }
+#endif
             if constexpr (NEXT) {
                 if (B - (c + 1) * CH < CH) zero_dead_rows(pn, B - (c + 1) * CH);
                 add_hits(c + 1);
@@ -1135,13 +1376,13 @@ void memread_apply_pipe_kernel(const vfn_memread_desc p) {
 
     float* dst = p.o_part + ((size_t)obj * p.nsplit + split) * p.HW * DV;
 #pragma unroll
-    for (int tq = 0; tq < 2; ++tq)
+    for (int tq = 0; tq < TQN; ++tq)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const int q = q0 + qhalf * 64 + tq * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+            const int q = q0 + qbase + tq * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
             if (q < p.HW) {
 #pragma unroll
-                for (int tc = 0; tc < 4; ++tc) dst[(size_t)q * DV + cq * 128 + tc * 32 + li] = o[tq][tc][r];
+                for (int tc = 0; tc < TCN; ++tc) dst[(size_t)q * DV + cbase + tc * 32 + li] = o[tq][tc][r];
             }
         }
 }
@@ -1504,6 +1745,20 @@ extern "C" int vfn_bank_scan(const vfn_bankscan_desc* d, void* stream) {
     const dim3 grid(items < 512 ? items : 512);        // two resident workgroups per CU (64 KB of LDS each)
     hipStream_t s = (hipStream_t)stream;
     if (hipMemsetAsync(d->work_counter, 0, sizeof(int), s) != hipSuccess) return VFN_ERR_LAUNCH;
+    if (d->precision == 1 && d->bank_k_lp) {
+        // plain bf16 on the kept key image (round 6): keys through registers, two chunks ahead; VFN_SCAN_PIPE=0 (read at every
+        // call: A/B in one process) restores bank_scan_kernel<MODE, 1>
+        const char* ep = getenv("VFN_SCAN_PIPE");
+        if (!(ep && atoi(ep) == 0)) {
+            // 32 KB of LDS and <= 160 registers: three workgroups fit a CU (the queue feeds any number of them)
+            static int wgs = 0;
+            if (!wgs) { const char* ew = getenv("VFN_SCAN_WGS"); wgs = ew ? atoi(ew) : 768; if (wgs < 1) wgs = 768; }
+            const dim3 gridp(items < wgs ? items : wgs);
+            if (d->mode == 0) hipLaunchKernelGGL((bank_scan_pipe_kernel<0>), gridp, dim3(256), SCAN_PIPE_LDS, s, *d);
+            else hipLaunchKernelGGL((bank_scan_pipe_kernel<1>), gridp, dim3(256), SCAN_PIPE_LDS, s, *d);
+            return vfn_check_launch();
+        }
+    }
     switch (d->mode * 3 + d->precision) {
         case 0: hipLaunchKernelGGL((bank_scan_kernel<0, 0>), grid, dim3(256), SCAN_LDS, s, *d); break;
         case 1: hipLaunchKernelGGL((bank_scan_kernel<0, 1>), grid, dim3(256), SCAN_LDS, s, *d); break;
