@@ -1,0 +1,145 @@
+"""Round 6: does the plain-bf16 result survive a task whose margins do NOT saturate?
+
+profiles/r05_bf16_trained_margins*.json rests on a checkpoint trained on tinted water with clean labels: median |logit margin| 32 (both
+logits at the +-16 clamp), which says little about a checkpoint trained on real water.  Here the synthetic checkpoint is trained on
+the HARD task (tools/synth.frame0_hard: water and land share their colour statistics and differ by texture only; tools/synth.noisy_labels:
+the labels of every training frame are displaced and flipped along the shoreline, ~10 % disagree with the image; CrossEntropy + 0.5 *
+uncertainty as train_video_seg.py:73-74) and the C3 / C2 / C5-shaped clips are built from the same hard frames.  Reported per clip:
+
+  * the f32 HIP run: logit-margin percentiles, mIoU against the clean ground truth (does the network segment the task at all?)
+  * bf16x3 and plain bf16 against the f32 HIP run: label mIoU min / mean over the clip, bank sizes, and the label AGREEMENT BINNED BY
+    THE F32 RUN'S MARGIN (network resolution, all frames pooled): where do the flips live?
+  * the f32 HIP run against the f32 CPU oracle on the first frames (the parity anchor on these weights).
+
+One process on the GPU box, no weights travel.  Writes gpurun_out/r06_bf16_margins_hard.json and /tmp/vfn_trained_hard.pth.
+usage: bf16_margins_hard.py [--steps 3000] [--lr 2e-5]"""
+import argparse
+import json
+import os
+import sys
+import time
+
+root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, root)
+import numpy as np
+import torch
+import vfloodnet_amd  # noqa: F401
+from vfloodnet_amd import AFB_URR
+from vfloodnet_amd.video_seg import ClipRunner
+from tools import synth
+
+ap = argparse.ArgumentParser()
+ap.add_argument('--steps', type=int, default=3000)
+ap.add_argument('--lr', type=float, default=2e-5)
+ap.add_argument('--size', type=int, default=400)
+ap.add_argument('--out', default=os.path.join(root, 'gpurun_out', 'r06_bf16_margins_hard.json'))
+ap.add_argument('--ckpt', default='/tmp/vfn_trained_hard.pth')
+ap.add_argument('--skip-oracle', action='store_true')
+ap.add_argument('--only', default='', help='comma list of workloads (C3,C2,C5_first_120); default all')
+args = ap.parse_args()
+dev = torch.device('cuda', 0)
+res = {'note': __doc__.split('\n\n')[0], 'train': {}, 'eval': {}}
+BINS = [0.0, 0.25, 0.5, 1.0, 2.0, 4.0, 8.0, 16.0, 1e9]
+
+from tools.train_synth import train_checkpoint
+sd1, res['train'] = train_checkpoint(dev, steps=args.steps, lr=args.lr, size=args.size, task='hard', log=lambda m: print(m, flush=True))
+print(res['train'], flush=True)
+torch.save({'epoch': 0, 'model': sd1, 'loss': res['train']['loss_last_50'], 'seed': 20200212, 'task': 'hard'}, args.ckpt)
+
+
+def miou(a, b):
+    v = []
+    for c in (0, 1):
+        inter = ((a == c) & (b == c)).sum().item()
+        union = ((a == c) | (b == c)).sum().item()
+        v.append(1.0 if union == 0 else inter / union)
+    return sum(v) / 2
+
+
+def run(sd, prec, frames, m0, budget, mem_every, keep_margins=False):
+    """-> labels u8[T,H0,W0] (host), network-resolution labels bool[T,h,w] (device), |margin| f16[T,h,w] (device, fp32 run only)."""
+    Tn, _, H0, W0 = frames.shape
+    model = AFB_URR(dev, update_bank=True, precision=prec).to(dev).eval()
+    model.load_state_dict(sd, strict=True)
+    m = (m0 > 0).to(torch.uint8)
+    onehot = torch.stack([1 - m, m], 0).unsqueeze(0).to(dev)
+    runner = ClipRunner(model, 2, budget, size=480, mem_every=mem_every)
+    runner.start(frames[0:1], onehot)
+    h, w = runner._net_frame(frames[0:1]).shape[-2:]
+    plan = model.engine().plan(h, w, 2)
+    labels = torch.empty(Tn, H0, W0, dtype=torch.uint8)
+    labels[0] = m
+    net = torch.zeros(Tn, h, w, dtype=torch.bool, device=dev)
+    marg = torch.zeros(Tn, h, w, dtype=torch.float16, device=dev) if keep_margins else None
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for t in range(1, Tn):
+        lab = runner.step(frames[t:t + 1], next_frames=[frames[u:u + 1] for u in range(t + 1, min(Tn, t + 4))])
+        np.copyto(labels.numpy()[t], lab.numpy())
+        sc = plan.score[0]
+        net[t] = sc[1] > sc[0]
+        if keep_margins:
+            marg[t] = (sc[1] - sc[0]).abs().clamp(max=60000.0).half()
+    torch.cuda.synchronize()
+    out = dict(labels=labels, net=net, marg=marg, fps=(Tn - 1) / (time.perf_counter() - t0), bank=runner.bank_sizes())
+    del runner, model
+    return out
+
+
+def evaluate(tag, sd, H, W, Tn, mem_every, seed, budget):
+    frames, m0 = synth.clip_hard(seed, Tn, H, W, device=dev)
+    gt = torch.stack([torch.roll(m0, (2 * t, 5 * t), (0, 1)) for t in range(Tn)], 0)
+    ref = run(sd, 'fp32', frames, m0, budget, mem_every, keep_margins=True)
+    d = ref['marg'][1:].float().flatten()
+    samp = d[torch.randperm(d.numel(), device=dev)[:2000000]]
+    q = torch.quantile(samp, torch.tensor([0.01, 0.05, 0.25, 0.5, 0.75, 0.95], device=dev))
+    g_iou = [miou(ref['labels'][t], gt[t]) for t in range(1, Tn)]
+    e = {'clip': f'{Tn} frames of {H}x{W} (tools/synth.clip_hard, seed {seed}), memorise every {mem_every}',
+         'fp32': {'fps': round(ref['fps'], 1), 'bank': ref['bank'],
+                  'abs_logit_margin_p1_p5_p25_p50_p75_p95': [round(float(x), 3) for x in q],
+                  'frac_margin_below_1': round(float((d < 1.0).float().mean()), 5), 'frac_at_clamp_ge_31': round(float((d >= 31.0).float().mean()), 5),
+                  'miou_vs_clean_ground_truth_min_mean': [round(min(g_iou), 4), round(float(np.mean(g_iou)), 4)]}}
+    bidx = torch.bucketize(ref['marg'][1:].float(), torch.tensor(BINS[1:-1], device=dev), right=True)          # 0 .. len(BINS) - 2
+    for prec in ('bf16x3', 'bf16'):
+        r = run(sd, prec, frames, m0, budget, mem_every)
+        ious = [miou(r['labels'][t], ref['labels'][t]) for t in range(1, Tn)]
+        agree = (r['net'][1:] == ref['net'][1:])
+        bins = []
+        for b in range(len(BINS) - 1):
+            sel = bidx == b
+            n = int(sel.sum())
+            bins.append({'margin': [BINS[b], BINS[b + 1] if BINS[b + 1] < 1e8 else None], 'pixels_frac': round(n / bidx.numel(), 5),
+                         'label_agreement': round(float(agree[sel].float().mean()), 6) if n else None})
+        e[prec] = {'fps': round(r['fps'], 1), 'bank': r['bank'], 'bank_sizes_equal': r['bank'] == ref['bank'],
+                   'miou_vs_fp32_min': round(min(ious), 5), 'miou_vs_fp32_mean': round(float(np.mean(ious)), 5), 'miou_vs_fp32_first': round(ious[0], 5),
+                   'miou_vs_fp32_worst_frame': int(np.argmin(ious)) + 1,
+                   'pixel_agreement_overall': round(float(agree.float().mean()), 6), 'agreement_by_fp32_margin': bins}
+    print(tag, json.dumps(e), flush=True)
+    del frames, ref
+    torch.cuda.empty_cache()
+    return e
+
+
+if not args.skip_oracle:
+    from oracle import afb_urr_ref as O
+    Hc, Wc, n_cpu = 480, 854, 4
+    frames, m0 = synth.clip_hard(1, n_cpu, Hc, Wc)
+    torch.set_num_threads(min(16, os.cpu_count() or 1))
+    t0 = time.perf_counter()
+    ref_lab = O.run_clip(sd1, frames, m0)['labels']
+    got = run(sd1, 'fp32', frames.to(dev), m0, 250000, 1)
+    ious = [miou(got['labels'][t], ref_lab[t]) for t in range(1, n_cpu)]
+    res['oracle_check_hard_weights'] = {'frames': n_cpu - 1, 'size': [Hc, Wc], 'miou_hip_f32_vs_cpu_oracle': [round(x, 5) for x in ious],
+                                        'seconds': round(time.perf_counter() - t0, 1)}
+    print(res['oracle_check_hard_weights'], flush=True)
+torch.set_num_threads(1)
+time.sleep(1.0)
+
+WORK = {'C3': (720, 1280, 100, 5, 3, 250000), 'C2': (480, 854, 100, 1, 1, 250000), 'C5_first_120': (1080, 1920, 120, 1, 9, 2 * int(1.25 * 2 * 122 * 1620) + 4)}
+only = [x for x in args.only.split(',') if x]
+for cname, (H_, W_, T_, me_, seed_, budget_) in WORK.items():
+    if only and cname not in only:
+        continue
+    res['eval'][cname] = evaluate(cname, sd1, H_, W_, T_, me_, seed_, budget_)
+    json.dump(res, open(args.out, 'w'), indent=1)
+print('wrote', args.out)

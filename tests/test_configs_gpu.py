@@ -238,3 +238,71 @@ def test_plain_bf16_meets_the_bar_on_trained_weights(gpu, trained_sd, workload):
     gt = [torch.roll(m0, (2 * t, 5 * t), (0, 1)) for t in range(T)]
     acc = [miou(labs['fp32'][t], gt[t]) for t in range(1, T)]
     assert min(acc) >= 0.9, acc
+
+
+# ------------------------------------------------------------------------------------------------ round 6: a task whose margins do not saturate
+@pytest.fixture(scope='module')
+def hard_sd(gpu):
+    """The synthetic checkpoint after 1200 steps on the HARD task (tools/train_synth.py task='hard', ~35 s): water and land share
+    their colour statistics and differ by texture only, every training label is displaced and flipped along the shoreline
+    (~10 % disagree with the image).  The loss plateaus near 0.5 instead of 0.1 and the logits keep moderate margins (median
+    |logit_1 - logit_0| 4-7, nothing at the clamp -- the tinted task of ``trained_sd`` has its median AT the clamp)."""
+    from tools.train_synth import train_checkpoint
+    sd_h, info = train_checkpoint(gpu, steps=1200, lr=2e-5, task='hard')
+    print('hard-task checkpoint:', info)
+    assert info['restores_after_collapse'] == 0 and 0.3 < info['loss_last_50'] < 0.7 < info['loss_first_50'], info
+    return sd_h
+
+
+def test_plain_bf16_on_a_task_with_unsaturated_margins(gpu, hard_sd):
+    """the bf16 claim on weights whose margins do not sit at the clamp.  C3 shape (720p, every 5th frame
+    memorised) on a hard clip: the f32 HIP run against the f32 CPU oracle (parity anchor on these weights), bf16x3 and plain bf16
+    against the f32 HIP run -- at what they honestly reach -- and WHERE plain bf16's flips are: only where the f32 margin is below
+    0.5.  The full-length measurement (3000 steps; C3 / C2 / C5 shapes, agreement binned by the f32 margin):
+    scripts/bf16_margins_hard.py -> profiles/r06_bf16_margins_hard.json (bf16 min mIoU 0.9985-0.9989 on C3 / C2, every flip
+    in the |margin| < 0.25 bin; bf16x3 1.0 with equal banks)."""
+    from tools import synth
+    from vfloodnet_amd import AFB_URR
+    from vfloodnet_amd.video_seg import ClipRunner
+    from oracle import afb_urr_ref as O
+    T, H, W, mem_every, seed = 14, 720, 1280, 5, 3
+    frames, m0 = synth.clip_hard(seed, T, H, W)
+    torch.set_num_threads(16)
+    ref = O.run_clip(hard_sd, frames[:6], m0, size=480, mem_every=mem_every)
+    torch.set_num_threads(1)
+    frames = frames.to(gpu)
+    m = (m0 > 0).to(torch.uint8)
+    onehot = torch.stack([1 - m, m], 0).unsqueeze(0).to(gpu)
+    runs = {}
+    for precision in ('fp32', 'bf16x3', 'bf16'):
+        model = AFB_URR(gpu, update_bank=True, precision=precision).to(gpu).eval()
+        model.load_state_dict(hard_sd, strict=True)
+        runner = ClipRunner(model, 2, 250000, size=480, mem_every=mem_every)
+        runner.start(frames[0:1], onehot)
+        h, w = runner._net_frame(frames[0:1]).shape[-2:]
+        plan = model.engine().plan(h, w, 2)
+        labels, net, marg = [m.clone()], [], []
+        for t in range(1, T):
+            lab = runner.step(frames[t:t + 1])
+            labels.append(torch.from_numpy(lab.numpy().copy()))
+            sc = plan.score[0]
+            net.append((sc[1] > sc[0]).cpu())
+            marg.append((sc[1] - sc[0]).abs().cpu())
+        runs[precision] = (labels, torch.stack(net), torch.stack(marg), runner.bank_sizes())
+    ious = [miou(runs['fp32'][0][t], ref['labels'][t]) for t in range(1, 6)]
+    assert min(ious) >= 0.999, ious                                       # the f32 HIP path on these weights == the CPU oracle
+    mg = runs['fp32'][2].flatten()
+    med, p5, clamp = float(mg.median()), float(mg.kthvalue(int(0.05 * mg.numel())).values), float((mg >= 31.0).float().mean())
+    print(f'hard task: f32 |margin| median {med:.2f}, p5 {p5:.2f}, at the clamp {clamp:.4f}')
+    assert med < 12.0 and p5 < 2.5 and clamp < 0.01, (med, p5, clamp)      # the margins really are unsaturated
+    gt = [torch.roll(m0, (2 * t, 5 * t), (0, 1)) for t in range(T)]
+    acc = [miou(runs['fp32'][0][t], gt[t]) for t in range(1, T)]
+    assert min(acc) >= 0.75, acc                                           # ... and the network segments the task (not a coin flip)
+    for precision, bar in (('bf16x3', 0.999), ('bf16', 0.99)):
+        ious = [miou(runs[precision][0][t], runs['fp32'][0][t]) for t in range(1, T)]
+        agree = runs[precision][1] == runs['fp32'][1]
+        far = runs['fp32'][2] >= 0.5
+        print(f'hard task {precision}: mIoU vs the f32 HIP run min {min(ious):.5f} mean {sum(ious) / len(ious):.5f}; pixel agreement '
+              f'{float(agree.float().mean()):.6f}, where the f32 margin >= 0.5: {float(agree[far].float().mean()):.6f}; bank {runs[precision][3]} vs {runs["fp32"][3]}')
+        assert min(ious) >= bar, (precision, ious)
+        assert float(agree[far].float().mean()) >= 0.9999, precision       # flips live where the f32 run itself is undecided

@@ -1,0 +1,166 @@
+"""Round 6: the software-pipelined plain-bf16 memory-read kernels against the kernels they replace -- same products in the same
+order, so the results must be IDENTICAL bit for bit (read-out, hit counts / info bump, per-slice scan partials) -- over bank sizes
+that exercise a single chunk, partial last chunks, two objects of different length and empty bank slices; the NaN-preserving
+ReLU floor of the branch-free epilogues; the bank-size vector of a real loop."""
+import math
+import os
+import types
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _bank(gpu, B, hw):
+    from vfloodnet_amd.feature_bank import FeatureBank
+    fb = FeatureBank(2, 250000, gpu, precision='bf16')
+    fb._hw = hw
+    fb._alloc(hw, B)
+    g = torch.Generator(device=gpu).manual_seed(B)
+    fb._kbuf[:, :B].copy_(torch.randn(2, B, 128, device=gpu, generator=g))
+    fb._vbuf[:, :B].copy_(torch.randn(2, B, 512, device=gpu, generator=g))
+    fb._set_lengths([B, max(1, B - 37)])             # object 1 ends inside another chunk than object 0
+    kvq = torch.randn(2, hw, 640, device=gpu, generator=g)
+    kvq[..., :128] *= 2.0
+    return fb, kvq
+
+
+@pytest.mark.parametrize('B,hw', [(60, 60), (64, 150), (65, 150), (127, 60), (128, 1620), (1000, 150), (5000, 1620), (25037, 1620)])
+def test_pipelined_bf16_apply_is_bit_identical(gpu, B, hw):
+    """memread_apply_pipe_kernel (softmax of chunk c+1 in the shadow of chunk c's P^T V, value rows a chunk ahead, keys through
+    registers, one barrier per chunk) == memread_apply_shw_kernel<false>, incl. the hit counts that feed fb.info."""
+    from vfloodnet_amd.engine import Engine
+    fb, kvq = _bank(gpu, B, hw)
+    plan = types.SimpleNamespace(HW=hw, kv_q=kvq[0:1], ml=torch.empty(2, hw, 2, device=gpu), ml_part=torch.empty(2, 256, hw, 2, device=gpu),
+                                 work=torch.zeros(4, dtype=torch.int32, device=gpu), o_part=torch.empty(2, 20, hw, 512, device=gpu),
+                                 dec_in=torch.empty(2, hw, 512, device=gpu))
+    out = {}
+    info0 = fb._ibuf.clone()
+    old = os.environ.get('VFN_APPLY_PIPE')
+    try:
+        for pipe in ('1', '0'):
+            os.environ['VFN_APPLY_PIPE'] = pipe
+            fb._ibuf.copy_(info0)
+            Engine._memory_read(types.SimpleNamespace(mode=1), plan, fb, True)
+            torch.cuda.synchronize()
+            out[pipe] = (plan.dec_in.clone(), fb._ibuf.clone())
+    finally:
+        if old is None:
+            os.environ.pop('VFN_APPLY_PIPE', None)
+        else:
+            os.environ['VFN_APPLY_PIPE'] = old
+    assert torch.isfinite(out['1'][0]).all()
+    assert torch.equal(out['1'][0], out['0'][0])
+    assert torch.equal(out['1'][1], out['0'][1])
+    assert int(fb._cnt.abs().sum()) == 0                      # the counters are at rest again
+    assert not torch.equal(out['1'][1], info0) or B < 2       # (the read really bumped fb.info)
+
+
+@pytest.mark.parametrize('mode', [0, 1])
+@pytest.mark.parametrize('B,hw', [(60, 60), (65, 150), (127, 60), (1000, 150), (5000, 1620), (25037, 1620)])
+def test_register_staged_bf16_scans_are_bit_identical(gpu, B, hw, mode):
+    """bank_scan_pipe_kernel<mode> (keys through registers two chunks ahead, the update scan's row scales with them through LDS, three
+    workgroups per CU) == the LDS-DMA image path of bank_scan_kernel<mode, 1>: every slice partial, bit for bit."""
+    from vfloodnet_amd import _lib
+    from vfloodnet_amd._lib import ptr, stream, check, BankScanDesc
+    from vfloodnet_amd.feature_bank import pick_scan_slices, MAX_SPLIT_SCAN, DK
+    fb, kvq = _bank(gpu, B, hw)
+    rs = torch.rand(2, fb._cap, device=gpu) + 0.5
+    klp, _ = fb.lp_image()
+    work = torch.zeros(4, dtype=torch.int32, device=gpu)
+    nsplit = pick_scan_slices(hw, 2, fb.len_upper())
+    parts = {}
+    old = os.environ.get('VFN_SCAN_PIPE')
+    try:
+        for pipe in ('1', '0'):
+            os.environ['VFN_SCAN_PIPE'] = pipe
+            part = torch.full((2, MAX_SPLIT_SCAN, hw, 2), float('nan'), device=gpu)
+            d = BankScanDesc()
+            d.q, d.bank_k, d.bank_len, d.part = ptr(kvq), ptr(fb._kbuf), ptr(fb._len_dev), ptr(part)
+            d.rowscale = ptr(rs) if mode == 1 else None
+            d.stride_q, d.stride_k, d.stride_rs = (hw * 640 if mode == 1 else 0), fb._cap * DK, (fb._cap if mode == 1 else 0)
+            d.scale = 1.0 / math.sqrt(DK)
+            d.ldq, d.q_per_obj, d.HW, d.obj_n, d.nsplit, d.mode = 640, (1 if mode == 1 else 0), hw, 2, nsplit, mode
+            d.precision = 1
+            d.work_counter = ptr(work)
+            d.bank_k_lp = ptr(klp)
+            check(_lib.lib().vfn_bank_scan(_lib.C.byref(d), stream()), 'vfn_bank_scan')
+            torch.cuda.synchronize()
+            parts[pipe] = part.flatten()[:2 * nsplit * hw * 2].clone()         # (the kernel's layout: [obj][nsplit][HW][2], densely packed)
+    finally:
+        if old is None:
+            os.environ.pop('VFN_SCAN_PIPE', None)
+        else:
+            os.environ['VFN_SCAN_PIPE'] = old
+    assert not torch.isnan(parts['1']).any()
+    assert torch.equal(parts['1'].view(torch.int32), parts['0'].view(torch.int32))
+
+
+def test_relu_floor_keeps_nan(gpu):
+    """the branch-free epilogues applied fmaxf(v, relu ? 0 : -inf), which turns a NaN accumulator of a layer WITHOUT ReLU
+    into -inf (and the next layer's ReLU into 0): a diverging run was silently kept alive.  The floor is now a NaN-preserving select:
+    a NaN in the input of a convolution (with and without ReLU on its output, direct and Winograd form) leaves a non-finite value in
+    the pixels whose window holds it -- and only there."""
+    from vfloodnet_amd import ops
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(1, 12, 16, 64, generator=g)
+    x[0, 5, 7, 3] = float('nan')
+    w = torch.randn(64, 64, 3, 3, generator=g) * 0.05
+    for relu_out in (False, True):
+        y = ops.conv2d_nhwc(x.to(gpu), ops.pad_rows(__import__('vfloodnet_amd').weights.pack_conv_weight(w)).to(gpu), 64, 3, 3, 1, 1, relu_out=relu_out)
+        torch.cuda.synchronize()
+        assert (~torch.isfinite(y[0, 5, 7])).any(), relu_out        # the pixel whose window holds the NaN
+        assert torch.isfinite(y[0, 0, 0]).all()                     # ... and nothing spreads beyond the window
+        yw = ops.conv2d_winograd(x.to(gpu), w.to(gpu), relu_out=relu_out)
+        torch.cuda.synchronize()
+        assert (~torch.isfinite(yw[0, 5, 7])).any(), relu_out
+        assert torch.isfinite(yw[0, 0, 12]).all()
+
+
+def test_loop_records_the_bank_size_vector(gpu):
+    """an int32[T] bank-size vector travels beside the masks.  ClipRunner keeps it (one row per collected frame);
+    dist.gather_bank_sizes carries it (tests/test_dist_gloo.py)."""
+    from tools import synth
+    from vfloodnet_amd import AFB_URR, dist as vdist
+    from vfloodnet_amd.video_seg import ClipRunner
+    model = AFB_URR(gpu, update_bank=True).to(gpu).eval()
+    model.load_state_dict(synth.make_state_dict(20200212), strict=True)
+    frames, m0 = synth.clip(2, 5, 96, 160)
+    frames = frames.to(gpu)
+    runner = ClipRunner(model, 2, 250000)
+    runner.start(frames[0:1], synth.onehot(m0).unsqueeze(0).to(gpu))
+    for t in range(1, 5):
+        runner.step(frames[t:t + 1])
+    assert len(runner.size_log) == 5 and runner.size_log[-1] == runner.bank_sizes()
+    assert all(b >= a for x, y in zip(runner.size_log, runner.size_log[1:]) for a, b in zip(x, y))
+    got = vdist.gather_bank_sizes([runner.size_log], 1, 0, 1, gpu)
+    assert got[0].dtype == torch.int32 and got[0].tolist() == runner.size_log
+
+
+def test_independent_stream_runs_beside_the_current_stream(gpu):
+    """A HIP stream is not a hardware queue: streams that share one (GPU_MAX_HW_QUEUES, default 4; PyTorch creates 32 per priority)
+    run in order.  ``_lib.independent_stream`` returns a stream measured NOT to share the current stream's queue: a tiny kernel
+    on it finishes while the current stream still has milliseconds of work queued -- the property the look-ahead stream, the PNG
+    sink and the decode stream of the loop need (round 6: the PNG sink on the frame loop's queue cost video_seg.main 0.85 ms of an
+    idle device per frame)."""
+    from vfloodnet_amd import _lib
+    cur = torch.cuda.current_stream(gpu)
+    s1 = _lib.independent_stream(gpu)
+    s2 = _lib.independent_stream(gpu, beside=[s1])
+    big = torch.zeros(32 * 1024 * 1024, device=gpu)
+    small = torch.zeros(16, device=gpu)
+    for cand, others in ((s1, [cur]), (s2, [cur, s1])):
+        for ref in others:
+            torch.cuda.synchronize()
+            ref_end, cand_end = torch.cuda.Event(), torch.cuda.Event()
+            with torch.cuda.stream(ref):
+                for _ in range(48):
+                    big.add_(1.0)
+                ref_end.record()
+            with torch.cuda.stream(cand):
+                small.add_(1.0)
+                cand_end.record()
+            cand_end.synchronize()
+            assert not ref_end.query(), 'the candidate stream waited for the busy stream: same hardware queue'
+            torch.cuda.synchronize()

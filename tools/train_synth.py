@@ -16,12 +16,18 @@ import torch
 from tools import synth
 
 
-def train_checkpoint(device, steps=3000, lr=2e-5, size=400, pool=48, seed=20200212, log=None):
-    """-> (state_dict on the CPU, info dict).  ``log``: callable for progress lines (None: silent)."""
+def train_checkpoint(device, steps=3000, lr=2e-5, size=400, pool=48, seed=20200212, log=None, task='easy'):
+    """-> (state_dict on the CPU, info dict).  ``log``: callable for progress lines (None: silent).
+    ``task``: 'easy' = tools/synth.frame0 (tinted water, clean labels: trains to saturated logits); 'hard' (round 6) =
+    tools/synth.frame0_hard (water differs from land by texture only) with annotation noise along the shoreline on every frame's
+    label (tools/synth.noisy_labels: ~10 % of the labels disagree with the image) -- a loss that plateaus well above zero and
+    logits whose margins do not sit at the clamp."""
     from vfloodnet_amd import AFB_URR, train as T
     g_host = torch.Generator().manual_seed(12345)
+    g_noise = torch.Generator().manual_seed(777)
     threads = torch.get_num_threads()
-    pf, pm = zip(*[synth.frame0(100000 + i, size, size) for i in range(pool)])     # (multi-octave texture: ~50 ms each on the host)
+    make = synth.frame0 if task == 'easy' else synth.frame0_hard
+    pf, pm = zip(*[make(100000 + i, size, size) for i in range(pool)])     # (multi-octave texture: ~50 ms each on the host)
     pool_f, pool_m = torch.stack(pf, 0).to(device), torch.stack(pm, 0).to(device).long()
     torch.set_num_threads(1)       # (an idle OpenMP pool spinning on the host's cores starves the launch thread)
 
@@ -31,6 +37,8 @@ def train_checkpoint(device, steps=3000, lr=2e-5, size=400, pool=48, seed=202002
         dy, dx = r[3] % 19 - 9, r[4] % 19 - 9
         fr = torch.stack([torch.roll(pool_f[i], (oy + dy * t, ox + dx * t), (1, 2)) for t in range(Tn)], 0)
         lab = torch.stack([torch.roll(pool_m[i], (oy + dy * t, ox + dx * t), (0, 1)) for t in range(Tn)], 0)
+        if task != 'easy':
+            lab = torch.stack([synth.noisy_labels(lab[t], g_noise) for t in range(Tn)], 0)
         if r[5] & 1:
             fr, lab = fr.flip(2), lab.flip(1)
         return fr.contiguous(), torch.nn.functional.one_hot(lab, 2).permute(0, 3, 1, 2).float().contiguous()
@@ -69,9 +77,9 @@ def train_checkpoint(device, steps=3000, lr=2e-5, size=400, pool=48, seed=202002
     model.eval()
     sd = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
     mean = lambda x: round(float(sum(x) / max(1, len(x))), 4)
-    info = {'steps_run': len(losses), 'lr': lr, 'lr_final': lr_now, 'restores_after_collapse': restores,
-            'sample': f'6 frames of {size}x{size}, 2 objects, synthetic (a pool of {pool} tools/synth.frame0 images at a random offset, rolled by a '
-                      f'random step per frame)',
+    info = {'task': task, 'steps_run': len(losses), 'lr': lr, 'lr_final': lr_now, 'restores_after_collapse': restores,
+            'sample': f'6 frames of {size}x{size}, 2 objects, synthetic (a pool of {pool} tools/synth.{make.__name__} images at a random offset, rolled by a '
+                      f'random step per frame' + ('' if task == 'easy' else '; every label displaced and flipped along the shoreline, tools/synth.noisy_labels') + ')',
             'seconds': round(train_s, 1), 'ms_per_step_incl_host_data': round(1e3 * train_s / max(1, len(losses)), 2),
             'loss_first_50': mean(losses[:50]), 'loss_last_50': mean(losses[-50:]),
             'loss_every_250': [mean(losses[i:i + 50]) for i in range(0, len(losses), 250)]}

@@ -260,3 +260,52 @@ def stream():
 def require_gpu(t, what='tensor'):
     if not t.is_cuda:
         raise RuntimeError(f'{what} must live on the GPU: the V-FloodNet hot path has no CPU fallback')
+
+
+# ---------------------------------------------------------------------------------------------- streams that really run beside each other
+# A HIP stream is not a hardware queue.  The runtime multiplexes every stream of a priority onto a few hardware queues
+# (GPU_MAX_HW_QUEUES, default 4), and PyTorch creates its whole pool of 32 streams per priority on the first
+# ``torch.cuda.Stream()``: streams that share a hardware queue execute IN ORDER, whatever their events say.  Round 6 found the
+# PNG sink's stream on the queue of the frame loop's stream: its five latency-bound kernels per image ran between two frames
+# instead of underneath the next one -- 0.85 ms of an idle matrix pipe per frame in ``video_seg.main`` (median gap between a
+# frame's last marker and the next frame's first: 0.855 ms; 0.012 ms with 24 hardware queues, which is no cure: the command
+# processor then time-slices and the loop runs at 76 frames/s).  So side streams are PICKED: a candidate is kept only if a tiny
+# kernel on it finishes while every stream in ``beside`` is still busy with a few milliseconds of queued work.
+_probe_cache = {}
+
+
+def independent_stream(device, beside=(), tries=12, priority=0):
+    """A ``torch.cuda.Stream`` whose hardware queue is not the one of the current stream nor of any stream in ``beside``
+    (measured, see above).  Falls back to the last candidate if none qualifies within ``tries`` (the loop then still works,
+    serialised as before)."""
+    device = torch.device(device)
+    cur = torch.cuda.current_stream(device)
+    others = [cur] + [s_ for s_ in beside if s_ is not None]
+    key = device.index
+    if key not in _probe_cache:
+        _probe_cache[key] = (torch.zeros(32 * 1024 * 1024, device=device), torch.zeros(16, device=device))
+    big, small = _probe_cache[key]
+
+    def overlaps(cand, ref):
+        torch.cuda.synchronize(device)
+        ref_end, cand_end = torch.cuda.Event(), torch.cuda.Event()
+        with torch.cuda.stream(ref):
+            for _ in range(48):                     # ~2-3 ms of bandwidth-bound work queued on ``ref``
+                big.add_(1.0)
+            ref_end.record()
+        with torch.cuda.stream(cand):
+            small.add_(1.0)
+            cand_end.record()
+        cand_end.synchronize()
+        ok = not ref_end.query()                    # the candidate's kernel finished while ``ref`` was still busy
+        torch.cuda.synchronize(device)
+        return ok
+
+    cand = None
+    for _ in range(tries):
+        cand = torch.cuda.Stream(device=device, priority=priority)
+        if all(overlaps(cand, o_) for o_ in others):
+            return cand
+    import warnings
+    warnings.warn('vfloodnet_amd: no stream with a hardware queue of its own found; side-stream work will run in order with the frame loop')
+    return cand

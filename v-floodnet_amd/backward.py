@@ -455,14 +455,20 @@ class ModelBackward:
         # data-gradient chain (whose small layers leave most of the chip idle): launches are deferred (_side_do) and issued in
         # groups (_flush: one event per group) after the main stream has produced their operands; the main stream joins the
         # side stream before the next forward overwrites the activations and before the gradients are read (join).
-        self.side = torch.cuda.Stream(dev, priority=_SIDE_PRIORITY) if _SIDE_WGRAD else None
+        # (round 6: every side stream is PICKED so that it shares no hardware queue with the main stream, the forward's look-ahead
+        # stream or another side stream -- _lib.independent_stream; streams that share one run in order whatever their events say)
+        from ._lib import independent_stream
+        fwd_side = engine.side_stream()
+        self.side = independent_stream(dev, beside=[fwd_side], priority=_SIDE_PRIORITY) if _SIDE_WGRAD else None
         self._pending, self._inflight, self._by_plan = [], [], {}
         # round 5: with the decoder batched the side stream IS the step's critical path (12.8 ms of weight-gradient launches that cannot
         # start before the backward pass does, one after the other).  The memory encoder's (finish_memorize: the last to be produced,
         # parameters no other launch touches) go to a second side stream and run beside the query encoder's.  ``_lane`` = where
         # _side_do queues; per-lane scratch for the BatchNorm sums (the convolution kernels' workspaces are keyed by stream already)
-        self.side2 = torch.cuda.Stream(dev, priority=_SIDE_PRIORITY) if (_SIDE_WGRAD and _SIDE2) else None
-        self.side3 = torch.cuda.Stream(dev, priority=_SIDE_PRIORITY) if (_SIDE_WGRAD and _SIDE2 and _SIDE3) else None
+        self.side2 = independent_stream(dev, beside=[self.side], priority=_SIDE_PRIORITY) if (_SIDE_WGRAD and _SIDE2) else None
+        # (four hardware queues: the main stream and three side streams; the third shares the forward look-ahead stream's queue,
+        # which is idle during a backward pass)
+        self.side3 = independent_stream(dev, beside=[self.side, self.side2], priority=_SIDE_PRIORITY) if (_SIDE_WGRAD and _SIDE2 and _SIDE3) else None
         self._pending2, self._pending3, self._lane = [], [], 0        # lane 0: decoder + KeyValue, 1: memory encoder, 2: query encoder
         self._ticket2 = torch.zeros(64, dtype=torch.int32, device=dev)
         self._ticket3 = torch.zeros(64, dtype=torch.int32, device=dev)

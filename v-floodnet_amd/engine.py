@@ -1321,8 +1321,7 @@ class Engine:
         if self.prefetch_pending(p):
             self.prefetch_finish(p)
         qs = self._idle_set(p)
-        if self._side is None:
-            self._side = torch.cuda.Stream(device=self.device)
+        self.side_stream()
         ready = torch.cuda.Event()
         ready.record()                                           # everything enqueued so far (the decoder of the current frame)
         with torch.cuda.stream(self._side):
@@ -1359,6 +1358,13 @@ class Engine:
                     qs.done.record()
                 self._side_busy = qs.done
                 qs.stage = 2
+
+    def side_stream(self):
+        """The stream the query side of the coming frames runs on, on a hardware queue of its own (the overlap is the point:
+        _lib.independent_stream); created on first use."""
+        if self._side is None:
+            self._side = _lib.independent_stream(self.device)
+        return self._side
 
     def prefetch_query(self, frame, obj_n):
         """One frame of look-ahead (round-1/2 API): ``prefetch_begin([frame], full=True)``."""

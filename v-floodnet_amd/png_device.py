@@ -122,11 +122,13 @@ class PngSink:
     are filtered + deflated on the GPU on a side stream (underneath the next frame's kernels), the few-KB / few-hundred-KB
     streams are copied to pinned memory, and writer threads add the chunk framing and write the files."""
 
-    def __init__(self, device, writer, slots=8):
+    def __init__(self, device, writer, slots=8, beside=()):
         self.device = device
         self.writer = writer                      # data.AsyncWriter
         self.slots = slots
-        self.stream = torch.cuda.Stream(device=device)
+        # (a stream on a hardware queue of its own: _lib.independent_stream)
+        from ._lib import independent_stream
+        self.stream = independent_stream(device, beside=beside)
 
     def _submit(self, img, palette, path, ready):
         bpp = 1 if img.dim() == 2 else 3

@@ -122,7 +122,7 @@ class ClipRunner:
                            post=torch.empty(H0, W0, dtype=torch.uint8, device=self.device),
                            pinned=torch.empty(H0, W0, dtype=torch.uint8).pin_memory(),
                            stats=torch.zeros(self.obj_n, 4, dtype=torch.int32).pin_memory(),
-                           done=torch.cuda.Event()) for _ in range(2)]
+                           done=torch.cuda.Event(enable_timing=os.environ.get('VFN_DONE_TIMING') == '1')) for _ in range(2)]
         self._cur = self._bufs[0]
         self._label_dev, self._post_dev, self._pinned = self._cur['label'], self._cur['post'], self._cur['pinned']
         self._ccl_scratch = torch.empty(2 * H0 * W0 + 8, dtype=torch.int32, device=self.device)
@@ -206,6 +206,7 @@ class ClipRunner:
             buf['pinned'].copy_(src, non_blocking=True)
         buf['stats'].copy_(self.fb.stats_device(), non_blocking=True)
         buf['done'].record()
+        buf['t'] = self.t
         self._pending.append(buf)
         return buf
 
@@ -213,6 +214,12 @@ class ClipRunner:
         """Wait for the oldest outstanding ``launch`` and take over its bank bookkeeping; returns its uint8 label map
         [H0,W0] as a pinned host tensor (valid until the launch after next)."""
         buf = self._pending.pop(0)
+        if os.environ.get('VFN_MAIN_TIMING') == '3':
+            q0 = buf['done'].query()
+            t_ = time.perf_counter()
+            buf['done'].synchronize()
+            self._collect_log = getattr(self, '_collect_log', [])
+            self._collect_log.append((q0, 1e3 * (time.perf_counter() - t_), buf.get('t'), self.t, len(self._pending)))
         buf['done'].synchronize()
         self.fb.absorb_stats(buf['stats'], in_flight=len(self._pending))
         self.size_log.append(list(self.fb._len_host))
@@ -327,18 +334,42 @@ def main(args, device):
     #     the bank bookkeeping of one frame hide under the kernels of the next
     #   * the PNGs are compressed on the GPU on a side stream (png_device.PngSink); writer threads only frame + write
     writer = AsyncWriter(getattr(args, 'png_workers', 4))
-    sink = PngSink(device, writer)
     with torch.no_grad():
-        it = iter(seq_loader)                    # (workers start decoding while the first frame is memorised)
+        # The loader is drained by a thread of its own: ``next()`` on an exhausted DataLoader iterator joins the worker processes
+        # (~100 ms), which on the launch thread left the device idle for the last frames of every clip
+        # (profiles/r06_main_throughput.txt: one 86-110 ms gap per 100-frame clip = 0.9 ms per frame of a short clip).
+        import queue
+        import threading
+        feed = queue.Queue(maxsize=16)
+
+        def _drain():
+            try:
+                for item_ in seq_loader:
+                    feed.put(item_)
+            except BaseException as exc_:         # (a decode error in a worker: re-raised on the launch thread)
+                feed.put(exc_)
+            feed.put(None)
+        threading.Thread(target=_drain, name='vfn-loader', daemon=True).start()
+
+        def _next_item():
+            item_ = feed.get()
+            if isinstance(item_, BaseException):
+                raise item_
+            return item_
+        it = iter(_next_item, None)              # (workers start decoding while the first frame is memorised)
         runner.start(ori_first_frame, ori_first_mask)
+        side_ = model.engine().side_stream()
 
         # Uploads go through pinned staging buffers on their own stream: a pageable-memory ``.to(device)`` is ordered
         # behind everything already enqueued on the compute stream and blocks the host until it has run -- that would
         # undo the launch / collect pipelining.  The rest of the decode (JPEG: inverse DCT ..., PNG: the scanline
         # filters, a serial recurrence that keeps ONE CU busy for ~0.8 ms per 480p frame) runs on a stream of its own, two
         # frames ahead of the network, so that it sits underneath the kernels of the frames before it.
-        copy_stream = torch.cuda.Stream(device=device)
-        decode_stream = torch.cuda.Stream(device=device)
+        # (streams are picked so that none shares a hardware queue with the frame loop's, _lib.independent_stream; uploads and decode
+        # kernels share ONE: five live streams on four hardware queues is how the PNG sink came to run in order with the loop)
+        from ._lib import independent_stream
+        copy_stream = decode_stream = independent_stream(device, beside=[side_])
+        sink = PngSink(device, writer, beside=[side_, decode_stream])
         main_stream = torch.cuda.current_stream()
         staging = {}
         slot = [0]
@@ -387,28 +418,50 @@ def main(args, device):
                 ahead.append(upload(item))
 
         prof = [0.0, 0.0, 0.0, 0.0, 0] if os.environ.get('VFN_MAIN_TIMING') else None   # host seconds: fill, launch, save, collect
+        dev_marks = []
+        collect_ret = {}
+        if prof is not None:                     # one axis for both clocks: an event recorded on an idle device ~ the host time of the record
+            torch.cuda.synchronize()
+            cal_ev = torch.cuda.Event(enable_timing=True)
+            cal_ev.record()
+            torch.cuda.synchronize()
+            cal_t = time.perf_counter()
         fill()
         while ahead:
             t0 = time.perf_counter()
             cur, cur_dev, cur_ready = ahead.popleft()
             fill()                               # frame t+2 starts decoding now, a whole frame before it is needed
             t1 = time.perf_counter()
+            if prof is not None:                 # device-side: when the stream got here / got past the waits / finished the frame
+                ev_a = torch.cuda.Event(enable_timing=True)
+                ev_a.record()
             main_stream.wait_event(cur_ready)
-            for a_ in ahead:
-                main_stream.wait_event(a_[2])            # (their decodes were enqueued one to three iterations ago)
+            for a_ in list(ahead)[:max(0, runner.lookahead)]:
+                main_stream.wait_event(a_[2])            # (their decodes were enqueued one to three iterations ago; the frame uploaded
+                                                         # in THIS iteration is not looked at yet: waiting for it too held every frame
+                                                         # 0.3-0.4 ms behind an upload that had only just been enqueued)
+            if prof is not None:
+                ev_b = torch.cuda.Event(enable_timing=True)
+                ev_b.record()
             buf = runner.launch(cur_dev, next_frames=[a_[1] for a_ in ahead], want_label=False)   # postprocessing_pred (:116) runs on the GPU
+            if prof is not None:
+                ev_c = torch.cuda.Event(enable_timing=True)
+                ev_c.record()
+                dev_marks.append((ev_a, ev_b, ev_c, t0, t1, time.perf_counter()))
             t2 = time.perf_counter()
             name = cur[1]
             if keep is not None:
                 keep.append(runner.label_device().clone())
-            buf['reader_done'] = sink.save(runner.label_device(), os.path.join(seg_dir, f'{name}.png'), color_palette,
-                                           frame=cur_dev[0] if args.viz else None,
-                                           overlay_path=os.path.join(overlay_dir, f'{name}.png') if args.viz else None)
+            if os.environ.get('VFN_NO_SINK') != '1':             # (experiment switch: the loop without its output side)
+                buf['reader_done'] = sink.save(runner.label_device(), os.path.join(seg_dir, f'{name}.png'), color_palette,
+                                               frame=cur_dev[0] if args.viz else None,
+                                               overlay_path=os.path.join(overlay_dir, f'{name}.png') if args.viz else None)
             t3 = time.perf_counter()
             if len(runner._pending) == 2:
                 runner.collect()                 # frame t-1: its bank statistics
             if prof is not None:
                 t4 = time.perf_counter()
+                collect_ret[len(dev_marks) - 2] = t4        # (the loop iteration whose frame this collect waited for)
                 for i_, d_ in enumerate((t1 - t0, t2 - t1, t3 - t2, t4 - t3)):
                     prof[i_] += d_
                 prof[4] += 1
@@ -417,6 +470,30 @@ def main(args, device):
                   % tuple(1e3 * v / prof[4] for v in prof[:4]))
         while runner._pending:
             runner.collect()
+        if getattr(runner, '_collect_log', None):
+            print('collect: done already complete at entry / wait ms / frame collected / newest frame / still pending:', ' '.join('%s/%.2f/%s/%s/%s' % (int(q), w, a, b, c) for q, w, a, b, c in runner._collect_log[40:50]))
+        if prof is not None and len(dev_marks) > 12:
+            torch.cuda.synchronize()
+            mk = dev_marks[8:]
+            n_ = len(mk) - 1
+            blocked = sum(m_[0].elapsed_time(m_[1]) for m_ in mk) / len(mk)
+            frame = sum(m_[1].elapsed_time(m_[2]) for m_ in mk) / len(mk)
+            if os.environ.get('VFN_MAIN_TIMING') == '2':           # host and device clocks of a few consecutive frames on one axis (ms)
+                base = cal_ev.elapsed_time(dev_marks[40][0])       # (print relative to frame 40's first marker)
+                hb = 1e3 * (cal_t - 0.0)
+                for j_ in range(40, min(50, len(dev_marks))):
+                    a_, b_, c_, h0, h1, h2 = dev_marks[j_]
+                    cr = collect_ret.get(j_)
+                    print('frame %d: host: iteration starts %.2f, launch() %.2f -> %.2f, collect() of THIS frame returned %.2f | device: reaches the frame %.2f, first kernel %.2f, last marker %.2f'
+                          % (j_, 1e3 * (h0 - cal_t) - base, 1e3 * (h1 - cal_t) - base, 1e3 * (h2 - cal_t) - base, (1e3 * (cr - cal_t) - base) if cr else float('nan'),
+                             cal_ev.elapsed_time(a_) - base, cal_ev.elapsed_time(b_) - base, cal_ev.elapsed_time(c_) - base))
+            period = mk[0][0].elapsed_time(mk[-1][0]) / n_
+            gaps = sorted(((mk[j_][2].elapsed_time(mk[j_ + 1][0]), j_ + 9) for j_ in range(len(mk) - 1)), reverse=True)
+            print('main loop: the largest gaps between a frame\'s last marker and the next frame\'s first (ms, frame): '
+                  + ' '.join('%.2f@%d' % g_ for g_ in gaps[:8]) + '; median %.3f' % gaps[len(gaps) // 2][0])
+            print('main loop device time per frame: period %.2f ms = %.2f ms the main stream is blocked in front of the frame (decode / look-ahead '
+                  'events) + %.2f ms from the first kernel of the frame to its last (queue idle between frames: %.2f ms)'
+                  % (period, blocked, frame, period - blocked - frame))
         if not png_decode.check_status(device):          # second line of defence: png_decode.inflate rejects such a frame itself
             raise RuntimeError('corrupt PNG frame data (invalid scanline filter type) in ' + args.test_path)
     writer.close()
