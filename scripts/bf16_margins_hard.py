@@ -88,7 +88,8 @@ def run(sd, prec, frames, m0, budget, mem_every, keep_margins=False):
 
 def evaluate(tag, sd, H, W, Tn, mem_every, seed, budget):
     frames, m0 = synth.clip_hard(seed, Tn, H, W, device=dev)
-    gt = torch.stack([torch.roll(m0, (2 * t, 5 * t), (0, 1)) for t in range(Tn)], 0)
+    dy, dx = synth.hard_step(H, W)
+    gt = torch.stack([torch.roll(m0, (dy * t, dx * t), (0, 1)) for t in range(Tn)], 0)
     ref = run(sd, 'fp32', frames, m0, budget, mem_every, keep_margins=True)
     d = ref['marg'][1:].float().flatten()
     samp = d[torch.randperm(d.numel(), device=dev)[:2000000]]

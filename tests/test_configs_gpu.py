@@ -295,7 +295,8 @@ def test_plain_bf16_on_a_task_with_unsaturated_margins(gpu, hard_sd):
     med, p5, clamp = float(mg.median()), float(mg.kthvalue(int(0.05 * mg.numel())).values), float((mg >= 31.0).float().mean())
     print(f'hard task: f32 |margin| median {med:.2f}, p5 {p5:.2f}, at the clamp {clamp:.4f}')
     assert med < 12.0 and p5 < 2.5 and clamp < 0.01, (med, p5, clamp)      # the margins really are unsaturated
-    gt = [torch.roll(m0, (2 * t, 5 * t), (0, 1)) for t in range(T)]
+    dy, dx = synth.hard_step(H, W)
+    gt = [torch.roll(m0, (dy * t, dx * t), (0, 1)) for t in range(T)]
     acc = [miou(runs['fp32'][0][t], gt[t]) for t in range(1, T)]
     assert min(acc) >= 0.75, acc                                           # ... and the network segments the task (not a coin flip)
     for precision, bar in (('bf16x3', 0.999), ('bf16', 0.99)):
