@@ -325,7 +325,7 @@ def main(argv=None):
     del warm
 
     # ---- the clip: pre-roll (untimed) | exactly K timed steps | rest of the clip (untimed)
-    runner = ClipRunner(model, 2, args.budget, size=net_size, mem_every=mem_every, postprocess=True)   # largest-blob filter (:116) on the device too
+    runner = ClipRunner(model, 2, args.budget, size=net_size, mem_every=mem_every, postprocess=True, capture_graphs=True)   # largest-blob filter (:116) on the device too
     runner.start(frames[0:1], onehot)
     n_lab = last_iter + 1
     labels = torch.empty(n_lab, H0, W0, dtype=torch.uint8, device=dev)        # what the loop emits (after :116)

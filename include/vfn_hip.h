@@ -491,6 +491,11 @@ typedef struct vfn_memread_desc {
     long long stride_scores;
 } vfn_memread_desc;
 
+/* Round 6, precision 1 (plain bf16) with the kept image (bank_k_lp / bank_v_lp): both entry points select software-pipelined
+ * kernels -- vfn_bank_scan: bank_scan_pipe_kernel<mode> (keys through registers two chunks ahead, three workgroups per CU);
+ * vfn_memread_apply: memread_apply_pipe_kernel (the softmax of chunk c+1 in the shadow of chunk c's P^T V, value rows a chunk
+ * ahead, one barrier per chunk).  Same products in the same order as the kernels they replace: bit-identical outputs
+ * (tests/test_round6_gpu.py).  VFN_SCAN_PIPE=0 / VFN_APPLY_PIPE=0 (read at every call) bring the round-5 kernels back. */
 int vfn_bank_scan(const vfn_bankscan_desc* d, void* stream);
 int vfn_bank_scan_finish(const float* part, int nsplit, int HW, int obj_n, int mode, float* ml, int* idx,
                          float* corr, const float* colscale, void* stream);

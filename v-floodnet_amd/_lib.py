@@ -271,9 +271,6 @@ def require_gpu(t, what='tensor'):
 # frame's last marker and the next frame's first: 0.855 ms; 0.012 ms with 24 hardware queues, which is no cure: the command
 # processor then time-slices and the loop runs at 76 frames/s).  So side streams are PICKED: a candidate is kept only if a tiny
 # kernel on it finishes while every stream in ``beside`` is still busy with a few milliseconds of queued work.
-_probe_cache = {}
-
-
 def independent_stream(device, beside=(), tries=12, priority=0):
     """A ``torch.cuda.Stream`` whose hardware queue is not the one of the current stream nor of any stream in ``beside``
     (measured, see above).  Falls back to the last candidate if none qualifies within ``tries`` (the loop then still works,
@@ -281,16 +278,13 @@ def independent_stream(device, beside=(), tries=12, priority=0):
     device = torch.device(device)
     cur = torch.cuda.current_stream(device)
     others = [cur] + [s_ for s_ in beside if s_ is not None]
-    key = device.index
-    if key not in _probe_cache:
-        _probe_cache[key] = (torch.zeros(32 * 1024 * 1024, device=device), torch.zeros(16, device=device))
-    big, small = _probe_cache[key]
+    big, small = torch.zeros(16 * 1024 * 1024, device=device), torch.zeros(16, device=device)     # (64 MB, returned to the allocator at exit)
 
     def overlaps(cand, ref):
         torch.cuda.synchronize(device)
         ref_end, cand_end = torch.cuda.Event(), torch.cuda.Event()
         with torch.cuda.stream(ref):
-            for _ in range(48):                     # ~2-3 ms of bandwidth-bound work queued on ``ref``
+            for _ in range(64):                     # ~2 ms of bandwidth-bound work queued on ``ref``
                 big.add_(1.0)
             ref_end.record()
         with torch.cuda.stream(cand):

@@ -71,8 +71,9 @@ class ClipRunner:
     """test_video_seg.py:83-121 on device tensors."""
 
     def __init__(self, model, obj_n=2, budget=250000, update_rate=0.1, thres_close=0.95, size=480, mem_every=1,
-                 postprocess=False, autotune=False):
+                 postprocess=False, autotune=False, capture_graphs=False):
         self.model = model
+        self.capture_graphs = capture_graphs  # capture the launch lists' HIP graphs in start(), before the loop (long loops: video_seg.main, bench.py)
         self.postprocess = postprocess       # run postprocessing_pred (:116) on the device before the D2H
         self.autotune = autotune             # measure tile / split-K choices for conv shapes the shipped tables lack
         self.device = model.device
@@ -110,9 +111,11 @@ class ClipRunner:
             m = ops.resize_nearest(m, h, w)                      # TF.resize(mask, 480, NEAREST) (:89)
         k, v = self.model.memorize(f, m)
         self.fb.init_bank(k, v)
-        if os.environ.get('VFN_CAPTURE_AT_START', '1') == '1':
-            # the launch lists' HIP graphs are captured here, before the loop (engine.Engine.capture), not on their third run inside it;
-            # the first frame's keys / values are already in the bank (init_bank copies them out of the plan's buffers)
+        if self.capture_graphs and os.environ.get('VFN_CAPTURE_AT_START', '1') == '1':
+            # the launch lists' HIP graphs are captured here, before the loop (engine.Engine.capture), not on their third run inside it
+            # (a capture enters with a device-wide synchronize + gc.collect + empty_cache: ADVICE r5); the first frame's keys / values
+            # are already in the bank (init_bank copies them out of the plan's buffers).  Opt-in: a loop of a few frames (most tests)
+            # is better off never capturing at all
             self.graph_captures_at_start = self.model.engine().capture(h, w, self.obj_n)
         self.t = 0
         self._net_cache = {}                                     # no look-ahead carried over from a previous clip
@@ -315,7 +318,7 @@ def main(args, device):
 
     obj_n = seq_dataset.obj_n
     runner = ClipRunner(model, obj_n, args.budget, update_rate=args.update_rate, thres_close=args.merge_thres,
-                        size=downsample_size, mem_every=getattr(args, 'mem_every', 1), postprocess=True, autotune=True)
+                        size=downsample_size, mem_every=getattr(args, 'mem_every', 1), postprocess=True, autotune=True, capture_graphs=True)
 
     ori_first_frame = seq_dataset.first_frame.unsqueeze(0).to(device)
     ori_first_mask = seq_dataset.first_mask.unsqueeze(0).to(device)
@@ -342,9 +345,11 @@ def main(args, device):
         import threading
         feed = queue.Queue(maxsize=16)
 
+        loader_it = iter(seq_loader)             # (the worker processes are forked HERE, on this thread, before the first HIP graph capture)
+
         def _drain():
             try:
-                for item_ in seq_loader:
+                for item_ in loader_it:
                     feed.put(item_)
             except BaseException as exc_:         # (a decode error in a worker: re-raised on the launch thread)
                 feed.put(exc_)
