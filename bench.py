@@ -132,6 +132,10 @@ def parse_args(argv=None):
     ap.add_argument('--native', action='store_true',
                     help='run the network at the input resolution instead of the reference semantics (resize to a 480-pixel '
                          'short edge, test_video_seg.py:46,107); only meaningful with --workload C3')
+    ap.add_argument('--clip', choices=['easy', 'hard'], default='easy',
+                    help="easy (default, every published line): tools/synth.clip -- tinted, textured water; hard: tools/synth.clip_hard -- water "
+                         "that differs from land by texture only (the frames a checkpoint from scripts/train_ckpt.py hard was trained on; a "
+                         "hard-task checkpoint on the easy clip is out of its distribution: its f32 margins collapse and so does any parity number)")
     ap.add_argument('--checkpoint', default=None,
                     help='weights from a checkpoint file in the reference\'s schema ({"model": state_dict, ...}, train_video_seg.py:159-177) '
                          'instead of the synthetic recipe (tools/synth.make_state_dict) -- e.g. the checkpoint scripts/bf16_trained_margins.py '
@@ -245,10 +249,11 @@ def main(argv=None):
     seed = rank + 1
     if stream_mode:
         n_frames = K + 1                           # a stream never repeats: all frames resident (2001 x 1080p = 50 GB of HBM)
-        frames, m0 = synth.clip_on_device(seed, n_frames, H0, W0, dev)
+        frames, m0 = (synth.clip_on_device(seed, n_frames, H0, W0, dev) if args.clip == 'easy' else
+                      synth.clip_hard(seed, n_frames, H0, W0, device=dev, in_place=True))
     else:
         n_frames = CLIP_FRAMES                     # the BASELINE clip, whatever --steps is (longer runs cycle through it)
-        frames, m0 = synth.clip(seed, n_frames, H0, W0)
+        frames, m0 = synth.clip(seed, n_frames, H0, W0) if args.clip == 'easy' else synth.clip_hard(seed, n_frames, H0, W0)
         frames = frames.to(dev)
     n_iter = n_frames - 1
     onehot = synth.onehot(m0).unsqueeze(0).to(dev)
@@ -604,7 +609,8 @@ def main(argv=None):
     out = {'metric': 'segmented frames/sec at 480p' if args.workload == 'C2' else f'segmented frames/sec at {H0}p', 'value': round(fps, 3), 'unit': 'frames/s', 'n_gpus': world,
            'steps': K, 'warmup': Wm, 'ms_per_step': round(1e3 * elapsed / K, 3), 'higher_is_better': True,
            'scaling': 'weak', 'vs_baseline': None, 'dtype': DTYPES[args.precision],
-           'data': 'synthetic' if not args.checkpoint else f'synthetic frames; weights from {os.path.basename(args.checkpoint)} (trained on synthetic clips)',
+           'data': ('synthetic' if args.clip == 'easy' else 'synthetic (hard clip: tools/synth.clip_hard, water and land differ by texture only)') if not args.checkpoint else
+                   f'synthetic frames ({args.clip} clip); weights from {os.path.basename(args.checkpoint)} (trained on synthetic clips)',
            'config': {'workload': f'{args.workload}: {n_frames}-frame {H0}x{W0} synthetic clip per GPU through the test_video_seg.py loop '
                                   f'(' + ('bicubic resize to 480p+' if (Hn, Wn) != (H0, W0) else '') +
                                   f'segment+softmax+memorize' + (f' every {mem_every}th frame' if mem_every > 1 else '') +

@@ -99,7 +99,7 @@ def hard_step(H, W_, net_size=480):
     return (num, 2 * num)
 
 
-def clip_hard(seed, T, H, W_, device=None, net_size=480):
+def clip_hard(seed, T, H, W_, device=None, net_size=480, in_place=False):
     """``clip`` / ``clip_on_device`` over ``frame0_hard``.  The hard task lives in the TEXTURE, whose scale the loop's resize to a
     ``net_size``-pixel short edge (test_video_seg.py:46,107) changes: a frame larger than that is synthesised at the network's
     resolution and enlarged (bicubic; the mask nearest), so that the network sees the texture statistics it was trained on
@@ -116,6 +116,11 @@ def clip_hard(seed, T, H, W_, device=None, net_size=480):
     if device is not None:
         f0 = f0.to(device)
     dy, dx = hard_step(H, W_, net_size)
+    if in_place:                              # (a long high-resolution stream: built frame by frame in device memory, as clip_on_device)
+        frames = torch.empty(T, 3, H, W_, device=f0.device)
+        for t in range(T):
+            frames[t] = torch.roll(f0, shifts=(dy * t, dx * t), dims=(1, 2))
+        return frames, m0
     frames = torch.stack([torch.roll(f0, shifts=(dy * t, dx * t), dims=(1, 2)) for t in range(T)], 0)
     return frames.contiguous(), m0
 
