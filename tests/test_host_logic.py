@@ -224,3 +224,36 @@ def test_video_ds_device_decode_sniffs_content_and_defers_bad_files_to_pil(tmp_p
     import pytest
     with pytest.raises(OSError):                                             # PIL's own verdict on the truncated file
         ds[2]
+
+
+def test_hard_task_generators_are_deterministic_and_colour_free():
+    """tools/synth.frame0_hard / noisy_labels / hard_step (round 6: the task whose margins do not saturate): reproducible bit for bit,
+    water and land share their colour statistics (no tint cue beyond 0.04 in any channel), ~10 % of the noisy labels disagree with the
+    image, and enlarged clips move by steps that are whole pixels at the network's resolution."""
+    import torch
+    from tools import synth
+    a, ma = synth.frame0_hard(7, 200, 320)
+    b, mb = synth.frame0_hard(7, 200, 320)
+    assert torch.equal(a, b) and torch.equal(ma, mb)
+    w = ma.bool()
+    assert 0.3 < float(ma.float().mean()) < 0.7
+    # (a single small frame carries a random offset from its low-frequency field; the SYSTEMATIC water - land difference is the 0.02-0.03 tint)
+    diffs = []
+    for sd_ in range(6):
+        x_, m_ = synth.frame0_hard(100 + sd_, 200, 320)
+        diffs.append([float(x_[c][m_.bool()].mean()) - float(x_[c][~m_.bool()].mean()) for c in range(3)])
+    for c in range(3):
+        assert abs(sum(d_[c] for d_ in diffs) / len(diffs)) < 0.05, diffs          # (frame0: 0.05-0.20 per channel, every frame)
+    assert max(abs(float(x[c][wx].mean()) - float(x[c][~wx].mean())) for x, wx in [(synth.frame0(7, 200, 320)[0], synth.frame0(7, 200, 320)[1].bool())]
+               for c in range(3)) > 0.1                                             # ... which the tinted task has
+    g1, g2 = torch.Generator().manual_seed(5), torch.Generator().manual_seed(5)
+    n1, n2 = synth.noisy_labels(ma.long(), g1), synth.noisy_labels(ma.long(), g2)
+    assert torch.equal(n1, n2)
+    fr = [float((synth.noisy_labels(ma.long(), g1) != ma.long()).float().mean()) for _ in range(8)]
+    assert 0.03 < sum(fr) / len(fr) < 0.25, fr
+    assert synth.hard_step(480, 854) == (2, 5) and synth.hard_step(720, 1280) == (3, 6) and synth.hard_step(1080, 1920) == (9, 18)
+    f, m = synth.clip_hard(3, 3, 720, 1280)
+    assert f.shape == (3, 3, 720, 1280) and m.shape == (720, 1280)
+    assert torch.equal(f[1], torch.roll(f[0], (3, 6), (1, 2)))
+    f2, _ = synth.clip_hard(3, 3, 720, 1280, in_place=True)
+    assert torch.equal(f, f2)

@@ -125,7 +125,7 @@ class ClipRunner:
                            post=torch.empty(H0, W0, dtype=torch.uint8, device=self.device),
                            pinned=torch.empty(H0, W0, dtype=torch.uint8).pin_memory(),
                            stats=torch.zeros(self.obj_n, 4, dtype=torch.int32).pin_memory(),
-                           done=torch.cuda.Event(enable_timing=os.environ.get('VFN_DONE_TIMING') == '1')) for _ in range(2)]
+                           done=torch.cuda.Event()) for _ in range(2)]
         self._cur = self._bufs[0]
         self._label_dev, self._post_dev, self._pinned = self._cur['label'], self._cur['post'], self._cur['pinned']
         self._ccl_scratch = torch.empty(2 * H0 * W0 + 8, dtype=torch.int32, device=self.device)
@@ -217,12 +217,6 @@ class ClipRunner:
         """Wait for the oldest outstanding ``launch`` and take over its bank bookkeeping; returns its uint8 label map
         [H0,W0] as a pinned host tensor (valid until the launch after next)."""
         buf = self._pending.pop(0)
-        if os.environ.get('VFN_MAIN_TIMING') == '3':
-            q0 = buf['done'].query()
-            t_ = time.perf_counter()
-            buf['done'].synchronize()
-            self._collect_log = getattr(self, '_collect_log', [])
-            self._collect_log.append((q0, 1e3 * (time.perf_counter() - t_), buf.get('t'), self.t, len(self._pending)))
         buf['done'].synchronize()
         self.fb.absorb_stats(buf['stats'], in_flight=len(self._pending))
         self.size_log.append(list(self.fb._len_host))
@@ -424,13 +418,6 @@ def main(args, device):
 
         prof = [0.0, 0.0, 0.0, 0.0, 0] if os.environ.get('VFN_MAIN_TIMING') else None   # host seconds: fill, launch, save, collect
         dev_marks = []
-        collect_ret = {}
-        if prof is not None:                     # one axis for both clocks: an event recorded on an idle device ~ the host time of the record
-            torch.cuda.synchronize()
-            cal_ev = torch.cuda.Event(enable_timing=True)
-            cal_ev.record()
-            torch.cuda.synchronize()
-            cal_t = time.perf_counter()
         fill()
         while ahead:
             t0 = time.perf_counter()
@@ -457,16 +444,14 @@ def main(args, device):
             name = cur[1]
             if keep is not None:
                 keep.append(runner.label_device().clone())
-            if os.environ.get('VFN_NO_SINK') != '1':             # (experiment switch: the loop without its output side)
-                buf['reader_done'] = sink.save(runner.label_device(), os.path.join(seg_dir, f'{name}.png'), color_palette,
-                                               frame=cur_dev[0] if args.viz else None,
-                                               overlay_path=os.path.join(overlay_dir, f'{name}.png') if args.viz else None)
+            buf['reader_done'] = sink.save(runner.label_device(), os.path.join(seg_dir, f'{name}.png'), color_palette,
+                                           frame=cur_dev[0] if args.viz else None,
+                                           overlay_path=os.path.join(overlay_dir, f'{name}.png') if args.viz else None)
             t3 = time.perf_counter()
             if len(runner._pending) == 2:
                 runner.collect()                 # frame t-1: its bank statistics
             if prof is not None:
                 t4 = time.perf_counter()
-                collect_ret[len(dev_marks) - 2] = t4        # (the loop iteration whose frame this collect waited for)
                 for i_, d_ in enumerate((t1 - t0, t2 - t1, t3 - t2, t4 - t3)):
                     prof[i_] += d_
                 prof[4] += 1
@@ -475,23 +460,12 @@ def main(args, device):
                   % tuple(1e3 * v / prof[4] for v in prof[:4]))
         while runner._pending:
             runner.collect()
-        if getattr(runner, '_collect_log', None):
-            print('collect: done already complete at entry / wait ms / frame collected / newest frame / still pending:', ' '.join('%s/%.2f/%s/%s/%s' % (int(q), w, a, b, c) for q, w, a, b, c in runner._collect_log[40:50]))
         if prof is not None and len(dev_marks) > 12:
             torch.cuda.synchronize()
             mk = dev_marks[8:]
             n_ = len(mk) - 1
             blocked = sum(m_[0].elapsed_time(m_[1]) for m_ in mk) / len(mk)
             frame = sum(m_[1].elapsed_time(m_[2]) for m_ in mk) / len(mk)
-            if os.environ.get('VFN_MAIN_TIMING') == '2':           # host and device clocks of a few consecutive frames on one axis (ms)
-                base = cal_ev.elapsed_time(dev_marks[40][0])       # (print relative to frame 40's first marker)
-                hb = 1e3 * (cal_t - 0.0)
-                for j_ in range(40, min(50, len(dev_marks))):
-                    a_, b_, c_, h0, h1, h2 = dev_marks[j_]
-                    cr = collect_ret.get(j_)
-                    print('frame %d: host: iteration starts %.2f, launch() %.2f -> %.2f, collect() of THIS frame returned %.2f | device: reaches the frame %.2f, first kernel %.2f, last marker %.2f'
-                          % (j_, 1e3 * (h0 - cal_t) - base, 1e3 * (h1 - cal_t) - base, 1e3 * (h2 - cal_t) - base, (1e3 * (cr - cal_t) - base) if cr else float('nan'),
-                             cal_ev.elapsed_time(a_) - base, cal_ev.elapsed_time(b_) - base, cal_ev.elapsed_time(c_) - base))
             period = mk[0][0].elapsed_time(mk[-1][0]) / n_
             gaps = sorted(((mk[j_][2].elapsed_time(mk[j_ + 1][0]), j_ + 9) for j_ in range(len(mk) - 1)), reverse=True)
             print('main loop: the largest gaps between a frame\'s last marker and the next frame\'s first (ms, frame): '
