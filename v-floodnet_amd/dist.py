@@ -179,7 +179,10 @@ def gather_bank_sizes(local_sizes, n_clips, rank, world, device):
     if n_clips <= 0:
         return []
     per = clips_per_rank(n_clips, world)
-    loc = [torch.as_tensor(x, dtype=torch.int32).reshape(len(x), -1).cpu() for x in local_sizes]
+    loc = []
+    for x in local_sizes:
+        x = torch.as_tensor(x, dtype=torch.int32).cpu()
+        loc.append(x.view(-1, 1) if x.dim() == 1 else x.reshape(x.shape[0], x.shape[1] if x.dim() > 1 else 0))   # ([T, 0]: a clip without sizes)
     dims = torch.zeros(2, dtype=torch.int64)
     if loc:
         dims = torch.tensor([max(int(x.shape[0]) for x in loc), max(int(x.shape[1]) for x in loc)], dtype=torch.int64)
