@@ -626,6 +626,9 @@ def main(argv=None):
                                                        'frame_mfma_frac_Fmin prices the frame at the ALGORITHMIC FLOP of SURVEY.md 8(d), '
                                                        'frame_mfma_frac_executed at what the matrix pipe runs)'},
                       'winograd_layers': sorted(set(wino_names)),
+                      # the look-ahead stream is picked so that it shares no hardware queue with the frame loop's stream (streams on one
+                      # queue run in order): [found, candidates tried] per probe of this process (vfloodnet_amd._lib.independent_stream)
+                      'side_stream_probes': [[bool(a_), int(b_)] for a_, b_ in vlib.PROBES],
                       'frame_mfma_frac_Fref_reference_equivalent': round(frame_frac_ref, 4) if mem_every == 1 else None},
            'full_clip_fps': round(full_clip_fps, 3),
            # `value` is K frames (0.12 s at the driver's --steps 20): a 1-2 % effect cannot be read off it.  The same run's other clocks

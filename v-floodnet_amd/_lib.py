@@ -271,6 +271,9 @@ def require_gpu(t, what='tensor'):
 # frame's last marker and the next frame's first: 0.855 ms; 0.012 ms with 24 hardware queues, which is no cure: the command
 # processor then time-slices and the loop runs at 76 frames/s).  So side streams are PICKED: a candidate is kept only if a tiny
 # kernel on it finishes while every stream in ``beside`` is still busy with a few milliseconds of queued work.
+PROBES = []          # (found, candidates tried) of every independent_stream call of this process (bench.py reports them)
+
+
 def independent_stream(device, beside=(), tries=12, priority=0):
     """A ``torch.cuda.Stream`` whose hardware queue is not the one of the current stream nor of any stream in ``beside``
     (measured, see above).  Falls back to the last candidate if none qualifies within ``tries`` (the loop then still works,
@@ -296,10 +299,12 @@ def independent_stream(device, beside=(), tries=12, priority=0):
         return ok
 
     cand = None
-    for _ in range(tries):
+    for n_ in range(tries):
         cand = torch.cuda.Stream(device=device, priority=priority)
         if all(overlaps(cand, o_) for o_ in others):
+            PROBES.append((True, n_ + 1))
             return cand
+    PROBES.append((False, tries))
     import warnings
     warnings.warn('vfloodnet_amd: no stream with a hardware queue of its own found; side-stream work will run in order with the frame loop')
     return cand
