@@ -257,3 +257,22 @@ def test_hard_task_generators_are_deterministic_and_colour_free():
     assert torch.equal(f[1], torch.roll(f[0], (3, 6), (1, 2)))
     f2, _ = synth.clip_hard(3, 3, 720, 1280, in_place=True)
     assert torch.equal(f, f2)
+
+
+def test_bank_snapshot_is_validated_before_any_device_work():
+    """FeatureBank.state_dict / load_state_dict (round 6, SURVEY section 5 "bank snapshot for long streams"): an empty bank has no
+    snapshot; a snapshot of another version, object count or with entries that do not match their recorded lengths is refused by
+    the host checks -- before the loader allocates on the device (which this CPU container does not have)."""
+    from vfloodnet_amd.feature_bank import FeatureBank, DK, DV
+    fb = FeatureBank(2, 1000, 'cpu')
+    with pytest.raises(RuntimeError, match='empty'):
+        fb.state_dict()
+    good = dict(version=1, obj_n=2, hw=60, dk=DK, dv=DV, class_budget=400.0, update_rate=0.1, thres_close=0.95, precision='fp32',
+                lens=[3, 2], n_updates=1, hist={0: [3, 2]}, peak_n=[3.0, 2.0], replace_n=[0.0, 0.0],
+                keys=[torch.zeros(3, DK), torch.zeros(2, DK)], values=[torch.zeros(3, DV), torch.zeros(2, DV)],
+                info=[torch.zeros(3, 2), torch.zeros(2, 2)])
+    for edit in (dict(version=2), dict(obj_n=3), dict(dk=64), dict(lens=[3, 3]), dict(info=[torch.zeros(3, 2), torch.zeros(2, 3)])):
+        with pytest.raises(ValueError):
+            fb.load_state_dict({**good, **edit})
+    with pytest.raises(RuntimeError, match='GPU'):               # a valid snapshot gets as far as the device allocation
+        fb.load_state_dict(good)

@@ -164,3 +164,61 @@ def test_independent_stream_runs_beside_the_current_stream(gpu):
             cand_end.synchronize()
             assert not ref_end.query(), 'the candidate stream waited for the busy stream: same hardware queue'
             torch.cuda.synchronize()
+
+
+@pytest.mark.parametrize('precision', ['fp32', 'bf16'])
+def test_stream_resumes_bit_identically_from_a_snapshot(gpu, precision, tmp_path):
+    """SURVEY.md section 5, "optional: bank snapshot for long streams" (the reference keeps no inference state,
+    FeatureBank.py:10-51).  A loop stopped after frame 7, written with torch.save, read back into a NEW runner and continued
+    gives the labels, the bank-size vector and the final bank (entries, birth frames, hit accumulators, peak / replace
+    statistics) of the uninterrupted loop bit for bit -- through the eviction regime (budget reached before the cut)."""
+    from tools import synth
+    from vfloodnet_amd import AFB_URR
+    from vfloodnet_amd.video_seg import ClipRunner
+    T, cut = 15, 7
+    model = AFB_URR(gpu, update_bank=True, precision=precision).to(gpu).eval()
+    model.load_state_dict(synth.make_state_dict(20200212), strict=True)
+    frames, m0 = synth.clip(5, T, 96, 160)
+    frames = frames.to(gpu)
+    onehot = synth.onehot(m0).unsqueeze(0).to(gpu)
+
+    def run(runner, lo, hi):
+        return [runner.step(frames[t:t + 1]).clone() for t in range(lo, hi)]
+
+    a = ClipRunner(model, 2, 600, size=96)
+    a.start(frames[0:1], onehot)
+    la = run(a, 1, T)
+    assert a.fb.replace_n.sum() > 0 and max(a.size_log[cut - 1]) >= a.fb.class_budget - 60      # evicting before the cut
+
+    b = ClipRunner(model, 2, 600, size=96)
+    b.start(frames[0:1], onehot)
+    lb = run(b, 1, cut)
+    b.launch(frames[cut:cut + 1])
+    with pytest.raises(RuntimeError):
+        b.snapshot()                                               # a frame in flight
+    b.collect()
+    b2 = ClipRunner(model, 2, 600, size=96)
+    b2.start(frames[0:1], onehot)
+    run(b2, 1, cut)
+    path = str(tmp_path / 'stream.pt')
+    torch.save(b2.snapshot(), path)
+    del b, b2
+
+    c = ClipRunner(model, 2, 600, size=96)
+    c.resume(torch.load(path))
+    assert c.t == cut - 1 and c.bank_sizes() == a.size_log[cut - 1]
+    lc = run(c, cut, T)
+    for t, (x, y) in enumerate(zip(la[:cut - 1], lb)):
+        assert torch.equal(x, y), f'frame {t + 1} differs between two uninterrupted runs'
+    for t, (x, y) in enumerate(zip(la[cut - 1:], lc)):
+        assert torch.equal(x, y), f'frame {cut + t}: the resumed stream differs from the uninterrupted one'
+    assert c.size_log == a.size_log[cut - 1:]
+    for i in range(2):
+        assert torch.equal(a.fb.keys[i], c.fb.keys[i]) and torch.equal(a.fb.values[i], c.fb.values[i])
+        assert torch.equal(a.fb.info[i], c.fb.info[i])
+    assert (a.fb.peak_n == c.fb.peak_n).all() and (a.fb.replace_n == c.fb.replace_n).all()
+
+    bad = torch.load(path)
+    bad['bank']['obj_n'] = 3
+    with pytest.raises(ValueError):
+        ClipRunner(model, 2, 600, size=96).resume(bad)

@@ -449,6 +449,57 @@ class FeatureBank:
         n = self._sync_len()
         return (self.class_budget - n[class_idx]) - request_n
 
+    # ------------------------------------------------------------------ snapshot / resume
+    def state_dict(self, device='cpu'):
+        """The bank as plain tensors and numbers, for ``torch.save``: a long stream can stop and pick up again
+        (``load_state_dict``) on the frame after.  The reference keeps no inference state (``FeatureBank.py:10-51`` holds
+        lists of live tensors only; SURVEY §5 lists the snapshot as optional).  What is kept is what the next frame depends
+        on: the live entries in slab order (keys, values, ``info`` = birth frame + hit accumulator), the peak / replace
+        statistics, and the update history the slicing of the scans is derived from (``len_upper``) -- with it a resumed run
+        slices the bank exactly as the uninterrupted one and gives bit-identical results.  Norms and the split-bf16 image
+        are functions of the entries and are rebuilt.  Synchronises (it reads the device lengths)."""
+        if self._kbuf is None:
+            raise RuntimeError('FeatureBank.state_dict: the bank is empty (init_bank first)')
+        n = self._sync_len()
+        dev = torch.device(device)
+        take = lambda t: t.detach().to(dev, copy=True)
+        return dict(version=1, obj_n=self.obj_n, hw=self._hw, dk=DK, dv=DV, class_budget=float(self.class_budget),
+                    update_rate=float(self.update_rate), thres_close=float(self.thres_close), precision=self.precision,
+                    lens=[int(x) for x in n], n_updates=int(self._n_updates),
+                    hist={int(k): [int(x) for x in v] for k, v in self._hist.items()},
+                    peak_n=[float(x) for x in self.peak_n], replace_n=[float(x) for x in self.replace_n],
+                    keys=[take(self._kbuf[i, :n[i]]) for i in range(self.obj_n)],
+                    values=[take(self._vbuf[i, :n[i]]) for i in range(self.obj_n)],
+                    info=[take(self._ibuf[i, :n[i]]) for i in range(self.obj_n)])
+
+    @torch.no_grad()
+    def load_state_dict(self, sd):
+        """Bring a bank written by ``state_dict`` back (entries as [n, 128] / [n, 512] / [n, 2] rows per object).  Budget,
+        update rate and merge threshold stay those this bank was constructed with (a stream may be resumed under a
+        different budget); the object count and the feature geometry must match."""
+        if sd.get('version') != 1:
+            raise ValueError(f'FeatureBank.load_state_dict: unknown snapshot version {sd.get("version")!r}')
+        if sd['obj_n'] != self.obj_n or sd['dk'] != DK or sd['dv'] != DV:
+            raise ValueError(f'FeatureBank.load_state_dict: snapshot of {sd["obj_n"]} objects with {sd["dk"]} / {sd["dv"]} channels, '
+                             f'bank of {self.obj_n} with {DK} / {DV}')
+        lens = [int(x) for x in sd['lens']]
+        for i in range(self.obj_n):
+            k, v, inf = sd['keys'][i], sd['values'][i], sd['info'][i]
+            if tuple(k.shape) != (lens[i], DK) or tuple(v.shape) != (lens[i], DV) or tuple(inf.shape) != (lens[i], 2):
+                raise ValueError(f'FeatureBank.load_state_dict: object {i}: entries {tuple(k.shape)} / {tuple(v.shape)} / '
+                                 f'{tuple(inf.shape)} do not match the recorded length {lens[i]}')
+        self._alloc(int(sd['hw']), max(lens))
+        for i in range(self.obj_n):
+            self._kbuf[i, :lens[i]].copy_(sd['keys'][i])
+            self._vbuf[i, :lens[i]].copy_(sd['values'][i])
+            self._ibuf[i, :lens[i]].copy_(sd['info'][i])
+        self.peak_n = np.maximum(self.peak_n, np.asarray(sd['peak_n'], dtype=np.float64))
+        self.replace_n = np.asarray(sd['replace_n'], dtype=np.float64).copy()
+        self._set_lengths(lens)
+        self._n_updates = int(sd['n_updates'])
+        self._hist = {int(k): [int(x) for x in v] for k, v in sd['hist'].items()}
+        self._graph_kv = None
+
     def print_peak_mem(self):
         """FeatureBank.py:145-149."""
         self._sync_len()

@@ -118,6 +118,9 @@ class ClipRunner:
             # is better off never capturing at all
             self.graph_captures_at_start = self.model.engine().capture(h, w, self.obj_n)
         self.t = 0
+        self._alloc_outputs(H0, W0)
+
+    def _alloc_outputs(self, H0, W0):
         self._net_cache = {}                                     # no look-ahead carried over from a previous clip
         # two sets of per-frame outputs: frame t+1 may be enqueued (launch) before the host has looked at frame t
         # (collect), and a side stream may still be compressing frame t's label map while frame t+1 runs
@@ -131,6 +134,34 @@ class ClipRunner:
         self._ccl_scratch = torch.empty(2 * H0 * W0 + 8, dtype=torch.int32, device=self.device)
         self._pending = []
         self.size_log = [list(self.fb._len_host)]                 # live entries per object: after init_bank, then after every collected frame
+
+    def snapshot(self, device='cpu'):
+        """Everything frame t + 1 depends on besides the weights, as a dictionary ``torch.save`` takes: the bank
+        (``FeatureBank.state_dict``), the frame counter (the bank's birth frames and the ``mem_every`` rhythm are counted
+        from it) and the clip geometry.  A long stream stops here and ``resume`` continues it -- bit-identically to the
+        uninterrupted loop when both look equally far ahead (the reference has no inference-state checkpoint: SURVEY §5
+        lists it as optional).  No frame may be in flight."""
+        if self._pending:
+            raise RuntimeError('ClipRunner.snapshot: frames in flight; collect() first')
+        return dict(version=1, t=int(self.t), ori_size=[int(x) for x in self.ori_size], obj_n=int(self.obj_n), size=int(self.size),
+                    mem_every=int(self.mem_every), bank=self.fb.state_dict(device))
+
+    def resume(self, snap):
+        """Take up the stream ``snapshot`` left: the next ``launch`` / ``step`` is frame ``snap['t'] + 1``."""
+        if snap.get('version') != 1 or snap['obj_n'] != self.obj_n:
+            raise ValueError(f'ClipRunner.resume: snapshot version {snap.get("version")!r} with {snap.get("obj_n")} objects, runner with {self.obj_n}')
+        if snap['size'] != self.size:
+            raise ValueError(f'ClipRunner.resume: snapshot taken at network size {snap["size"]}, runner at {self.size}: the bank holds one frame geometry')
+        H0, W0 = snap['ori_size']
+        self.ori_size = (H0, W0)
+        self.fb.load_state_dict(snap['bank'])
+        h, w = resized_hw(H0, W0, self.size)
+        if self.autotune and os.environ.get('VFN_AUTOTUNE', '1') != '0':
+            self.model.engine().autotune(h, w, self.obj_n, only_missing=True)
+        if self.capture_graphs and os.environ.get('VFN_CAPTURE_AT_START', '1') == '1':
+            self.graph_captures_at_start = self.model.engine().capture(h, w, self.obj_n)
+        self.t = int(snap['t'])
+        self._alloc_outputs(H0, W0)
 
     def _net_cached(self, frame):
         """The network-resolution tensor of ``frame``, resized once however often the look-ahead sees it.  The key is an
