@@ -132,6 +132,9 @@ def parse_args(argv=None):
     ap.add_argument('--native', action='store_true',
                     help='run the network at the input resolution instead of the reference semantics (resize to a 480-pixel '
                          'short edge, test_video_seg.py:46,107); only meaningful with --workload C3')
+    ap.add_argument('--group', action='store_true',
+                    help='workloads that memorise only every n-th frame (C3: n = 5): the frames between two memorize calls as ONE batched pass '
+                         '(ClipRunner.launch_group / AFB_URR.segment_group); same frames, same bank updates, labels equal up to summation order')
     ap.add_argument('--clip', choices=['easy', 'hard'], default='easy',
                     help="easy (default, every published line): tools/synth.clip -- tinted, textured water; hard: tools/synth.clip_hard -- water "
                          "that differs from land by texture only (the frames a checkpoint from scripts/train_ckpt.py hard was trained on; a "
@@ -297,13 +300,13 @@ def main(argv=None):
         return rc
     L_.vfn_memread_apply = timed_apply
 
-    def timed_memread(self_, p_, fb_, update_bank_, kv_q_=None):
+    def timed_memread(self_, p_, fb_, update_bank_, kv_q_=None, out=None):
         if not timer.active:
-            return orig_memread(self_, p_, fb_, update_bank_, kv_q_)
+            return orig_memread(self_, p_, fb_, update_bank_, kv_q_, out)
         cur_mem.update(entries=sum(fb_._len_host), HW=p_.HW)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        orig_memread(self_, p_, fb_, update_bank_, kv_q_)
+        orig_memread(self_, p_, fb_, update_bank_, kv_q_, out)
         e1.record()
         mem_records.append((sum(fb_._len_host), p_.HW, e0, e1))
     Engine._memory_read = timed_memread
@@ -311,6 +314,10 @@ def main(argv=None):
     Hn, Wn = resized_hw(H0, W0, net_size)            # reference semantics: the network always sees the 480p frame
     eng.autotune(Hn, Wn, 2, only_missing=not args.autotune)      # the shipped tables cover C2 / C3 / C5 at reference semantics
     plan = eng.plan(Hn, Wn, 2)
+    group_n = mem_every if (args.group and mem_every > 1) else 0
+    if group_n:                                      # the batched lists exist before the tuner and the timers look at the plan
+        plan.batch_set(group_n).dec_batch()
+        eng.autotune(Hn, Wn, 2, only_missing=True)
     for lst in plan.all_lists():
         for l in lst:
             if l.fn is timer.orig:
@@ -331,6 +338,7 @@ def main(argv=None):
 
     # ---- the clip: pre-roll (untimed) | exactly K timed steps | rest of the clip (untimed)
     runner = ClipRunner(model, 2, args.budget, size=net_size, mem_every=mem_every, postprocess=True, capture_graphs=True)   # largest-blob filter (:116) on the device too
+    runner.group_capture = group_n
     runner.start(frames[0:1], onehot)
     n_lab = last_iter + 1
     labels = torch.empty(n_lab, H0, W0, dtype=torch.uint8, device=dev)        # what the loop emits (after :116)
@@ -387,6 +395,57 @@ def main(argv=None):
                 collect_one()
         while runner._pending:
             collect_one()
+
+    def collect_group_one():
+        g_before = len(runner.size_log)
+        runner.collect_group()
+        new_sizes = runner.size_log[g_before:]
+        now = time.perf_counter()
+        for sz in new_sizes:
+            bank_sizes.append(list(sz))
+            frame_ms.append((len(bank_sizes), 1e3 * (now - last_collect[0]) / len(new_sizes)))
+        last_collect[0] = now
+
+    def run_groups(t_from, t_to, sampling):
+        """--group: frames t_from..t_to as groups that end on a memorised frame (ClipRunner.launch_group), one group in flight while
+        the host collects the one before; the next group's frame-only side is prefetched on the side stream.  A group that holds
+        a sampled frame runs eagerly with its launches timed, nothing prefetched into or out of it."""
+        last_collect[0] = time.perf_counter()
+
+        def group_at(t):
+            return min(group_n - (t - 1) % group_n, t_to - t + 1)
+
+        def is_sampled_group(t, g):
+            # (a sampled group runs G frames eagerly: every (sample_every x G)-th frame picks one, so about as many FRAMES are instrumented
+            # as in the frame-by-frame loop; at least one group of a short window)
+            every = min(args.sample_every * group_n, max(group_n, (K // group_n) * group_n))
+            return sampling and any(s_first <= u <= s_first + K - 1 and ((u - s_first + 1) % every == 0) for u in range(t, t + g))
+        t = t_from
+        while t <= t_to:
+            g = group_at(t)
+            timer.active = is_sampled_group(t, g) and g == group_n
+            eng.eager = timer.active
+            nxt = None
+            t2 = t + g
+            if not args.no_overlap and not timer.active and t2 <= t_to:
+                g2 = group_at(t2)
+                if not (is_sampled_group(t2, g2) and g2 == group_n):
+                    nxt = [frames[frame_of(u):frame_of(u) + 1] for u in range(t2, t2 + g2)]
+            runner.launch_group([frames[frame_of(u):frame_of(u) + 1] for u in range(t, t + g)], want_label=True, next_frames=nxt)
+            timer.active = False
+            eng.eager = False
+            for i, fo in enumerate(runner._glast['frames'][:g]):
+                if t + i < n_lab:
+                    labels[t + i].copy_(fo['post'], non_blocking=True)
+                    labels_raw[t + i].copy_(fo['label'], non_blocking=True)
+            t = t2
+            if len(runner._gpending) == 2:
+                collect_group_one()
+        while runner._gpending:
+            collect_group_one()
+
+    if group_n:
+        run_iters = run_groups
 
     def bracket():
         torch.cuda.synchronize()
@@ -614,7 +673,9 @@ def main(argv=None):
            'config': {'workload': f'{args.workload}: {n_frames}-frame {H0}x{W0} synthetic clip per GPU through the test_video_seg.py loop '
                                   f'(' + ('bicubic resize to 480p+' if (Hn, Wn) != (H0, W0) else '') +
                                   f'segment+softmax+memorize' + (f' every {mem_every}th frame' if mem_every > 1 else '') +
-                                  f'+bank update+argmax+CCL), {args.precision}, budget {args.budget}; {timed_desc}',
+                                  f'+bank update+argmax+CCL), {args.precision}, budget {args.budget}; {timed_desc}' +
+                                  (f'; the frames between two memorize calls as one batched pass (--group: groups of {group_n})' if group_n else ''),
+                      'grouped_frames': group_n or None,
                       'timed_frames': [s_first, s_first + K - 1], 'preroll_frames': s_first - 1, 'warm_steps_run': warm_steps,
                       'mean_bank_entries_per_object': round(b_mean, 1),
                       'full_clip_mean_bank_entries_per_object': round(b_mean_clip, 1),

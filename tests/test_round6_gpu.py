@@ -222,3 +222,49 @@ def test_stream_resumes_bit_identically_from_a_snapshot(gpu, precision, tmp_path
     bad['bank']['obj_n'] = 3
     with pytest.raises(ValueError):
         ClipRunner(model, 2, 600, size=96).resume(bad)
+
+
+@pytest.mark.parametrize('prefetch', [False, True])
+def test_grouped_frames_match_the_frame_by_frame_loop(gpu, prefetch):
+    """ClipRunner.launch_group / AFB_URR.segment_group: with a key-frame interval (test_video_seg.py:110-112 with mem_every = n; BASELINE
+    config C3) the frames between two memorize calls see the same bank, so they go through the query side, ONE memory read and the
+    decoder as one batch.  Given the bank the frames are independent: same labels as the frame-by-frame loop up to the summation
+    order of the larger GEMMs, the same bank-size vector, the same birth frames, hit accumulators that differ only where a
+    probability sits on the 1e-3 threshold -- with and without the next group's frame-only side prefetched on the side stream."""
+    from tools import synth
+    from vfloodnet_amd import AFB_URR
+    from vfloodnet_amd.video_seg import ClipRunner
+    T, n = 12, 3
+    model = AFB_URR(gpu, update_bank=True).to(gpu).eval()
+    model.load_state_dict(synth.make_state_dict(20200212), strict=True)
+    frames, m0 = synth.clip(4, T, 96, 160)
+    frames = frames.to(gpu)
+    onehot = synth.onehot(m0).unsqueeze(0).to(gpu)
+    a = ClipRunner(model, 2, 250000, size=96, mem_every=n)
+    a.start(frames[0:1], onehot)
+    la = [a.step(frames[t:t + 1]).clone() for t in range(1, T)]
+
+    b = ClipRunner(model, 2, 250000, size=96, mem_every=n)
+    b.start(frames[0:1], onehot)
+    with pytest.raises(ValueError):                               # frame 3 is memorised: the frames behind it must see its update
+        b.launch_group([frames[t:t + 1] for t in range(1, 5)])
+    lb, t = [], 1
+    while t < T:
+        g = min(n - (t - 1) % n, T - t)
+        nxt = [frames[u:u + 1] for u in range(t + g, min(T, t + g + n))] if prefetch else None
+        b.launch_group([frames[u:u + 1] for u in range(t, t + g)], next_frames=nxt or None)
+        with pytest.raises(RuntimeError):
+            b.launch(frames[t:t + 1])                             # a group in flight
+        lb += [x.clone() for x in b.collect_group()]
+        t += g
+    assert len(lb) == len(la) == T - 1
+    for t, (x, y) in enumerate(zip(la, lb)):
+        inter = ((x == 1) & (y == 1)).sum().item()
+        union = ((x == 1) | (y == 1)).sum().item()
+        assert union == 0 or inter / union > 0.999, f'frame {t + 1}: grouped labels differ from the frame-by-frame loop ({inter}/{union})'
+    assert a.size_log == b.size_log
+    for i in range(2):
+        ia, ib = a.fb.info[i], b.fb.info[i]
+        assert torch.equal(ia[:, 0], ib[:, 0])
+        assert float(((ia[:, 1] - ib[:, 1]).abs() > 2).float().mean()) < 0.01
+        assert torch.allclose(a.fb.keys[i], b.fb.keys[i], atol=2e-4, rtol=1e-3)

@@ -82,6 +82,7 @@ def pad_divide_by(h, w, d=16):
 WS_FLOATS = 16 * 1024 * 1024        # split-K workspace (64 MB), shared by all launches of a plan
 _WINOGRAD_TRAIN = os.environ.get('VFN_WINOGRAD_TRAIN', '1') == '1'     # the training plans' forward convolutions too
 _BATCH_MEMREAD = os.environ.get('VFN_TRAIN_BATCH_MEMREAD', '1') == '1'     # segment_batch: one memory read for all frames of the sample
+MAX_GROUP = 16                # Engine.segment_group: frames per batched pass (the batch's buffers are G times a frame's)
 _TRAIN_SLOTS = int(os.environ.get('VFN_TRAIN_SLOTS', 2))      # training plans segment() alternates between (see Engine.plan)
 # Winograd F(4x4, 3x3) for the 3x3 / stride-1 layers (csrc/conv_winograd.hip): 1 (default) = where the measured table says so
 # (wino_gfx950.json: "M,cin,cout" -> 0 / 1, scripts/tune_winograd.py; shapes it lacks: >= 128 channels either side and at least
@@ -891,12 +892,20 @@ class DecoderBatch:
         self.score = f(G, K, p.H0, p.W0)
         # the memory read of all G frames in one pass: G * HW query columns against the bank, read-out object-major [K, G * HW, 512]
         # (then one strided copy into the frame-major ``dec_in``); its own statistics / partial buffers, sized by G * HW
-        import types
-        HWb = G * p.HW
-        self.mr = types.SimpleNamespace(HW=HWb, ml=f(K, HWb, 2), ml_part=f(K, MAX_SPLIT_SCAN, HWb, 2), o_part=f(K, MAX_SPLIT, HWb, DV),
-                                        work=torch.zeros(4, dtype=torch.int32, device=p.eng.device), dec_in=f(K, HWb, DV))
+        self._mr = None                       # (built on first use: the inference loop's groups read frame by frame)
         self.post = []
         self._build()
+
+    @property
+    def mr(self):
+        if self._mr is None:
+            import types
+            p, G, K = self.plan, self.G, self.plan.obj_n
+            f = lambda *s_: torch.empty(*s_, device=p.eng.device, dtype=torch.float32)
+            HWb = G * p.HW
+            self._mr = types.SimpleNamespace(HW=HWb, ml=f(K, HWb, 2), ml_part=f(K, MAX_SPLIT_SCAN, HWb, 2), o_part=f(K, MAX_SPLIT, HWb, DV),
+                                             work=torch.zeros(4, dtype=torch.int32, device=p.eng.device), dec_in=f(K, HWb, DV))
+        return self._mr
 
     def __getattr__(self, name):               # (only what is not set above: geometry, workspaces, obj_n, ...)
         return getattr(self.plan, name)
@@ -1259,6 +1268,108 @@ class Engine:
         self.last_batch = (b, qs)
         return b.score
 
+    # ------------------------------------------------------------------ inference: the frames between two memorize calls in one pass
+    @torch.no_grad()
+    def segment_group(self, frames, fb, update_bank, prefetch=None):
+        """``segment`` for G consecutive frames f32[G,3,h,w] that see the SAME bank -- the frames between two ``memorize`` /
+        ``FeatureBank.update`` calls when only every n-th frame is memorised (test_video_seg.py:110-112 with a key-frame interval;
+        BASELINE config C3: every 5th) -- in one pass: the frame-only side over the G frames at once, the G memory reads back to back
+        (each bumps the hit accumulators as its own ``segment`` call would), the decoder once over G x obj_n images
+        (QuerySet(nq=G) / DecoderBatch, the structures the training step batches a sample with).  Given the bank the frames are
+        independent, so the logits are those of G ``segment`` calls up to the summation order inside the convolutions (larger
+        GEMMs pick other tiles) and of the bank slices.  Returns logits f32[G,obj_n,h,w] (a buffer of the plan: valid until the next
+        group of this size); eval-mode padding as ``segment``.  ``frames``: a tensor, or a list of G f32[1,3,h,w] tensors;
+        ``prefetch``: the NEXT group as such a list -- its frame-only side then runs on the side stream behind this group's decoder
+        (``prefetch_group``) and the next call, given the same tensors, finds it done."""
+        if isinstance(frames, (list, tuple)):             # G tensors f32[1,3,h,w]: copied straight into the batch's frame slots
+            for fr in frames:
+                self._check_frame(fr)
+                if fr.shape != frames[0].shape:
+                    raise RuntimeError(f'segment_group: frames of one size, got {tuple(fr.shape)} and {tuple(frames[0].shape)}')
+            G, H, Wd = len(frames), frames[0].shape[2], frames[0].shape[3]
+        else:
+            self._check_frame(frames, batch_ok=True)
+            G, H, Wd = frames.shape[0], frames.shape[2], frames.shape[3]
+        K = fb.obj_n
+        p = self.plan(H, Wd, K)
+        self._join_backward(p)
+        if fb._kbuf is None:
+            raise RuntimeError('feature bank is empty: call fb.init_bank() first')
+        if fb._hw != p.HW:
+            raise RuntimeError('feature bank was built for a different frame size')
+        if G > MAX_GROUP:
+            raise RuntimeError(f'segment_group: at most {MAX_GROUP} frames per group, got {G}')
+        keys = [self._key(fr) for fr in frames] if isinstance(frames, (list, tuple)) else None
+        qs = self._group_qset(p, G)
+        hit = keys is not None and qs.stage == 2 and qs.keys == keys and not any(qs.consumed)
+        b = qs.dec_batch()
+        if self.refresher._tables is None:                 # (the batch lists registered new derived tensors: Winograd banks)
+            self._settle()
+        if hit:
+            torch.cuda.current_stream().wait_event(qs.done)      # prefetch_group ran the frame-only side on the side stream
+        else:
+            if self._side_busy is not None:                 # whatever the side stream is doing shares the lists' workspace
+                torch.cuda.current_stream().wait_event(self._side_busy)
+            if isinstance(frames, (list, tuple)):
+                for i, fr in enumerate(frames):
+                    qs.frames[i].copy_(fr[0])
+            else:
+                qs.frames[:G].copy_(frames)
+            p.graphs.run(qs.pre[qs.nq], eager=self.eager)
+        qs.consumed, qs.held, qs.stage = [True] * G, [None] * G, 0
+        # one memory read per frame: the hit accumulator is bumped by log(hits + 1) PER FRAME (AFB_URR.py:165-174), which a read over
+        # all G x HW query columns cannot reproduce from its summed counts (and it would save nothing: 5 x 113 against 554 us at C3)
+        for g in range(G):
+            self._memory_read(p, fb, update_bank, qs.kv_q[g:g + 1], out=b.grp(b.dec_in, g))
+        p.graphs.run(b.post, eager=self.eager)
+        if prefetch:
+            # the next group's frame-only side: on the side stream, BEHIND this group's decoder (a second set of buffers and an earlier
+            # start -- under the memory read or the decoder -- measured 2-3 % slower: profiles/r06_group_variants.txt)
+            self.prefetch_group(prefetch, K)
+        self.fwd_count += G
+        return b.score[:G]
+
+    @staticmethod
+    def _group_qset(p, G):
+        """The batch set a group of G frames runs through: its own, or -- for the short group at the end of a clip -- the smallest
+        set already built that holds at least G frames (the surplus slots keep the frames of an earlier group: their images run
+        through the lists and are not looked at; no hit counts come from them, the memory reads are per frame).  Building a set
+        costs tens of milliseconds of allocations and descriptors: not for one group."""
+        if G not in p._qbatch:
+            built = [n for n, q_ in p._qbatch.items() if n > G and q_._dec_batch is not None]
+            if built:
+                return p._qbatch[min(built)]
+        return p.batch_set(G)
+
+    def prefetch_group(self, frames, obj_n):
+        """The frame-only side of the NEXT group (a list of G f32[1,3,h,w] tensors on the GPU) on the side stream, behind everything
+        enqueued so far -- call it after the current group's ``segment_group``: it then runs underneath that group's memorize /
+        update / label tail, and the next ``segment_group`` with these very tensors picks it up.  The set of a group size is
+        single-buffered: the decoder of the current group has finished with it when the side stream starts."""
+        for fr in frames:
+            self._check_frame(fr)
+        G = len(frames)
+        p = self.plan(frames[0].shape[2], frames[0].shape[3], obj_n)
+        qs = self._group_qset(p, G)
+        qs.dec_batch()
+        if self.refresher._tables is None:
+            self._settle()
+        self.side_stream()
+        ready = torch.cuda.Event()
+        ready.record()
+        with torch.cuda.stream(self._side):
+            self._side.wait_event(ready)
+            for i, fr in enumerate(frames):
+                qs.frames[i].copy_(fr[0])
+            p.graphs.run(qs.pre[qs.nq], eager=self.eager)
+            qs.done = torch.cuda.Event()
+            qs.done.record()
+        self._side_busy = qs.done
+        qs.keys = [self._key(fr) for fr in frames]
+        qs.held = list(frames)
+        qs.consumed = [False] * G
+        qs.n, qs.stage = G, 2
+
     def _batched_slot(self, frame):
         if self._batch is None:
             return None
@@ -1417,7 +1528,7 @@ class Engine:
         check(L.vfn_memread_apply(_lib.C.byref(m), s), 'vfn_memread_apply')
         check(L.vfn_memread_finish(_lib.C.byref(m), s), 'vfn_memread_finish')
 
-    def capture(self, H0, W0, obj_n):
+    def capture(self, H0, W0, obj_n, group=0):
         """Capture the HIP graphs of this frame size's launch lists NOW -- at plan warm-up, before the frame loop -- instead of on
         each list's third run inside the loop (torch.cuda.graph() enters with a device-wide synchronize, a gc.collect and
         an empty_cache; inside the loop those one-off stalls land in a timed region and drain the side stream's prefetch).  The
@@ -1438,6 +1549,13 @@ class Engine:
                     p.graphs.warm(lst, qs.split[n], None)
             for L in qs.post:
                 p.graphs.warm(L)
+        for G in ([group] if group and group > 1 else []):           # segment_group's lists for groups of this size
+            qs = p.batch_set(G)
+            b = qs.dec_batch()
+            if self.refresher._tables is None:
+                self._settle()
+            p.graphs.warm(qs.pre[G])
+            p.graphs.warm(b.post)
         torch.cuda.current_stream().synchronize()
         return p.graphs.captures - before
 

@@ -164,5 +164,16 @@ class AFB_URR(nn.Module):
             return score, ops.segment_uncertainty(score.contiguous())
         return score, None
 
+    @torch.no_grad()
+    def segment_group(self, frames, fb_global, prefetch=None):
+        """``segment`` for G consecutive frames f32[G,3,h,w] that see the same bank (the frames between two ``memorize`` calls
+        when only every n-th frame is memorised): one batched pass, logits f32[G,obj_n,h,w] (Engine.segment_group).  Eval mode only;
+        an extension -- the reference segments frame by frame (test_video_seg.py:108)."""
+        if self.training:
+            raise RuntimeError('segment_group is the inference loop\'s batching; the training step batches through train.train_step')
+        if fb_global.obj_n < 2:
+            raise RuntimeError('segment needs at least two objects (background + 1): selected index k out of range')
+        return self.engine().segment_group(frames, fb_global, self.update_bank, prefetch=prefetch)
+
     def forward(self, x):  # AFB_URR.py:320-321
         pass

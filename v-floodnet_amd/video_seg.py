@@ -73,6 +73,7 @@ class ClipRunner:
     def __init__(self, model, obj_n=2, budget=250000, update_rate=0.1, thres_close=0.95, size=480, mem_every=1,
                  postprocess=False, autotune=False, capture_graphs=False):
         self.model = model
+        self.group_capture = 0                # (with capture_graphs: also capture launch_group's lists for groups of this many frames in start())
         self.capture_graphs = capture_graphs  # capture the launch lists' HIP graphs in start(), before the loop (long loops: video_seg.main, bench.py)
         self.postprocess = postprocess       # run postprocessing_pred (:116) on the device before the D2H
         self.autotune = autotune             # measure tile / split-K choices for conv shapes the shipped tables lack
@@ -87,6 +88,7 @@ class ClipRunner:
         self.t = 0
         self._pinned = None
         self._stats_pinned = None
+        self._net_cache_cap = 8
         self._net_cache = {}                 # source frame (data_ptr, version, shape) -> (the source frame, its network-resolution tensor)
         self.lookahead = int(os.environ.get('VFN_LOOKAHEAD', 3))    # frames of look-ahead the query side may use (0..3)
 
@@ -104,6 +106,8 @@ class ClipRunner:
         self.ori_size = (H0, W0)
         f = self._net_frame(first_frame)
         h, w = f.shape[-2:]
+        if self.group_capture > 1:                                 # launch_group's lists exist before the tuner / the capture look at the plan
+            self.model.engine().plan(h, w, self.obj_n).batch_set(self.group_capture).dec_batch()
         if self.autotune and os.environ.get('VFN_AUTOTUNE', '1') != '0':    # (VFN_AUTOTUNE=0: the heuristic choices for unlisted shapes)
             self.model.engine().autotune(h, w, self.obj_n, only_missing=True)
         m = first_mask_onehot.to(torch.float32).contiguous()
@@ -116,11 +120,13 @@ class ClipRunner:
             # (a capture enters with a device-wide synchronize + gc.collect + empty_cache: ADVICE r5); the first frame's keys / values
             # are already in the bank (init_bank copies them out of the plan's buffers).  Opt-in: a loop of a few frames (most tests)
             # is better off never capturing at all
-            self.graph_captures_at_start = self.model.engine().capture(h, w, self.obj_n)
+            self.graph_captures_at_start = self.model.engine().capture(h, w, self.obj_n, group=self.group_capture)
         self.t = 0
         self._alloc_outputs(H0, W0)
 
     def _alloc_outputs(self, H0, W0):
+        if self.lookahead > 0:                 # the look-ahead's stream is probed for a hardware queue of its own (~10 ms): here, not in the loop
+            self.model.engine().side_stream()
         self._net_cache = {}                                     # no look-ahead carried over from a previous clip
         # two sets of per-frame outputs: frame t+1 may be enqueued (launch) before the host has looked at frame t
         # (collect), and a side stream may still be compressing frame t's label map while frame t+1 runs
@@ -133,6 +139,9 @@ class ClipRunner:
         self._label_dev, self._post_dev, self._pinned = self._cur['label'], self._cur['post'], self._cur['pinned']
         self._ccl_scratch = torch.empty(2 * H0 * W0 + 8, dtype=torch.int32, device=self.device)
         self._pending = []
+        self._gsets, self._gturn, self._gpending, self._glast = {}, {}, [], None      # launch_group
+        if self.group_capture > 1:             # (pinned allocations cost milliseconds each: not inside the loop)
+            self._group_set(self.group_capture)
         self.size_log = [list(self.fb._len_host)]                 # live entries per object: after init_bank, then after every collected frame
 
     def snapshot(self, device='cpu'):
@@ -141,7 +150,7 @@ class ClipRunner:
         from it) and the clip geometry.  A long stream stops here and ``resume`` continues it -- bit-identically to the
         uninterrupted loop when both look equally far ahead (the reference has no inference-state checkpoint: SURVEY §5
         lists it as optional).  No frame may be in flight."""
-        if self._pending:
+        if self._pending or self._gpending:
             raise RuntimeError('ClipRunner.snapshot: frames in flight; collect() first')
         return dict(version=1, t=int(self.t), ori_size=[int(x) for x in self.ori_size], obj_n=int(self.obj_n), size=int(self.size),
                     mem_every=int(self.mem_every), bank=self.fb.state_dict(device))
@@ -172,7 +181,7 @@ class ClipRunner:
         hit = self._net_cache.get(key)
         if hit is None:
             hit = (frame, self._net_frame(frame))
-            if len(self._net_cache) >= 8:
+            if len(self._net_cache) >= self._net_cache_cap:
                 self._net_cache.pop(next(iter(self._net_cache)))
             self._net_cache[key] = hit
         return hit[1]
@@ -213,6 +222,8 @@ class ClipRunner:
         frame)."""
         if len(self._pending) >= 2:
             raise RuntimeError('ClipRunner: two frames already in flight; collect() first')
+        if self._gpending:
+            raise RuntimeError('ClipRunner: a group of frames in flight; collect_group() first')
         self.t += 1
         buf = self._bufs[self.t & 1]
         if buf.get('reader_done') is not None:                    # e.g. the PNG side stream still reading frame t-2
@@ -259,6 +270,98 @@ class ClipRunner:
         self.launch(frame, next_frame, want_label, next_frames)
         lab = self.collect()
         return lab if want_label else None
+
+    # ------------------------------------------------------------------ groups of frames between two memorize calls (mem_every > 1)
+    def _group_set(self, G):
+        """Two alternating sets of G per-frame outputs (one group may be in flight while the host reads the one before)."""
+        G = max(G, self.group_capture)        # (the short group at a clip's end uses the full-size sets: no pinned allocation in the loop)
+        sets = self._gsets.get(G)
+        if sets is None:
+            H0, W0 = self.ori_size
+            mk = lambda: dict(label=torch.empty(H0, W0, dtype=torch.uint8, device=self.device),
+                              post=torch.empty(H0, W0, dtype=torch.uint8, device=self.device),
+                              pinned=torch.empty(H0, W0, dtype=torch.uint8).pin_memory())
+            sets = self._gsets[G] = [dict(frames=[mk() for _ in range(G)], prob=None, done=torch.cuda.Event(),
+                                          stats=torch.zeros(self.obj_n, 4, dtype=torch.int32).pin_memory()) for _ in range(2)]
+            self._gturn[G] = 0
+        self._gturn[G] ^= 1
+        return sets[self._gturn[G]]
+
+    def launch_group(self, frames, want_label=True, next_frames=None):
+        """Enqueue the hot loop for the G frames ``frames`` (a list of f32[1,3,H0,W0] on the GPU: frames t+1 .. t+G) in ONE batched
+        pass (``AFB_URR.segment_group``): they must all see the same bank, i.e. only the LAST of them may be a frame the loop
+        memorises (``t % mem_every == 0``) -- with a key-frame interval of n that is groups of up to n frames ending on a key frame
+        (BASELINE config C3: n = 5).  Same labels as G ``launch`` calls up to the summation order of the larger GEMMs; the bank
+        is updated once, behind the group, exactly as the frame-by-frame loop would have.  ``collect_group()`` returns the G label
+        maps.  At most two groups may be outstanding; do not mix with ``launch`` while one is.  ``next_frames``: the frames of the
+        group after this one (already on the GPU) -- their frame-only side then runs on the side stream underneath this group's
+        memorize / update (``Engine.prefetch_group``)."""
+        G = len(frames)
+        if G < 1:
+            raise ValueError('launch_group: no frames')
+        if self._pending:
+            raise RuntimeError('ClipRunner: single frames in flight; collect() first')
+        if len(self._gpending) >= 2:
+            raise RuntimeError('ClipRunner: two groups already in flight; collect_group() first')
+        for g in range(G - 1):
+            if (self.t + 1 + g) % self.mem_every == 0:
+                raise ValueError(f'launch_group: frame {self.t + 1 + g} is memorised (mem_every = {self.mem_every}) but is not the last '
+                                 f'of the group: the frames behind it would not see its update')
+        self._net_cache_cap = max(self._net_cache_cap, 2 * G + 2)    # this group's frames and the next one's stay resident
+        gs = self._group_set(G)
+        outs = gs['frames'][:G]
+        for fo in outs:
+            if fo.get('reader_done') is not None:
+                torch.cuda.current_stream().wait_event(fo['reader_done'])
+                fo['reader_done'] = None
+        nets = [self._net_cached(f) for f in frames]
+        # (next_frames: the frame-only side of the NEXT group goes to the side stream behind this group's decoder, i.e. underneath
+        # its memorize / update / label tail -- Engine.prefetch_group)
+        nxt = [self._net_cached(f) for f in next_frames] if next_frames and self.lookahead > 0 else None
+        scores = self.model.segment_group(nets, self.fb, prefetch=nxt)        # :108 for the G frames
+        if gs['prob'] is None or gs['prob'].shape[1:] != scores.shape[1:] or gs['prob'].shape[0] < G:
+            gs['prob'] = torch.empty((len(gs['frames']),) + tuple(scores.shape[1:]), device=scores.device, dtype=scores.dtype)
+        for g in range(G):
+            ops.softmax_objects(scores[g:g + 1], out=gs['prob'][g:g + 1])    # :109
+        self.t += G
+        has_update = self.t % self.mem_every == 0
+        if has_update:
+            k, v = self.model.memorize(nets[-1], gs['prob'][G - 1:G])        # :111-112
+            self.fb.update(k, v, self.t)
+        H0, W0 = self.ori_size
+        for g in range(G):
+            fo = outs[g]
+            ops.resize_argmax(gs['prob'][g:g + 1], H0, W0, out=fo['label'])  # :114-115
+            src = fo['label']
+            if self.postprocess:
+                src = ops.postprocess_pred_device(fo['label'], fo['post'], self._ccl_scratch)
+            if want_label:
+                fo['pinned'].copy_(src, non_blocking=True)
+        gs['stats'].copy_(self.fb.stats_device(), non_blocking=True)
+        gs['done'].record()
+        gs['has_update'], gs['G'], gs['t'] = has_update, G, self.t
+        self._gpending.append(gs)
+        self._glast = gs
+        return gs
+
+    def collect_group(self):
+        """Wait for the oldest outstanding ``launch_group``; returns its G uint8 label maps [H0,W0] (pinned host tensors, valid
+        until the group after next of the same size)."""
+        gs = self._gpending.pop(0)
+        gs['done'].synchronize()
+        before = list(self.fb._len_host)
+        self.fb.absorb_stats(gs['stats'], in_flight=sum(1 for x in self._gpending if x['has_update']))
+        self.size_log += [before] * (gs['G'] - 1) + [list(self.fb._len_host)]
+        return [fo['pinned'] for fo in gs['frames'][:gs['G']]]
+
+    def step_group(self, frames, want_label=True):
+        self.launch_group(frames, want_label)
+        labs = self.collect_group()
+        return labs if want_label else None
+
+    def group_labels_device(self):
+        """The label maps of the last group as they left the GPU (post-processed when ``postprocess``), still on the device."""
+        return [fo['post'] if self.postprocess else fo['label'] for fo in self._glast['frames'][:self._glast['G']]]
 
     def label_device(self):
         """The label map of the last step as it left the GPU (post-processed when ``postprocess``), still on the device."""
