@@ -1,6 +1,6 @@
 """Per layer shape: the direct implicit-GEMM convolution (tuned choice) against Winograd F(4x4, 3x3) (input transform + the 36
 batched-filter GEMMs with their best tile configuration + output transform), every 3x3 / stride-1 layer of the C2 / C3 / C5 plans.
-usage: tune_winograd.py [HxW ...] (default: the bench sizes; 400x400 = the training sample).
+usage: tune_winograd.py [HxW ...] (default: the bench sizes; 400x400 = the training sample).  VFN_WINO_GROUP=n: also the shapes of groups of n frames.
 Writes gpurun_out/wino_gfx950.json ("M,cin,cout" -> 1 where Winograd is at least 5 % faster) and the GEMM shapes' entries
 into gpurun_out/tuned_gfx950.json."""
 import sys, os, json
@@ -48,8 +48,11 @@ if MODE:                                                  # (reduced-precision d
     for l_ in layers:
         if getattr(l_, 'k', 0) == 3 and l_.cin % 64 == 0:
             by_w[l_.w_lp(MODE).data_ptr()] = l_
+GROUP = int(os.environ.get('VFN_WINO_GROUP', '0'))         # also the batched lists of Engine.segment_group for groups of this many frames
 for (h, w) in sizes:
     p = eng.plan(h, w, 2)
+    if GROUP > 1:
+        p.batch_set(GROUP).dec_batch()
     for lst in p.all_lists():
         for l in lst:
             if l.fn is not ops.conv2d_launch or int(l.args[2]) != MODE:

@@ -268,3 +268,40 @@ def test_grouped_frames_match_the_frame_by_frame_loop(gpu, prefetch):
         assert torch.equal(ia[:, 0], ib[:, 0])
         assert float(((ia[:, 1] - ib[:, 1]).abs() > 2).float().mean()) < 0.01
         assert torch.allclose(a.fb.keys[i], b.fb.keys[i], atol=2e-4, rtol=1e-3)
+
+
+def test_tuned_split_k_keeps_each_stream_on_its_own_workspace(gpu, monkeypatch):
+    """Engine.autotune re-applies the measured (tile, split-K) choice to every launch of a plan; a split-K launch gets the workspace
+    of the stream its LIST runs on.  The batch sets' frame-only lists run on the side stream in an inference plan
+    (Engine.prefetch_group, beside memorize / update on the main stream): handed the main workspace they raced with memorize's
+    split-K layers (C3 bf16x3 grouped: mIoU 0.39 on one run in two before the fix).  Every choice forced to a K split here."""
+    from tools import synth
+    from vfloodnet_amd import AFB_URR, engine, ops
+    model = AFB_URR(gpu, update_bank=True).to(gpu).eval()
+    model.load_state_dict(synth.make_state_dict(20200212), strict=True)
+    eng = model.engine()
+    p = eng.plan(96, 160, 2)
+    qs = p.batch_set(3)
+    b = qs.dec_batch()
+    monkeypatch.setattr(engine, 'tune_desc', lambda d, bf, ws, cnt, **kw: (3, 2, 0))       # 64 x 64 tiles, K cut in two, from tile 0
+    saved = [dict(t) for t in engine._TABLES]
+    try:
+        eng.autotune(96, 160, 2, only_missing=False)
+    finally:
+        for t, s_ in zip(engine._TABLES, saved):
+            t.clear()
+            t.update(s_)
+
+    def inside(ptr_, t):
+        return t.data_ptr() <= ptr_ < t.data_ptr() + t.numel() * t.element_size()
+    seen = {'side': 0, 'main': 0}
+    side = [qs.pre[n] for n in qs.sizes] + [q_.pre[n] for q_ in p.qsets for n in q_.sizes]
+    main = [b.post, p.mem] + [L for q_ in p.qsets for L in q_.post]
+    for kind, lists, ws in (('side', side, p.ws_q), ('main', main, p.ws)):
+        for lst in lists:
+            for l in lst:
+                if l.fn is ops.conv2d_launch and l.args[0].ksplit > 1:
+                    part = int(l.args[0].partial or 0)
+                    assert inside(part, ws), f'{l.name}: split-K partials outside the {kind} stream\'s workspace'
+                    seen[kind] += 1
+    assert seen['side'] > 10 and seen['main'] > 10

@@ -1566,7 +1566,10 @@ class Engine:
         tables were not tuned for costs a few seconds once, e.g. at the start of ``video_seg.main``)."""
         p = self.plan(H0, W0, obj_n)
         seen = {}
-        side_lists = [id(qs.pre[n]) for qs in p.qsets for n in (1, 2)]
+        # lists that run on the side stream keep the side stream's split-K workspace: the look-ahead sets' and -- in an inference plan,
+        # where Engine.prefetch_group runs them beside memorize / update -- the batch sets' frame-only lists
+        side_sets = list(p.qsets) + ([] if p.keep_acts else list(p._qbatch.values()))
+        side_lists = [id(qs.pre[n]) for qs in side_sets for n in qs.sizes]
         for lst in p.all_lists():
             for l in lst:
                 l_side = id(lst) in side_lists
