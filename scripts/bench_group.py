@@ -19,7 +19,7 @@ if ck:
     model.load_state_dict(torch.load(ck, map_location='cpu')['model'], strict=False)
 else:
     model.load_state_dict(synth.make_state_dict(20200212), strict=True)
-frames, m0 = synth.clip(3, T, H0, W0)
+frames, m0 = synth.clip(3, T, H0, W0) if os.environ.get('GROUP_CLIP', 'easy') == 'easy' else synth.clip_hard(3, T, H0, W0)
 frames = frames.to(dev)
 onehot = synth.onehot(m0).unsqueeze(0).to(dev)
 
@@ -79,7 +79,7 @@ for rep in range(3):
         fps, labs, sizes = fn(True)
         res.setdefault(name, []).append(fps)
         res[name + '/labs'], res[name + '/sizes'] = labs, sizes
-print(f'{prec}, {T}-frame {H0}x{W0} clip, key frame every {n}th:')
+print(f'{prec}, {T}-frame {H0}x{W0} clip ({os.environ.get("GROUP_CLIP", "easy")} frames, weights: {os.path.basename(ck) if ck else "synthetic"}), key frame every {n}th:')
 for name in ('frame by frame', 'grouped'):
     print(f'  {name:15s} ' + ' / '.join(f'{x:.1f}' for x in res[name]) + ' frames/s')
 m = miou(res['frame by frame/labs'][1:], res['grouped/labs'][1:])

@@ -305,3 +305,43 @@ def test_tuned_split_k_keeps_each_stream_on_its_own_workspace(gpu, monkeypatch):
                     assert inside(part, ws), f'{l.name}: split-K partials outside the {kind} stream\'s workspace'
                     seen[kind] += 1
     assert seen['side'] > 10 and seen['main'] > 10
+
+
+def test_main_with_a_key_frame_interval_groups_the_frames(gpu, tmp_path, monkeypatch):
+    """``video_seg.main --mem-every 3`` on 17 JPEG frames with overlays: the frames between two key frames go through the network as one
+    batched pass (ClipRunner.launch_group); the mask PNGs agree with the frame-by-frame loop (VFN_MAIN_GROUP=0) up to the summation
+    order of the batched convolutions, every frame and every overlay is written, and the bank-size vectors of the two runs are
+    equal."""
+    import argparse
+    import numpy as np
+    from PIL import Image
+    from tools import synth
+    from vfloodnet_amd import video_seg
+    from vfloodnet_amd.data import save_seg_mask, color_palette
+    monkeypatch.setenv('VFN_AUTOTUNE', '0')
+    T, H, W = 17, 120, 200
+    frames, m0 = synth.clip(21, T, H, W)
+    fdir = tmp_path / 'frames'
+    fdir.mkdir()
+    for t in range(T):
+        Image.fromarray((frames[t].permute(1, 2, 0).numpy() * 255).astype(np.uint8)).save(str(fdir / f'{t:05d}.jpg'), quality=95)
+    ckpt = str(tmp_path / 'ckpt.pth')
+    torch.save({'epoch': 0, 'model': synth.make_state_dict(20200212), 'loss': 0.0, 'seed': 20200212}, ckpt)
+    out, sizes = {}, {}
+    for tag, grp in (('grouped', '1'), ('frames', '0')):
+        run = tmp_path / tag
+        (run / 'output' / 'segs' / 'clip' / 'mask').mkdir(parents=True)
+        save_seg_mask(m0.numpy().astype(np.uint8), str(run / 'output' / 'segs' / 'clip' / 'mask' / '00000.png'), color_palette)
+        monkeypatch.chdir(run)
+        monkeypatch.setenv('VFN_MAIN_GROUP', grp)
+        args = argparse.Namespace(gpu=0, budget=250000, viz=True, model_path=ckpt, update_rate=0.1, merge_thres=0.95,
+                                  test_path=str(fdir), test_name='clip', size=96, load_workers=2, mem_every=3, keep_labels=True)
+        runner = video_seg.main(args, gpu)
+        out[tag] = [np.array(Image.open(str(run / 'output' / 'segs' / 'clip' / 'mask' / f'{t:05d}.png'))) for t in range(T)]
+        assert all((run / 'output' / 'segs' / 'clip' / 'overlay' / f'{t:05d}.png').is_file() for t in range(T))
+        sizes[tag] = runner.kept_sizes.tolist() if runner is not None else None
+    for t, (a, b) in enumerate(zip(out['grouped'], out['frames'])):
+        inter, union = ((a == 1) & (b == 1)).sum(), ((a == 1) | (b == 1)).sum()
+        assert union == 0 or inter / union > 0.995, f'frame {t}: {inter} / {union}'
+    if sizes['grouped'] is not None:
+        assert sizes['grouped'] == sizes['frames'] and len(sizes['grouped']) == T

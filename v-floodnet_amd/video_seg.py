@@ -447,6 +447,8 @@ def main(args, device):
     obj_n = seq_dataset.obj_n
     runner = ClipRunner(model, obj_n, args.budget, update_rate=args.update_rate, thres_close=args.merge_thres,
                         size=downsample_size, mem_every=getattr(args, 'mem_every', 1), postprocess=True, autotune=True, capture_graphs=True)
+    if runner.mem_every > 1 and os.environ.get('VFN_MAIN_GROUP', '1') != '0':
+        runner.group_capture = runner.mem_every        # (the batched lists are built, tuned and captured in start(), before the loop)
 
     ori_first_frame = seq_dataset.first_frame.unsqueeze(0).to(device)
     ori_first_mask = seq_dataset.first_mask.unsqueeze(0).to(device)
@@ -543,8 +545,14 @@ def main(args, device):
         from collections import deque
         ahead = deque()                          # (item, frame on the device, its decode-finished event)
 
+        # a key-frame interval (--mem-every n > 1): the frames between two memorize calls go through the network as ONE batched pass
+        # (ClipRunner.launch_group; VFN_MAIN_GROUP=0: frame by frame).  The loop then keeps two groups of frames decoded ahead
+        group_n = runner.mem_every if (runner.mem_every > 1 and os.environ.get('VFN_MAIN_GROUP', '1') != '0') else 0
+        n_ahead = max(4, 2 * group_n)
+        N_SLOTS = max(N_SLOTS, n_ahead + 2)
+
         def fill():
-            while len(ahead) < 4:
+            while len(ahead) < n_ahead:
                 item = next(it, None)
                 if item is None:
                     return
@@ -553,6 +561,25 @@ def main(args, device):
         prof = [0.0, 0.0, 0.0, 0.0, 0] if os.environ.get('VFN_MAIN_TIMING') else None   # host seconds: fill, launch, save, collect
         dev_marks = []
         fill()
+        while ahead and group_n:
+            g = min(group_n - runner.t % group_n, len(ahead))     # up to and including the next key frame
+            grp = [ahead.popleft() for _ in range(g)]
+            fill()
+            nxt = list(ahead)[:min(group_n, len(ahead))] if runner.lookahead > 0 else []
+            for x_ in grp + nxt:
+                main_stream.wait_event(x_[2])
+            gs = runner.launch_group([x_[1] for x_ in grp], want_label=False, next_frames=[x_[1] for x_ in nxt] or None)
+            for (item_, dev_, _), fo, lab in zip(grp, gs['frames'], runner.group_labels_device()):
+                name = item_[1]
+                if keep is not None:
+                    keep.append(lab.clone())
+                fo['reader_done'] = sink.save(lab, os.path.join(seg_dir, f'{name}.png'), color_palette,
+                                              frame=dev_[0] if args.viz else None,
+                                              overlay_path=os.path.join(overlay_dir, f'{name}.png') if args.viz else None)
+            if len(runner._gpending) == 2:
+                runner.collect_group()
+        while runner._gpending:
+            runner.collect_group()
         while ahead:
             t0 = time.perf_counter()
             cur, cur_dev, cur_ready = ahead.popleft()
