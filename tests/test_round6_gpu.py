@@ -345,3 +345,36 @@ def test_main_with_a_key_frame_interval_groups_the_frames(gpu, tmp_path, monkeyp
         assert union == 0 or inter / union > 0.995, f'frame {t}: {inter} / {union}'
     if sizes['grouped'] is not None:
         assert sizes['grouped'] == sizes['frames'] and len(sizes['grouped']) == T
+
+
+def test_c3_shape_grouped_against_frame_by_frame(gpu):
+    """BASELINE config C3 at its own size (720 x 1280 frames, network at 480 x 853, key frame every 5th), f32: 11 frames as groups of
+    5 + 5 + 1 with the next group prefetched, against the frame-by-frame loop with its look-ahead -- labels within the summation-order
+    noise of the larger GEMMs, bank-size vectors equal."""
+    from tools import synth
+    from vfloodnet_amd import AFB_URR
+    from vfloodnet_amd.video_seg import ClipRunner
+    T, n = 12, 5
+    model = AFB_URR(gpu, update_bank=True).to(gpu).eval()
+    model.load_state_dict(synth.make_state_dict(20200212), strict=True)
+    frames, m0 = synth.clip(6, T, 720, 1280)
+    frames = frames.to(gpu)
+    onehot = synth.onehot(m0).unsqueeze(0).to(gpu)
+    a = ClipRunner(model, 2, 250000, mem_every=n, postprocess=True)
+    a.start(frames[0:1], onehot)
+    la = [a.step(frames[t:t + 1], next_frames=[frames[u:u + 1] for u in range(t + 1, min(T, t + 4))]).clone() for t in range(1, T)]
+    b = ClipRunner(model, 2, 250000, mem_every=n, postprocess=True)
+    b.group_capture = n
+    b.start(frames[0:1], onehot)
+    lb, t = [], 1
+    while t < T:
+        g = min(n - (t - 1) % n, T - t)
+        nxt = [frames[u:u + 1] for u in range(t + g, min(T, t + g + n))]
+        b.launch_group([frames[u:u + 1] for u in range(t, t + g)], next_frames=nxt or None)
+        lb += [x.clone() for x in b.collect_group()]
+        t += g
+    for t, (x, y) in enumerate(zip(la, lb)):
+        inter = ((x == 1) & (y == 1)).sum().item()
+        union = ((x == 1) | (y == 1)).sum().item()
+        assert union == 0 or inter / union > 0.9995, f'frame {t + 1}: {inter} / {union}'
+    assert a.size_log == b.size_log
