@@ -85,5 +85,13 @@ for name in ('frame by frame', 'grouped'):
 m = miou(res['frame by frame/labs'][1:], res['grouped/labs'][1:])
 same = (res['frame by frame/labs'][1:] == res['grouped/labs'][1:]).flatten(1).all(1).float().mean()
 print(f'  labels grouped vs frame by frame: mIoU min {float(m.min()):.5f} mean {float(m.mean()):.5f}; identical frames {float(same):.3f}')
+if os.environ.get('GROUP_DETAIL'):
+    first = next((i for i, (x, y) in enumerate(zip(res['frame by frame/sizes'], res['grouped/sizes'])) if x != y), None)
+    print(f'  first frame whose bank sizes differ: {first}; frames with mIoU < 0.999: ' + ' '.join(f'{i + 1}:{float(v):.4f}' for i, v in enumerate(m) if v < 0.999)[:600])
+    f2, l2, s2 = grp(True)
+    same_g = bool((l2[1:] == res['grouped/labs'][1:]).all())
+    f3, l3, s3 = seq(True)
+    same_s = bool((l3[1:] == res['frame by frame/labs'][1:]).all())
+    print(f'  a second grouped run equals the first bit for bit: {same_g} (sizes {s2 == res["grouped/sizes"]}); a second frame-by-frame run equals the first: {same_s} (sizes {s3 == res["frame by frame/sizes"]})')
 sa, sb = res['frame by frame/sizes'], res['grouped/sizes']
 print(f'  bank sizes at the end: {sa[-1]} vs {sb[-1]}; size vectors equal: {sa == sb}')
