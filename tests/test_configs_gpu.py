@@ -46,14 +46,17 @@ def c3_oracle(sd):
     return frames, m0, ref
 
 
+@pytest.mark.parametrize('group', [False, True])
 @pytest.mark.parametrize('precision', ['bf16x3', 'bf16'])
-def test_c3_720p_every_5th_reduced_precision(gpu, sd, c3_oracle, precision):
+def test_c3_720p_every_5th_reduced_precision(gpu, sd, c3_oracle, precision, group):
+    """``group``: the frames between two key frames as one batched pass (ClipRunner.launch_group, round 6) -- held to the oracle
+    exactly as the frame-by-frame loop is."""
     from vfloodnet_amd import AFB_URR
     from vfloodnet_amd.video_seg import run_clip
     frames, m0, ref = c3_oracle
     model = AFB_URR(gpu, update_bank=True, precision=precision).to(gpu).eval()
     model.load_state_dict(sd, strict=True)
-    out = run_clip(model, frames.to(gpu), m0, size=480, mem_every=5)
+    out = run_clip(model, frames.to(gpu), m0, size=480, mem_every=5, group=group)
     T = frames.shape[0]
     assert out['labels'].shape == (T, 720, 1280)
     ious = [miou(out['labels'][t], ref['labels'][t]) for t in range(1, T)]
@@ -220,18 +223,19 @@ def test_plain_bf16_meets_the_bar_on_trained_weights(gpu, trained_sd, workload):
     ref = O.run_clip(trained_sd, frames, m0, size=480, mem_every=mem_every)
     torch.set_num_threads(1)
     labs = {}
-    for precision in ('fp32', 'bf16x3', 'bf16'):
-        model = AFB_URR(gpu, update_bank=True, precision=precision).to(gpu).eval()
+    for precision in ('fp32', 'bf16x3', 'bf16') + (('bf16 grouped',) if mem_every > 1 else ()):
+        model = AFB_URR(gpu, update_bank=True, precision=precision.split()[0]).to(gpu).eval()
         model.load_state_dict(trained_sd, strict=True)
-        out = run_clip(model, frames.to(gpu), m0, size=480, mem_every=mem_every)
+        # ('bf16 grouped': C3's frames between two key frames as one batched pass, ClipRunner.launch_group -- the same bar)
+        out = run_clip(model, frames.to(gpu), m0, size=480, mem_every=mem_every, group=precision.endswith('grouped'))
         labs[precision] = out['labels']
         ious = [miou(out['labels'][t], ref['labels'][t]) for t in range(1, T)]
         drift = max(abs(a - b) for x, y in zip(out['bank_sizes'], ref['bank_sizes']) for a, b in zip(x, y))
         print(f'{workload} {precision} on trained weights: mIoU vs the f32 oracle min {min(ious):.5f} mean {sum(ious) / len(ious):.5f}; '
               f'bank {out["bank_sizes"][-1]} vs {ref["bank_sizes"][-1]} (drift {drift})')
         assert min(ious) >= 0.99, (precision, ious)
-        assert drift <= (2 if precision != 'bf16' else 0.01 * max(ref['bank_sizes'][-1]) + 2), (precision, drift)
-    for precision in ('bf16x3', 'bf16'):
+        assert drift <= (2 if not precision.startswith('bf16 ') and precision != 'bf16' else 0.01 * max(ref['bank_sizes'][-1]) + 2), (precision, drift)
+    for precision in [k for k in labs if k != 'fp32']:
         ious = [miou(labs[precision][t], labs['fp32'][t]) for t in range(1, T)]
         assert min(ious) >= 0.995, (precision, ious)
     # the ground truth of the synthetic clip (the mask rolled with the frame): the trained network actually segments it

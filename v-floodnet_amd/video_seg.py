@@ -354,8 +354,8 @@ class ClipRunner:
         self.size_log += [before] * (gs['G'] - 1) + [list(self.fb._len_host)]
         return [fo['pinned'] for fo in gs['frames'][:gs['G']]]
 
-    def step_group(self, frames, want_label=True):
-        self.launch_group(frames, want_label)
+    def step_group(self, frames, want_label=True, next_frames=None):
+        self.launch_group(frames, want_label, next_frames)
         labs = self.collect_group()
         return labs if want_label else None
 
@@ -372,9 +372,10 @@ class ClipRunner:
 
 
 def run_clip(model, frames, first_mask_u8, budget=250000, update_rate=0.1, thres_close=0.95, size=480,
-             mem_every=1, postprocess=False, overlap=True):
+             mem_every=1, postprocess=False, overlap=True, group=False):
     """frames f32[T,3,H0,W0] on the GPU, first mask u8[H0,W0] (>0 = water).
-    Returns labels u8[T,H0,W0] (host; frame 0 = the given mask) and per-frame bank sizes."""
+    Returns labels u8[T,H0,W0] (host; frame 0 = the given mask) and per-frame bank sizes.
+    ``group`` (with ``mem_every`` > 1): the frames between two memorised frames as one batched pass (``ClipRunner.launch_group``)."""
     T, _, H0, W0 = frames.shape
     m = (first_mask_u8 > 0).to(torch.uint8)
     onehot = torch.stack([1 - m, m], 0).unsqueeze(0).to(frames.device)        # Water_DS.py:93-101
@@ -384,6 +385,17 @@ def run_clip(model, frames, first_mask_u8, budget=250000, update_rate=0.1, thres
     labels_np = labels.numpy()
     labels[0] = m.cpu()
     sizes = []
+    if group and mem_every > 1:
+        t = 1
+        while t < T:
+            g = min(mem_every - (t - 1) % mem_every, T - t)
+            nxt = [frames[u:u + 1] for u in range(t + g, min(T, t + g + mem_every))] if overlap else None
+            labs = runner.step_group([frames[u:u + 1] for u in range(t, t + g)], next_frames=nxt or None)
+            for i, lab in enumerate(labs):
+                np.copyto(labels_np[t + i], lab.numpy())
+            sizes += [list(x) for x in runner.size_log[-g:]]
+            t += g
+        return dict(labels=labels, bank_sizes=sizes, fb=runner.fb)
     for t in range(1, T):
         lab = runner.step(frames[t:t + 1], next_frames=[frames[u:u + 1] for u in range(t + 1, min(T, t + 4))] if overlap else None)
         # plain memcpy: a torch CPU copy_ wakes the whole OpenMP pool (128 threads on the MI355X hosts), whose
