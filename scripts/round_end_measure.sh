@@ -17,11 +17,16 @@ timeout 900 $B --workload C5 --precision bf16x3 --steps 2000 --warmup 2 > $O/r06
 timeout 900 $B --workload C5 --precision bf16 --steps 2000 --warmup 2 > $O/r06_bench_c5_bf16.json 2> $O/c5b.err
 VFN_APPLY_PIPE=0 VFN_SCAN_PIPE=0 timeout 900 $B --workload C5 --precision bf16 --steps 2000 --warmup 2 --no-cpu-baseline > $O/r06_bench_c5_bf16_round5_kernels.json 2>> $O/c5b.err
 for T in easy hard; do
+# (each checkpoint is benchmarked on ITS task's frames: the hard-task checkpoint on the easy clip is out of distribution)
+if [ $T = easy ]; then N=trained_easy; else N=hard_task; fi
 timeout 600 python3 scripts/train_ckpt.py $T 3000 /tmp/vfn_trained_$T.pth > $O/r06_train_ckpt_$T.log 2>&1
-timeout 400 $B --workload C3 --precision bf16 --checkpoint /tmp/vfn_trained_$T.pth > $O/r06_bench_c3_bf16_trained_$T.json 2>> $O/trained.err
-timeout 400 $B --workload C3 --precision bf16 --group --clip $T --checkpoint /tmp/vfn_trained_$T.pth > $O/r06_bench_c3_bf16_trained_${T}_clip_grouped.json 2>> $O/trained.err
-timeout 900 $B --workload C5 --precision bf16 --steps 2000 --warmup 2 --checkpoint /tmp/vfn_trained_$T.pth > $O/r06_bench_c5_bf16_trained_$T.json 2>> $O/trained.err
+timeout 400 $B --workload C3 --precision bf16 --clip $T --checkpoint /tmp/vfn_trained_$T.pth > $O/r06_bench_c3_bf16_$N.json 2>> $O/trained.err
+timeout 400 $B --workload C3 --precision bf16 --group --clip $T --checkpoint /tmp/vfn_trained_$T.pth > $O/r06_bench_c3_bf16_${N}_grouped.json 2>> $O/trained.err
+timeout 900 $B --workload C5 --precision bf16 --steps 2000 --warmup 2 --clip $T --checkpoint /tmp/vfn_trained_$T.pth > $O/r06_bench_c5_bf16_$N.json 2>> $O/trained.err
 done
+timeout 400 $B --workload C3 --precision bf16x3 --clip hard --checkpoint /tmp/vfn_trained_hard.pth > $O/r06_bench_c3_bf16x3_hard_task.json 2>> $O/trained.err
+timeout 400 $B --workload C3 --precision bf16x3 --group --clip hard --checkpoint /tmp/vfn_trained_hard.pth > $O/r06_bench_c3_bf16x3_hard_task_grouped.json 2>> $O/trained.err
+timeout 400 $B --gpus 1 --steps 20 --warmup 5 --clip hard --checkpoint /tmp/vfn_trained_hard.pth > $O/r06_bench_c2_fp32_hard_task.json 2>> $O/trained.err
 timeout 900 $B --workload C5 --precision bf16x3 --steps 2000 --warmup 2 --checkpoint /tmp/vfn_trained_easy.pth > $O/r06_bench_c5_bf16x3_trained_easy.json 2>> $O/trained.err
 timeout 400 $B --gpus 1 --steps 20 --warmup 5 --checkpoint /tmp/vfn_trained_easy.pth > $O/r06_bench_c2_fp32_trained_easy.json 2>> $O/trained.err
 timeout 900 python3 scripts/profile_round.py fp32 > $O/profile_round_fp32.log 2>&1
