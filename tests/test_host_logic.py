@@ -276,3 +276,24 @@ def test_bank_snapshot_is_validated_before_any_device_work():
             fb.load_state_dict({**good, **edit})
     with pytest.raises(RuntimeError, match='GPU'):               # a valid snapshot gets as far as the device allocation
         fb.load_state_dict(good)
+
+
+def test_group_partition_ends_on_memorised_frames():
+    """ClipRunner.group_len (round 6: the frames between two memorize calls as one batched pass): groups end on the frames the loop
+    memorises (t % mem_every == 0), the first group of a resumed or unaligned stream is shorter, the last one takes what is left."""
+    import types
+    from vfloodnet_amd.video_seg import ClipRunner
+    r = ClipRunner(types.SimpleNamespace(device=torch.device('cpu'), precision='fp32'), 2, 1000, mem_every=5)
+    got, t, T = [], 0, 23
+    while t < T:
+        r.t = t
+        g = r.group_len(T - t)
+        got.append(g)
+        assert all((t + 1 + i) % 5 != 0 for i in range(g - 1))          # only the last frame of a group may be memorised
+        t += g
+    assert got == [5, 5, 5, 5, 3]
+    r.t = 7                                                            # e.g. resumed from a snapshot after frame 7
+    assert r.group_len(100) == 3 and r.group_len(2) == 2 and r.group_len(0) == 0
+    r1 = ClipRunner(types.SimpleNamespace(device=torch.device('cpu'), precision='fp32'), 2, 1000, mem_every=1)
+    r1.t = 11
+    assert r1.group_len(4) == 1

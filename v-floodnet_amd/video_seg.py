@@ -287,6 +287,10 @@ class ClipRunner:
         self._gturn[G] ^= 1
         return sets[self._gturn[G]]
 
+    def group_len(self, available):
+        """How many of the next ``available`` frames form the next group: up to and including the next memorised frame."""
+        return max(0, min(self.mem_every - self.t % self.mem_every, available))
+
     def launch_group(self, frames, want_label=True, next_frames=None):
         """Enqueue the hot loop for the G frames ``frames`` (a list of f32[1,3,H0,W0] on the GPU: frames t+1 .. t+G) in ONE batched
         pass (``AFB_URR.segment_group``): they must all see the same bank, i.e. only the LAST of them may be a frame the loop
@@ -388,7 +392,7 @@ def run_clip(model, frames, first_mask_u8, budget=250000, update_rate=0.1, thres
     if group and mem_every > 1:
         t = 1
         while t < T:
-            g = min(mem_every - (t - 1) % mem_every, T - t)
+            g = runner.group_len(T - t)
             nxt = [frames[u:u + 1] for u in range(t + g, min(T, t + g + mem_every))] if overlap else None
             labs = runner.step_group([frames[u:u + 1] for u in range(t, t + g)], next_frames=nxt or None)
             for i, lab in enumerate(labs):
@@ -574,7 +578,7 @@ def main(args, device):
         dev_marks = []
         fill()
         while ahead and group_n:
-            g = min(group_n - runner.t % group_n, len(ahead))     # up to and including the next key frame
+            g = runner.group_len(len(ahead))                      # up to and including the next key frame
             grp = [ahead.popleft() for _ in range(g)]
             fill()
             nxt = list(ahead)[:min(group_n, len(ahead))] if runner.lookahead > 0 else []
