@@ -135,6 +135,10 @@ def parse_args(argv=None):
     ap.add_argument('--group', action='store_true',
                     help='workloads that memorise only every n-th frame (C3: n = 5): the frames between two memorize calls as ONE batched pass '
                          '(ClipRunner.launch_group / AFB_URR.segment_group); same frames, same bank updates, labels equal up to summation order')
+    ap.add_argument('--main-loop', type=int, default=0, metavar='FRAMES',
+                    help='also run the files-to-files loop (vfloodnet_amd.video_seg.main: JPEG frames on disk -> mask + overlay PNG files on '
+                         'disk) on a clip of this many 480p frames in a CHILD process after the measurement and report its frames/s under '
+                         '`extra` (scripts/main_throughput.py; about 40 s; rank 0 at N = 1 only)')
     ap.add_argument('--clip', choices=['easy', 'hard'], default='easy',
                     help="easy (default, every published line): tools/synth.clip -- tinted, textured water; hard: tools/synth.clip_hard -- water "
                          "that differs from land by texture only (the frames a checkpoint from scripts/train_ckpt.py hard was trained on; a "
@@ -742,6 +746,22 @@ def main(argv=None):
                               'frames_per_s': round(1e3 * blk / sum(ms_blk), 2)})
         out['bank_curve'] = {'block_frames': blk, 'points': curve,
                              'note': 'host wall between step completions, this rank; sampled frames (events around every launch) included'}
+    if args.main_loop and world == 1:
+        # the loop a user of test_video_seg.py runs, files to files, beside the HBM-resident number: its own
+        # process (DataLoader workers, writer threads, its own model), started as a child -- this one keeps its GPU state
+        import re
+        import subprocess
+        try:
+            cp = subprocess.run([sys.executable, os.path.join(ROOT, 'scripts', 'main_throughput.py'), str(int(args.main_loop))],
+                                capture_output=True, text=True, timeout=600)
+            m_ = re.search(r'main\(\) frame loop: (\d+) frames, viz=(\w+): ([0-9.]+) frames/s', cp.stdout)
+            out['extra'] = {'main_files_to_files_fps': float(m_.group(3)) if m_ else None, 'frames': int(m_.group(1)) if m_ else None,
+                            'overlays': (m_.group(2) == 'True') if m_ else None,
+                            'what': 'vfloodnet_amd.video_seg.main: 480p JPEG files on disk -> mask + overlay PNG files on disk, frame loop after 4 '
+                                    'start-up iterations, second run of the process (scripts/main_throughput.py)',
+                            'error': None if m_ else (cp.stderr or cp.stdout)[-300:]}
+        except Exception as exc_:                     # (never fail the bench line over the side measurement)
+            out['extra'] = {'main_files_to_files_fps': None, 'error': repr(exc_)[:300]}
     print(json.dumps(out), flush=True)
     if os.environ.get('VFN_BENCH_DUMP'):            # per-step host times of the whole run (diagnostics)
         with open(os.environ['VFN_BENCH_DUMP'], 'w') as f:
